@@ -1,0 +1,331 @@
+/*
+ * sparkl_hip.h -- C ABI of libsparkl_hip.so, the MI355X (gfx950) MPM hot path.
+ *
+ * This is the drop-in boundary for sparkl3d's (dim3, f32) MPM substep:
+ *   sort/bin -> [fluid volume recompute] -> adaptive dt -> P2G (+stress) ->
+ *   grid update -> G2P (+F update, plasticity)
+ * i.e. what `MlsSolver::step` does on the CPU
+ *   (reference: src/dynamics/solver/mls_solver.rs:15-139)
+ * exposed through the *shape* of the reference's GPU host API
+ *   (reference: src/cuda/cuda_mpm_pipeline.rs:246-271, src/cuda/cuda_particle_set.rs:12-177,
+ *    src/cuda/cuda_particle_model_set.rs:37-84, src/cuda/cuda_collider_set.rs:46-127).
+ *
+ * Every struct below is layout-identical to the `#[repr(C)]` Rust type it cites,
+ * so a Rust host can pass `&[ParticlePosition]`, `&SolverParameters`, ... directly.
+ * All functions return 0 on success or a SPARKL_ERR_* / hipError-derived code;
+ * `sparkl_hip_last_error_string()` gives the text.  Nothing here aborts.
+ * A handle is NOT thread-safe (one caller thread at a time, as in the reference,
+ * src/cuda/cuda_mpm_pipeline.rs:235-237).
+ */
+#ifndef SPARKL_HIP_H
+#define SPARKL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ errors */
+enum {
+    SPARKL_OK = 0,
+    SPARKL_ERR_INVALID_ARGUMENT = 1,
+    SPARKL_ERR_UNSUPPORTED = 2,      /* e.g. Core*Model::Custom(u32): device code cannot cross a C ABI */
+    SPARKL_ERR_NO_DEVICE = 3,        /* no HIP device / HIP runtime failure at create */
+    SPARKL_ERR_HIP = 4,              /* a HIP call failed; see last_error_string */
+    SPARKL_ERR_NAN_TIMESTEP = 5,     /* reference panics here (timestep_estimator.rs:46) */
+    SPARKL_ERR_OUT_OF_MEMORY = 6,
+    SPARKL_ERR_INTERNAL = 7
+};
+
+/* ------------------------------------------- particle components (SoA, f32)
+ * reference: src_core/dynamics/particle.rs:18-219 */
+typedef struct { float point[3]; } SparklParticlePosition;           /* :18-21, 12 B */
+typedef struct { float vector[3]; } SparklParticleVelocity;          /* :54-57, 12 B */
+typedef struct {                                                     /* :64-72, 52 B */
+    float mass;
+    float volume0;
+    float radius0;
+    float deformation_gradient[9];            /* column-major (nalgebra Matrix3) */
+    float plastic_deformation_gradient_det;
+} SparklParticleVolume;
+typedef struct {                                                     /* :114-122, 24 B */
+    uint8_t failed;
+    uint8_t is_static;
+    uint8_t kinematic_vel_enabled;
+    uint8_t _pad0;
+    float kinematic_vel[3];
+    uint64_t model_index;                     /* Rust usize */
+} SparklParticleStatus;
+typedef struct { float phase; float psi_pos; } SparklParticlePhase;  /* :138-143, 8 B */
+typedef struct {                                                     /* :201-208, 16 B */
+    float nacc_alpha;
+    float plastic_hardening;
+    float elastic_hardening;
+    float log_vol_gain;
+} SparklParticleData;
+/* CPU-path-only state: `Particle::velocity_gradient` (src/dynamics/particle.rs:16).
+ * The reference CUDA path never stores it (fused g2p2g); the CPU ordering needs it
+ * between G2P and the next P2G.  Column-major. */
+typedef struct { float m[9]; } SparklVelocityGradient;               /* 36 B */
+
+/* --------------------------------------------------------- solver parameters
+ * reference: src_core/dynamics/solver/solver_parameters.rs:7-68 */
+enum { SPARKL_DOFS_LOCK_NONE = 0, SPARKL_DOFS_LOCK_X = 1, SPARKL_DOFS_LOCK_Y = 2, SPARKL_DOFS_LOCK_Z = 4 };
+enum { SPARKL_BOUNDARY_STICK = 0, SPARKL_BOUNDARY_FRICTION = 1, SPARKL_BOUNDARY_FRICTION_Z_UP = 2, SPARKL_BOUNDARY_NONE = 3 };
+enum { SPARKL_DAMAGE_CDMPM = 0, SPARKL_DAMAGE_EIGENEROSION = 1, SPARKL_DAMAGE_MODIFIED_EIGENEROSION = 2, SPARKL_DAMAGE_NONE = 3 };
+
+typedef struct {                                                     /* :42-54, 28 B */
+    float dt;
+    float max_substep_dt;
+    uint32_t max_num_substeps;
+    int32_t boundary_handling;
+    int32_t damage_model;
+    uint8_t force_fluids_volume_recomputation;
+    uint8_t enable_boundary_particle_projection;
+    uint8_t stop_after_one_substep;
+    uint8_t _pad0;
+    uint32_t simulation_dofs;
+} SparklSolverParams;
+
+/* -------------------------------------------------------------------- models
+ * `#[repr(C)] enum` with payload == { tag; union } in C.
+ * reference: src_core/dynamics/models/constitutive_model.rs:14-23,
+ *            plastic_model.rs:5-15, failure_model.rs:4-11 */
+typedef struct { uint8_t split_stress_on_failure; uint8_t _pad[3]; float cfl_coeff; float lambda; float mu; }
+    SparklCorotatedLinearElasticity;        /* elasticity_corotated_linear.rs:8-16 */
+typedef struct { float cfl_coeff; float lambda; float mu; }
+    SparklNeoHookeanElasticity;             /* elasticity_neo_hookean.rs:7-14 */
+typedef struct { float pressure0; uint32_t gamma; float viscosity; float max_neg_pressure; }
+    SparklMonaghanSphEos;                   /* eos_monaghan_sph.rs:7-16 */
+enum {
+    SPARKL_CONSTITUTIVE_COROTATED_LINEAR = 0,
+    SPARKL_CONSTITUTIVE_NEO_HOOKEAN = 1,
+    SPARKL_CONSTITUTIVE_EOS_MONAGHAN_SPH = 2,
+    SPARKL_CONSTITUTIVE_CUSTOM = 3
+};
+typedef struct {
+    uint32_t tag;
+    union {
+        SparklCorotatedLinearElasticity corotated;
+        SparklNeoHookeanElasticity neo_hookean;
+        SparklMonaghanSphEos monaghan;
+        uint32_t custom_id;
+    } u;
+} SparklConstitutiveModel;                  /* 20 B */
+
+typedef struct {                            /* plasticity_drucker_prager.rs:6-19, 32 B */
+    float h0, h1, h2, h3;
+    float lambda, mu;
+    uint8_t only_active_when_failed; uint8_t _pad[3];
+    float volume_correction;
+} SparklDruckerPragerPlasticity;
+typedef struct { float mu, kappa; uint8_t hardening_enabled; uint8_t _pad[3]; float hardening_factor, cohesion, friction; }
+    SparklNaccPlasticity;                   /* plasticity_nacc.rs:8-19 */
+typedef struct { float mu, lambda, tensile_strength, softening_rate; }
+    SparklRankinePlasticity;                /* plasticity_rankine.rs:7-16 */
+typedef struct { float min_epsilon, max_epsilon, hardening_coeff; }
+    SparklSnowPlasticity;                   /* plasticity_snow.rs:7-15 */
+enum {
+    SPARKL_PLASTIC_DRUCKER_PRAGER = 0,
+    SPARKL_PLASTIC_NACC = 1,
+    SPARKL_PLASTIC_RANKINE = 2,
+    SPARKL_PLASTIC_SNOW = 3,
+    SPARKL_PLASTIC_CUSTOM = 4
+};
+typedef struct {
+    uint32_t tag;
+    union {
+        SparklDruckerPragerPlasticity drucker_prager;
+        SparklNaccPlasticity nacc;
+        SparklRankinePlasticity rankine;
+        SparklSnowPlasticity snow;
+        uint32_t custom_id;
+    } u;
+} SparklPlasticModel;                       /* 36 B */
+
+typedef struct { float max_principal_stress, max_shear_stress; } SparklMaximumStressFailure;
+enum { SPARKL_FAILURE_MAXIMUM_STRESS = 0, SPARKL_FAILURE_CUSTOM = 1 };
+typedef struct {
+    uint32_t tag;
+    union { SparklMaximumStressFailure maximum_stress; uint32_t custom_id; } u;
+} SparklFailureModel;                       /* 12 B */
+
+/* `ParticleModel{constitutive_model, plastic_model: Option, failure_model: Option}`
+ * (src/dynamics/particle_model.rs:14-18) after `to_core_model()`.  Rust `Option` has no
+ * C layout, hence the explicit has_* bytes. */
+typedef struct {
+    SparklConstitutiveModel constitutive_model;
+    uint32_t has_plastic_model;
+    SparklPlasticModel plastic_model;
+    uint32_t has_failure_model;
+    SparklFailureModel failure_model;
+} SparklParticleModel;
+
+/* ----------------------------------------------------------------- colliders
+ * First slice of `CudaColliderSet::from_collider_set` (src/cuda/cuda_collider_set.rs:46-127)
+ * and of the CPU `RigidWorld{colliders}` loop (src/dynamics/solver/grid_update.rs:77-128):
+ * cuboids only.  `position` is a Rapier isometry: unit quaternion (i,j,k,w) + translation. */
+typedef struct {
+    float half_extents[3];
+    float rotation[4];      /* (i, j, k, w) */
+    float translation[3];
+    float friction;         /* collider.friction(), grid_update.rs:113 */
+} SparklCuboidCollider;
+
+/* ------------------------------------------------------------------- timings
+ * reference: CudaTimestepTimings / CudaSubstepTimings / CudaDeviceTimings
+ * (src/cuda/cuda_mpm_pipeline.rs:28-85).  Milliseconds from hipEvents, summed over the
+ * substeps of the last `sparkl_hip_pipeline_step` call.  g2p2g is split in p2g + g2p. */
+typedef struct {
+    float dt;                       /* simulated time of the call */
+    uint32_t num_substeps;
+    uint32_t num_resorts;           /* how many substeps re-binned the particles */
+    float grid_resize_and_sort_ms;
+    float reset_grid_ms;            /* always 0: tiles are written whole, nothing to reset */
+    float estimate_timestep_ms;
+    float p2g_ms;
+    float grid_update_ms;
+    float g2p_ms;
+    float halo_ms;                  /* pack + merge of ghost planes (multi-GPU slabs) */
+    float total_ms;
+} SparklTimings;
+
+/* ------------------------------------------------------------------ pipeline */
+typedef struct SparklPipeline SparklPipeline;
+
+typedef struct {
+    int32_t device_id;      /* HIP device ordinal */
+    float cell_width;       /* SpGrid::new(cell_width), src/geometry/sp_grid.rs:168 */
+    /* log2 of the virtual SPGrid size in bytes; 30 reproduces the intended 1 GiB map
+     * (src/geometry/sp_grid.rs:175) => valid cell coords 0..255 per axis.
+     * Particles whose neighbourhood leaves the domain are flagged `failed`
+     * (src/dynamics/particle_set.rs:129-136).  Allowed: 30, 33, 36, 39. */
+    uint32_t domain_log2_bytes;
+    void* stream;           /* hipStream_t to run on, or NULL for a library-owned stream */
+} SparklPipelineDesc;
+
+/* CudaMpmPipeline::new + load_module + CudaSparseGrid::new
+ * (cuda_mpm_pipeline.rs:247-260, cuda_sparse_grid.rs:49-90) */
+int sparkl_hip_pipeline_create(const SparklPipelineDesc* desc, SparklPipeline** out);
+void sparkl_hip_pipeline_destroy(SparklPipeline* p);
+
+/* CudaParticleSet::from_particles (cuda_particle_set.rs:33-71) + the shared ParticleData
+ * attribute buffer (cuda_particle_model.rs:14-29).  `velocity_gradients` may be NULL (zeros,
+ * as `Particle::new`, src/dynamics/particle.rs:79).  Host arrays are only borrowed. */
+int sparkl_hip_particles_upload(SparklPipeline* p, uint64_t n,
+                                const SparklParticleStatus* status,
+                                const SparklParticlePosition* pos,
+                                const SparklParticleVelocity* vel,
+                                const SparklParticleVolume* volume,
+                                const SparklParticlePhase* phase,
+                                const SparklParticleData* data,
+                                const SparklVelocityGradient* velocity_gradients);
+/* CudaParticleSet::append (cuda_particle_set.rs:135-177) */
+int sparkl_hip_particles_append(SparklPipeline* p, uint64_t n,
+                                const SparklParticleStatus* status,
+                                const SparklParticlePosition* pos,
+                                const SparklParticleVelocity* vel,
+                                const SparklParticleVolume* volume,
+                                const SparklParticlePhase* phase,
+                                const SparklParticleData* data,
+                                const SparklVelocityGradient* velocity_gradients);
+/* CudaParticleSet::remove_range / truncate / len (cuda_particle_set.rs:73-133) */
+int sparkl_hip_particles_remove_range(SparklPipeline* p, uint64_t start, uint64_t end);
+int sparkl_hip_particles_truncate(SparklPipeline* p, uint64_t new_len);
+uint64_t sparkl_hip_particles_len(const SparklPipeline* p);
+
+/* CudaParticleSet::read_* (cuda_particle_set.rs:91-121).  Arrays come back in CALLER order
+ * (the library keeps particles physically block-sorted on the device).  `n` must equal len. */
+int sparkl_hip_particles_read_positions(SparklPipeline* p, SparklParticlePosition* out, uint64_t n);
+int sparkl_hip_particles_read_velocities(SparklPipeline* p, SparklParticleVelocity* out, uint64_t n);
+int sparkl_hip_particles_read_volumes(SparklPipeline* p, SparklParticleVolume* out, uint64_t n);
+int sparkl_hip_particles_read_statuses(SparklPipeline* p, SparklParticleStatus* out, uint64_t n);
+int sparkl_hip_particles_read_phases(SparklPipeline* p, SparklParticlePhase* out, uint64_t n);
+int sparkl_hip_particles_read_data(SparklPipeline* p, SparklParticleData* out, uint64_t n);
+int sparkl_hip_particles_read_velocity_gradients(SparklPipeline* p, SparklVelocityGradient* out, uint64_t n);
+/* read_sorted_particle_ids: caller index of the particle stored in each sorted slot */
+int sparkl_hip_particles_read_sorted_ids(SparklPipeline* p, uint32_t* out, uint64_t n);
+
+/* CudaParticleModelSet::from_model_set / ensure_models_are_uploaded
+ * (cuda_particle_model_set.rs:37-84): call again whenever a model changed. */
+int sparkl_hip_models_set(SparklPipeline* p, uint32_t n, const SparklParticleModel* models);
+/* CudaColliderSet::from_collider_set (cuboids) */
+int sparkl_hip_colliders_set_cuboids(SparklPipeline* p, uint32_t n, const SparklCuboidCollider* colliders);
+
+/* MpmPipeline::step / CudaMpmPipeline::step
+ * (src/pipelines/mpm_pipeline.rs:15-42, src/cuda/cuda_mpm_pipeline.rs:262-271):
+ * advances by params->dt in adaptive substeps (CPU-path rules, mls_solver.rs:33-59,125);
+ * returns the simulated time (params->dt, or the substep dt if stop_after_one_substep). */
+int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params,
+                             const float gravity[3], SparklTimings* timings_or_null,
+                             float* simulated_time);
+
+/* ---- extensions (no reference counterpart; used by bench / parity tests) ---- */
+/* Run `nsubsteps` substeps of fixed length `dt` with NO host synchronisation inside
+ * (the dt estimator is skipped; equivalent to the reference when max_substep_dt == dt
+ * is the binding bound).  Only params->{boundary_handling, simulation_dofs,
+ * force_fluids_volume_recomputation, damage_model} are read.  Asynchronous: returns after
+ * enqueueing unless a re-bin was needed; call sparkl_hip_pipeline_sync to wait. */
+int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* params,
+                                 const float gravity[3], float dt, uint32_t nsubsteps);
+int sparkl_hip_pipeline_sync(SparklPipeline* p);
+/* Elapsed GPU time (ms, hipEvents on the pipeline's stream) and launch count of the
+ * p2g / grid_update / g2p kernels accumulated since the last reset. */
+typedef struct {
+    double p2g_ms, grid_update_ms, g2p_ms, sort_ms, dt_ms, halo_ms;
+    uint64_t substeps, resorts;
+} SparklKernelClock;
+int sparkl_hip_pipeline_clock_enable(SparklPipeline* p, int enable);
+int sparkl_hip_pipeline_clock_read(SparklPipeline* p, SparklKernelClock* out, int reset);
+
+/* Sparse-grid introspection (parity tests): active node blocks after the last substep. */
+typedef struct {
+    int32_t cell[3];        /* integer node coordinate (position = cell * cell_width) */
+    float mass;
+    float momentum[3];
+    float velocity[3];
+} SparklGridNode;
+uint64_t sparkl_hip_grid_num_active_blocks(SparklPipeline* p);
+uint64_t sparkl_hip_grid_num_particle_blocks(SparklPipeline* p);
+/* Writes up to `cap` nodes with mass != 0; returns the count through *n_out.
+ * Momentum is only kept when debug capture is on (sparkl_hip_grid_debug_capture). */
+int sparkl_hip_grid_debug_capture(SparklPipeline* p, int enable);
+int sparkl_hip_grid_read_nodes(SparklPipeline* p, SparklGridNode* out, uint64_t cap, uint64_t* n_out);
+
+/* ---- multi-GPU slabs (one process per GPU; the exchange itself is the host's: RCCL) ----
+ * A slab owns the particles whose home block x-index is in [block_lo, block_hi).
+ * Per substep (enable with set_slab): after P2G the library packs the partial (mass,
+ * momentum) of the node blocks in the two block planes at each cut into a send buffer;
+ * the host exchanges them with the neighbour rank (ncclSend/ncclRecv over xGMI) and
+ * hands the received buffer back; the library adds it and both sides run the same grid
+ * update.  See DESIGN.md "Multi-GPU". */
+typedef struct {
+    int32_t axis;           /* 0: x */
+    int32_t block_lo;       /* first owned block index along axis (INT32_MIN: open) */
+    int32_t block_hi;       /* one past the last owned block (INT32_MAX: open) */
+} SparklSlab;
+typedef struct {
+    uint64_t key;           /* block key */
+    float nodes[64][4];     /* (mass, px, py, pz) per node, x fastest */
+} SparklHaloBlock;          /* 1032 B */
+int sparkl_hip_slab_set(SparklPipeline* p, const SparklSlab* slab);
+/* Split-phase substep for slabs: p2g -> [halo pack | host exchange | halo merge] -> finish */
+int sparkl_hip_substep_begin(SparklPipeline* p, const SparklSolverParams* params,
+                             const float gravity[3], float dt);
+/* side: 0 = low cut, 1 = high cut.  Returns device pointer + count of packed blocks. */
+int sparkl_hip_halo_pack(SparklPipeline* p, int side, void** dev_blocks, uint64_t* n_blocks);
+int sparkl_hip_halo_merge(SparklPipeline* p, int side, const void* dev_blocks, uint64_t n_blocks);
+int sparkl_hip_substep_finish(SparklPipeline* p);
+/* Particle migration at re-bin time: particles whose home block left the slab. */
+int sparkl_hip_slab_extract_emigrants(SparklPipeline* p, int side, uint64_t* n_out);
+
+const char* sparkl_hip_last_error_string(void);
+/* "sparkl_hip <version> gfx950" */
+const char* sparkl_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARKL_HIP_H */

@@ -1,0 +1,321 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see mpm_oracle.hpp).  extern "C" surface for ctypes.
+#include "mpm_oracle.hpp"
+
+#include <array>
+#include <chrono>
+
+using namespace oracle;
+
+namespace {
+struct Handle {
+    bool f64;
+    Oracle<float>* of = nullptr;
+    Oracle<double>* od = nullptr;
+};
+
+template <class R>
+void set_particles(Oracle<R>& o, uint64_t n, const SparklParticleStatus* st, const SparklParticlePosition* pos,
+                   const SparklParticleVelocity* vel, const SparklParticleVolume* vol, const SparklParticlePhase* ph,
+                   const SparklParticleData* data, const SparklVelocityGradient* vg) {
+    o.particles.resize(n);
+    o.order.clear();
+    for (uint64_t i = 0; i < n; ++i) {
+        Particle<R>& p = o.particles[i];
+        p.model = st[i].model_index;
+        p.mass = vol[i].mass; p.volume0 = vol[i].volume0; p.radius0 = vol[i].radius0;
+        for (int a = 0; a < 3; ++a) { p.position[a] = pos[i].point[a]; p.velocity[a] = vel[i].vector[a]; p.kinematic_vel[a] = st[i].kinematic_vel[a]; }
+        p.kinematic_vel_enabled = st[i].kinematic_vel_enabled != 0;
+        for (int k = 0; k < 9; ++k) { p.deformation_gradient.m[k] = vol[i].deformation_gradient[k]; p.velocity_gradient.m[k] = vg ? (R)vg[i].m[k] : R(0); }
+        p.plastic_deformation_gradient_det = vol[i].plastic_deformation_gradient_det;
+        p.grid_index = 0;
+        p.failed = st[i].failed != 0; p.is_static = st[i].is_static != 0;
+        p.psi_pos = ph[i].psi_pos; p.phase = ph[i].phase;
+        p.parameter1 = p.parameter2 = 0; p.crack_propagation_factor = 0; p.crack_threshold = std::numeric_limits<R>::max();
+        p.nacc_alpha = data[i].nacc_alpha; p.plastic_hardening = data[i].plastic_hardening;
+        p.elastic_hardening = data[i].elastic_hardening; p.log_vol_gain = data[i].log_vol_gain;
+    }
+}
+
+template <class R>
+void get_particles(const Oracle<R>& o, SparklParticleStatus* st, SparklParticlePosition* pos, SparklParticleVelocity* vel,
+                   SparklParticleVolume* vol, SparklParticlePhase* ph, SparklParticleData* data, SparklVelocityGradient* vg) {
+    for (size_t i = 0; i < o.particles.size(); ++i) {
+        const Particle<R>& p = o.particles[i];
+        if (st) {
+            std::memset(&st[i], 0, sizeof(st[i]));
+            st[i].failed = p.failed; st[i].is_static = p.is_static; st[i].kinematic_vel_enabled = p.kinematic_vel_enabled;
+            for (int a = 0; a < 3; ++a) st[i].kinematic_vel[a] = (float)p.kinematic_vel[a];
+            st[i].model_index = p.model;
+        }
+        if (pos) for (int a = 0; a < 3; ++a) pos[i].point[a] = (float)p.position[a];
+        if (vel) for (int a = 0; a < 3; ++a) vel[i].vector[a] = (float)p.velocity[a];
+        if (vol) {
+            vol[i].mass = (float)p.mass; vol[i].volume0 = (float)p.volume0; vol[i].radius0 = (float)p.radius0;
+            for (int k = 0; k < 9; ++k) vol[i].deformation_gradient[k] = (float)p.deformation_gradient.m[k];
+            vol[i].plastic_deformation_gradient_det = (float)p.plastic_deformation_gradient_det;
+        }
+        if (ph) { ph[i].phase = (float)p.phase; ph[i].psi_pos = (float)p.psi_pos; }
+        if (data) {
+            data[i].nacc_alpha = (float)p.nacc_alpha; data[i].plastic_hardening = (float)p.plastic_hardening;
+            data[i].elastic_hardening = (float)p.elastic_hardening; data[i].log_vol_gain = (float)p.log_vol_gain;
+        }
+        if (vg) for (int k = 0; k < 9; ++k) vg[i].m[k] = (float)p.velocity_gradient.m[k];
+    }
+}
+
+template <class R>
+void get_state_f64(const Oracle<R>& o, double* pos, double* vel, double* F, double* C) {
+    for (size_t i = 0; i < o.particles.size(); ++i) {
+        const Particle<R>& p = o.particles[i];
+        for (int a = 0; a < 3; ++a) { if (pos) pos[3 * i + a] = (double)p.position[a]; if (vel) vel[3 * i + a] = (double)p.velocity[a]; }
+        for (int k = 0; k < 9; ++k) { if (F) F[9 * i + k] = (double)p.deformation_gradient.m[k]; if (C) C[9 * i + k] = (double)p.velocity_gradient.m[k]; }
+    }
+}
+
+template <class R>
+void set_cuboids(Oracle<R>& o, uint32_t n, const SparklCuboidCollider* c) {
+    o.cuboids.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        for (int a = 0; a < 3; ++a) { o.cuboids[i].he[a] = c[i].half_extents[a]; o.cuboids[i].t[a] = c[i].translation[a]; }
+        for (int a = 0; a < 4; ++a) o.cuboids[i].q[a] = c[i].rotation[a];
+        o.cuboids[i].friction = c[i].friction;
+    }
+}
+
+template <class R>
+uint64_t get_nodes(Oracle<R>& o, SparklGridNode* out, uint64_t cap) {
+    uint64_t n = 0;
+    for (const auto& reg : o.regions)
+        for (uint64_t i = 0; i < 64; ++i) {
+            uint64_t id = reg.id | (i << PACK_ALIGN);
+            const GridNode<R>& g = o.node(id);
+            if (g.mass == R(0)) continue;
+            if (n < cap && out) {
+                uint32_t c[3]; unpack(id, c);
+                for (int a = 0; a < 3; ++a) { out[n].cell[a] = (int32_t)c[a]; out[n].momentum[a] = (float)g.momentum[a]; out[n].velocity[a] = (float)g.velocity[a]; }
+                out[n].mass = (float)g.mass;
+            }
+            ++n;
+        }
+    return n;
+}
+template <class R> static void stress_impl(const SparklConstitutiveModel* cm, double phase, double hardening, const double* F, double mass,
+                                          double volume0, double fluid_j, const double* C, double* out) {
+    Mat3<R> f, c; for (int i = 0; i < 9; ++i) { f.m[i] = (R)F[i]; c.m[i] = (R)C[i]; }
+    Mat3<R> s = Mat3<R>::zeros();
+    switch (cm->tag) {
+        case SPARKL_CONSTITUTIVE_COROTATED_LINEAR: s = corotated_kirchhoff<R>(cm->u.corotated, (R)phase, (R)hardening, f); break;
+        case SPARKL_CONSTITUTIVE_NEO_HOOKEAN: s = neo_hookean_kirchhoff<R>(cm->u.neo_hookean, (R)phase, (R)hardening, f); break;
+        case SPARKL_CONSTITUTIVE_EOS_MONAGHAN_SPH: {
+            R density_fluid = ((R)mass / (R)volume0) / f(0, 0);
+            s = monaghan_kirchhoff<R>(cm->u.monaghan, (R)mass, (R)volume0, density_fluid, (R)fluid_j, c);
+            break;
+        }
+    }
+    for (int i = 0; i < 9; ++i) out[i] = (double)s.m[i];
+}
+}  // namespace
+
+#define DISPATCH(h, expr_f, expr_d) (((Handle*)(h))->f64 ? (expr_d) : (expr_f))
+
+extern "C" {
+
+void* oracle_create(int use_f64, float cell_width, uint32_t domain_log2_bytes) {
+    Handle* h = new Handle;
+    h->f64 = use_f64 != 0;
+    if (h->f64) h->od = new Oracle<double>((double)cell_width, domain_log2_bytes);
+    else h->of = new Oracle<float>(cell_width, domain_log2_bytes);
+    if ((h->f64 && !h->od->mem) || (!h->f64 && !h->of->mem)) { delete h->od; delete h->of; delete h; return nullptr; }
+    return h;
+}
+void oracle_destroy(void* hv) { Handle* h = (Handle*)hv; if (!h) return; delete h->of; delete h->od; delete h; }
+void oracle_set_num_threads(void* hv, int n) { Handle* h = (Handle*)hv; if (h->f64) h->od->num_threads = n; else h->of->num_threads = n; }
+
+void oracle_set_particles(void* hv, uint64_t n, const SparklParticleStatus* st, const SparklParticlePosition* pos,
+                          const SparklParticleVelocity* vel, const SparklParticleVolume* vol, const SparklParticlePhase* ph,
+                          const SparklParticleData* data, const SparklVelocityGradient* vg) {
+    Handle* h = (Handle*)hv;
+    if (h->f64) set_particles(*h->od, n, st, pos, vel, vol, ph, data, vg); else set_particles(*h->of, n, st, pos, vel, vol, ph, data, vg);
+}
+uint64_t oracle_num_particles(void* hv) { Handle* h = (Handle*)hv; return h->f64 ? h->od->particles.size() : h->of->particles.size(); }
+void oracle_get_particles(void* hv, SparklParticleStatus* st, SparklParticlePosition* pos, SparklParticleVelocity* vel,
+                          SparklParticleVolume* vol, SparklParticlePhase* ph, SparklParticleData* data, SparklVelocityGradient* vg) {
+    Handle* h = (Handle*)hv;
+    if (h->f64) get_particles(*h->od, st, pos, vel, vol, ph, data, vg); else get_particles(*h->of, st, pos, vel, vol, ph, data, vg);
+}
+void oracle_get_state_f64(void* hv, double* pos, double* vel, double* F, double* C) {
+    Handle* h = (Handle*)hv;
+    if (h->f64) get_state_f64(*h->od, pos, vel, F, C); else get_state_f64(*h->of, pos, vel, F, C);
+}
+void oracle_set_models(void* hv, uint32_t n, const SparklParticleModel* m) {
+    Handle* h = (Handle*)hv;
+    if (h->f64) h->od->models.assign(m, m + n); else h->of->models.assign(m, m + n);
+}
+void oracle_set_cuboids(void* hv, uint32_t n, const SparklCuboidCollider* c) {
+    Handle* h = (Handle*)hv;
+    if (h->f64) set_cuboids(*h->od, n, c); else set_cuboids(*h->of, n, c);
+}
+
+double oracle_step(void* hv, const SparklSolverParams* params, const float g[3]) {
+    Handle* h = (Handle*)hv;
+    if (h->f64) return h->od->step(*params, Vec3<double>{{g[0], g[1], g[2]}});
+    return h->of->step(*params, Vec3<float>{{g[0], g[1], g[2]}});
+}
+int oracle_last_num_substeps(void* hv) { Handle* h = (Handle*)hv; return h->f64 ? h->od->last_num_substeps : h->of->last_num_substeps; }
+void oracle_last_dts(void* hv, double* out) {
+    Handle* h = (Handle*)hv;
+    const auto& v = h->f64 ? h->od->last_dts : h->of->last_dts;
+    for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+}
+// one substep at a fixed dt (sort -> [fluid volumes] -> p2g -> grid update -> g2p)
+double oracle_substep_fixed(void* hv, const SparklSolverParams* params, const float g[3], double dt) {
+    Handle* h = (Handle*)hv;
+    if (h->f64) return h->od->substep(*params, Vec3<double>{{g[0], g[1], g[2]}}, 0.0, 0.0, dt);
+    return h->of->substep(*params, Vec3<float>{{g[0], g[1], g[2]}}, 0.0f, 0.0f, (float)dt);
+}
+// phase-by-phase access
+void oracle_sort(void* hv) { Handle* h = (Handle*)hv; if (h->f64) h->od->sort(); else h->of->sort(); }
+void oracle_recompute_fluids_volumes(void* hv) { Handle* h = (Handle*)hv; if (h->f64) h->od->recompute_fluids_volumes(); else h->of->recompute_fluids_volumes(); }
+double oracle_estimate_dt(void* hv, double max_dt) {
+    Handle* h = (Handle*)hv;
+    return h->f64 ? h->od->adaptive_timestep_length(max_dt) : (double)h->of->adaptive_timestep_length((float)max_dt);
+}
+void oracle_p2g(void* hv, double dt, const float g[3]) {
+    Handle* h = (Handle*)hv;
+    if (h->f64) h->od->p2g(dt, Vec3<double>{{g[0], g[1], g[2]}}); else h->of->p2g((float)dt, Vec3<float>{{g[0], g[1], g[2]}});
+}
+void oracle_grid_update(void* hv, double dt, int boundary_handling, uint32_t dofs) {
+    Handle* h = (Handle*)hv;
+    if (h->f64) h->od->grid_update(dt, boundary_handling, dofs); else h->of->grid_update((float)dt, boundary_handling, dofs);
+}
+void oracle_g2p(void* hv, double dt) { Handle* h = (Handle*)hv; if (h->f64) h->od->g2p(dt); else h->of->g2p((float)dt); }
+uint64_t oracle_get_nodes(void* hv, SparklGridNode* out, uint64_t cap) {
+    Handle* h = (Handle*)hv;
+    return h->f64 ? get_nodes(*h->od, out, cap) : get_nodes(*h->of, out, cap);
+}
+uint64_t oracle_num_regions(void* hv) { Handle* h = (Handle*)hv; return h->f64 ? h->od->regions.size() : h->of->regions.size(); }
+uint64_t oracle_num_particle_regions(void* hv) {
+    Handle* h = (Handle*)hv; uint64_t n = 0;
+    if (h->f64) { for (auto& r : h->od->regions) n += r.end > r.begin; } else { for (auto& r : h->of->regions) n += r.end > r.begin; }
+    return n;
+}
+uint64_t oracle_num_bins(void* hv) { Handle* h = (Handle*)hv; return h->f64 ? h->od->bins.size() : h->of->bins.size(); }
+void oracle_get_order(void* hv, uint64_t* out) {
+    Handle* h = (Handle*)hv;
+    const auto& o = h->f64 ? h->od->order : h->of->order;
+    for (size_t i = 0; i < o.size(); ++i) out[i] = o[i];
+}
+void oracle_get_grid_indices(void* hv, uint64_t* out) {
+    Handle* h = (Handle*)hv;
+    if (h->f64) { for (size_t i = 0; i < h->od->particles.size(); ++i) out[i] = h->od->particles[i].grid_index; }
+    else { for (size_t i = 0; i < h->of->particles.size(); ++i) out[i] = h->of->particles[i].grid_index; }
+}
+
+// ---- SPGrid addressing (pinned by the reference's own tests, sp_grid.rs:411-555)
+uint64_t oracle_pack(uint32_t x, uint32_t y, uint32_t z) { return pack(x, y, z); }
+void oracle_unpack(uint64_t id, uint32_t out[3]) { unpack(id, out); }
+uint64_t oracle_packed_add(uint64_t a, uint64_t b) { return packed_add(a, b); }
+uint64_t oracle_morton_encode3(uint32_t x, uint32_t y, uint32_t z) { return morton_encode3(x, y, z); }
+void oracle_nbh_shift(int k, int out[3]) { for (int a = 0; a < 3; ++a) out[a] = NBH_SHIFTS[k][a]; }
+uint64_t oracle_packed_nbh_shift(int k) { return packed_nbh_shift(k); }
+uint64_t oracle_packed_region_shift(int k) { return pack(NBH_REGION_SHIFTS[k][0], NBH_REGION_SHIFTS[k][1], NBH_REGION_SHIFTS[k][2]); }
+int oracle_region_color(uint64_t region_id) { for (int c = 0; c < 8; ++c) if (Oracle<float>::region_has_color(region_id, c)) return c; return -1; }
+// vectorised forms so the exhaustive reference tests run in C, not in Python loops
+// returns the number of mismatches of unpack(pack(c)) == c over [x0,x1) x [y0,y1) x [z0,z1)
+uint64_t oracle_check_pack_roundtrip(uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1) {
+    uint64_t bad = 0;
+    for (uint32_t i = x0; i < x1; ++i) for (uint32_t j = y0; j < y1; ++j) for (uint32_t k = z0; k < z1; ++k) {
+        uint32_t u[3]; unpack(pack(i, j, k), u);
+        bad += !(u[0] == i && u[1] == j && u[2] == k);
+    }
+    return bad;
+}
+// test_morton_sum (sp_grid.rs:502-529): packed_add(pack(c), PACKED_NBH_SHIFTS[s]) == pack(c + NBH_SHIFTS[s])
+uint64_t oracle_check_packed_add(uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1) {
+    uint64_t bad = 0;
+    for (uint32_t i = x0; i < x1; ++i) for (uint32_t j = y0; j < y1; ++j) for (uint32_t k = z0; k < z1; ++k) {
+        uint64_t packed = pack(i, j, k);
+        for (int s = 0; s < 27; ++s) {
+            uint32_t u[3]; unpack(packed_add(packed, packed_nbh_shift(s)), u);
+            bad += !(u[0] == i + NBH_SHIFTS[s][0] && u[1] == j + NBH_SHIFTS[s][1] && u[2] == k + NBH_SHIFTS[s][2]);
+        }
+    }
+    return bad;
+}
+
+// ---- unit-level model math (double in/out; computed in the requested precision)
+void oracle_eval_all(int f64, double x, double out[3]) {
+    if (f64) { double o[3]; eval_all<double>(x, o); for (int i = 0; i < 3; ++i) out[i] = o[i]; }
+    else { float o[3]; eval_all<float>((float)x, o); for (int i = 0; i < 3; ++i) out[i] = o[i]; }
+}
+void oracle_svd3(const double A[9], double U[9], double S[3], double V[9]) { svd3_f64(A, U, S, V); }
+
+void oracle_kirchhoff_stress(int f64, const SparklConstitutiveModel* cm, double phase, double hardening, const double F[9], double mass,
+                             double volume0, double fluid_j, const double C[9], double out[9]) {
+    if (f64) stress_impl<double>(cm, phase, hardening, F, mass, volume0, fluid_j, C, out);
+    else stress_impl<float>(cm, phase, hardening, F, mass, volume0, fluid_j, C, out);
+}
+double oracle_pos_energy(int f64, const SparklConstitutiveModel* cm, double phase, double hardening, const double F[9]) {
+    if (f64) {
+        Mat3<double> f; for (int i = 0; i < 9; ++i) f.m[i] = F[i];
+        if (cm->tag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR) return corotated_pos_energy<double>(cm->u.corotated, f, hardening);
+        if (cm->tag == SPARKL_CONSTITUTIVE_NEO_HOOKEAN) return neo_hookean_pos_energy<double>(cm->u.neo_hookean, phase, hardening, f);
+        return 0;
+    }
+    Mat3<float> f; for (int i = 0; i < 9; ++i) f.m[i] = (float)F[i];
+    if (cm->tag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR) return corotated_pos_energy<float>(cm->u.corotated, f, (float)hardening);
+    if (cm->tag == SPARKL_CONSTITUTIVE_NEO_HOOKEAN) return neo_hookean_pos_energy<float>(cm->u.neo_hookean, (float)phase, (float)hardening, f);
+    return 0;
+}
+double oracle_dp_alpha(int f64, const SparklDruckerPragerPlasticity* m, double q) {
+    return f64 ? dp_alpha<double>(*m, q) : (double)dp_alpha<float>(*m, (float)q);
+}
+// state = {Jp, q, log_vol_gain}
+void oracle_dp_update(int f64, const SparklDruckerPragerPlasticity* m, double phase, double F[9], double state[3]) {
+    if (f64) {
+        Mat3<double> f; for (int i = 0; i < 9; ++i) f.m[i] = F[i];
+        dp_update_particle<double>(*m, phase, f, state[0], state[1], state[2]);
+        for (int i = 0; i < 9; ++i) F[i] = f.m[i];
+    } else {
+        Mat3<float> f; for (int i = 0; i < 9; ++i) f.m[i] = (float)F[i];
+        float jp = (float)state[0], q = (float)state[1], lvg = (float)state[2];
+        dp_update_particle<float>(*m, (float)phase, f, jp, q, lvg);
+        for (int i = 0; i < 9; ++i) F[i] = f.m[i];
+        state[0] = jp; state[1] = q; state[2] = lvg;
+    }
+}
+// returns 0 (None) / 1 (Some); out = {s0, s1, s2, dq}
+int oracle_dp_project(int f64, const SparklDruckerPragerPlasticity* m, const double sv[3], double lvg, double alpha, double out[4]) {
+    if (f64) {
+        Vec3<double> o; double dq = 0;
+        int r = dp_project<double>(*m, Vec3<double>{{sv[0], sv[1], sv[2]}}, lvg, alpha, o, dq);
+        if (r) { out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; out[3] = dq; }
+        return r;
+    }
+    Vec3<float> o; float dq = 0;
+    int r = dp_project<float>(*m, Vec3<float>{{(float)sv[0], (float)sv[1], (float)sv[2]}}, (float)lvg, (float)alpha, o, dq);
+    if (r) { out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; out[3] = dq; }
+    return r;
+}
+void oracle_cuboid_project(const SparklCuboidCollider* c, const double pt[3], double out[3], int* is_inside) {
+    Cuboid<double> cu;
+    for (int a = 0; a < 3; ++a) { cu.he[a] = c->half_extents[a]; cu.t[a] = c->translation[a]; }
+    for (int a = 0; a < 4; ++a) cu.q[a] = c->rotation[a];
+    cu.friction = c->friction;
+    Projection<double> p = cuboid_project_point(cu, Vec3<double>{{pt[0], pt[1], pt[2]}});
+    for (int a = 0; a < 3; ++a) out[a] = p.point[a];
+    *is_inside = p.is_inside;
+}
+double oracle_model_timestep_bound(void* hv, uint64_t particle) {
+    Handle* h = (Handle*)hv;
+    return h->f64 ? h->od->model_timestep_bound(h->od->particles[particle]) : (double)h->of->model_timestep_bound(h->of->particles[particle]);
+}
+
+// ---- timed run for bench.py's cpu_baseline leg: `nsub` fixed-dt substeps; returns seconds
+double oracle_timed_substeps(void* hv, const SparklSolverParams* params, const float g[3], double dt, int nsub) {
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < nsub; ++i) oracle_substep_fixed(hv, params, g, dt);
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // extern "C"

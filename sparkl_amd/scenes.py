@@ -1,0 +1,177 @@
+"""Synthetic inputs of SURVEY.md section 8(d): the common lattice generator and the five BASELINE configs.
+
+`cube_particles` mirrors examples3d/helper.rs:6-40 (lattice at spacing 2*radius, i-major / k-minor order);
+the jitter is PCG32(seed=42, stream=54) drawn in lattice order, +-0.25 spacing per axis.
+"""
+import numpy as np
+
+from . import abi
+from .models import (CorotatedLinearElasticity, DruckerPragerPlasticity, MonaghanSphEos,
+                     NeoHookeanElasticity, ParticleModel, ParticleModelSet)
+from .particles import ParticleComponents, new_particles
+
+f32 = np.float32
+_MULT = np.uint64(6364136223846793005)
+
+
+def pcg32_stream(n, seed=42, stream=54):
+    """First n outputs (uint32) of PCG32 XSH-RR with the reference seeding sequence, vectorised by LCG jumps."""
+    mask = (1 << 64) - 1
+    mult = int(_MULT)
+    inc = ((stream << 1) | 1) & mask
+    state = 0
+    state = (state * mult + inc) & mask
+    state = (state + seed) & mask
+    state = (state * mult + inc) & mask
+    blk = 1 << 16
+    # (A_k, C_k): state_{k} = A_k * s0 + C_k
+    A = np.empty(blk, np.uint64)
+    Cc = np.empty(blk, np.uint64)
+    a, c = 1, 0
+    for k in range(blk):
+        A[k], Cc[k] = a, c
+        a, c = (a * mult) & mask, (c * mult + inc) & mask
+    jump_a, jump_c = a, c
+    out = np.empty(n, np.uint32)
+    with np.errstate(over="ignore"):
+        for start in range(0, n, blk):
+            m = min(blk, n - start)
+            old = A[:m] * np.uint64(state) + Cc[:m]
+            xorshifted = (((old >> np.uint64(18)) ^ old) >> np.uint64(27)).astype(np.uint32)
+            rot = (old >> np.uint64(59)).astype(np.uint32)
+            out[start:start + m] = (xorshifted >> rot) | (xorshifted << ((np.uint32(32) - rot) & np.uint32(31)))
+            state = (state * jump_a + jump_c) & mask
+    return out
+
+
+def cube_positions(origin, ni, nj, nk, radius, jitter=True, rng_offset=0, seed=42):
+    """Lattice positions (i-major) at spacing s = 2*radius, optional +-0.25 s PCG32 jitter."""
+    s = f32(radius) * f32(2.0)
+    i, j, k = np.meshgrid(np.arange(ni, dtype=f32), np.arange(nj, dtype=f32), np.arange(nk, dtype=f32), indexing="ij")
+    pos = np.stack([i.ravel() * s, j.ravel() * s, k.ravel() * s], axis=1).astype(f32)
+    pos += np.asarray(origin, dtype=f32)[None, :]
+    if jitter:
+        n = ni * nj * nk
+        r = pcg32_stream(3 * (n + rng_offset), seed=seed)[3 * rng_offset:]
+        u = (r >> np.uint32(8)).astype(f32) * f32(2.0 ** -24)          # [0, 1)
+        pos += ((u - f32(0.5)) * f32(0.5) * s).reshape(n, 3).astype(f32)
+    return np.ascontiguousarray(pos, dtype=f32)
+
+
+def floor_cuboid(top_y, friction=0.5, half=1000.0, thickness=50.0):
+    c = abi.CuboidColliderC()
+    c.half_extents[:] = [half, thickness, half]
+    c.rotation[:] = [0.0, 0.0, 0.0, 1.0]
+    c.translation[:] = [0.0, top_y - thickness, 0.0]
+    c.friction = friction
+    return c
+
+
+class Scene:
+    def __init__(self, name, cell_width, models, particles, colliders, params, gravity, fixed_dt, domain_log2_bytes=30):
+        self.name, self.cell_width, self.models, self.particles = name, cell_width, models, particles
+        self.colliders, self.params, self.gravity, self.fixed_dt = colliders, params, gravity, fixed_dt
+        self.domain_log2_bytes = domain_log2_bytes
+
+
+def _domain_bits_for(max_cell):
+    for bits, dom in ((30, 256), (33, 512), (36, 1024), (39, 2048)):
+        if max_cell + 8 < dom:
+            return bits
+    raise ValueError("scene does not fit the largest virtual grid")
+
+
+def sand_column(nx, ny, nz, h=0.2, with_block=False, jitter=True, name=None):
+    """Configs 1/3: Drucker-Prager sand (corotated, E=1e7, nu=0.2, rho=2700) on a friction floor.
+
+    with_block=True stacks the sand on an elastic block of the same size (config 1, examples3d/sand3.rs:39-78).
+    """
+    E, NU = 1.0e7, 0.2
+    models = ParticleModelSet()
+    sand = models.insert(ParticleModel.with_plasticity(CorotatedLinearElasticity(E, NU), DruckerPragerPlasticity(E, NU)))
+    r = h / 4.0
+    origin = np.array([4 * h, 4 * h, 4 * h], dtype=f32) + f32(r)  # >= 2 cells inside the domain
+    parts = []
+    y0 = origin[1]
+    if with_block:
+        block = models.insert(ParticleModel.new(CorotatedLinearElasticity(E, NU)))
+        parts.append(new_particles(block, cube_positions(origin, nx, ny, nz, r, jitter), r, 2700.0))
+        y0 = origin[1] + f32(ny) * f32(2 * r)
+        parts.append(new_particles(sand, cube_positions([origin[0], y0, origin[2]], nx, ny, nz, r, jitter, rng_offset=nx * ny * nz), r, 2700.0))
+    else:
+        parts.append(new_particles(sand, cube_positions(origin, nx, ny, nz, r, jitter), r, 2700.0))
+    comps = ParticleComponents.concatenate(parts)
+    floor = floor_cuboid(top_y=4 * h - 0.5 * h + 0.0, friction=0.5)
+    params = abi.SolverParameters()
+    max_cell = int(np.ceil(comps.position["point"].max() / h)) + 2
+    return Scene(name or f"sand_column_{nx}x{ny}x{nz}", h, models, comps, [floor], params, (0.0, -9.81, 0.0), 2.5e-4,
+                 _domain_bits_for(max_cell))
+
+
+def elastic_cube(n, h=0.2, jitter=True, name=None):
+    """Config 2: neo-Hookean cube n^3 (E=1e6, nu=0.3, rho=1000), no gravity/collider, spinning + expanding."""
+    models = ParticleModelSet()
+    mid = models.insert(ParticleModel.new(NeoHookeanElasticity(1.0e6, 0.3)))
+    r = h / 4.0
+    origin = np.array([4 * h, 4 * h, 4 * h], dtype=f32) + f32(r)
+    pos = cube_positions(origin, n, n, n, r, jitter)
+    comps = new_particles(mid, pos, r, 1000.0)
+    c = pos.mean(axis=0, dtype=np.float64).astype(f32)
+    d = pos - c
+    omega = np.array([0.0, 0.0, 2.0], dtype=f32)
+    comps.velocity["vector"] = (np.cross(np.broadcast_to(omega, d.shape), d) + f32(0.1) * d).astype(f32)
+    params = abi.SolverParameters()
+    params.boundary_handling = abi.BOUNDARY_NONE
+    max_cell = int(np.ceil(pos.max() / h)) + 2
+    return Scene(name or f"elastic_cube_{n}", h, models, comps, [], params, (0.0, 0.0, 0.0), 1.0e-4, _domain_bits_for(max_cell))
+
+
+def fluid_dam(nx, ny, nz, h=0.8, r=0.1, jitter=True, name=None):
+    """Config 4: fluids3-like dam break (examples3d/fluids3.rs:17-43), 64 particles per cell."""
+    models = ParticleModelSet()
+    mid = models.insert(ParticleModel.new(MonaghanSphEos(1.0e6, 7, 1.01e-3)))
+    origin = np.array([4 * h, 4 * h, 4 * h], dtype=f32) + f32(r)
+    pos = cube_positions(origin, nx, ny, nz, r, jitter)
+    comps = new_particles(mid, pos, r, 1000.0)
+    floor = floor_cuboid(top_y=4 * h - 0.5 * h, friction=0.0)
+    params = abi.SolverParameters()
+    params.force_fluids_volume_recomputation = 1
+    max_cell = int(np.ceil(pos.max() / h)) + 2
+    return Scene(name or f"fluid_dam_{nx}x{ny}x{nz}", h, models, comps, [floor], params, (0.0, -9.81, 0.0), 1.0e-4,
+                 _domain_bits_for(max_cell))
+
+
+def cube_through_sand(nx, ny, nz, cube_n=25, h=0.2, jitter=True, name=None):
+    """Config 5: sand bed + kinematic cube moving at (10,0,0) (examples3d/cube_through_sand3.rs:40-81)."""
+    sc = sand_column(nx, ny, nz, h=h, jitter=jitter)
+    r = h / 4.0
+    kin_model = sc.models.insert(ParticleModel.new(CorotatedLinearElasticity(1.0e7, 0.2)))
+    top = sc.particles.position["point"][:, 1].max()
+    origin = [4 * h + r, top + 2 * h, 4 * h + r + (nz // 2 - cube_n // 2) * 2 * r]
+    kin = new_particles(kin_model, cube_positions(origin, cube_n, cube_n, cube_n, r, jitter, rng_offset=nx * ny * nz), r, 2700.0)
+    kin.status["kinematic_vel_enabled"] = 1
+    kin.status["kinematic_vel"] = np.array([10.0, 0.0, 0.0], dtype=f32)
+    sc.particles = ParticleComponents.concatenate([sc.particles, kin])
+    sc.name = name or f"cube_through_sand_{nx}x{ny}x{nz}"
+    max_cell = int(np.ceil(sc.particles.position["point"].max() / h)) + 2
+    sc.domain_log2_bytes = _domain_bits_for(max_cell)
+    return sc
+
+
+# The BASELINE.json configs, by index
+def baseline_config(i, scale=1.0):
+    if i == 0:
+        return sand_column(50, 25, 20, with_block=True, name="config1_sand3_50k")
+    if i == 1:
+        n = max(4, int(round(100 * scale ** (1 / 3))))
+        return elastic_cube(n, name=f"config2_neo_hookean_{n}^3")
+    if i == 2:
+        f = scale ** (1 / 3)
+        return sand_column(max(4, int(200 * f)), max(4, int(250 * f)), max(4, int(200 * f)), name="config3_drucker_prager_column")
+    if i == 3:
+        f = scale ** (1 / 3)
+        return fluid_dam(max(8, int(500 * f)), max(8, int(200 * f)), max(8, int(200 * f)), name="config4_fluid_dam")
+    if i == 4:
+        f = scale ** (1 / 3)
+        return cube_through_sand(max(8, int(800 * f)), max(8, int(250 * f)), max(8, int(400 * f)), name="config5_cube_through_sand")
+    raise IndexError(i)
