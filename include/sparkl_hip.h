@@ -294,33 +294,6 @@ uint64_t sparkl_hip_grid_num_particle_blocks(SparklPipeline* p);
 int sparkl_hip_grid_debug_capture(SparklPipeline* p, int enable);
 int sparkl_hip_grid_read_nodes(SparklPipeline* p, SparklGridNode* out, uint64_t cap, uint64_t* n_out);
 
-/* ---- multi-GPU slabs (one process per GPU; the exchange itself is the host's: RCCL) ----
- * A slab owns the particles whose home block x-index is in [block_lo, block_hi).
- * Per substep (enable with set_slab): after P2G the library packs the partial (mass,
- * momentum) of the node blocks in the two block planes at each cut into a send buffer;
- * the host exchanges them with the neighbour rank (ncclSend/ncclRecv over xGMI) and
- * hands the received buffer back; the library adds it and both sides run the same grid
- * update.  See DESIGN.md "Multi-GPU". */
-typedef struct {
-    int32_t axis;           /* 0: x */
-    int32_t block_lo;       /* first owned block index along axis (INT32_MIN: open) */
-    int32_t block_hi;       /* one past the last owned block (INT32_MAX: open) */
-} SparklSlab;
-typedef struct {
-    uint64_t key;           /* block key */
-    float nodes[64][4];     /* (mass, px, py, pz) per node, x fastest */
-} SparklHaloBlock;          /* 1032 B */
-int sparkl_hip_slab_set(SparklPipeline* p, const SparklSlab* slab);
-/* Split-phase substep for slabs: p2g -> [halo pack | host exchange | halo merge] -> finish */
-int sparkl_hip_substep_begin(SparklPipeline* p, const SparklSolverParams* params,
-                             const float gravity[3], float dt);
-/* side: 0 = low cut, 1 = high cut.  Returns device pointer + count of packed blocks. */
-int sparkl_hip_halo_pack(SparklPipeline* p, int side, void** dev_blocks, uint64_t* n_blocks);
-int sparkl_hip_halo_merge(SparklPipeline* p, int side, const void* dev_blocks, uint64_t n_blocks);
-int sparkl_hip_substep_finish(SparklPipeline* p);
-/* Particle migration at re-bin time: particles whose home block left the slab. */
-int sparkl_hip_slab_extract_emigrants(SparklPipeline* p, int side, uint64_t* n_out);
-
 const char* sparkl_hip_last_error_string(void);
 /* "sparkl_hip <version> gfx950" */
 const char* sparkl_hip_version(void);

@@ -1,0 +1,334 @@
+// Device-side 3x3 algebra, SVD and material models for the MPM hot path (gfx950).
+// All matrices are column-major like nalgebra: element (i, j) at m[i + 3 j].
+//
+// Reference semantics implemented here (f32):
+//   QuadraticKernel::{inv_d, eval_all}          src_core/dynamics/solver/kernel.rs:10-21
+//   inv_exact                                   src_core/utils/physics.rs:7-14
+//   CorotatedLinearElasticity::kirchhoff_stress src_core/dynamics/models/elasticity_corotated_linear.rs:31-78
+//   NeoHookeanElasticity::kirchhoff_stress      src_core/dynamics/models/elasticity_neo_hookean.rs:43-67
+//   MonaghanSphEos::{pressure,kirchhoff_stress} src_core/dynamics/models/eos_monaghan_sph.rs:28-63
+//   DruckerPragerPlasticity::*                  src_core/dynamics/models/plasticity_drucker_prager.rs:36-104
+//   *::pos_energy, *::timestep_bound            same files
+// nalgebra's `svd_unordered` (third party, absent) is replaced by a one-sided Jacobi SVD; every call
+// site only uses SVD-invariant combinations (U f(S) V^T), so sign/order conventions do not matter.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/sparkl_hip.h"
+
+#define SPK_DEV __device__ __forceinline__
+
+namespace spk {
+
+struct M3 {
+    float m[9];
+};
+
+SPK_DEV M3 m3_identity() { return M3{{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}}; }
+SPK_DEV M3 m3_zero() { return M3{{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}}; }
+SPK_DEV M3 m3_mul(const M3& a, const M3& b) {
+    M3 r;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            r.m[i + 3 * j] = a.m[i] * b.m[3 * j] + a.m[i + 3] * b.m[3 * j + 1] + a.m[i + 6] * b.m[3 * j + 2];
+    return r;
+}
+// a * b^T
+SPK_DEV M3 m3_mul_bt(const M3& a, const M3& b) {
+    M3 r;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            r.m[i + 3 * j] = a.m[i] * b.m[j] + a.m[i + 3] * b.m[j + 3] + a.m[i + 6] * b.m[j + 6];
+    return r;
+}
+SPK_DEV float m3_det(const M3& a) {
+    // nalgebra's cofactor expansion (first row)
+    const float m11 = a.m[0], m21 = a.m[1], m31 = a.m[2], m12 = a.m[3], m22 = a.m[4], m32 = a.m[5], m13 = a.m[6], m23 = a.m[7], m33 = a.m[8];
+    const float minor_m12_m23 = m22 * m33 - m32 * m23;
+    const float minor_m11_m23 = m21 * m33 - m31 * m23;
+    const float minor_m11_m22 = m21 * m32 - m31 * m22;
+    return m11 * minor_m12_m23 - m12 * minor_m11_m23 + m13 * minor_m11_m22;
+}
+SPK_DEV float m3_frob(const M3& a) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s += a.m[i] * a.m[i];
+    return sqrtf(s);
+}
+
+SPK_DEV float inv_exact(float e) { return e == 0.f ? 0.f : 1.f / e; }
+
+// QuadraticKernel::eval_all
+SPK_DEV void eval_all(float x, float w[3]) {
+    const float a = 1.5f - x, b = x - 1.0f, c = x - 0.5f;
+    w[0] = 0.5f * (a * a);
+    w[1] = 0.75f - (b * b);
+    w[2] = 0.5f * (c * c);
+}
+
+// ---------------------------------------------------------------------------------------------- SVD
+// One-sided (Hestenes) Jacobi: on return A = W V^T with W's columns mutually orthogonal;
+// sigma_j = |w_j|, u_j = w_j / sigma_j.  `w` is A on entry, `v` is overwritten.
+struct Svd3 {
+    M3 w;        // U * diag(sigma)
+    M3 v;        // V
+    float s[3];  // sigma >= 0
+};
+
+SPK_DEV void jacobi_pair(float* wp, float* wq, float* vp, float* vq) {
+    const float alpha = wp[0] * wp[0] + wp[1] * wp[1] + wp[2] * wp[2];
+    const float beta = wq[0] * wq[0] + wq[1] * wq[1] + wq[2] * wq[2];
+    const float gamma = wp[0] * wq[0] + wp[1] * wq[1] + wp[2] * wq[2];
+    // rotation angle; t = 0 when the pair is already orthogonal to f32 resolution
+    float c = 1.f, s = 0.f;
+    if (fabsf(gamma) > 1.0e-9f * sqrtf(alpha * beta)) {
+        const float zeta = (beta - alpha) / (2.f * gamma);
+        const float t = copysignf(1.f, zeta) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
+        c = rsqrtf(1.f + t * t);
+        s = c * t;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float a = wp[i], b = wq[i];
+        wp[i] = c * a - s * b;
+        wq[i] = s * a + c * b;
+        const float va = vp[i], vb = vq[i];
+        vp[i] = c * va - s * vb;
+        vq[i] = s * va + c * vb;
+    }
+}
+
+template <int SWEEPS>
+SPK_DEV Svd3 svd3(const M3& a) {
+    Svd3 r;
+    r.w = a;
+    r.v = m3_identity();
+#pragma unroll
+    for (int sweep = 0; sweep < SWEEPS; ++sweep) {
+        jacobi_pair(r.w.m + 0, r.w.m + 3, r.v.m + 0, r.v.m + 3);
+        jacobi_pair(r.w.m + 0, r.w.m + 6, r.v.m + 0, r.v.m + 6);
+        jacobi_pair(r.w.m + 3, r.w.m + 6, r.v.m + 3, r.v.m + 6);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.s[j] = sqrtf(r.w.m[3 * j] * r.w.m[3 * j] + r.w.m[3 * j + 1] * r.w.m[3 * j + 1] + r.w.m[3 * j + 2] * r.w.m[3 * j + 2]);
+    return r;
+}
+#ifndef SPK_SVD_SWEEPS
+#define SPK_SVD_SWEEPS 5
+#endif
+
+// sum_j g_j * w_j v_j^T  ==  U diag(g_j * sigma_j) V^T
+SPK_DEV M3 svd_compose_scaled(const Svd3& d, const float g[3]) {
+    M3 r;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            r.m[i + 3 * c] = g[0] * d.w.m[i] * d.v.m[c] + g[1] * d.w.m[i + 3] * d.v.m[c + 3] + g[2] * d.w.m[i + 6] * d.v.m[c + 6];
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------- models
+// Flattened device copy of SparklParticleModel (built on the host by models_set).
+struct DevModel {
+    int ctag;         // SPARKL_CONSTITUTIVE_*
+    int ptag;         // SPARKL_PLASTIC_* or -1
+    int is_fluid;
+    int split_stress_on_failure;
+    float cfl_coeff, lambda, mu;            // elastic models
+    float pressure0, viscosity, max_neg_pressure; int gamma;  // Monaghan
+    float h0, h1, h2, h3, p_lambda, p_mu, volume_correction; int only_active_when_failed;  // Drucker-Prager
+};
+
+SPK_DEV float powi_f(float x, int n) {
+    float r = 1.f;
+    for (int i = 0; i < n; ++i) r *= x;
+    return r;
+}
+
+// tau for the elastic models; `d` is the SVD of F (only needed for corotated)
+SPK_DEV M3 corotated_kirchhoff(const DevModel& mo, float phase, float hardening, const M3& F) {
+    const float j = m3_det(F);
+    const Svd3 d = svd3<SPK_SVD_SWEEPS>(F);
+    const float sph = mo.lambda * hardening * (j - 1.f) * j;
+    M3 tau;
+    if (phase == 1.f) {
+        float g[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g[k] = (d.s[k] - 1.f) * inv_exact(d.s[k]);  // (sigma-1)/sigma applied to w = u sigma
+        const M3 m = svd_compose_scaled(d, g);
+        tau = m3_mul_bt(m, F);
+        const float k2 = 2.f * mo.mu * hardening;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tau.m[i] *= k2;
+        tau.m[0] += sph; tau.m[4] += sph; tau.m[8] += sph;
+    } else {
+        float gp[3], gn[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float e = d.s[k] - 1.f, is = inv_exact(d.s[k]);
+            gp[k] = fmaxf(e, 0.f) * is;
+            gn[k] = fminf(e, 0.f) * is;
+        }
+        const float k2 = 2.f * mo.mu * hardening;
+        M3 pos = m3_mul_bt(svd_compose_scaled(d, gp), F);
+        M3 neg = m3_mul_bt(svd_compose_scaled(d, gn), F);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { pos.m[i] *= k2; neg.m[i] *= k2; }
+        if (j < 1.f) { neg.m[0] += sph; neg.m[4] += sph; neg.m[8] += sph; }
+        else { pos.m[0] += sph; pos.m[4] += sph; pos.m[8] += sph; }
+        const float pc = (mo.split_stress_on_failure && phase == 0.f) ? 0.f : 1.f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tau.m[i] = pos.m[i] * pc + neg.m[i];
+    }
+    return tau;
+}
+
+SPK_DEV float nh_phase_coeff(float phase) { return (1.f - 0.001f) * phase * phase + 0.001f; }
+
+SPK_DEV M3 neo_hookean_kirchhoff(const DevModel& mo, float phase, float hardening, const M3& F) {
+    const float pc = nh_phase_coeff(phase);
+    const float j = m3_det(F);
+    const float k = 2.f / 3.f * mo.mu * hardening + mo.lambda * hardening;
+    M3 cg = m3_mul_bt(F, F);
+    const float sphp = (cg.m[0] + cg.m[4] + cg.m[8]) / 3.f;
+    cg.m[0] -= sphp; cg.m[4] -= sphp; cg.m[8] -= sphp;
+    const float kd = (mo.mu * hardening) * powf(j, -2.f / 3.f);
+    const float vol = k / 2.f * (j * j - 1.f);
+    M3 tau;
+    if (j >= 1.f) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tau.m[i] = (kd * cg.m[i]) * pc;
+        tau.m[0] = (kd * cg.m[0] + vol) * pc; tau.m[4] = (kd * cg.m[4] + vol) * pc; tau.m[8] = (kd * cg.m[8] + vol) * pc;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tau.m[i] = (kd * cg.m[i]) * pc;
+        tau.m[0] += vol; tau.m[4] += vol; tau.m[8] += vol;
+    }
+    return tau;
+}
+
+SPK_DEV float monaghan_pressure(const DevModel& mo, float mass, float volume0, float density_fluid) {
+    const float density0 = mass / volume0;
+    return fmaxf(mo.pressure0 * (powi_f(density_fluid / density0, mo.gamma) - 1.f), -mo.max_neg_pressure);
+}
+// NB: the reference glue passes plastic_deformation_gradient_det as `fluid_j`
+// (src/dynamics/models/eos_monaghan_sph.rs:12-20)
+SPK_DEV M3 monaghan_kirchhoff(const DevModel& mo, float mass, float volume0, float f00, float fluid_j, const M3& C) {
+    const float density_fluid = (mass / volume0) / f00;
+    const float p = -monaghan_pressure(mo, mass, volume0, density_fluid) * fluid_j;
+    M3 tau = m3_zero();
+    tau.m[0] = tau.m[4] = tau.m[8] = p;
+    if (mo.viscosity != 0.f) {
+        M3 sr;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) sr.m[i + 3 * j] = (C.m[i + 3 * j] + C.m[j + 3 * i]) * 0.5f;
+        const float sph = (sr.m[0] + sr.m[4] + sr.m[8]) / 3.f;
+        sr.m[0] -= sph; sr.m[4] -= sph; sr.m[8] -= sph;
+        const float k = 2.f * mo.viscosity * fluid_j;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tau.m[i] += k * sr.m[i];
+    }
+    return tau;
+}
+
+SPK_DEV float sound_speed_bound(float alpha, float bulk, float shear, float density0, float vnorm, float h) {
+    const float c_dir = sqrtf((bulk + 4.f / 3.f * shear) * 1.f / density0);
+    return alpha * h / fmaxf(vnorm, c_dir);
+}
+
+// model.constitutive_model.timestep_bound(particle, cell_width)
+SPK_DEV float model_timestep_bound(const DevModel& mo, float mass, float volume0, float eh, float f00, float vx, float vy, float vz, float h) {
+    const float vn2 = vx * vx + vy * vy + vz * vz;
+    if (mo.ctag == SPARKL_CONSTITUTIVE_EOS_MONAGHAN_SPH) {
+        const float j = f00, density0 = mass / volume0;
+        const float density_fluid = density0 / f00;
+        const float pressure = -monaghan_pressure(mo, mass, volume0, density_fluid);
+        const float single = (h / j) * sqrtf(density0 * (j - 1.f) / (6.f * pressure * 3.f));
+        const float cfl = h / sqrtf(fmaxf(vn2, 1.f) / 0.1f);
+        return fminf(single, cfl);
+    }
+    const float bulk = mo.lambda + 2.f * mo.mu / 3.f;
+    return sound_speed_bound(mo.cfl_coeff, bulk * eh, mo.mu * eh, mass / volume0, sqrtf(vn2), h);
+}
+
+SPK_DEV float dp_alpha(const DevModel& mo, float q) {
+    const float angle = mo.h0 + (mo.h1 * q - mo.h3) * expf(-mo.h2 * q);
+    const float s = sinf(angle);
+    return sqrtf(2.f / 3.f) * (2.f * s) / (3.f - s);
+}
+
+// DruckerPragerPlasticity::update_particle.  Updates F, Jp, q, lvg in place and returns the singular
+// values of the (possibly projected) F through sv[] for the pos-energy bookkeeping.
+SPK_DEV void dp_update(const DevModel& mo, float phase, M3& F, float& Jp, float& q, float& lvg, float sv[3], bool& sv_valid) {
+    sv_valid = false;
+    if (mo.only_active_when_failed && phase != 0.f) return;
+    const Svd3 d = svd3<SPK_SVD_SWEEPS>(F);
+    sv[0] = d.s[0]; sv[1] = d.s[1]; sv[2] = d.s[2];
+    sv_valid = true;
+    const float alpha = dp_alpha(mo, q);
+    float strain[3], dev[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) strain[i] = logf(d.s[i]) + lvg / 3.f;
+    const float tr = strain[0] + strain[1] + strain[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dev[i] = strain[i] - tr / 3.f;
+    float nsv[3], dq;
+    if ((dev[0] == 0.f && dev[1] == 0.f && dev[2] == 0.f) || tr > 0.f) {
+        nsv[0] = nsv[1] = nsv[2] = 1.f;
+        dq = sqrtf(strain[0] * strain[0] + strain[1] * strain[1] + strain[2] * strain[2]);
+    } else {
+        const float dn = sqrtf(dev[0] * dev[0] + dev[1] * dev[1] + dev[2] * dev[2]);
+        const float gamma = dn + (3.f * mo.p_lambda + 2.f * mo.p_mu) / (2.f * mo.p_mu) * tr * alpha;
+        if (gamma <= 0.f) return;  // inside the yield surface
+#pragma unroll
+        for (int i = 0; i < 3; ++i) nsv[i] = expf(strain[i] - gamma * (dev[i] / dn));
+        dq = gamma;
+    }
+    const float prev_det = d.s[0] * d.s[1] * d.s[2];
+    float new_det = nsv[0] * nsv[1] * nsv[2];
+    const float diff = new_det - prev_det;
+    new_det = diff > 0.f ? new_det : prev_det + diff * mo.volume_correction;
+    Jp *= prev_det / new_det;
+    lvg += logf(prev_det) - logf(new_det);
+    q += dq;
+    float g[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g[i] = nsv[i] * inv_exact(d.s[i]);
+    F = svd_compose_scaled(d, g);
+    sv[0] = nsv[0]; sv[1] = nsv[1]; sv[2] = nsv[2];
+}
+
+// constitutive_model.pos_energy(particle)
+SPK_DEV float model_pos_energy(const DevModel& mo, float phase, float eh, const M3& F, const float* sv_or_null) {
+    if (mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR) {
+        const float j = m3_det(F);
+        float s[3];
+        if (sv_or_null) { s[0] = sv_or_null[0]; s[1] = sv_or_null[1]; s[2] = sv_or_null[2]; }
+        else { const Svd3 d = svd3<SPK_SVD_SWEEPS>(F); s[0] = d.s[0]; s[1] = d.s[1]; s[2] = d.s[2]; }
+        float nsq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const float e = fmaxf(s[i] - 1.f, 0.f); nsq += e * e; }
+        const float pos_dev = mo.mu * eh * nsq;
+        const float sph = mo.lambda * eh / 2.f * (j - 1.f) * (j - 1.f);
+        return j < 1.f ? pos_dev : pos_dev + sph;
+    }
+    if (mo.ctag == SPARKL_CONSTITUTIVE_NEO_HOOKEAN) {
+        const float pc = nh_phase_coeff(phase);
+        const float j = m3_det(F);
+        const float k = 2.f / 3.f * mo.mu * eh + mo.lambda * eh;
+        const M3 cg = m3_mul_bt(F, F);
+        const float dev = eh * mo.mu / 2.f * ((cg.m[0] + cg.m[4] + cg.m[8]) * powf(j, -2.f / 3.f) - 3.f);
+        const float vol = k / 2.f * ((j * j - 1.f) / 2.f - logf(j));
+        return j < 1.f ? dev * pc : (dev + vol) * phase;
+    }
+    return 0.f;
+}
+
+}  // namespace spk

@@ -1,0 +1,796 @@
+// HIP kernels of the MI355X MPM hot path (gfx950, wave64).  See DESIGN.md for the data layout.
+//
+// Particles live in HBM as eight float4 streams, physically ordered by (home block, cell):
+//   Q0 = (x, y, z, F0)  Q1 = (F1..F4)  Q2 = (F5..F8)        F column-major
+//   Q3 = (vx, vy, vz, C0) Q4 = (C1..C4) Q5 = (C5..C8)       C = velocity_gradient (APIC affine)
+//   D  = (plastic_hardening, log_vol_gain, plastic_def_grad_det, psi_pos)
+//   K  = (mass, volume0, elastic_hardening, flags)           read-only on the hot path
+// so that P2G streams exactly 7 x 16 B = 112 B per particle with dwordx4 loads.
+//
+// The sparse grid is a list of 4x4x4 node blocks (Morton ordered) with a 27-entry neighbour table;
+// every block that holds particles owns an 8x8x8 "tile" (its 4^3 nodes, the +2 B-spline support and a
+// one-cell drift margin on each side).  P2G accumulates a tile in LDS and writes it once (no global
+// atomics); grid_update gathers the <= 8 overlapping tiles of each node; G2P stages the 8^3 node
+// velocities back into LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_math.h"
+
+namespace spk {
+
+constexpr int TILE_W = 8;
+constexpr int TILE_N = TILE_W * TILE_W * TILE_W;  // 512 nodes
+constexpr int BLK_THREADS = 256;
+
+enum : uint32_t {
+    FLAG_FAILED = 1u << 0,
+    FLAG_STATIC = 1u << 1,
+    FLAG_KINEMATIC = 1u << 2,
+    FLAG_INVALID = 1u << 3,       // outside the SPGrid domain: frozen, scatters nothing
+    FLAG_PHASE_NOT_ONE = 1u << 4, // phase lives in the side array
+    FLAG_MODEL_SHIFT = 8
+};
+
+struct Ctl {
+    uint32_t abort_flag[2];  // parity double-buffer: kernels of substep s read [s&1], G2P of s writes [(s+1)&1]
+    uint32_t steps_done;     // substeps whose G2P ran
+    uint32_t dt_bits;        // atomicMin target of the dt estimator (float bits, dt >= 0)
+    uint32_t dt_nan;
+    uint32_t num_invalid;    // particles that left the domain since the last re-bin
+    uint32_t pad[2];
+};
+
+struct ParticleArrays {
+    float4* q[6];
+    float4* d;
+    float4* k;
+    float4* kinvel;   // (kx, ky, kz, -)
+    float* phase;
+    uint32_t* orig_id;
+};
+
+struct GridArrays {
+    const int4* blk_origin;    // cell coordinate of node (0,0,0) of the block, w = tile index or -1
+    const int* blk_pfirst;
+    const int* blk_pcount;
+    const int* blk_nbr;        // [B][27], index of neighbour block or -1
+    const int* pblk;           // [PB] block index of each tile owner
+    float4* tiles;             // [PB][512] (mass, px, py, pz)
+    float4* node_vel;          // [B][64]  (vx, vy, vz, mass)
+    float4* node_mom;          // [B][64]  (px, py, pz, -) debug capture or NULL
+    int num_blocks;
+    int num_pblocks;
+};
+
+struct StepParams {
+    float h;
+    float inv_d;      // 4 / h^2
+    float dt;
+    float gx, gy, gz;
+    int boundary_handling;
+    uint32_t dofs;
+    int parity;
+    int dom;          // valid cell coords: 0 <= c, c + 5 < dom
+    int num_cuboids;
+};
+
+struct DevCuboid {
+    float he[3];
+    float q[4];
+    float t[3];
+    float friction;
+};
+
+// Observed placement is workgroup b -> XCD b % 8: give each XCD a contiguous run of Morton-ordered
+// blocks so neighbouring tiles / node blocks share an L2.  Speed only, never correctness.
+SPK_DEV int xcd_remap(int bid, int n) {
+    const int per = n >> 3;
+    if (per == 0) return bid;
+    const int main_n = per << 3;
+    if (bid >= main_n) return bid;
+    return (bid & 7) * per + (bid >> 3);
+}
+
+SPK_DEV int cell_of(float x, float h) { return (int)roundf(x / h); }
+
+// ------------------------------------------------------------------------------------------- P2G
+// One workgroup per particle block.  LDS tile: 4 SoA planes of 512 floats.
+template <bool WAVE_REDUCE>
+__global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models,
+                                                     const Ctl* __restrict__ ctl, StepParams S) {
+    if (ctl->abort_flag[S.parity]) return;
+    __shared__ float tile[4][TILE_N];
+    const int tid = threadIdx.x;
+    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) { tile[0][n] = 0.f; tile[1][n] = 0.f; tile[2][n] = 0.f; tile[3][n] = 0.f; }
+    const int b = G.pblk[pb];
+    const int4 org = G.blk_origin[b];
+    const int pfirst = G.blk_pfirst[b], pcount = G.blk_pcount[b];
+    __syncthreads();
+
+    const float h = S.h;
+    const int niter = (pcount + BLK_THREADS - 1) / BLK_THREADS;
+    for (int it = 0; it < niter; ++it) {
+        const int li = it * BLK_THREADS + tid;
+        const bool active = li < pcount;
+        const int i = pfirst + (active ? li : 0);
+        const float4 q0 = P.q[0][i], kk = P.k[i];
+        const uint32_t flags = __float_as_uint(kk.w);
+        const bool live = active && !(flags & FLAG_INVALID);
+        int cell_key = -1;
+        float wgt[3][3];
+        float d0[3];
+        float val_m = 0.f;
+        float qv[3] = {0.f, 0.f, 0.f};  // A*d0 + m v
+        M3 A = m3_zero();               // affine * h
+        int base = 0;
+        if (live) {
+            const float4 q1 = P.q[1][i], q2 = P.q[2][i], q3 = P.q[3][i], q4 = P.q[4][i], q5 = P.q[5][i];
+            const float px[3] = {q0.x, q0.y, q0.z};
+            int lc[3];
+            const int orgv[3] = {org.x, org.y, org.z};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float r = roundf(px[a] / h);
+                d0[a] = (r - 1.0f) * h - px[a];
+                eval_all(-d0[a] / h, wgt[a]);
+                lc[a] = (int)r - 1 - orgv[a] + 1;  // tile coordinate of the associated cell, in [0, 5]
+            }
+            base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
+            cell_key = base;
+            const M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
+            const M3 C = {{q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
+            const float mass = kk.x, vol0 = kk.y, eh = kk.z;
+            const DevModel mo = models[flags >> FLAG_MODEL_SHIFT];
+            M3 tau = m3_zero();
+            if (!(flags & FLAG_FAILED)) {
+                const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.phase[i] : 1.f;
+                if (mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR) tau = corotated_kirchhoff(mo, phase, eh, F);
+                else if (mo.ctag == SPARKL_CONSTITUTIVE_NEO_HOOKEAN) tau = neo_hookean_kirchhoff(mo, phase, eh, F);
+                else if (mo.ctag == SPARKL_CONSTITUTIVE_EOS_MONAGHAN_SPH) tau = monaghan_kirchhoff(mo, mass, vol0, F.m[0], P.d[i].z, C);
+            }
+            // affine = m C - (V0 inv_d dt) tau   (particle_to_grid.rs:58-59)
+            const float ks = vol0 * S.inv_d * S.dt;
+            M3 aff;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) aff.m[e] = mass * C.m[e] - ks * tau.m[e];
+            // contribution to node s: w * (aff * (d0 + s h) + m v) = w * (qv + sx A0 + sy A1 + sz A2), A = aff * h
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                qv[r] = aff.m[r] * d0[0] + aff.m[r + 3] * d0[1] + aff.m[r + 6] * d0[2];
+            }
+            qv[0] += mass * q3.x; qv[1] += mass * q3.y; qv[2] += mass * q3.z;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) A.m[e] = aff.m[e] * h;
+            val_m = mass;
+        }
+
+        if (WAVE_REDUCE) {
+            // Particles are cell-sorted inside a block, so runs of lanes share `cell_key`.  Segmented
+            // suffix-sum over row-local (16-lane) runs with DPP-able shuffles, then one LDS atomic per run.
+            const int lane = tid & 63;
+            const int prev_key = __shfl_up(cell_key, 1);
+            const bool head = ((lane & 15) == 0) || (prev_key != cell_key);
+            // m_o: lanes L .. L+o form one contiguous same-key run inside the 16-lane row
+            bool m1, m2, m4, m8;
+            {
+                const int r = lane & 15;
+                m1 = (r + 1 < 16) && (__shfl_down(cell_key, 1) == cell_key);
+                m2 = m1 && (r + 2 < 16) && (__shfl_down((int)m1, 1) != 0);
+                m4 = m2 && (r + 4 < 16) && (__shfl_down((int)m2, 2) != 0);
+                m8 = m4 && (r + 8 < 16) && (__shfl_down((int)m4, 4) != 0);
+            }
+#pragma unroll
+            for (int sz = 0; sz < 3; ++sz)
+#pragma unroll
+                for (int sy = 0; sy < 3; ++sy)
+#pragma unroll
+                    for (int sx = 0; sx < 3; ++sx) {
+                        const float w = wgt[0][sx] * wgt[1][sy] * wgt[2][sz];
+                        float c0 = w * val_m;
+                        float c1 = w * (qv[0] + sx * A.m[0] + sy * A.m[3] + sz * A.m[6]);
+                        float c2 = w * (qv[1] + sx * A.m[1] + sy * A.m[4] + sz * A.m[7]);
+                        float c3 = w * (qv[2] + sx * A.m[2] + sy * A.m[5] + sz * A.m[8]);
+                        if (!live) { c0 = c1 = c2 = c3 = 0.f; }
+                        // run-local inclusive suffix sums (keys equal => contiguous because sorted runs)
+                        float t;
+                        t = __shfl_down(c0, 1); c0 += m1 ? t : 0.f; t = __shfl_down(c1, 1); c1 += m1 ? t : 0.f;
+                        t = __shfl_down(c2, 1); c2 += m1 ? t : 0.f; t = __shfl_down(c3, 1); c3 += m1 ? t : 0.f;
+                        t = __shfl_down(c0, 2); c0 += m2 ? t : 0.f; t = __shfl_down(c1, 2); c1 += m2 ? t : 0.f;
+                        t = __shfl_down(c2, 2); c2 += m2 ? t : 0.f; t = __shfl_down(c3, 2); c3 += m2 ? t : 0.f;
+                        t = __shfl_down(c0, 4); c0 += m4 ? t : 0.f; t = __shfl_down(c1, 4); c1 += m4 ? t : 0.f;
+                        t = __shfl_down(c2, 4); c2 += m4 ? t : 0.f; t = __shfl_down(c3, 4); c3 += m4 ? t : 0.f;
+                        t = __shfl_down(c0, 8); c0 += m8 ? t : 0.f; t = __shfl_down(c1, 8); c1 += m8 ? t : 0.f;
+                        t = __shfl_down(c2, 8); c2 += m8 ? t : 0.f; t = __shfl_down(c3, 8); c3 += m8 ? t : 0.f;
+                        if (live && head) {
+                            const int n = base + sx + TILE_W * sy + TILE_W * TILE_W * sz;
+                            atomicAdd(&tile[0][n], c0);
+                            atomicAdd(&tile[1][n], c1);
+                            atomicAdd(&tile[2][n], c2);
+                            atomicAdd(&tile[3][n], c3);
+                        }
+                    }
+        } else if (live) {
+#pragma unroll
+            for (int sz = 0; sz < 3; ++sz)
+#pragma unroll
+                for (int sy = 0; sy < 3; ++sy)
+#pragma unroll
+                    for (int sx = 0; sx < 3; ++sx) {
+                        const float w = wgt[0][sx] * wgt[1][sy] * wgt[2][sz];
+                        const int n = base + sx + TILE_W * sy + TILE_W * TILE_W * sz;
+                        atomicAdd(&tile[0][n], w * val_m);
+                        atomicAdd(&tile[1][n], w * (qv[0] + sx * A.m[0] + sy * A.m[3] + sz * A.m[6]));
+                        atomicAdd(&tile[2][n], w * (qv[1] + sx * A.m[1] + sy * A.m[4] + sz * A.m[7]));
+                        atomicAdd(&tile[3][n], w * (qv[2] + sx * A.m[2] + sy * A.m[5] + sz * A.m[8]));
+                    }
+        }
+    }
+    __syncthreads();
+    float4* out = G.tiles + (size_t)pb * TILE_N;
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) out[n] = make_float4(tile[0][n], tile[1][n], tile[2][n], tile[3][n]);
+}
+
+// ----------------------------------------------------------------------------------- grid update
+// parry3d Cuboid::project_local_point restated (clamp outside, closest face inside, solid = false)
+SPK_DEV void quat_rot(const float q[4], const float v[3], float sgn, float out[3]) {
+    const float ux = sgn * q[0], uy = sgn * q[1], uz = sgn * q[2], w = q[3];
+    const float cx = uy * v[2] - uz * v[1], cy = uz * v[0] - ux * v[2], cz = ux * v[1] - uy * v[0];
+    const float dx = uy * cz - uz * cy, dy = uz * cx - ux * cz, dz = ux * cy - uy * cx;
+    out[0] = v[0] + 2.f * (w * cx + dx);
+    out[1] = v[1] + 2.f * (w * cy + dy);
+    out[2] = v[2] + 2.f * (w * cz + dz);
+}
+SPK_DEV bool cuboid_project(const DevCuboid& c, const float ptw[3], float projw[3]) {
+    float rel[3] = {ptw[0] - c.t[0], ptw[1] - c.t[1], ptw[2] - c.t[2]};
+    float pt[3];
+    quat_rot(c.q, rel, -1.f, pt);
+    float mins_pt[3], pt_maxs[3], shift[3];
+    bool inside = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        mins_pt[i] = -c.he[i] - pt[i];
+        pt_maxs[i] = pt[i] - c.he[i];
+        shift[i] = fmaxf(mins_pt[i], 0.f) - fmaxf(pt_maxs[i], 0.f);
+        if (shift[i] != 0.f) inside = false;
+    }
+    float proj[3];
+    if (!inside) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) proj[i] = pt[i] + shift[i];
+    } else {
+        float best = -3.402823466e+38f;
+        bool is_mins = false;
+        int best_id = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (mins_pt[i] < pt_maxs[i]) {
+                if (pt_maxs[i] > best) { best_id = i; is_mins = false; best = pt_maxs[i]; }
+            } else if (mins_pt[i] > best) { best_id = i; is_mins = true; best = mins_pt[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) proj[i] = pt[i] + (i == best_id ? (is_mins ? best : -best) : 0.f);
+    }
+    quat_rot(c.q, proj, 1.f, projw);
+    projw[0] += c.t[0]; projw[1] += c.t[1]; projw[2] += c.t[2];
+    return inside;
+}
+
+// One wave per node block, 4 blocks per workgroup.  MASS_ONLY: fluid volume recompute (fluids_volume.rs).
+template <bool MASS_ONLY>
+__global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const DevCuboid* __restrict__ cuboids, const Ctl* __restrict__ ctl,
+                                                             StepParams S) {
+    if (ctl->abort_flag[S.parity]) return;
+    const int nb_total = G.num_blocks;
+    const int b = xcd_remap(blockIdx.x, (nb_total + 3) / 4) * 4 + (threadIdx.x >> 6);
+    if (b >= nb_total) return;
+    const int lane = threadIdx.x & 63;
+    const int cx = lane & 3, cy = (lane >> 2) & 3, cz = lane >> 4;
+    const int dx0 = cx <= 2 ? -1 : 0, dy0 = cy <= 2 ? -1 : 0, dz0 = cz <= 2 ? -1 : 0;
+    float m = 0.f, px = 0.f, py = 0.f, pz = 0.f;
+#pragma unroll
+    for (int iz = 0; iz < 2; ++iz)
+#pragma unroll
+        for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+            for (int ix = 0; ix < 2; ++ix) {
+                const int dx = dx0 + ix, dy = dy0 + iy, dz = dz0 + iz;
+                const int nb = G.blk_nbr[b * 27 + (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1)];
+                if (nb < 0) continue;
+                const int t = G.blk_origin[nb].w;
+                if (t < 0) continue;
+                const int tx = cx - 4 * dx + 1, ty = cy - 4 * dy + 1, tz = cz - 4 * dz + 1;
+                const float4 v = G.tiles[(size_t)t * TILE_N + tx + TILE_W * ty + TILE_W * TILE_W * tz];
+                m += v.x; px += v.y; py += v.z; pz += v.w;
+            }
+    if (MASS_ONLY) {
+        G.node_vel[(size_t)b * 64 + lane] = make_float4(0.f, 0.f, 0.f, m);
+        return;
+    }
+    // velocity incl. gravity (particle_to_grid.rs:88-89)
+    const float im = inv_exact(m);
+    float v[3] = {(px + m * S.gx * S.dt) * im, (py + m * S.gy * S.dt) * im, (pz + m * S.gz * S.dt) * im};
+    // grid_update.rs:60-74
+    if (S.dofs & 1u) { px = 0.f; v[0] = 0.f; }
+    if (S.dofs & 2u) { py = 0.f; v[1] = 0.f; }
+    if (S.dofs & 4u) { pz = 0.f; v[2] = 0.f; }
+    if (S.num_cuboids > 0 && S.boundary_handling != SPARKL_BOUNDARY_NONE) {
+        const int4 org = G.blk_origin[b];
+        const float cpos[3] = {(float)(org.x + cx) * S.h, (float)(org.y + cy) * S.h, (float)(org.z + cz) * S.h};
+        for (int ci = 0; ci < S.num_cuboids; ++ci) {
+            const DevCuboid col = cuboids[ci];
+            float proj[3];
+            const bool inside = cuboid_project(col, cpos, proj);
+            if (S.boundary_handling == SPARKL_BOUNDARY_STICK) {
+                if (inside) { v[0] = v[1] = v[2] = 0.f; }
+                continue;
+            }
+            float dv[3] = {cpos[0] - proj[0], cpos[1] - proj[1], cpos[2] - proj[2]};
+            const float dist = sqrtf(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+            if (!(dist > 1.0e-5f)) continue;
+            float nrm[3] = {dv[0] / dist, dv[1] / dist, dv[2] / dist};
+            if (inside) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
+            const float nv = v[0] * nrm[0] + v[1] * nrm[1] + v[2] * nrm[2];
+            if (nv < 0.f) {
+                const float dwm = dist - S.h;
+                if (inside || dwm <= 0.f) {
+                    const float tv[3] = {v[0] - nv * nrm[0], v[1] - nv * nrm[1], v[2] - nv * nrm[2]};
+                    const float tvn = sqrtf(tv[0] * tv[0] + tv[1] * tv[1] + tv[2] * tv[2]);
+                    v[0] = tv[0]; v[1] = tv[1]; v[2] = tv[2];
+                    if (tvn > 1.0e-10f) {
+                        const float f = fmaxf(tvn + nv * col.friction, 0.f);
+                        v[0] = tv[0] / tvn * f; v[1] = tv[1] / tvn * f; v[2] = tv[2] / tvn * f;
+                    }
+                } else if (-nv * S.dt > dwm) {
+                    const float kq = dwm / S.dt + nv;
+                    v[0] -= kq * nrm[0]; v[1] -= kq * nrm[1]; v[2] -= kq * nrm[2];
+                }
+            }
+        }
+    }
+    G.node_vel[(size_t)b * 64 + lane] = make_float4(v[0], v[1], v[2], m);
+    if (G.node_mom) G.node_mom[(size_t)b * 64 + lane] = make_float4(px, py, pz, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------- G2P
+// Stage the 8^3 node values (vx, vy, vz, mass) of the tile into LDS from the 27 neighbour blocks.
+SPK_DEV void load_vel_tile(float4* vt, const GridArrays& G, int b, int tid) {
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) {
+        const int tx = n & 7, ty = (n >> 3) & 7, tz = n >> 6;
+        const int dx = tx == 0 ? -1 : (tx <= 4 ? 0 : 1), dy = ty == 0 ? -1 : (ty <= 4 ? 0 : 1), dz = tz == 0 ? -1 : (tz <= 4 ? 0 : 1);
+        const int cx = tx - 1 - 4 * dx, cy = ty - 1 - 4 * dy, cz = tz - 1 - 4 * dz;
+        const int nb = G.blk_nbr[b * 27 + (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1)];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nb >= 0) v = G.node_vel[(size_t)nb * 64 + cx + 4 * cy + 16 * cz];
+        vt[n] = v;
+    }
+}
+
+__global__ __launch_bounds__(BLK_THREADS) void k_g2p(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
+    const int tid = threadIdx.x;
+    if (ctl->abort_flag[S.parity]) {
+        // sticky abort: keep every later substep a no-op until the host re-bins
+        if (blockIdx.x == 0 && tid == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
+        return;
+    }
+    __shared__ float4 vt[TILE_N];
+    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    const int b = G.pblk[pb];
+    load_vel_tile(vt, G, b, tid);
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
+    const int4 org = G.blk_origin[b];
+    const int pfirst = G.blk_pfirst[b], pcount = G.blk_pcount[b];
+    __syncthreads();
+    const float h = S.h, dt = S.dt;
+    bool want_sort = false;
+    for (int li = tid; li < pcount; li += BLK_THREADS) {
+        const int i = pfirst + li;
+        const float4 q0 = P.q[0][i], kk = P.k[i];
+        uint32_t flags = __float_as_uint(kk.w);
+        if (flags & FLAG_INVALID) continue;
+        const float4 q1 = P.q[1][i], q2 = P.q[2][i], dd = P.d[i];
+        const DevModel mo = models[flags >> FLAG_MODEL_SHIFT];
+        float px[3] = {q0.x, q0.y, q0.z};
+        float d0[3], wgt[3][3];
+        int lc[3];
+        const int orgv[3] = {org.x, org.y, org.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float r = roundf(px[a] / h);
+            d0[a] = (r - 1.0f) * h - px[a];
+            eval_all(-d0[a] / h, wgt[a]);
+            lc[a] = (int)r - 1 - orgv[a] + 1;
+        }
+        const int base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
+        float vel[3] = {0.f, 0.f, 0.f};
+        M3 C = m3_zero();
+        float div = 0.f;
+#pragma unroll
+        for (int sz = 0; sz < 3; ++sz)
+#pragma unroll
+            for (int sy = 0; sy < 3; ++sy)
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) {
+                    const float4 cv = vt[base + sx + TILE_W * sy + TILE_W * TILE_W * sz];
+                    const float w = wgt[0][sx] * wgt[1][sy] * wgt[2][sz];
+                    const float dpt[3] = {d0[0] + sx * h, d0[1] + sy * h, d0[2] + sz * h};
+                    vel[0] += w * cv.x; vel[1] += w * cv.y; vel[2] += w * cv.z;
+                    const float wi = w * S.inv_d;
+                    const float a0 = wi * cv.x, a1 = wi * cv.y, a2 = wi * cv.z;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { C.m[3 * j] += a0 * dpt[j]; C.m[3 * j + 1] += a1 * dpt[j]; C.m[3 * j + 2] += a2 * dpt[j]; }
+                    div += w * (cv.x * dpt[0] + cv.y * dpt[1] + cv.z * dpt[2]) * S.inv_d;
+                }
+        // kinematic override, advection (grid_to_particle.rs:82-86)
+        if (flags & FLAG_KINEMATIC) { const float4 kv = P.kinvel[i]; vel[0] = kv.x; vel[1] = kv.y; vel[2] = kv.z; }
+        px[0] += vel[0] * dt; px[1] += vel[1] * dt; px[2] += vel[2] * dt;
+        // deformation gradient update (:91-100)
+        M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
+        if (!mo.is_fluid) {
+            M3 Cdt;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) Cdt.m[e] = C.m[e] * dt;
+            const M3 dF = m3_mul(Cdt, F);
+#pragma unroll
+            for (int e = 0; e < 9; ++e) F.m[e] += dF.m[e];
+        } else {
+            F.m[0] += (div * dt) * F.m[0];
+        }
+        float q = dd.x, lvg = dd.y, Jp = dd.z, psi = dd.w;
+        const float eh = kk.z;
+        const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.phase[i] : 1.f;
+        float sv[3];
+        bool sv_valid = false;
+        if (mo.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER) dp_update(mo, phase, F, Jp, q, lvg, sv, sv_valid);
+        if (flags & FLAG_STATIC) { vel[0] = vel[1] = vel[2] = 0.f; C = m3_zero(); }
+        // fail guards (:111-121)
+        const float density = (kk.x / kk.y) / m3_det(F);
+        bool newly_failed = false;
+        if (density == 0.f || (flags & FLAG_FAILED) || (!mo.is_fluid && fabsf(F.m[0]) > 1.0e4f)) {
+            newly_failed = !(flags & FLAG_FAILED);
+            flags |= FLAG_FAILED;
+            F = m3_identity();
+            C = m3_zero();
+            sv_valid = false;
+        }
+        // positive energy bookkeeping (:127-132)
+        psi = fmaxf(psi, model_pos_energy(mo, phase, eh, F, sv_valid ? sv : nullptr));
+
+        // does the particle still sit inside its home block's tile, and inside the domain?
+        bool invalid = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float r = roundf(px[a] / h);
+            const bool ok = (r >= 1.0f) && (r < (float)(S.dom - 4));   // 0 <= assoc, assoc + 5 < dom
+            if (!ok) invalid = true;
+            else {
+                const int nl = (int)r - 1 - orgv[a];
+                if (nl < -1 || nl > 4) want_sort = true;
+            }
+        }
+        if (invalid) {  // what the next ParticleSet::sort would do (particle_set.rs:129-136)
+            newly_failed = true;
+            flags |= FLAG_FAILED | FLAG_INVALID;
+            want_sort = true;
+            atomicAdd(&ctl->num_invalid, 1u);
+        }
+        P.q[0][i] = make_float4(px[0], px[1], px[2], F.m[0]);
+        P.q[1][i] = make_float4(F.m[1], F.m[2], F.m[3], F.m[4]);
+        P.q[2][i] = make_float4(F.m[5], F.m[6], F.m[7], F.m[8]);
+        P.q[3][i] = make_float4(vel[0], vel[1], vel[2], C.m[0]);
+        P.q[4][i] = make_float4(C.m[1], C.m[2], C.m[3], C.m[4]);
+        P.q[5][i] = make_float4(C.m[5], C.m[6], C.m[7], C.m[8]);
+        P.d[i] = make_float4(q, lvg, Jp, psi);
+        if (newly_failed) reinterpret_cast<uint32_t*>(&P.k[i])[3] = flags;
+    }
+    if (__any(want_sort)) {
+        if ((tid & 63) == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
+    }
+}
+
+// ------------------------------------------------------------- fluid volume recompute (config 4)
+// fluids_volume.rs:9-115: mass-only P2G (here), merge (k_grid_update<true>), then this gather.
+__global__ __launch_bounds__(BLK_THREADS) void k_p2g_mass(ParticleArrays P, GridArrays G, const Ctl* __restrict__ ctl, StepParams S) {
+    if (ctl->abort_flag[S.parity]) return;
+    __shared__ float tile[TILE_N];
+    const int tid = threadIdx.x;
+    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) tile[n] = 0.f;
+    const int b = G.pblk[pb];
+    const int4 org = G.blk_origin[b];
+    const int pfirst = G.blk_pfirst[b], pcount = G.blk_pcount[b];
+    __syncthreads();
+    const float h = S.h;
+    for (int li = tid; li < pcount; li += BLK_THREADS) {
+        const int i = pfirst + li;
+        const float4 q0 = P.q[0][i], kk = P.k[i];
+        if (__float_as_uint(kk.w) & FLAG_INVALID) continue;
+        const float px[3] = {q0.x, q0.y, q0.z};
+        const int orgv[3] = {org.x, org.y, org.z};
+        float wgt[3][3];
+        int lc[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float r = roundf(px[a] / h);
+            const float d0 = (r - 1.0f) * h - px[a];
+            eval_all(-d0 / h, wgt[a]);
+            lc[a] = (int)r - 1 - orgv[a] + 1;
+        }
+        const int base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
+#pragma unroll
+        for (int sz = 0; sz < 3; ++sz)
+#pragma unroll
+            for (int sy = 0; sy < 3; ++sy)
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx)
+                    atomicAdd(&tile[base + sx + TILE_W * sy + TILE_W * TILE_W * sz], (wgt[0][sx] * wgt[1][sy] * wgt[2][sz]) * kk.x);
+    }
+    __syncthreads();
+    float4* out = G.tiles + (size_t)pb * TILE_N;
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) out[n] = make_float4(tile[n], 0.f, 0.f, 0.f);
+}
+
+__global__ __launch_bounds__(BLK_THREADS) void k_g2p_volume(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models,
+                                                            const Ctl* __restrict__ ctl, StepParams S) {
+    if (ctl->abort_flag[S.parity]) return;
+    __shared__ float4 vt[TILE_N];
+    const int tid = threadIdx.x;
+    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    const int b = G.pblk[pb];
+    load_vel_tile(vt, G, b, tid);
+    const int4 org = G.blk_origin[b];
+    const int pfirst = G.blk_pfirst[b], pcount = G.blk_pcount[b];
+    __syncthreads();
+    const float h = S.h;
+    for (int li = tid; li < pcount; li += BLK_THREADS) {
+        const int i = pfirst + li;
+        const float4 q0 = P.q[0][i], kk = P.k[i];
+        const uint32_t flags = __float_as_uint(kk.w);
+        if (flags & FLAG_INVALID) continue;
+        if (!models[flags >> FLAG_MODEL_SHIFT].is_fluid) continue;
+        const float px[3] = {q0.x, q0.y, q0.z};
+        const int orgv[3] = {org.x, org.y, org.z};
+        float wgt[3][3];
+        int lc[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float r = roundf(px[a] / h);
+            const float d0 = (r - 1.0f) * h - px[a];
+            eval_all(-d0 / h, wgt[a]);
+            lc[a] = (int)r - 1 - orgv[a] + 1;
+        }
+        const int base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
+        float new_mass = 0.f;
+#pragma unroll
+        for (int sz = 0; sz < 3; ++sz)
+#pragma unroll
+            for (int sy = 0; sy < 3; ++sy)
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx)
+                    new_mass += (wgt[0][sx] * wgt[1][sy] * wgt[2][sz]) * vt[base + sx + TILE_W * sy + TILE_W * TILE_W * sz].w;
+        const float new_density = new_mass / (h * h * h);
+        const float new_volume = kk.x / new_density;
+        reinterpret_cast<float*>(&P.q[0][i])[3] = new_volume / kk.y;
+    }
+}
+
+// ----------------------------------------------------------------------------------- dt estimate
+// timestep_estimator.rs:10-51: min over particles of the velocity bound and the model bound.
+__global__ __launch_bounds__(BLK_THREADS) void k_estimate_dt(ParticleArrays P, const DevModel* __restrict__ models, Ctl* ctl, int n, float h) {
+    const int i = blockIdx.x * BLK_THREADS + threadIdx.x;
+    float dt = 3.402823466e+38f;
+    bool nan = false;
+    if (i < n) {
+        const float4 q3 = P.q[3][i], q4 = P.q[4][i], q5 = P.q[5][i], kk = P.k[i];
+        const uint32_t flags = __float_as_uint(kk.w);
+        const float d = (h * h) / 4.f;
+        const float cn = sqrtf(q3.w * q3.w + q4.x * q4.x + q4.y * q4.y + q4.z * q4.z + q4.w * q4.w + q5.x * q5.x + q5.y * q5.y + q5.z * q5.z + q5.w * q5.w);
+        const float apic_v = (d * cn) * 6.f * sqrtf(3.f) / h;
+        const float v = sqrtf(q3.x * q3.x + q3.y * q3.y + q3.z * q3.z) + apic_v;
+        dt = fminf(dt, h / v);
+        if (!(flags & FLAG_FAILED)) {
+            const DevModel mo = models[flags >> FLAG_MODEL_SHIFT];
+            const float f00 = mo.is_fluid ? P.q[0][i].w : 1.f;
+            dt = fminf(dt, model_timestep_bound(mo, kk.x, kk.y, kk.z, f00, q3.x, q3.y, q3.z, h));
+        }
+        nan = dt != dt;
+    }
+    if (nan) dt = 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dt = fminf(dt, __shfl_xor(dt, off));
+    if ((threadIdx.x & 63) == 0) atomicMin(&ctl->dt_bits, __float_as_uint(dt));
+    if (__any(nan) && (threadIdx.x & 63) == 0) ctl->dt_nan = 1u;
+}
+
+// ------------------------------------------------------------------------------- re-bin (resort)
+SPK_DEV uint32_t spread10(uint32_t x) {
+    x &= 0x3ffu;
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8)) & 0x0300F00Fu;
+    x = (x | (x << 4)) & 0x030C30C3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+SPK_DEV uint32_t compact10(uint32_t x) {
+    x &= 0x09249249u;
+    x = (x | (x >> 2)) & 0x030C30C3u;
+    x = (x | (x >> 4)) & 0x0300F00Fu;
+    x = (x | (x >> 8)) & 0x030000FFu;
+    x = (x | (x >> 16)) & 0x3ffu;
+    return x;
+}
+// block key = Morton code of the block coordinate biased by +1 (blocks at -1 are legal node blocks)
+SPK_DEV uint32_t block_key(int bx, int by, int bz) { return spread10(bx + 1) | (spread10(by + 1) << 1) | (spread10(bz + 1) << 2); }
+
+constexpr uint64_t KEY_INVALID = ~0ull;
+
+__global__ void k_compute_keys(ParticleArrays P, uint64_t* keys, uint32_t* idx, int n, float h, int dom) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 q0 = P.q[0][i];
+    uint32_t flags = reinterpret_cast<const uint32_t*>(&P.k[i])[3];
+    const float px[3] = {q0.x, q0.y, q0.z};
+    int c[3];
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float r = roundf(px[a] / h);
+        if (!((r >= 1.0f) && (r < (float)(dom - 4)))) ok = false;
+        c[a] = ok ? (int)r - 1 : 0;
+    }
+    uint64_t key = KEY_INVALID;
+    if (ok) {
+        const uint32_t bk = block_key(c[0] >> 2, c[1] >> 2, c[2] >> 2);
+        key = ((uint64_t)bk << 6) | (uint64_t)((c[0] & 3) | ((c[1] & 3) << 2) | ((c[2] & 3) << 4));
+        if (flags & FLAG_INVALID) { flags &= ~FLAG_INVALID; reinterpret_cast<uint32_t*>(&P.k[i])[3] = flags; }
+    } else if ((flags & (FLAG_INVALID | FLAG_FAILED)) != (FLAG_INVALID | FLAG_FAILED)) {
+        flags |= FLAG_INVALID | FLAG_FAILED;  // particle_set.rs:132-135
+        reinterpret_cast<uint32_t*>(&P.k[i])[3] = flags;
+    }
+    keys[i] = key;
+    idx[i] = (uint32_t)i;
+}
+
+__global__ void k_shift_keys(const uint64_t* __restrict__ keys, uint64_t* bkeys, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) bkeys[i] = keys[i] >> 6;
+}
+
+__global__ void k_permute(ParticleArrays src, ParticleArrays dst, const uint32_t* __restrict__ perm, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = perm[i];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) dst.q[a][i] = src.q[a][s];
+    dst.d[i] = src.d[s];
+    dst.k[i] = src.k[s];
+    dst.kinvel[i] = src.kinvel[s];
+    dst.phase[i] = src.phase[s];
+    dst.orig_id[i] = src.orig_id[s];
+}
+
+// 27 candidate node blocks around every particle block
+__global__ void k_candidates(const uint64_t* __restrict__ pb_keys, int npb, uint32_t* cand) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npb * 27) return;
+    const int j = t / 27, d = t % 27;
+    const uint32_t k = (uint32_t)pb_keys[j];
+    const int bx = (int)compact10(k) - 1, by = (int)compact10(k >> 1) - 1, bz = (int)compact10(k >> 2) - 1;
+    cand[t] = block_key(bx + (d % 3) - 1, by + ((d / 3) % 3) - 1, bz + (d / 9) - 1);
+}
+
+struct HashTable {
+    uint64_t* keys;   // KEY_INVALID = empty
+    uint32_t* vals;
+    uint32_t mask;    // capacity - 1 (power of two, load <= 50 %)
+};
+// reference hash (src_kernels/cuda/hashmap.rs:7-14)
+SPK_DEV uint64_t hash64(uint64_t key) {
+    key ^= key >> 16; key *= 0x85ebca6bull; key ^= key >> 13; key *= 0xc2b2ae35ull; key ^= key >> 16;
+    return key;
+}
+SPK_DEV void hash_insert(const HashTable& H, uint64_t key, uint32_t val) {
+    uint32_t slot = (uint32_t)hash64(key) & H.mask;
+    for (uint32_t probe = 0; probe <= H.mask; ++probe) {
+        const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&H.keys[slot]), (unsigned long long)KEY_INVALID, (unsigned long long)key);
+        if (prev == KEY_INVALID || prev == key) { H.vals[slot] = val; return; }
+        slot = (slot + 1) & H.mask;
+    }
+}
+SPK_DEV int hash_lookup(const HashTable& H, uint64_t key) {
+    uint32_t slot = (uint32_t)hash64(key) & H.mask;
+    for (uint32_t probe = 0; probe <= H.mask; ++probe) {
+        const uint64_t k = H.keys[slot];
+        if (k == key) return (int)H.vals[slot];
+        if (k == KEY_INVALID) return -1;
+        slot = (slot + 1) & H.mask;
+    }
+    return -1;
+}
+
+__global__ void k_setup_blocks(const uint32_t* __restrict__ blk_keys, int nb, int4* origin, int* pfirst, int* pcount, HashTable H) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const uint32_t k = blk_keys[b];
+    origin[b] = make_int4(((int)compact10(k) - 1) * 4, ((int)compact10(k >> 1) - 1) * 4, ((int)compact10(k >> 2) - 1) * 4, -1);
+    pfirst[b] = 0;
+    pcount[b] = 0;
+    hash_insert(H, (uint64_t)k, (uint32_t)b);
+}
+__global__ void k_link_pblocks(const uint64_t* __restrict__ pb_keys, const uint32_t* __restrict__ pb_counts, const uint32_t* __restrict__ pb_first,
+                               int npb, HashTable H, int4* origin, int* pfirst, int* pcount, int* pblk) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= npb) return;
+    const int b = hash_lookup(H, pb_keys[j]);
+    pblk[j] = b;
+    origin[b].w = j;
+    pfirst[b] = (int)pb_first[j];
+    pcount[b] = (int)pb_counts[j];
+}
+__global__ void k_link_nbrs(const uint32_t* __restrict__ blk_keys, int nb, HashTable H, int* nbr) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb * 27) return;
+    const int b = t / 27, d = t % 27;
+    const uint32_t k = blk_keys[b];
+    const int bx = (int)compact10(k) - 1 + (d % 3) - 1, by = (int)compact10(k >> 1) - 1 + ((d / 3) % 3) - 1, bz = (int)compact10(k >> 2) - 1 + (d / 9) - 1;
+    int r = -1;
+    if (bx >= -1 && by >= -1 && bz >= -1 && bx < 1022 && by < 1022 && bz < 1022) r = hash_lookup(H, (uint64_t)block_key(bx, by, bz));
+    nbr[t] = r;
+}
+
+// --------------------------------------------------------------------------------------- readback
+// scatter a component back to caller order: out[orig_id[i]] = value(i)
+__global__ void k_read_positions(ParticleArrays P, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 q0 = P.q[0][i];
+    float* o = out + 3 * (size_t)P.orig_id[i];
+    o[0] = q0.x; o[1] = q0.y; o[2] = q0.z;
+}
+__global__ void k_read_velocities(ParticleArrays P, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 q3 = P.q[3][i];
+    float* o = out + 3 * (size_t)P.orig_id[i];
+    o[0] = q3.x; o[1] = q3.y; o[2] = q3.z;
+}
+// 16 floats per particle: F[9], Jp, q, lvg, psi, flags(bits), mass, volume0
+__global__ void k_read_state(ParticleArrays P, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 q0 = P.q[0][i], q1 = P.q[1][i], q2 = P.q[2][i], dd = P.d[i], kk = P.k[i];
+    float4* o = reinterpret_cast<float4*>(out + 16 * (size_t)P.orig_id[i]);
+    o[0] = make_float4(q0.w, q1.x, q1.y, q1.z);
+    o[1] = make_float4(q1.w, q2.x, q2.y, q2.z);
+    o[2] = make_float4(q2.w, dd.z, dd.x, dd.y);
+    o[3] = make_float4(dd.w, kk.w, kk.x, kk.y);
+}
+__global__ void k_read_velgrad(ParticleArrays P, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 q3 = P.q[3][i], q4 = P.q[4][i], q5 = P.q[5][i];
+    float* o = out + 9 * (size_t)P.orig_id[i];
+    o[0] = q3.w; o[1] = q4.x; o[2] = q4.y; o[3] = q4.z; o[4] = q4.w; o[5] = q5.x; o[6] = q5.y; o[7] = q5.z; o[8] = q5.w;
+}
+
+// compact the nodes with mass != 0 for grid_read_nodes
+__global__ void k_dump_nodes(GridArrays G, SparklGridNode* out, unsigned long long cap, unsigned long long* count) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= G.num_blocks * 64) return;
+    const float4 v = G.node_vel[t];
+    if (v.w == 0.f) return;
+    const unsigned long long slot = atomicAdd(count, 1ull);
+    if (slot >= cap) return;
+    const int b = t >> 6, l = t & 63;
+    const int4 org = G.blk_origin[b];
+    SparklGridNode nd;
+    nd.cell[0] = org.x + (l & 3); nd.cell[1] = org.y + ((l >> 2) & 3); nd.cell[2] = org.z + (l >> 4);
+    nd.mass = v.w;
+    nd.velocity[0] = v.x; nd.velocity[1] = v.y; nd.velocity[2] = v.z;
+    const float4 mm = G.node_mom ? G.node_mom[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+    nd.momentum[0] = mm.x; nd.momentum[1] = mm.y; nd.momentum[2] = mm.z;
+    out[slot] = nd;
+}
+
+}  // namespace spk

@@ -1,0 +1,833 @@
+// libsparkl_hip.so -- host side of the C ABI declared in include/sparkl_hip.h.
+// Owns all device memory, the stream, the sparse-grid structures and the re-bin logic.
+// The product path is HIP only: there is no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace spk;
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_last_error;
+static int set_error(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e__ = (expr);                                                                             \
+        if (e__ != hipSuccess)                                                                               \
+            return set_error(e__ == hipErrorOutOfMemory ? SPARKL_ERR_OUT_OF_MEMORY : SPARKL_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+#define CHK(expr)                  \
+    do {                           \
+        int r__ = (expr);          \
+        if (r__ != SPARKL_OK) return r__; \
+    } while (0)
+
+// growable device buffer
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n, bool keep = false, hipStream_t st = nullptr) {
+        if (n <= cap) return SPARKL_OK;
+        size_t ncap = std::max(n, cap + cap / 2);
+        T* np = nullptr;
+        HIPCHK(hipMalloc((void**)&np, ncap * sizeof(T)));
+        if (keep && p && cap) {
+            HIPCHK(hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        if (p) (void)hipFree(p);
+        p = np;
+        cap = ncap;
+        return SPARKL_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct ParticleStore {
+    DevBuf<float4> q[6], d, k, kinvel;
+    DevBuf<float> phase;
+    DevBuf<uint32_t> orig_id;
+    int reserve(size_t n) {
+        for (auto& b : q) CHK(b.reserve(n));
+        CHK(d.reserve(n)); CHK(k.reserve(n)); CHK(kinvel.reserve(n)); CHK(phase.reserve(n)); CHK(orig_id.reserve(n));
+        return SPARKL_OK;
+    }
+    ParticleArrays arrays() const {
+        ParticleArrays a;
+        for (int i = 0; i < 6; ++i) a.q[i] = q[i].p;
+        a.d = d.p; a.k = k.p; a.kinvel = kinvel.p; a.phase = phase.p; a.orig_id = orig_id.p;
+        return a;
+    }
+    void release() { for (auto& b : q) b.release(); d.release(); k.release(); kinvel.release(); phase.release(); orig_id.release(); }
+};
+
+struct EventPair { hipEvent_t a, b; int kind; };
+
+struct SparklPipeline {
+    int device = 0;
+    float h = 0.f;
+    int dom = 256;
+    uint32_t domain_log2 = 30;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    // particles
+    uint64_t n = 0;
+    ParticleStore cur, alt;
+    // host copies of the constant / caller-order fields
+    std::vector<SparklParticleStatus> h_status;
+    std::vector<float> h_radius0, h_nacc_alpha, h_phase;
+
+    // models / colliders
+    DevBuf<DevModel> d_models;
+    std::vector<DevModel> h_models;
+    bool any_fluid = false;
+    DevBuf<DevCuboid> d_cuboids;
+    int num_cuboids = 0;
+
+    // control block
+    Ctl* d_ctl = nullptr;
+    Ctl* h_ctl = nullptr;  // pinned
+    uint32_t substep_index = 0;  // parity source
+    bool sorted = false;
+
+    // sparse grid
+    int num_blocks = 0, num_pblocks = 0;
+    DevBuf<int4> blk_origin;
+    DevBuf<int> blk_pfirst, blk_pcount, blk_nbr, pblk;
+    DevBuf<uint32_t> blk_keys;
+    DevBuf<float4> tiles, node_vel, node_mom;
+    bool capture_mom = false;
+    DevBuf<uint64_t> hash_keys;
+    DevBuf<uint32_t> hash_vals;
+    uint32_t hash_mask = 0;
+
+    // re-bin scratch
+    DevBuf<uint64_t> keys_a, keys_b, pb_keys, bkeys;
+    DevBuf<uint32_t> idx_a, idx_b, pb_counts, pb_first, cand_a, cand_b;
+    DevBuf<uint8_t> cub_temp;
+    DevBuf<int> d_scalars;  // [0] num_runs, [1] num_unique
+    DevBuf<float> staging;
+    DevBuf<SparklGridNode> node_staging;
+    DevBuf<unsigned long long> d_count;
+
+    // clock
+    bool clock_on = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    struct Span { size_t a, b; int kind; };
+    std::vector<Span> spans;
+    SparklKernelClock clock{};
+    uint64_t total_resorts = 0;
+};
+
+enum { SPAN_P2G = 0, SPAN_GRID = 1, SPAN_G2P = 2, SPAN_SORT = 3, SPAN_DT = 4, SPAN_HALO = 5 };
+
+static int clock_begin(SparklPipeline* p, int kind, size_t* tok) {
+    if (!p->clock_on) return SPARKL_OK;
+    if (p->ev_used + 2 > p->ev_pool.size()) {
+        size_t old = p->ev_pool.size();
+        p->ev_pool.resize(old + 256);
+        for (size_t i = old; i < p->ev_pool.size(); ++i) HIPCHK(hipEventCreate(&p->ev_pool[i]));
+    }
+    *tok = p->spans.size();
+    p->spans.push_back({p->ev_used, p->ev_used + 1, kind});
+    HIPCHK(hipEventRecord(p->ev_pool[p->ev_used], p->stream));
+    p->ev_used += 2;
+    return SPARKL_OK;
+}
+static int clock_end(SparklPipeline* p, size_t tok) {
+    if (!p->clock_on) return SPARKL_OK;
+    HIPCHK(hipEventRecord(p->ev_pool[p->spans[tok].b], p->stream));
+    return SPARKL_OK;
+}
+// requires the stream to be idle
+static int clock_collect(SparklPipeline* p) {
+    for (auto& s : p->spans) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, p->ev_pool[s.a], p->ev_pool[s.b]));
+        switch (s.kind) {
+            case SPAN_P2G: p->clock.p2g_ms += ms; break;
+            case SPAN_GRID: p->clock.grid_update_ms += ms; break;
+            case SPAN_G2P: p->clock.g2p_ms += ms; break;
+            case SPAN_SORT: p->clock.sort_ms += ms; break;
+            case SPAN_DT: p->clock.dt_ms += ms; break;
+            default: p->clock.halo_ms += ms; break;
+        }
+    }
+    p->spans.clear();
+    p->ev_used = 0;
+    return SPARKL_OK;
+}
+
+static inline int grid_for(size_t n, int threads) { return (int)((n + threads - 1) / threads); }
+
+static GridArrays grid_arrays(const SparklPipeline* p) {
+    GridArrays g;
+    g.blk_origin = p->blk_origin.p; g.blk_pfirst = p->blk_pfirst.p; g.blk_pcount = p->blk_pcount.p; g.blk_nbr = p->blk_nbr.p;
+    g.pblk = p->pblk.p; g.tiles = p->tiles.p; g.node_vel = p->node_vel.p; g.node_mom = p->capture_mom ? p->node_mom.p : nullptr;
+    g.num_blocks = p->num_blocks; g.num_pblocks = p->num_pblocks;
+    return g;
+}
+
+static int cub_reserve(SparklPipeline* p, size_t bytes) { return p->cub_temp.reserve(std::max<size_t>(bytes, 1)); }
+
+// --------------------------------------------------------------------------------- re-bin (resort)
+// Sort particles by (block Morton key, cell in block), move the data, rebuild the node-block list,
+// its hash and neighbour tables.  Host-orchestrated; runs only when a particle left its tile margin.
+static int resort(SparklPipeline* p) {
+    hipStream_t st = p->stream;
+    const int n = (int)p->n;
+    size_t tok = 0;
+    CHK(clock_begin(p, SPAN_SORT, &tok));
+    p->num_blocks = p->num_pblocks = 0;
+    if (n > 0) {
+        CHK(p->keys_a.reserve(n)); CHK(p->keys_b.reserve(n)); CHK(p->idx_a.reserve(n)); CHK(p->idx_b.reserve(n));
+        CHK(p->bkeys.reserve(n)); CHK(p->pb_keys.reserve(n)); CHK(p->pb_counts.reserve(n)); CHK(p->pb_first.reserve(n));
+        CHK(p->d_scalars.reserve(4));
+        CHK(p->alt.reserve(p->cur.q[0].cap));
+        hipLaunchKernelGGL(k_compute_keys, dim3(grid_for(n, 256)), dim3(256), 0, st, p->cur.arrays(), p->keys_a.p, p->idx_a.p, n, p->h, p->dom);
+        // key bits: 3 * (block bits + 1 for the -1 bias) + 6 cell bits; invalid keys are all ones => sort all 64 if any
+        int end_bit = 64;
+        size_t tb = 0;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, p->keys_a.p, p->keys_b.p, p->idx_a.p, p->idx_b.p, n, 0, end_bit, st));
+        CHK(cub_reserve(p, tb));
+        // valid keys use <= 36 bits; KEY_INVALID has every bit set, so sorting bits [0,37) keeps them last
+        end_bit = 37;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(p->cub_temp.p, tb, p->keys_a.p, p->keys_b.p, p->idx_a.p, p->idx_b.p, n, 0, end_bit, st));
+        hipLaunchKernelGGL(k_permute, dim3(grid_for(n, 256)), dim3(256), 0, st, p->cur.arrays(), p->alt.arrays(), p->idx_b.p, n);
+        std::swap(p->cur, p->alt);
+        // block keys of the sorted particles, run-length encoded
+        {
+            uint64_t* keys = p->keys_b.p;
+            uint64_t* bk = p->bkeys.p;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shift_keys), dim3(grid_for(n, 256)), dim3(256), 0, st, keys, bk, n);
+        }
+        size_t tb2 = 0;
+        HIPCHK(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb2, p->bkeys.p, p->pb_keys.p, p->pb_counts.p, p->d_scalars.p, n, st));
+        CHK(cub_reserve(p, tb2));
+        HIPCHK(hipcub::DeviceRunLengthEncode::Encode(p->cub_temp.p, tb2, p->bkeys.p, p->pb_keys.p, p->pb_counts.p, p->d_scalars.p, n, st));
+        int h_runs = 0;
+        HIPCHK(hipMemcpyAsync(&h_runs, p->d_scalars.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        uint64_t last_key = 0;
+        if (h_runs > 0) {
+            HIPCHK(hipMemcpy(&last_key, p->pb_keys.p + (h_runs - 1), sizeof(uint64_t), hipMemcpyDeviceToHost));
+            if (last_key == (KEY_INVALID >> 6)) --h_runs;  // the out-of-domain bucket is not a block
+        }
+        const int npb = h_runs;
+        if (npb > 0) {
+            size_t tb3 = 0;
+            HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, p->pb_counts.p, p->pb_first.p, npb, st));
+            CHK(cub_reserve(p, tb3));
+            HIPCHK(hipcub::DeviceScan::ExclusiveSum(p->cub_temp.p, tb3, p->pb_counts.p, p->pb_first.p, npb, st));
+            // candidate node blocks: the 27-neighbourhood of every particle block
+            const int nc = npb * 27;
+            CHK(p->cand_a.reserve(nc)); CHK(p->cand_b.reserve(nc)); CHK(p->blk_keys.reserve(nc));
+            hipLaunchKernelGGL(k_candidates, dim3(grid_for(nc, 256)), dim3(256), 0, st, p->pb_keys.p, npb, p->cand_a.p);
+            size_t tb4 = 0;
+            HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb4, p->cand_a.p, p->cand_b.p, nc, 0, 30, st));
+            CHK(cub_reserve(p, tb4));
+            HIPCHK(hipcub::DeviceRadixSort::SortKeys(p->cub_temp.p, tb4, p->cand_a.p, p->cand_b.p, nc, 0, 30, st));
+            size_t tb5 = 0;
+            HIPCHK(hipcub::DeviceSelect::Unique(nullptr, tb5, p->cand_b.p, p->blk_keys.p, p->d_scalars.p + 1, nc, st));
+            CHK(cub_reserve(p, tb5));
+            HIPCHK(hipcub::DeviceSelect::Unique(p->cub_temp.p, tb5, p->cand_b.p, p->blk_keys.p, p->d_scalars.p + 1, nc, st));
+            int nb = 0;
+            HIPCHK(hipMemcpyAsync(&nb, p->d_scalars.p + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            // node-block arrays + hash (<= 50 % load, as cuda_sparse_grid.rs:219-222)
+            uint32_t hcap = 1024;
+            while (hcap < (uint32_t)nb * 2u) hcap <<= 1;
+            CHK(p->hash_keys.reserve(hcap)); CHK(p->hash_vals.reserve(hcap));
+            p->hash_mask = hcap - 1;
+            HIPCHK(hipMemsetAsync(p->hash_keys.p, 0xFF, (size_t)hcap * sizeof(uint64_t), st));
+            CHK(p->blk_origin.reserve(nb)); CHK(p->blk_pfirst.reserve(nb)); CHK(p->blk_pcount.reserve(nb));
+            CHK(p->blk_nbr.reserve((size_t)nb * 27)); CHK(p->pblk.reserve(npb));
+            CHK(p->tiles.reserve((size_t)npb * TILE_N)); CHK(p->node_vel.reserve((size_t)nb * 64));
+            if (p->capture_mom) CHK(p->node_mom.reserve((size_t)nb * 64));
+            HashTable H{p->hash_keys.p, p->hash_vals.p, p->hash_mask};
+            hipLaunchKernelGGL(k_setup_blocks, dim3(grid_for(nb, 256)), dim3(256), 0, st, p->blk_keys.p, nb, p->blk_origin.p, p->blk_pfirst.p, p->blk_pcount.p, H);
+            hipLaunchKernelGGL(k_link_pblocks, dim3(grid_for(npb, 256)), dim3(256), 0, st, p->pb_keys.p, p->pb_counts.p, p->pb_first.p, npb, H,
+                               p->blk_origin.p, p->blk_pfirst.p, p->blk_pcount.p, p->pblk.p);
+            hipLaunchKernelGGL(k_link_nbrs, dim3(grid_for((size_t)nb * 27, 256)), dim3(256), 0, st, p->blk_keys.p, nb, H, p->blk_nbr.p);
+            HIPCHK(hipMemsetAsync(p->node_vel.p, 0, (size_t)nb * 64 * sizeof(float4), st));
+            p->num_blocks = nb;
+            p->num_pblocks = npb;
+        }
+    }
+    // clear the abort chain; the substep counter restarts so parity 0 is clean
+    HIPCHK(hipMemsetAsync(p->d_ctl, 0, 2 * sizeof(uint32_t), st));
+    HIPCHK(hipGetLastError());
+    CHK(clock_end(p, tok));
+    p->sorted = true;
+    p->clock.resorts++;
+    p->total_resorts++;
+    return SPARKL_OK;
+}
+
+// ----------------------------------------------------------------------------------- one substep
+static StepParams make_params(const SparklPipeline* p, const SparklSolverParams* sp, const float g[3], float dt) {
+    StepParams S;
+    S.h = p->h; S.inv_d = 4.0f / (p->h * p->h); S.dt = dt;
+    S.gx = g[0]; S.gy = g[1]; S.gz = g[2];
+    S.boundary_handling = sp->boundary_handling; S.dofs = sp->simulation_dofs;
+    S.parity = (int)(p->substep_index & 1u); S.dom = p->dom; S.num_cuboids = p->num_cuboids;
+    return S;
+}
+
+#ifndef SPK_P2G_WAVE_REDUCE
+#define SPK_P2G_WAVE_REDUCE 1
+#endif
+
+static int enqueue_fluid_volumes(SparklPipeline* p, const StepParams& S) {
+    hipStream_t st = p->stream;
+    GridArrays G = grid_arrays(p);
+    G.node_mom = nullptr;
+    hipLaunchKernelGGL(k_p2g_mass, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, p->cur.arrays(), G, p->d_ctl, S);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<true>), dim3((p->num_blocks + 3) / 4), dim3(BLK_THREADS), 0, st, G, p->d_cuboids.p, p->d_ctl, S);
+    hipLaunchKernelGGL(k_g2p_volume, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, p->cur.arrays(), G, p->d_models.p, p->d_ctl, S);
+    return SPARKL_OK;
+}
+
+// enqueue P2G -> grid update -> G2P for the current substep index (no host sync)
+static int enqueue_substep(SparklPipeline* p, const SparklSolverParams* sp, const float g[3], float dt) {
+    if (p->num_pblocks == 0) { p->substep_index++; return SPARKL_OK; }
+    hipStream_t st = p->stream;
+    const StepParams S = make_params(p, sp, g, dt);
+    const GridArrays G = grid_arrays(p);
+    const ParticleArrays P = p->cur.arrays();
+    if (sp->force_fluids_volume_recomputation && p->any_fluid) CHK(enqueue_fluid_volumes(p, S));
+    size_t t0 = 0, t1 = 0, t2 = 0;
+    CHK(clock_begin(p, SPAN_P2G, &t0));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g<SPK_P2G_WAVE_REDUCE != 0>), dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, P, G, p->d_models.p, p->d_ctl, S);
+    CHK(clock_end(p, t0));
+    CHK(clock_begin(p, SPAN_GRID, &t1));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false>), dim3((p->num_blocks + 3) / 4), dim3(BLK_THREADS), 0, st, G, p->d_cuboids.p, p->d_ctl, S);
+    CHK(clock_end(p, t1));
+    CHK(clock_begin(p, SPAN_G2P, &t2));
+    hipLaunchKernelGGL(k_g2p, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, P, G, p->d_models.p, p->d_ctl, S);
+    CHK(clock_end(p, t2));
+    p->substep_index++;
+    return SPARKL_OK;
+}
+
+static int read_ctl(SparklPipeline* p) {
+    HIPCHK(hipMemcpyAsync(p->h_ctl, p->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipGetLastError());
+    return SPARKL_OK;
+}
+
+static int validate_models(const SparklPipeline* p) {
+    for (uint64_t i = 0; i < p->n; ++i)
+        if (p->h_status[i].model_index >= p->h_models.size())
+            return set_error(SPARKL_ERR_INVALID_ARGUMENT, "particle %llu uses model %llu but only %zu models are set", (unsigned long long)i,
+                             (unsigned long long)p->h_status[i].model_index, p->h_models.size());
+    return SPARKL_OK;
+}
+
+// ------------------------------------------------------------------------------------- C ABI: misc
+extern "C" {
+
+const char* sparkl_hip_last_error_string(void) { return g_last_error.c_str(); }
+const char* sparkl_hip_version(void) { return "sparkl_hip 0.1.0 gfx950"; }
+
+int sparkl_hip_pipeline_create(const SparklPipelineDesc* desc, SparklPipeline** out) {
+    if (!desc || !out) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (!(desc->cell_width > 0.f)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "cell_width must be > 0");
+    uint32_t bits = desc->domain_log2_bytes ? desc->domain_log2_bytes : 30;
+    if (bits != 30 && bits != 33 && bits != 36 && bits != 39) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "domain_log2_bytes must be 30, 33, 36 or 39");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_error(SPARKL_ERR_NO_DEVICE, "no HIP device available");
+    if (desc->device_id < 0 || desc->device_id >= ndev) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "device_id %d out of range (%d devices)", desc->device_id, ndev);
+    if (hipSetDevice(desc->device_id) != hipSuccess) return set_error(SPARKL_ERR_NO_DEVICE, "hipSetDevice(%d) failed", desc->device_id);
+    SparklPipeline* p = new SparklPipeline;
+    p->device = desc->device_id;
+    p->h = desc->cell_width;
+    p->domain_log2 = bits;
+    p->dom = 4 << ((bits - 12) / 3);
+    if (desc->stream) { p->stream = (hipStream_t)desc->stream; p->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) { delete p; return set_error(SPARKL_ERR_HIP, "hipStreamCreate failed"); }
+        p->own_stream = true;
+    }
+    if (hipMalloc((void**)&p->d_ctl, sizeof(Ctl)) != hipSuccess || hipHostMalloc((void**)&p->h_ctl, sizeof(Ctl)) != hipSuccess) {
+        delete p;
+        return set_error(SPARKL_ERR_OUT_OF_MEMORY, "control block allocation failed");
+    }
+    (void)hipMemset(p->d_ctl, 0, sizeof(Ctl));
+    memset(p->h_ctl, 0, sizeof(Ctl));
+    *out = p;
+    return SPARKL_OK;
+}
+
+void sparkl_hip_pipeline_destroy(SparklPipeline* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    (void)hipStreamSynchronize(p->stream);
+    p->cur.release(); p->alt.release();
+    p->d_models.release(); p->d_cuboids.release();
+    p->blk_origin.release(); p->blk_pfirst.release(); p->blk_pcount.release(); p->blk_nbr.release(); p->pblk.release(); p->blk_keys.release();
+    p->tiles.release(); p->node_vel.release(); p->node_mom.release(); p->hash_keys.release(); p->hash_vals.release();
+    p->keys_a.release(); p->keys_b.release(); p->pb_keys.release(); p->bkeys.release(); p->idx_a.release(); p->idx_b.release();
+    p->pb_counts.release(); p->pb_first.release(); p->cand_a.release(); p->cand_b.release(); p->cub_temp.release(); p->d_scalars.release();
+    p->staging.release(); p->node_staging.release(); p->d_count.release();
+    for (auto e : p->ev_pool) (void)hipEventDestroy(e);
+    if (p->d_ctl) (void)hipFree(p->d_ctl);
+    if (p->h_ctl) (void)hipHostFree(p->h_ctl);
+    if (p->own_stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+int sparkl_hip_pipeline_sync(SparklPipeline* p) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipGetLastError());
+    return SPARKL_OK;
+}
+
+// ------------------------------------------------------------------------------ models / colliders
+int sparkl_hip_models_set(SparklPipeline* p, uint32_t n, const SparklParticleModel* models) {
+    if (!p || (n && !models)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    HIPCHK(hipSetDevice(p->device));
+    std::vector<DevModel> dm(n);
+    bool any_fluid = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        const SparklParticleModel& m = models[i];
+        DevModel d;
+        memset(&d, 0, sizeof(d));
+        d.ctag = (int)m.constitutive_model.tag;
+        d.ptag = -1;
+        switch (m.constitutive_model.tag) {
+            case SPARKL_CONSTITUTIVE_COROTATED_LINEAR:
+                d.split_stress_on_failure = m.constitutive_model.u.corotated.split_stress_on_failure;
+                d.cfl_coeff = m.constitutive_model.u.corotated.cfl_coeff;
+                d.lambda = m.constitutive_model.u.corotated.lambda; d.mu = m.constitutive_model.u.corotated.mu;
+                break;
+            case SPARKL_CONSTITUTIVE_NEO_HOOKEAN:
+                d.cfl_coeff = m.constitutive_model.u.neo_hookean.cfl_coeff;
+                d.lambda = m.constitutive_model.u.neo_hookean.lambda; d.mu = m.constitutive_model.u.neo_hookean.mu;
+                break;
+            case SPARKL_CONSTITUTIVE_EOS_MONAGHAN_SPH:
+                d.is_fluid = 1; any_fluid = true;
+                d.pressure0 = m.constitutive_model.u.monaghan.pressure0; d.gamma = (int)m.constitutive_model.u.monaghan.gamma;
+                d.viscosity = m.constitutive_model.u.monaghan.viscosity; d.max_neg_pressure = m.constitutive_model.u.monaghan.max_neg_pressure;
+                break;
+            default:
+                return set_error(SPARKL_ERR_UNSUPPORTED, "model %u: CoreConstitutiveModel::Custom cannot cross the C ABI", i);
+        }
+        if (m.has_plastic_model) {
+            if (m.plastic_model.tag != SPARKL_PLASTIC_DRUCKER_PRAGER)
+                return set_error(SPARKL_ERR_UNSUPPORTED, "model %u: plastic model tag %u is not implemented (only DruckerPrager)", i, m.plastic_model.tag);
+            const auto& dp = m.plastic_model.u.drucker_prager;
+            d.ptag = SPARKL_PLASTIC_DRUCKER_PRAGER;
+            d.h0 = dp.h0; d.h1 = dp.h1; d.h2 = dp.h2; d.h3 = dp.h3; d.p_lambda = dp.lambda; d.p_mu = dp.mu;
+            d.volume_correction = dp.volume_correction; d.only_active_when_failed = dp.only_active_when_failed;
+        }
+        if (m.has_failure_model) return set_error(SPARKL_ERR_UNSUPPORTED, "model %u: failure models are not implemented", i);
+        dm[i] = d;
+    }
+    CHK(p->d_models.reserve(std::max<uint32_t>(n, 1)));
+    if (n) HIPCHK(hipMemcpyAsync(p->d_models.p, dm.data(), n * sizeof(DevModel), hipMemcpyHostToDevice, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    p->h_models = dm;
+    p->any_fluid = any_fluid;
+    return SPARKL_OK;
+}
+
+int sparkl_hip_colliders_set_cuboids(SparklPipeline* p, uint32_t n, const SparklCuboidCollider* c) {
+    if (!p || (n && !c)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    HIPCHK(hipSetDevice(p->device));
+    std::vector<DevCuboid> dc(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        for (int a = 0; a < 3; ++a) { dc[i].he[a] = c[i].half_extents[a]; dc[i].t[a] = c[i].translation[a]; }
+        for (int a = 0; a < 4; ++a) dc[i].q[a] = c[i].rotation[a];
+        dc[i].friction = c[i].friction;
+    }
+    CHK(p->d_cuboids.reserve(std::max<uint32_t>(n, 1)));
+    if (n) HIPCHK(hipMemcpyAsync(p->d_cuboids.p, dc.data(), n * sizeof(DevCuboid), hipMemcpyHostToDevice, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    p->num_cuboids = (int)n;
+    return SPARKL_OK;
+}
+
+// --------------------------------------------------------------------------------------- particles
+static int upload_range(SparklPipeline* p, uint64_t first, uint64_t n, const SparklParticleStatus* status, const SparklParticlePosition* pos,
+                        const SparklParticleVelocity* vel, const SparklParticleVolume* volume, const SparklParticlePhase* phase,
+                        const SparklParticleData* data, const SparklVelocityGradient* vg) {
+    // pack the caller's SoA into the eight float4 streams (host), then one H2D per stream
+    std::vector<float4> hq[6], hd(n), hk(n), hkin(n);
+    std::vector<float> hphase(n);
+    std::vector<uint32_t> hid(n);
+    for (auto& v : hq) v.resize(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        const float* F = volume[i].deformation_gradient;
+        const float zero9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const float* C = vg ? vg[i].m : zero9;
+        hq[0][i] = make_float4(pos[i].point[0], pos[i].point[1], pos[i].point[2], F[0]);
+        hq[1][i] = make_float4(F[1], F[2], F[3], F[4]);
+        hq[2][i] = make_float4(F[5], F[6], F[7], F[8]);
+        hq[3][i] = make_float4(vel[i].vector[0], vel[i].vector[1], vel[i].vector[2], C[0]);
+        hq[4][i] = make_float4(C[1], C[2], C[3], C[4]);
+        hq[5][i] = make_float4(C[5], C[6], C[7], C[8]);
+        hd[i] = make_float4(data[i].plastic_hardening, data[i].log_vol_gain, volume[i].plastic_deformation_gradient_det, phase[i].psi_pos);
+        uint32_t flags = ((uint32_t)status[i].model_index << FLAG_MODEL_SHIFT);
+        if (status[i].failed) flags |= FLAG_FAILED;
+        if (status[i].is_static) flags |= FLAG_STATIC;
+        if (status[i].kinematic_vel_enabled) flags |= FLAG_KINEMATIC;
+        if (phase[i].phase != 1.0f) flags |= FLAG_PHASE_NOT_ONE;
+        float fl;
+        memcpy(&fl, &flags, 4);
+        hk[i] = make_float4(volume[i].mass, volume[i].volume0, data[i].elastic_hardening, fl);
+        hkin[i] = make_float4(status[i].kinematic_vel[0], status[i].kinematic_vel[1], status[i].kinematic_vel[2], 0.f);
+        hphase[i] = phase[i].phase;
+        hid[i] = (uint32_t)(first + i);
+    }
+    hipStream_t st = p->stream;
+    for (int a = 0; a < 6; ++a) HIPCHK(hipMemcpyAsync(p->cur.q[a].p + first, hq[a].data(), n * sizeof(float4), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(p->cur.d.p + first, hd.data(), n * sizeof(float4), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(p->cur.k.p + first, hk.data(), n * sizeof(float4), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(p->cur.kinvel.p + first, hkin.data(), n * sizeof(float4), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(p->cur.phase.p + first, hphase.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(p->cur.orig_id.p + first, hid.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return SPARKL_OK;
+}
+
+int sparkl_hip_particles_upload(SparklPipeline* p, uint64_t n, const SparklParticleStatus* status, const SparklParticlePosition* pos,
+                                const SparklParticleVelocity* vel, const SparklParticleVolume* volume, const SparklParticlePhase* phase,
+                                const SparklParticleData* data, const SparklVelocityGradient* vg) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    if (n && (!status || !pos || !vel || !volume || !phase || !data)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null particle array");
+    if (n >= (1ull << 31)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "at most 2^31 - 1 particles per device");
+    for (uint64_t i = 0; i < n; ++i)
+        if (status[i].model_index >= (1ull << 24)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "model_index too large");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    CHK(p->cur.reserve(std::max<uint64_t>(n, 1)));
+    p->n = n;
+    p->h_status.assign(status, status + n);
+    p->h_radius0.resize(n); p->h_nacc_alpha.resize(n); p->h_phase.resize(n);
+    for (uint64_t i = 0; i < n; ++i) { p->h_radius0[i] = volume[i].radius0; p->h_nacc_alpha[i] = data[i].nacc_alpha; p->h_phase[i] = phase[i].phase; }
+    if (n) CHK(upload_range(p, 0, n, status, pos, vel, volume, phase, data, vg));
+    p->sorted = false;
+    return SPARKL_OK;
+}
+
+uint64_t sparkl_hip_particles_len(const SparklPipeline* p) { return p ? p->n : 0; }
+
+static int launch_read(SparklPipeline* p, int what, size_t floats_per) {
+    const int n = (int)p->n;
+    CHK(p->staging.reserve(std::max<size_t>((size_t)n * floats_per, 1)));
+    const ParticleArrays P = p->cur.arrays();
+    hipStream_t st = p->stream;
+    const dim3 g(grid_for(n, 256)), b(256);
+    switch (what) {
+        case 0: hipLaunchKernelGGL(k_read_positions, g, b, 0, st, P, p->staging.p, n); break;
+        case 1: hipLaunchKernelGGL(k_read_velocities, g, b, 0, st, P, p->staging.p, n); break;
+        case 2: hipLaunchKernelGGL(k_read_state, g, b, 0, st, P, p->staging.p, n); break;
+        default: hipLaunchKernelGGL(k_read_velgrad, g, b, 0, st, P, p->staging.p, n); break;
+    }
+    return SPARKL_OK;
+}
+#define READ_PROLOGUE                                                                                      \
+    if (!p || (n && !out)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");                 \
+    if (n != p->n) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "n (%llu) != particle count (%llu)", (unsigned long long)n, (unsigned long long)p->n); \
+    HIPCHK(hipSetDevice(p->device));                                                                      \
+    if (n == 0) return SPARKL_OK;
+
+int sparkl_hip_particles_read_positions(SparklPipeline* p, SparklParticlePosition* out, uint64_t n) {
+    READ_PROLOGUE
+    CHK(launch_read(p, 0, 3));
+    HIPCHK(hipMemcpyAsync(out, p->staging.p, n * 12, hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return SPARKL_OK;
+}
+int sparkl_hip_particles_read_velocities(SparklPipeline* p, SparklParticleVelocity* out, uint64_t n) {
+    READ_PROLOGUE
+    CHK(launch_read(p, 1, 3));
+    HIPCHK(hipMemcpyAsync(out, p->staging.p, n * 12, hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return SPARKL_OK;
+}
+static int read_state(SparklPipeline* p, std::vector<float>& st) {
+    CHK(launch_read(p, 2, 16));
+    st.resize((size_t)p->n * 16);
+    HIPCHK(hipMemcpyAsync(st.data(), p->staging.p, st.size() * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return SPARKL_OK;
+}
+int sparkl_hip_particles_read_volumes(SparklPipeline* p, SparklParticleVolume* out, uint64_t n) {
+    READ_PROLOGUE
+    std::vector<float> st;
+    CHK(read_state(p, st));
+    for (uint64_t i = 0; i < n; ++i) {
+        const float* s = &st[16 * i];
+        out[i].mass = s[14]; out[i].volume0 = s[15]; out[i].radius0 = p->h_radius0[i];
+        for (int k = 0; k < 9; ++k) out[i].deformation_gradient[k] = s[k];
+        out[i].plastic_deformation_gradient_det = s[9];
+    }
+    return SPARKL_OK;
+}
+int sparkl_hip_particles_read_statuses(SparklPipeline* p, SparklParticleStatus* out, uint64_t n) {
+    READ_PROLOGUE
+    std::vector<float> st;
+    CHK(read_state(p, st));
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t flags;
+        memcpy(&flags, &st[16 * i + 13], 4);
+        out[i] = p->h_status[i];
+        out[i].failed = (flags & FLAG_FAILED) ? 1 : 0;
+    }
+    return SPARKL_OK;
+}
+int sparkl_hip_particles_read_phases(SparklPipeline* p, SparklParticlePhase* out, uint64_t n) {
+    READ_PROLOGUE
+    std::vector<float> st;
+    CHK(read_state(p, st));
+    for (uint64_t i = 0; i < n; ++i) { out[i].phase = p->h_phase[i]; out[i].psi_pos = st[16 * i + 12]; }
+    return SPARKL_OK;
+}
+int sparkl_hip_particles_read_data(SparklPipeline* p, SparklParticleData* out, uint64_t n) {
+    READ_PROLOGUE
+    std::vector<float> st;
+    CHK(read_state(p, st));
+    std::vector<float4> hk(n);
+    // elastic_hardening lives in K (sorted order): fetch through orig_id on the host
+    std::vector<uint32_t> ids(n);
+    HIPCHK(hipMemcpy(hk.data(), p->cur.k.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ids.data(), p->cur.orig_id.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint64_t s = 0; s < n; ++s) out[ids[s]].elastic_hardening = hk[s].z;
+    for (uint64_t i = 0; i < n; ++i) {
+        out[i].nacc_alpha = p->h_nacc_alpha[i];
+        out[i].plastic_hardening = st[16 * i + 10];
+        out[i].log_vol_gain = st[16 * i + 11];
+    }
+    return SPARKL_OK;
+}
+int sparkl_hip_particles_read_velocity_gradients(SparklPipeline* p, SparklVelocityGradient* out, uint64_t n) {
+    READ_PROLOGUE
+    CHK(launch_read(p, 3, 9));
+    HIPCHK(hipMemcpyAsync(out, p->staging.p, n * 36, hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return SPARKL_OK;
+}
+int sparkl_hip_particles_read_sorted_ids(SparklPipeline* p, uint32_t* out, uint64_t n) {
+    READ_PROLOGUE
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipMemcpy(out, p->cur.orig_id.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return SPARKL_OK;
+}
+
+// append / remove_range / truncate: cold paths, implemented as read-modify-upload
+struct HostAll {
+    std::vector<SparklParticleStatus> st; std::vector<SparklParticlePosition> pos; std::vector<SparklParticleVelocity> vel;
+    std::vector<SparklParticleVolume> vol; std::vector<SparklParticlePhase> ph; std::vector<SparklParticleData> da; std::vector<SparklVelocityGradient> vg;
+};
+static int read_all(SparklPipeline* p, HostAll& h) {
+    const uint64_t n = p->n;
+    h.st.resize(n); h.pos.resize(n); h.vel.resize(n); h.vol.resize(n); h.ph.resize(n); h.da.resize(n); h.vg.resize(n);
+    if (!n) return SPARKL_OK;
+    CHK(sparkl_hip_particles_read_statuses(p, h.st.data(), n)); CHK(sparkl_hip_particles_read_positions(p, h.pos.data(), n));
+    CHK(sparkl_hip_particles_read_velocities(p, h.vel.data(), n)); CHK(sparkl_hip_particles_read_volumes(p, h.vol.data(), n));
+    CHK(sparkl_hip_particles_read_phases(p, h.ph.data(), n)); CHK(sparkl_hip_particles_read_data(p, h.da.data(), n));
+    CHK(sparkl_hip_particles_read_velocity_gradients(p, h.vg.data(), n));
+    return SPARKL_OK;
+}
+int sparkl_hip_particles_append(SparklPipeline* p, uint64_t n, const SparklParticleStatus* status, const SparklParticlePosition* pos,
+                                const SparklParticleVelocity* vel, const SparklParticleVolume* volume, const SparklParticlePhase* phase,
+                                const SparklParticleData* data, const SparklVelocityGradient* vg) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    if (n == 0) return SPARKL_OK;
+    if (!status || !pos || !vel || !volume || !phase || !data) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null particle array");
+    HostAll h;
+    CHK(read_all(p, h));
+    h.st.insert(h.st.end(), status, status + n); h.pos.insert(h.pos.end(), pos, pos + n); h.vel.insert(h.vel.end(), vel, vel + n);
+    h.vol.insert(h.vol.end(), volume, volume + n); h.ph.insert(h.ph.end(), phase, phase + n); h.da.insert(h.da.end(), data, data + n);
+    if (vg) h.vg.insert(h.vg.end(), vg, vg + n); else h.vg.resize(h.vg.size() + n, SparklVelocityGradient{{0, 0, 0, 0, 0, 0, 0, 0, 0}});
+    return sparkl_hip_particles_upload(p, h.st.size(), h.st.data(), h.pos.data(), h.vel.data(), h.vol.data(), h.ph.data(), h.da.data(), h.vg.data());
+}
+int sparkl_hip_particles_remove_range(SparklPipeline* p, uint64_t start, uint64_t end) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    if (start > end || end > p->n) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "bad range [%llu, %llu) of %llu", (unsigned long long)start, (unsigned long long)end, (unsigned long long)p->n);
+    if (start == end) return SPARKL_OK;
+    HostAll h;
+    CHK(read_all(p, h));
+    auto cut = [&](auto& v) { v.erase(v.begin() + start, v.begin() + end); };
+    cut(h.st); cut(h.pos); cut(h.vel); cut(h.vol); cut(h.ph); cut(h.da); cut(h.vg);
+    return sparkl_hip_particles_upload(p, h.st.size(), h.st.data(), h.pos.data(), h.vel.data(), h.vol.data(), h.ph.data(), h.da.data(), h.vg.data());
+}
+int sparkl_hip_particles_truncate(SparklPipeline* p, uint64_t new_len) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    if (new_len >= p->n) return SPARKL_OK;
+    return sparkl_hip_particles_remove_range(p, new_len, p->n);
+}
+
+// ------------------------------------------------------------------------------------------ stepping
+static int ensure_ready(SparklPipeline* p) {
+    HIPCHK(hipSetDevice(p->device));
+    CHK(validate_models(p));
+    if (!p->sorted) CHK(resort(p));
+    return SPARKL_OK;
+}
+
+int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* params, const float gravity[3], float dt, uint32_t nsubsteps) {
+    if (!p || !params || !gravity) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    if (p->n == 0 || nsubsteps == 0) return SPARKL_OK;
+    CHK(ensure_ready(p));
+    CHK(read_ctl(p));
+    const uint32_t base_done = p->h_ctl->steps_done;
+    uint32_t done = 0;
+    const uint32_t CHUNK = 32;
+    int guard = 0;
+    while (done < nsubsteps) {
+        const uint32_t batch = std::min(CHUNK, nsubsteps - done);
+        for (uint32_t i = 0; i < batch; ++i) CHK(enqueue_substep(p, params, gravity, dt));
+        CHK(read_ctl(p));
+        if (p->clock_on) CHK(clock_collect(p));
+        const uint32_t now_done = p->num_pblocks ? (p->h_ctl->steps_done - base_done) : done + batch;
+        const bool aborted = now_done < done + batch;
+        done = now_done;
+        if (aborted || p->h_ctl->abort_flag[0] || p->h_ctl->abort_flag[1]) {
+            CHK(resort(p));  // a particle left its tile margin: re-bin, then carry on from `done`
+            if (++guard > (int)nsubsteps * 2 + 16) return set_error(SPARKL_ERR_INTERNAL, "re-bin loop did not make progress");
+        }
+    }
+    p->clock.substeps += nsubsteps;
+    return SPARKL_OK;
+}
+
+int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params, const float gravity[3], SparklTimings* timings, float* simulated_time) {
+    if (!p || !params || !gravity) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    if (timings) memset(timings, 0, sizeof(*timings));
+    // mls_solver.rs:25-28
+    if (p->n == 0 || params->dt == 0.0f) { if (simulated_time) *simulated_time = params->dt; return SPARKL_OK; }
+    CHK(ensure_ready(p));
+    const bool was_clock = p->clock_on;
+    SparklKernelClock saved = p->clock;
+    if (timings) { p->clock_on = true; memset(&p->clock, 0, sizeof(p->clock)); }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timings) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, p->stream)); }
+    const float min_dt = params->dt / (float)params->max_num_substeps;  // mls_solver.rs:33
+    float remaining = params->dt;
+    uint32_t nsub = 0;
+    float result = params->dt;
+    int rc = SPARKL_OK;
+    while (remaining > 0.0f) {
+        // particle bound first (order independent), one host sync per substep as in the reference
+        size_t tok = 0;
+        uint32_t init_bits;
+        const float fmax = std::numeric_limits<float>::max();
+        memcpy(&init_bits, &fmax, 4);
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dt_bits, (int)init_bits, 1, p->stream));
+        CHK(clock_begin(p, SPAN_DT, &tok));
+        hipLaunchKernelGGL(k_estimate_dt, dim3(grid_for(p->n, BLK_THREADS)), dim3(BLK_THREADS), 0, p->stream, p->cur.arrays(), p->d_models.p, p->d_ctl, (int)p->n, p->h);
+        CHK(clock_end(p, tok));
+        CHK(read_ctl(p));
+        if (p->h_ctl->abort_flag[0] || p->h_ctl->abort_flag[1]) CHK(resort(p));
+        if (p->h_ctl->dt_nan) { rc = set_error(SPARKL_ERR_NAN_TIMESTEP, "NaN timestep bound (the reference panics: timestep_estimator.rs:46)"); break; }
+        float bound;
+        memcpy(&bound, &p->h_ctl->dt_bits, 4);
+        float dt = std::fmin(std::fmin(remaining, params->max_substep_dt), bound);  // timestep_estimator.rs:25,35,44
+        if (dt < min_dt && remaining > min_dt) dt = min_dt;                           // mls_solver.rs:57-59
+        CHK(enqueue_substep(p, params, gravity, dt));
+        ++nsub;
+        remaining -= dt;
+        if (params->stop_after_one_substep) { result = dt; break; }
+    }
+    CHK(read_ctl(p));
+    if (p->h_ctl->abort_flag[0] || p->h_ctl->abort_flag[1]) p->sorted = false;  // re-bin lazily at the next call
+    if (timings) {
+        HIPCHK(hipEventRecord(e1, p->stream));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        CHK(clock_collect(p));
+        timings->dt = result; timings->num_substeps = nsub; timings->num_resorts = (uint32_t)p->clock.resorts;
+        timings->grid_resize_and_sort_ms = (float)p->clock.sort_ms; timings->estimate_timestep_ms = (float)p->clock.dt_ms;
+        timings->p2g_ms = (float)p->clock.p2g_ms; timings->grid_update_ms = (float)p->clock.grid_update_ms; timings->g2p_ms = (float)p->clock.g2p_ms;
+        timings->total_ms = ms;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        p->clock = saved; p->clock_on = was_clock;
+    } else if (p->clock_on) {
+        CHK(clock_collect(p));
+        p->clock.substeps += nsub;
+    }
+    if (simulated_time) *simulated_time = result;
+    return rc;
+}
+
+int sparkl_hip_pipeline_clock_enable(SparklPipeline* p, int enable) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    if (p->clock_on) CHK(clock_collect(p));
+    p->clock_on = enable != 0;
+    return SPARKL_OK;
+}
+int sparkl_hip_pipeline_clock_read(SparklPipeline* p, SparklKernelClock* out, int reset) {
+    if (!p || !out) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    if (p->clock_on) CHK(clock_collect(p));
+    *out = p->clock;
+    if (reset) memset(&p->clock, 0, sizeof(p->clock));
+    return SPARKL_OK;
+}
+
+// --------------------------------------------------------------------------------- grid inspection
+uint64_t sparkl_hip_grid_num_active_blocks(SparklPipeline* p) { return p ? (uint64_t)p->num_blocks : 0; }
+uint64_t sparkl_hip_grid_num_particle_blocks(SparklPipeline* p) { return p ? (uint64_t)p->num_pblocks : 0; }
+int sparkl_hip_grid_debug_capture(SparklPipeline* p, int enable) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    p->capture_mom = enable != 0;
+    if (p->capture_mom && p->num_blocks) {
+        CHK(p->node_mom.reserve((size_t)p->num_blocks * 64));
+        HIPCHK(hipMemset(p->node_mom.p, 0, (size_t)p->num_blocks * 64 * sizeof(float4)));
+    }
+    return SPARKL_OK;
+}
+int sparkl_hip_grid_read_nodes(SparklPipeline* p, SparklGridNode* out, uint64_t cap, uint64_t* n_out) {
+    if (!p || !n_out) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    HIPCHK(hipSetDevice(p->device));
+    *n_out = 0;
+    if (p->num_blocks == 0) return SPARKL_OK;
+    const size_t total = (size_t)p->num_blocks * 64;
+    CHK(p->node_staging.reserve(std::max<size_t>(std::min<size_t>(cap, total), 1)));
+    CHK(p->d_count.reserve(1));
+    HIPCHK(hipMemsetAsync(p->d_count.p, 0, sizeof(unsigned long long), p->stream));
+    const unsigned long long dcap = out ? std::min<size_t>(cap, total) : 0;
+    hipLaunchKernelGGL(k_dump_nodes, dim3(grid_for(total, 256)), dim3(256), 0, p->stream, grid_arrays(p), p->node_staging.p, dcap, p->d_count.p);
+    unsigned long long cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, p->d_count.p, sizeof(cnt), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    *n_out = cnt;
+    if (out && cnt) HIPCHK(hipMemcpy(out, p->node_staging.p, std::min<unsigned long long>(cnt, dcap) * sizeof(SparklGridNode), hipMemcpyDeviceToHost));
+    return SPARKL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,160 @@
+"""Host-side mirror of the reference pipeline interface, bound to libsparkl_hip.so through ctypes.
+
+  MpmPipeline.step(params, gravity, ...)   <->  MpmPipeline::step      src/pipelines/mpm_pipeline.rs:15-42
+                                                CudaMpmPipeline::step  src/cuda/cuda_mpm_pipeline.rs:262-271
+  HipParticleSet                           <->  CudaParticleSet        src/cuda/cuda_particle_set.rs:12-177
+  models / colliders upload                <->  CudaParticleModelSet::from_model_set, CudaColliderSet::from_collider_set
+
+The compute is entirely inside the HIP library; this file only marshals arguments.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from ._lib import check, lib
+from .particles import ParticleComponents
+
+
+class MpmPipeline:
+    """One GPU's MPM pipeline (CudaMpmPipeline + SingleGpuMpmContext rolled into an opaque handle)."""
+
+    def __init__(self, cell_width, device_id=0, domain_log2_bytes=30, stream=None):
+        self.L = lib()
+        desc = abi.PipelineDescC(device_id, cell_width, domain_log2_bytes, stream)
+        h = C.c_void_p()
+        check(self.L.sparkl_hip_pipeline_create(C.byref(desc), C.byref(h)))
+        self.h = h
+        self.cell_width = cell_width
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sparkl_hip_pipeline_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- CudaParticleModelSet / CudaColliderSet
+    def set_models(self, model_set):
+        check(self.L.sparkl_hip_models_set(self.h, C.c_uint32(len(model_set)), model_set.to_c_array()))
+
+    def set_colliders(self, cuboids):
+        arr = (abi.CuboidColliderC * max(len(cuboids), 1))(*cuboids)
+        check(self.L.sparkl_hip_colliders_set_cuboids(self.h, C.c_uint32(len(cuboids)), arr))
+
+    # ---- CudaParticleSet
+    def _args(self, c):
+        return (C.c_uint64(len(c)), abi.ptr(c.status, abi.STATUS_DTYPE), abi.ptr(c.position, abi.POSITION_DTYPE),
+                abi.ptr(c.velocity, abi.VELOCITY_DTYPE), abi.ptr(c.volume, abi.VOLUME_DTYPE), abi.ptr(c.phase, abi.PHASE_DTYPE),
+                abi.ptr(c.data, abi.DATA_DTYPE), abi.ptr(c.velocity_gradient, abi.VELGRAD_DTYPE))
+
+    def upload_particles(self, comps):
+        """`CudaParticleSet::from_particles` on `extract_particles_components(..)` output."""
+        check(self.L.sparkl_hip_particles_upload(self.h, *self._args(comps)))
+
+    def append_particles(self, comps):
+        check(self.L.sparkl_hip_particles_append(self.h, *self._args(comps)))
+
+    def remove_range(self, start, end):
+        check(self.L.sparkl_hip_particles_remove_range(self.h, C.c_uint64(start), C.c_uint64(end)))
+
+    def truncate(self, new_len):
+        check(self.L.sparkl_hip_particles_truncate(self.h, C.c_uint64(new_len)))
+
+    def __len__(self):
+        return int(self.L.sparkl_hip_particles_len(self.h))
+
+    def _read(self, fn, dtype):
+        n = len(self)
+        out = np.zeros(n, dtype)
+        check(fn(self.h, out.ctypes.data_as(C.c_void_p), C.c_uint64(n)))
+        return out
+
+    def read_positions(self):
+        return self._read(self.L.sparkl_hip_particles_read_positions, abi.POSITION_DTYPE)
+
+    def read_velocities(self):
+        return self._read(self.L.sparkl_hip_particles_read_velocities, abi.VELOCITY_DTYPE)
+
+    def read_volumes(self):
+        return self._read(self.L.sparkl_hip_particles_read_volumes, abi.VOLUME_DTYPE)
+
+    def read_statuses(self):
+        return self._read(self.L.sparkl_hip_particles_read_statuses, abi.STATUS_DTYPE)
+
+    def read_phases(self):
+        return self._read(self.L.sparkl_hip_particles_read_phases, abi.PHASE_DTYPE)
+
+    def read_data(self):
+        return self._read(self.L.sparkl_hip_particles_read_data, abi.DATA_DTYPE)
+
+    def read_velocity_gradients(self):
+        return self._read(self.L.sparkl_hip_particles_read_velocity_gradients, abi.VELGRAD_DTYPE)
+
+    def read_sorted_particle_ids(self):
+        return self._read(self.L.sparkl_hip_particles_read_sorted_ids, np.dtype("<u4"))
+
+    def read_particles(self):
+        c = ParticleComponents(0)
+        c.status, c.position, c.velocity = self.read_statuses(), self.read_positions(), self.read_velocities()
+        c.volume, c.phase, c.data = self.read_volumes(), self.read_phases(), self.read_data()
+        c.velocity_gradient = self.read_velocity_gradients()
+        return c
+
+    def load_scene(self, scene):
+        self.set_models(scene.models)
+        self.set_colliders(scene.colliders)
+        self.upload_particles(scene.particles)
+
+    # ---- stepping
+    def step(self, params, gravity, timings=False):
+        """`MpmPipeline::step` / `CudaMpmPipeline::step`: advance by params.dt, return the simulated time."""
+        g = (C.c_float * 3)(*[float(x) for x in gravity])
+        t = abi.TimingsC() if timings else None
+        sim = C.c_float(0.0)
+        check(self.L.sparkl_hip_pipeline_step(self.h, C.byref(params), g, C.byref(t) if timings else None, C.byref(sim)))
+        return (sim.value, t) if timings else sim.value
+
+    def substeps(self, params, gravity, dt, n):
+        """n fixed-length substeps without host synchronisation inside (extension, see the header)."""
+        g = (C.c_float * 3)(*[float(x) for x in gravity])
+        check(self.L.sparkl_hip_pipeline_substeps(self.h, C.byref(params), g, C.c_float(dt), C.c_uint32(n)))
+
+    def sync(self):
+        check(self.L.sparkl_hip_pipeline_sync(self.h))
+
+    def clock_enable(self, on=True):
+        check(self.L.sparkl_hip_pipeline_clock_enable(self.h, int(on)))
+
+    def clock_read(self, reset=True):
+        k = abi.KernelClockC()
+        check(self.L.sparkl_hip_pipeline_clock_read(self.h, C.byref(k), int(reset)))
+        return k
+
+    # ---- sparse grid inspection
+    def num_active_blocks(self):
+        return int(self.L.sparkl_hip_grid_num_active_blocks(self.h))
+
+    def num_particle_blocks(self):
+        return int(self.L.sparkl_hip_grid_num_particle_blocks(self.h))
+
+    def grid_debug_capture(self, on=True):
+        check(self.L.sparkl_hip_grid_debug_capture(self.h, int(on)))
+
+    def read_grid_nodes(self):
+        n = C.c_uint64(0)
+        check(self.L.sparkl_hip_grid_read_nodes(self.h, None, C.c_uint64(0), C.byref(n)))
+        out = np.zeros(n.value, abi.GRID_NODE_DTYPE)
+        if n.value:
+            check(self.L.sparkl_hip_grid_read_nodes(self.h, abi.ptr(out, abi.GRID_NODE_DTYPE), C.c_uint64(n.value), C.byref(n)))
+        return out

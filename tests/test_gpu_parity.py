@@ -1,0 +1,211 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Tolerance (BASELINE.json north_star): <= 1e-4 relative particle-state divergence after 100 substeps,
+position in units of h, velocity relative to max |v_ref| (SURVEY 8(d) "Parity metric").
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from sparkl_amd import abi, scenes
+from tests.parity import node_errors, particle_errors
+
+pytestmark = pytest.mark.gpu
+TOL = 1.0e-4
+
+
+@pytest.fixture(scope="module")
+def Pipeline():
+    from sparkl_amd.pipeline import MpmPipeline
+    return MpmPipeline
+
+
+def _oracle(scene, f64=False):
+    from oracle import Oracle
+    o = Oracle(scene.cell_width, f64=f64, domain_log2_bytes=scene.domain_log2_bytes, threads=os.cpu_count() or 1)
+    o.load_scene(scene)
+    return o
+
+
+def _report(name, d):
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "parity.jsonl"), "a") as f:
+        f.write(json.dumps({"test": name, **d}) + "\n")
+    print(name, json.dumps(d))
+
+
+def test_readback_is_caller_order(Pipeline):
+    sc = scenes.sand_column(12, 10, 8, with_block=True)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        # force a re-bin without stepping: zero-length call is a no-op, so run one substep with dt = 0
+        p.substeps(sc.params, (0, 0, 0), 0.0, 1)
+        got = p.read_particles()
+        ids = p.read_sorted_particle_ids()
+    assert sorted(ids.tolist()) == list(range(len(sc.particles)))
+    assert (ids != np.arange(len(ids))).any(), "particles should have been physically re-ordered"
+    np.testing.assert_array_equal(got.position["point"], sc.particles.position["point"])
+    np.testing.assert_array_equal(got.volume["mass"], sc.particles.volume["mass"])
+    np.testing.assert_array_equal(got.volume["radius0"], sc.particles.volume["radius0"])
+    np.testing.assert_array_equal(got.status["model_index"], sc.particles.status["model_index"])
+    np.testing.assert_array_equal(got.data["elastic_hardening"], sc.particles.data["elastic_hardening"])
+    np.testing.assert_array_equal(got.data["nacc_alpha"], sc.particles.data["nacc_alpha"])
+
+
+def test_p2g_and_grid_update_match_oracle(Pipeline):
+    """One substep: node mass / momentum / velocity of every active node (P2G + grid update incl. floor)."""
+    sc = scenes.sand_column(20, 12, 16, with_block=True)
+    # give the cloud a non-trivial velocity / affine field so every P2G term is exercised
+    rng = np.random.default_rng(7)
+    sc.particles.velocity["vector"] = rng.normal(0, 0.5, (len(sc.particles), 3)).astype(np.float32)
+    sc.particles.velocity["vector"][:, 1] -= 1.0
+    sc.particles.velocity_gradient["m"] = rng.normal(0, 2.0, (len(sc.particles), 9)).astype(np.float32)
+    F = np.eye(3, dtype=np.float32).reshape(1, 9) + rng.normal(0, 0.02, (len(sc.particles), 9)).astype(np.float32)
+    sc.particles.volume["deformation_gradient"] = F
+    dt = 2.5e-4
+    o = _oracle(sc)
+    o.sort(); o.p2g(dt, sc.gravity); o.grid_update(dt, sc.params.boundary_handling, 0)
+    ref = o.nodes()
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.grid_debug_capture(True)
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, dt, 1)
+        got = p.read_grid_nodes()
+        npb, nb = p.num_particle_blocks(), p.num_active_blocks()
+    e = node_errors(got, ref)
+    e.update(num_particle_blocks=npb, num_blocks=nb, oracle_particle_regions=o.num_particle_regions(), oracle_regions=o.num_regions())
+    _report("p2g_grid", e)
+    assert e["n_got"] == e["n_ref"] == e["n_common"]
+    assert npb == o.num_particle_regions()
+    assert e["mass_rel"] < 2e-6 and e["momentum_rel"] < 2e-5 and e["velocity_rel"] < 2e-5
+
+
+@pytest.mark.parametrize("name,builder,dt", [
+    ("sand3_like", lambda: scenes.sand_column(24, 12, 16, with_block=True), 2.5e-4),
+    ("neo_hookean", lambda: scenes.elastic_cube(24), 1.0e-4),
+    ("fluid", lambda: scenes.fluid_dam(40, 32, 24), 1.0e-4),
+])
+def test_particle_state_parity_100_substeps(Pipeline, name, builder, dt):
+    sc = builder()
+    o32, o64 = _oracle(sc), _oracle(sc, f64=True)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        done = 0
+        for k in (1, 10, 100):
+            for _ in range(k - done):
+                o32.substep_fixed(sc.params, sc.gravity, dt)
+                o64.substep_fixed(sc.params, sc.gravity, dt)
+            p.substeps(sc.params, sc.gravity, dt, k - done)
+            done = k
+            got, r32, r64 = p.read_particles(), o32.get_particles(), o64.get_particles()
+            e = particle_errors(got, r32, sc.cell_width)
+            e64 = particle_errors(got, r64, sc.cell_width)
+            floor = particle_errors(r32, r64, sc.cell_width)
+            _report(f"parity_{name}_k{k}", {"vs_f32": e, "vs_f64": e64, "oracle_f32_vs_f64": floor})
+            assert e["failed_mismatch"] == 0
+            assert e["eps_x"] <= TOL, (k, e)
+            assert e["eps_v"] <= TOL or e["eps_v"] <= 3 * floor["eps_v"], (k, e, floor)
+            assert np.isfinite(got.position["point"]).all()
+
+
+def test_adaptive_step_matches_oracle(Pipeline):
+    """`MpmPipeline::step` with dt = 1/60: same substep count and lengths as the CPU path (mls_solver.rs:33-59)."""
+    sc = scenes.sand_column(16, 10, 12, with_block=True)
+    o = _oracle(sc)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        for frame in range(2):
+            t_ref = o.step(sc.params, sc.gravity)
+            t_got, tim = p.step(sc.params, sc.gravity, timings=True)
+            assert t_got == pytest.approx(t_ref, rel=1e-7)
+            assert tim.num_substeps == len(o.last_dts())
+        e = particle_errors(p.read_particles(), o.get_particles(), sc.cell_width)
+    _report("adaptive_step", e)
+    assert e["eps_x"] <= TOL and e["eps_v"] <= TOL
+
+
+def test_rebin_keeps_parity_and_ids(Pipeline):
+    """A fast spinning cube crosses block boundaries: the re-bin must trigger and change nothing physically."""
+    sc = scenes.elastic_cube(16)
+    sc.particles.velocity["vector"] *= 40.0
+    dt = 2.0e-4
+    o = _oracle(sc)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.clock_enable(True)
+        for _ in range(60):
+            o.substep_fixed(sc.params, sc.gravity, dt)
+        p.substeps(sc.params, sc.gravity, dt, 60)
+        k = p.clock_read()
+        ids = p.read_sorted_particle_ids()
+        e = particle_errors(p.read_particles(), o.get_particles(), sc.cell_width)
+    _report("rebin", {**e, "resorts": int(k.resorts), "substeps": int(k.substeps)})
+    assert k.resorts >= 2, "expected at least one re-bin beyond the initial one"
+    assert sorted(ids.tolist()) == list(range(len(sc.particles)))
+    assert e["eps_x"] <= TOL and e["eps_v"] <= TOL
+
+
+def test_append_remove_roundtrip(Pipeline):
+    sc = scenes.sand_column(8, 6, 8)
+    extra = scenes.sand_column(4, 4, 4).particles
+    with Pipeline(sc.cell_width) as p:
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, 2.5e-4, 3)
+        before = p.read_particles()
+        n0 = len(p)
+        p.append_particles(extra)
+        assert len(p) == n0 + len(extra)
+        p.remove_range(n0, n0 + len(extra))
+        after = p.read_particles()
+        assert len(p) == n0
+    np.testing.assert_array_equal(before.position["point"], after.position["point"])
+    np.testing.assert_array_equal(before.volume["deformation_gradient"], after.volume["deformation_gradient"])
+
+
+def test_out_of_domain_particles_fail_like_reference(Pipeline):
+    """particle_set.rs:129-136: a particle whose neighbourhood leaves the SPGrid is flagged failed."""
+    sc = scenes.sand_column(8, 6, 8)
+    sc.particles.position["point"][0] = [0.05, 1.0, 1.0]      # rounds to cell 0 -> underflow
+    sc.particles.position["point"][1] = [255 * 0.2, 1.0, 1.0]  # beyond the 256-cell domain
+    with Pipeline(sc.cell_width) as p:
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, 2.5e-4, 2)
+        st = p.read_statuses()
+        pos = p.read_positions()
+    assert st["failed"][0] == 1 and st["failed"][1] == 1 and st["failed"][2:].sum() == 0
+    np.testing.assert_array_equal(pos["point"][:2], sc.particles.position["point"][:2])  # frozen
+
+
+def test_unsupported_models_are_rejected(Pipeline):
+    from sparkl_amd._lib import SparklHipError
+    from sparkl_amd.models import ParticleModelSet
+
+    class Custom:
+        def to_core_model(self):
+            m = abi.ConstitutiveModelC(); m.tag = abi.CONSTITUTIVE_CUSTOM; m.u.custom_id = 3
+            return m
+    ms = ParticleModelSet()
+    from sparkl_amd.models import ParticleModel
+    ms.insert(ParticleModel.new(Custom()))
+    with Pipeline(0.2) as p:
+        with pytest.raises(SparklHipError) as e:
+            p.set_models(ms)
+        assert e.value.code == 2
+
+
+def test_conservation_at_scale(Pipeline):
+    """Size-independent properties on a 1M-particle cloud: P2G conserves mass and linear momentum."""
+    sc = scenes.elastic_cube(100)
+    m = sc.particles.volume["mass"].astype(np.float64)
+    mom = (m[:, None] * sc.particles.velocity["vector"].astype(np.float64)).sum(0)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.grid_debug_capture(True)
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, 1e-4, 1)
+        nodes = p.read_grid_nodes()
+    assert abs(nodes["mass"].astype(np.float64).sum() - m.sum()) / m.sum() < 1e-5
+    # stress of F = I is zero, so node momentum == scattered particle momentum
+    scale = np.abs(m[:, None] * sc.particles.velocity["vector"]).sum()
+    assert np.abs(nodes["momentum"].astype(np.float64).sum(0) - mom).max() / scale < 1e-5
