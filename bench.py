@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/s of the MI355X MPM hot path on BASELINE.json's 10M-particle Drucker-Prager column.
+
+One "step" = one substep (P2G -> grid update -> G2P, re-bin when a particle leaves its tile margin) of fixed
+length dt = 2.5e-4 on synthetic, HBM-resident particles.  Prints ONE JSON line.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--particles P] [--no-cpu-baseline]
+N > 1 is launched by torch.distributed.run (one rank per GPU); see DESIGN.md "Multi-GPU".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# algorithmic bytes: per particle and per active node, by kernel
+BYTES = {
+    "sand": {"p2g": 112, "g2p_r": 64, "g2p_w": 108},
+    "elastic": {"p2g": 112, "g2p_r": 52, "g2p_w": 96},
+    "fluid": {"p2g": 76, "g2p_r": 20, "g2p_w": 64},
+}
+NODE_BYTES = {"p2g": 16, "grid_update": 28, "g2p": 12}
+
+
+def column_dims(n_particles):
+    """200 x 250 x 200 at 10M (SURVEY config 3), scaled isotropically otherwise."""
+    f = (n_particles / 10.0e6) ** (1.0 / 3.0)
+    return max(8, int(round(200 * f))), max(8, int(round(250 * f))), max(8, int(round(200 * f)))
+
+
+def cpu_baseline(threads, seconds_budget=20.0):
+    """The oracle (restated sparkl CPU path, f32, OpenMP) on a bounded sample of the same workload."""
+    from sparkl_amd import scenes
+    from oracle import Oracle
+    nx, ny, nz = column_dims(400_000)
+    sc = scenes.sand_column(nx, ny, nz, name="cpu_sample")
+    o = Oracle(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes, threads=threads)
+    o.load_scene(sc)
+    o.substep_fixed(sc.params, sc.gravity, sc.fixed_dt)  # first touch of the mmap'd grid
+    t1 = o.timed_substeps(sc.params, sc.gravity, sc.fixed_dt, 1)
+    nsub = int(max(2, min(50, seconds_budget / max(t1, 1e-3))))
+    t = o.timed_substeps(sc.params, sc.gravity, sc.fixed_dt, nsub)
+    n = len(sc.particles)
+    o.close()
+    return {"value": n * nsub / t, "unit": "particle-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{n}-particle Drucker-Prager column ({nx}x{ny}x{nz}), {nsub} substeps of dt=2.5e-4, f32 oracle (oracle/mpm_oracle.hpp), OpenMP"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--particles", type=float, default=10.0e6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-clock", action="store_true", help="skip the per-kernel hipEvent spans")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+
+    from sparkl_amd import scenes
+    from sparkl_amd.pipeline import MpmPipeline
+
+    # weak scaling: every rank advances its own column of `particles` (replicas until slab halo lands)
+    nx, ny, nz = column_dims(args.particles)
+    t0 = time.time()
+    sc = scenes.sand_column(nx, ny, nz, name="config3_drucker_prager_column")
+    n_particles = len(sc.particles)
+    gen_s = time.time() - t0
+    pipe = MpmPipeline(sc.cell_width, device_id=local_rank, domain_log2_bytes=sc.domain_log2_bytes)
+    t0 = time.time()
+    pipe.load_scene(sc)
+    upload_s = time.time() - t0
+    dt = sc.fixed_dt
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        pipe.sync()
+
+    pipe.substeps(sc.params, sc.gravity, dt, args.warmup)
+    if not args.no_kernel_clock:
+        pipe.clock_enable(True)
+        pipe.clock_read(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    pipe.substeps(sc.params, sc.gravity, dt, args.steps)   # EXACTLY K substeps; synchronises at the end
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    clock = None if args.no_kernel_clock else pipe.clock_read(reset=False)
+    n_blocks, n_pblocks = pipe.num_active_blocks(), pipe.num_particle_blocks()
+
+    if rank == 0:
+        total_particles = n_particles * world
+        value = total_particles * args.steps / elapsed
+        nodes = n_blocks * 64
+        b = BYTES["sand"]
+        per_kernel_bytes = {
+            "p2g": n_particles * b["p2g"] + nodes * NODE_BYTES["p2g"],
+            "grid_update": nodes * NODE_BYTES["grid_update"],
+            "g2p": n_particles * (b["g2p_r"] + b["g2p_w"]) + nodes * NODE_BYTES["g2p"],
+        }
+        step_bytes = sum(per_kernel_bytes.values())
+        out = {
+            "metric": "particle-steps/sec (whole node) + achieved HBM GB/s, 3D sand 10M particles",
+            "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"3D Drucker-Prager sand column collapse, {n_particles} particles/GPU ({nx}x{ny}x{nz} lattice, 8 ppc, h=0.2, "
+                                   f"E=1e7 nu=0.2 rho=2700, cuboid friction floor), fixed dt={dt}", "particles_per_gpu": n_particles,
+                       "active_node_blocks": n_blocks, "particle_blocks": n_pblocks,
+                       "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (slab halo exchange not enabled)"},
+            "step_gbs": step_bytes * world / (elapsed / args.steps) / 1e9,
+            "step_frac_of_hbm_peak": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+            "setup_s": {"generate": gen_s, "upload_and_pack": upload_s},
+        }
+        if clock is not None and clock.substeps > 0:
+            k = {"p2g": clock.p2g_ms, "grid_update": clock.grid_update_ms, "g2p": clock.g2p_ms}
+            launches = args.steps
+            avg_ms = {name: ms / launches for name, ms in k.items()}
+            dom = max(avg_ms, key=avg_ms.get)
+            achieved = per_kernel_bytes[dom] / (avg_ms[dom] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": {"p2g": "k_p2g", "g2p": "k_g2p", "grid_update": "k_grid_update"}[dom],
+                               "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "algorithmic_bytes_per_launch": per_kernel_bytes[dom], "avg_launch_ms": avg_ms[dom]}
+            out["kernels_ms_per_step"] = avg_ms
+            out["kernels_gbs"] = {name: per_kernel_bytes[name] / (avg_ms[name] * 1e-3) / 1e9 for name in avg_ms if avg_ms[name] > 0}
+            out["resort"] = {"count": int(clock.resorts), "ms_total": clock.sort_ms}
+        if not args.no_cpu_baseline:
+            threads = len(os.sched_getaffinity(0))
+            out["cpu_baseline"] = cpu_baseline(threads)
+        print(json.dumps(out))
+    pipe.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

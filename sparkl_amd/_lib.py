@@ -6,7 +6,7 @@ import subprocess
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsparkl_hip.so")
+LIB_PATH = os.environ.get("SPARKL_HIP_LIB") or os.path.join(_HERE, "lib", "libsparkl_hip.so")  # env override: A/B builds of the same HIP library
 _LIB = None
 
 # every symbol include/sparkl_hip.h declares (tests/test_abi_layout.py cross-checks against the header text)

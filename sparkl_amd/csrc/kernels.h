@@ -175,11 +175,18 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
             // m_o: lanes L .. L+o form one contiguous same-key run inside the 16-lane row
             bool m1, m2, m4, m8;
             {
+                // NB: every shuffle is executed by ALL lanes first (no `&&` short-circuit around a shuffle:
+                // ds_bpermute from a lane that is masked off returns garbage).
                 const int r = lane & 15;
-                m1 = (r + 1 < 16) && (__shfl_down(cell_key, 1) == cell_key);
-                m2 = m1 && (r + 2 < 16) && (__shfl_down((int)m1, 1) != 0);
-                m4 = m2 && (r + 4 < 16) && (__shfl_down((int)m2, 2) != 0);
-                m8 = m4 && (r + 8 < 16) && (__shfl_down((int)m4, 4) != 0);
+                const int k1 = __shfl_down(cell_key, 1);
+                const int i1 = ((r + 1 < 16) & (k1 == cell_key)) ? 1 : 0;
+                const int s1 = __shfl_down(i1, 1);
+                const int i2 = (i1 & s1 & (r + 2 < 16 ? 1 : 0));
+                const int s2 = __shfl_down(i2, 2);
+                const int i4 = (i2 & s2 & (r + 4 < 16 ? 1 : 0));
+                const int s4 = __shfl_down(i4, 4);
+                const int i8 = (i4 & s4 & (r + 8 < 16 ? 1 : 0));
+                m1 = i1 != 0; m2 = i2 != 0; m4 = i4 != 0; m8 = i8 != 0;
             }
 #pragma unroll
             for (int sz = 0; sz < 3; ++sz)

