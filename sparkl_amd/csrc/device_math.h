@@ -79,16 +79,22 @@ struct Svd3 {
     float s[3];  // sigma >= 0
 };
 
-SPK_DEV void jacobi_pair(float* wp, float* wq, float* vp, float* vq) {
+// fast reciprocal / rsqrt / sqrt (1 ulp hardware ops): a Jacobi rotation only has to be *nearly* optimal,
+// and c^2 + s^2 = 1 holds to ~1e-7, which keeps V orthogonal to f32 resolution.
+SPK_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+SPK_DEV float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+SPK_DEV float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+// returns |t| (tangent of the rotation): ~ size of the remaining off-diagonal coupling
+SPK_DEV float jacobi_pair(float* wp, float* wq, float* vp, float* vq) {
     const float alpha = wp[0] * wp[0] + wp[1] * wp[1] + wp[2] * wp[2];
     const float beta = wq[0] * wq[0] + wq[1] * wq[1] + wq[2] * wq[2];
     const float gamma = wp[0] * wq[0] + wp[1] * wq[1] + wp[2] * wq[2];
-    // rotation angle; t = 0 when the pair is already orthogonal to f32 resolution
-    float c = 1.f, s = 0.f;
-    if (fabsf(gamma) > 1.0e-9f * sqrtf(alpha * beta)) {
-        const float zeta = (beta - alpha) / (2.f * gamma);
-        const float t = copysignf(1.f, zeta) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
-        c = rsqrtf(1.f + t * t);
+    float c = 1.f, s = 0.f, t = 0.f;
+    if (gamma * gamma > 1.0e-18f * (alpha * beta)) {
+        const float zeta = (beta - alpha) * fast_rcp(2.f * gamma);
+        t = copysignf(1.f, zeta) * fast_rcp(fabsf(zeta) + fast_sqrt(1.f + zeta * zeta));
+        c = fast_rsq(1.f + t * t);
         s = c * t;
     }
 #pragma unroll
@@ -100,25 +106,28 @@ SPK_DEV void jacobi_pair(float* wp, float* wq, float* vp, float* vq) {
         vp[i] = c * va - s * vb;
         vq[i] = s * va + c * vb;
     }
+    return fabsf(t);
 }
 
-template <int SWEEPS>
+// Cyclic one-sided Jacobi with a wave-uniform early exit: a sweep whose largest rotation tangent is
+// below 2e-4 leaves couplings ~ t^2 < 1e-7, i.e. converged in f32.  F near identity needs 2-3 sweeps.
+template <int MAX_SWEEPS>
 SPK_DEV Svd3 svd3(const M3& a) {
     Svd3 r;
     r.w = a;
     r.v = m3_identity();
-#pragma unroll
-    for (int sweep = 0; sweep < SWEEPS; ++sweep) {
-        jacobi_pair(r.w.m + 0, r.w.m + 3, r.v.m + 0, r.v.m + 3);
-        jacobi_pair(r.w.m + 0, r.w.m + 6, r.v.m + 0, r.v.m + 6);
-        jacobi_pair(r.w.m + 3, r.w.m + 6, r.v.m + 3, r.v.m + 6);
+    for (int sweep = 0; sweep < MAX_SWEEPS; ++sweep) {
+        float t = jacobi_pair(r.w.m + 0, r.w.m + 3, r.v.m + 0, r.v.m + 3);
+        t = fmaxf(t, jacobi_pair(r.w.m + 0, r.w.m + 6, r.v.m + 0, r.v.m + 6));
+        t = fmaxf(t, jacobi_pair(r.w.m + 3, r.w.m + 6, r.v.m + 3, r.v.m + 6));
+        if (!__any(t > 2.0e-4f)) break;
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) r.s[j] = sqrtf(r.w.m[3 * j] * r.w.m[3 * j] + r.w.m[3 * j + 1] * r.w.m[3 * j + 1] + r.w.m[3 * j + 2] * r.w.m[3 * j + 2]);
+    for (int j = 0; j < 3; ++j) r.s[j] = fast_sqrt(r.w.m[3 * j] * r.w.m[3 * j] + r.w.m[3 * j + 1] * r.w.m[3 * j + 1] + r.w.m[3 * j + 2] * r.w.m[3 * j + 2]);
     return r;
 }
 #ifndef SPK_SVD_SWEEPS
-#define SPK_SVD_SWEEPS 5
+#define SPK_SVD_SWEEPS 8
 #endif
 
 // sum_j g_j * w_j v_j^T  ==  U diag(g_j * sigma_j) V^T
@@ -150,23 +159,48 @@ SPK_DEV float powi_f(float x, int n) {
     return r;
 }
 
-// tau for the elastic models; `d` is the SVD of F (only needed for corotated)
+// Rotation factor of F (polar decomposition) by Newton's iteration R <- (R + R^-T) / 2.
+// Quadratically convergent and self-correcting; 3-4 iterations for MPM-sized strains.
+SPK_DEV M3 polar_rotation(const M3& F) {
+    M3 R = F;
+    for (int it = 0; it < 12; ++it) {
+        // cofactor matrix = det * R^-T; columns are cross products of R's columns
+        M3 cof;
+        cof.m[0] = R.m[4] * R.m[8] - R.m[5] * R.m[7]; cof.m[1] = R.m[5] * R.m[6] - R.m[3] * R.m[8]; cof.m[2] = R.m[3] * R.m[7] - R.m[4] * R.m[6];
+        cof.m[3] = R.m[7] * R.m[2] - R.m[8] * R.m[1]; cof.m[4] = R.m[8] * R.m[0] - R.m[6] * R.m[2]; cof.m[5] = R.m[6] * R.m[1] - R.m[7] * R.m[0];
+        cof.m[6] = R.m[1] * R.m[5] - R.m[2] * R.m[4]; cof.m[7] = R.m[2] * R.m[3] - R.m[0] * R.m[5]; cof.m[8] = R.m[0] * R.m[4] - R.m[1] * R.m[3];
+        const float det = R.m[0] * cof.m[0] + R.m[1] * cof.m[1] + R.m[2] * cof.m[2];
+        const float hid = 0.5f * fast_rcp(det);
+        float delta = 0.f;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            const float n = 0.5f * R.m[e] + hid * cof.m[e];
+            delta = fmaxf(delta, fabsf(n - R.m[e]));
+            R.m[e] = n;
+        }
+        if (!__any(delta > 3.0e-4f)) break;  // next update would be ~delta^2 < 1e-7
+    }
+    return R;
+}
+
+// tau for the corotated model.  phase == 1 (every particle unless a damage model is active) only needs
+// the rotation R: U (S - I) V^T = F - R.
 SPK_DEV M3 corotated_kirchhoff(const DevModel& mo, float phase, float hardening, const M3& F) {
     const float j = m3_det(F);
-    const Svd3 d = svd3<SPK_SVD_SWEEPS>(F);
     const float sph = mo.lambda * hardening * (j - 1.f) * j;
     M3 tau;
     if (phase == 1.f) {
-        float g[3];
+        const M3 R = polar_rotation(F);
+        M3 m;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) g[k] = (d.s[k] - 1.f) * inv_exact(d.s[k]);  // (sigma-1)/sigma applied to w = u sigma
-        const M3 m = svd_compose_scaled(d, g);
+        for (int i = 0; i < 9; ++i) m.m[i] = F.m[i] - R.m[i];
         tau = m3_mul_bt(m, F);
         const float k2 = 2.f * mo.mu * hardening;
 #pragma unroll
         for (int i = 0; i < 9; ++i) tau.m[i] *= k2;
         tau.m[0] += sph; tau.m[4] += sph; tau.m[8] += sph;
     } else {
+        const Svd3 d = svd3<SPK_SVD_SWEEPS>(F);
         float gp[3], gn[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -258,9 +292,28 @@ SPK_DEV float model_timestep_bound(const DevModel& mo, float mass, float volume0
     return sound_speed_bound(mo.cfl_coeff, bulk * eh, mo.mu * eh, mass / volume0, sqrtf(vn2), h);
 }
 
+// ln(s) for s near 1 through 2 atanh((s-1)/(s+1)): relative error ~3e-8 for |s-1| < 0.3
+SPK_DEV float log_near_one(float sgm) {
+    const float e = sgm - 1.f;
+    if (fabsf(e) < 0.3f) {
+        const float z = e * fast_rcp(sgm + 1.f), z2 = z * z;
+        return 2.f * z * (1.f + z2 * (1.f / 3.f + z2 * (1.f / 5.f + z2 * (1.f / 7.f + z2 * (1.f / 9.f)))));
+    }
+    return logf(sgm);
+}
+
+// sin(x) by its Taylor series to x^13 on |x| < 1.6 (friction angles), libm otherwise
+SPK_DEV float sin_small(float x) {
+    if (fabsf(x) < 1.6f) {
+        const float x2 = x * x;
+        return x * (1.f + x2 * (-1.f / 6.f + x2 * (1.f / 120.f + x2 * (-1.f / 5040.f + x2 * (1.f / 362880.f + x2 * (-1.f / 39916800.f + x2 * (1.f / 6227020800.f)))))));
+    }
+    return sinf(x);
+}
+
 SPK_DEV float dp_alpha(const DevModel& mo, float q) {
-    const float angle = mo.h0 + (mo.h1 * q - mo.h3) * expf(-mo.h2 * q);
-    const float s = sinf(angle);
+    const float angle = mo.h0 + (mo.h1 * q - mo.h3) * __expf(-mo.h2 * q);
+    const float s = sin_small(angle);
     return sqrtf(2.f / 3.f) * (2.f * s) / (3.f - s);
 }
 
@@ -275,10 +328,10 @@ SPK_DEV void dp_update(const DevModel& mo, float phase, M3& F, float& Jp, float&
     const float alpha = dp_alpha(mo, q);
     float strain[3], dev[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) strain[i] = logf(d.s[i]) + lvg / 3.f;
+    for (int i = 0; i < 3; ++i) strain[i] = log_near_one(d.s[i]) + lvg * (1.f / 3.f);
     const float tr = strain[0] + strain[1] + strain[2];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) dev[i] = strain[i] - tr / 3.f;
+    for (int i = 0; i < 3; ++i) dev[i] = strain[i] - tr * (1.f / 3.f);
     float nsv[3], dq;
     if ((dev[0] == 0.f && dev[1] == 0.f && dev[2] == 0.f) || tr > 0.f) {
         nsv[0] = nsv[1] = nsv[2] = 1.f;
@@ -287,30 +340,31 @@ SPK_DEV void dp_update(const DevModel& mo, float phase, M3& F, float& Jp, float&
         const float dn = sqrtf(dev[0] * dev[0] + dev[1] * dev[1] + dev[2] * dev[2]);
         const float gamma = dn + (3.f * mo.p_lambda + 2.f * mo.p_mu) / (2.f * mo.p_mu) * tr * alpha;
         if (gamma <= 0.f) return;  // inside the yield surface
+        const float gdn = gamma * fast_rcp(dn);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) nsv[i] = expf(strain[i] - gamma * (dev[i] / dn));
+        for (int i = 0; i < 3; ++i) nsv[i] = __expf(strain[i] - gdn * dev[i]);
         dq = gamma;
     }
     const float prev_det = d.s[0] * d.s[1] * d.s[2];
     float new_det = nsv[0] * nsv[1] * nsv[2];
     const float diff = new_det - prev_det;
     new_det = diff > 0.f ? new_det : prev_det + diff * mo.volume_correction;
-    Jp *= prev_det / new_det;
-    lvg += logf(prev_det) - logf(new_det);
+    Jp *= prev_det * fast_rcp(new_det);
+    lvg += log_near_one(prev_det) - log_near_one(new_det);
     q += dq;
     float g[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) g[i] = nsv[i] * inv_exact(d.s[i]);
+    for (int i = 0; i < 3; ++i) g[i] = d.s[i] == 0.f ? 0.f : nsv[i] * fast_rcp(d.s[i]);
     F = svd_compose_scaled(d, g);
     sv[0] = nsv[0]; sv[1] = nsv[1]; sv[2] = nsv[2];
 }
 
 // constitutive_model.pos_energy(particle)
-SPK_DEV float model_pos_energy(const DevModel& mo, float phase, float eh, const M3& F, const float* sv_or_null) {
+SPK_DEV float model_pos_energy(const DevModel& mo, float phase, float eh, const M3& F, const float sv[3], bool sv_valid) {
     if (mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR) {
         const float j = m3_det(F);
         float s[3];
-        if (sv_or_null) { s[0] = sv_or_null[0]; s[1] = sv_or_null[1]; s[2] = sv_or_null[2]; }
+        if (sv_valid) { s[0] = sv[0]; s[1] = sv[1]; s[2] = sv[2]; }
         else { const Svd3 d = svd3<SPK_SVD_SWEEPS>(F); s[0] = d.s[0]; s[1] = d.s[1]; s[2] = d.s[2]; }
         float nsq = 0.f;
 #pragma unroll

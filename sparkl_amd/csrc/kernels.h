@@ -92,24 +92,52 @@ SPK_DEV int xcd_remap(int bid, int n) {
     return (bid & 7) * per + (bid >> 3);
 }
 
-SPK_DEV int cell_of(float x, float h) { return (int)roundf(x / h); }
+// round(x / h) as the reference computes it (sp_grid.rs:217), but through one multiply: the quotient is
+// only re-done with the exact division when x * (1/h) lands within a few ulp of a .5 tie.
+SPK_DEV float round_cell(float x, float h, float inv_h) {
+    const float t = x * inv_h;
+    const float fr = t - floorf(t);
+    if (fabsf(fr - 0.5f) < 1.0e-6f * fmaxf(fabsf(t), 1.f)) return roundf(x / h);
+    return roundf(t);
+}
+
+// DPP row shifts inside a 16-lane row: lane i reads lane i + N (zero beyond the row end).
+template <int N>
+SPK_DEV float dpp_shl(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x100 + N, 0xF, 0xF, true));
+}
+template <int N>
+SPK_DEV int dpp_shl_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xF, 0xF, true); }
+SPK_DEV int dpp_shr1_i(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xF, 0xF, false); }
 
 // ------------------------------------------------------------------------------------------- P2G
 // One workgroup per particle block.  LDS tile: 4 SoA planes of 512 floats.
-template <bool WAVE_REDUCE>
+// one reduction step over the four chains c0..c3 (asm operands %0..%3), mask operand M
+#define SPK_FMAC_DPP(SH, M)                                                                      \
+    "v_fmac_f32_dpp %0, %0, " M " row_shl:" SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"    \
+    "v_fmac_f32_dpp %1, %1, " M " row_shl:" SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"    \
+    "v_fmac_f32_dpp %2, %2, " M " row_shl:" SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"    \
+    "v_fmac_f32_dpp %3, %3, " M " row_shl:" SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+
+// REDUCE_STEPS = log2 of the lane-group size over which same-cell particles are pre-summed with DPP
+// before the LDS atomics (0: none, 2: groups of 4, 3: of 8, 4: of 16).
+template <int REDUCE_STEPS>
 __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models,
                                                      const Ctl* __restrict__ ctl, StepParams S) {
     if (ctl->abort_flag[S.parity]) return;
-    __shared__ float tile[4][TILE_N];
+    // Measured on gfx950: ds_add_f32 retires ~1 lane per 2.6 cycles (169 cycles for a full wave), while
+    // ds_add_f64 is pipelined (7.6 cycles per wave instruction).  So the tile is accumulated in f64 --
+    // 20x cheaper *and* more accurate (sums are rounded to f32 once, at write-out).
+    __shared__ double tile[4][TILE_N];
     const int tid = threadIdx.x;
     const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
-    for (int n = tid; n < TILE_N; n += BLK_THREADS) { tile[0][n] = 0.f; tile[1][n] = 0.f; tile[2][n] = 0.f; tile[3][n] = 0.f; }
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
     const int b = G.pblk[pb];
     const int4 org = G.blk_origin[b];
     const int pfirst = G.blk_pfirst[b], pcount = G.blk_pcount[b];
     __syncthreads();
 
-    const float h = S.h;
+    const float h = S.h, inv_h = 1.0f / S.h;
     const int niter = (pcount + BLK_THREADS - 1) / BLK_THREADS;
     for (int it = 0; it < niter; ++it) {
         const int li = it * BLK_THREADS + tid;
@@ -132,9 +160,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
             const int orgv[3] = {org.x, org.y, org.z};
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const float r = roundf(px[a] / h);
+                const float r = round_cell(px[a], h, inv_h);
                 d0[a] = (r - 1.0f) * h - px[a];
-                eval_all(-d0[a] / h, wgt[a]);
+                eval_all(-d0[a] * inv_h, wgt[a]);
                 lc[a] = (int)r - 1 - orgv[a] + 1;  // tile coordinate of the associated cell, in [0, 5]
             }
             base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
@@ -166,28 +194,23 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
             val_m = mass;
         }
 
-        if (WAVE_REDUCE) {
-            // Particles are cell-sorted inside a block, so runs of lanes share `cell_key`.  Segmented
-            // suffix-sum over row-local (16-lane) runs with DPP-able shuffles, then one LDS atomic per run.
+        if (REDUCE_STEPS > 0) {
+            // Particles are cell-sorted inside a block, so runs of lanes share `cell_key`.  Segmented suffix
+            // sums over runs inside aligned groups of G = 2^REDUCE_STEPS lanes, all in DPP (VALU, no LDS
+            // traffic), then one LDS atomic per run head.  Every lane executes every DPP (no divergence).
+            constexpr int G = 1 << REDUCE_STEPS;
             const int lane = tid & 63;
-            const int prev_key = __shfl_up(cell_key, 1);
-            const bool head = ((lane & 15) == 0) || (prev_key != cell_key);
-            // m_o: lanes L .. L+o form one contiguous same-key run inside the 16-lane row
-            bool m1, m2, m4, m8;
-            {
-                // NB: every shuffle is executed by ALL lanes first (no `&&` short-circuit around a shuffle:
-                // ds_bpermute from a lane that is masked off returns garbage).
-                const int r = lane & 15;
-                const int k1 = __shfl_down(cell_key, 1);
-                const int i1 = ((r + 1 < 16) & (k1 == cell_key)) ? 1 : 0;
-                const int s1 = __shfl_down(i1, 1);
-                const int i2 = (i1 & s1 & (r + 2 < 16 ? 1 : 0));
-                const int s2 = __shfl_down(i2, 2);
-                const int i4 = (i2 & s2 & (r + 4 < 16 ? 1 : 0));
-                const int s4 = __shfl_down(i4, 4);
-                const int i8 = (i4 & s4 & (r + 8 < 16 ? 1 : 0));
-                m1 = i1 != 0; m2 = i2 != 0; m4 = i4 != 0; m8 = i8 != 0;
-            }
+            const int r = lane & (G - 1);
+            // (cross-lane ops are hoisted out of every `&&` / `||`: they must run with all lanes enabled)
+            const int key_prev = dpp_shr1_i(cell_key, -2), key_next = dpp_shl_i<1>(cell_key);
+            const bool head = (r == 0) | (key_prev != cell_key);
+            // f_o = 1.0 when lanes L .. L+o form one contiguous same-key run inside the group
+            const int i1 = ((r + 1 < G) & (key_next == cell_key)) ? 1 : 0;
+            const int i2 = (REDUCE_STEPS >= 2) ? (i1 & dpp_shl_i<1>(i1) & (r + 2 < G ? 1 : 0)) : 0;
+            const int i4 = (REDUCE_STEPS >= 3) ? (i2 & dpp_shl_i<2>(i2) & (r + 4 < G ? 1 : 0)) : 0;
+            const int i8 = (REDUCE_STEPS >= 4) ? (i4 & dpp_shl_i<4>(i4) & (r + 8 < G ? 1 : 0)) : 0;
+            const float f1 = (float)i1, f2 = (float)i2, f4 = (float)i4, f8 = (float)i8;
+            if (!live) { val_m = 0.f; qv[0] = qv[1] = qv[2] = 0.f; A = m3_zero(); wgt[0][0] = wgt[0][1] = wgt[0][2] = 0.f; wgt[1][0] = wgt[1][1] = wgt[1][2] = 0.f; wgt[2][0] = wgt[2][1] = wgt[2][2] = 0.f; }
 #pragma unroll
             for (int sz = 0; sz < 3; ++sz)
 #pragma unroll
@@ -199,23 +222,29 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
                         float c1 = w * (qv[0] + sx * A.m[0] + sy * A.m[3] + sz * A.m[6]);
                         float c2 = w * (qv[1] + sx * A.m[1] + sy * A.m[4] + sz * A.m[7]);
                         float c3 = w * (qv[2] + sx * A.m[2] + sy * A.m[5] + sz * A.m[8]);
-                        if (!live) { c0 = c1 = c2 = c3 = 0.f; }
-                        // run-local inclusive suffix sums (keys equal => contiguous because sorted runs)
-                        float t;
-                        t = __shfl_down(c0, 1); c0 += m1 ? t : 0.f; t = __shfl_down(c1, 1); c1 += m1 ? t : 0.f;
-                        t = __shfl_down(c2, 1); c2 += m1 ? t : 0.f; t = __shfl_down(c3, 1); c3 += m1 ? t : 0.f;
-                        t = __shfl_down(c0, 2); c0 += m2 ? t : 0.f; t = __shfl_down(c1, 2); c1 += m2 ? t : 0.f;
-                        t = __shfl_down(c2, 2); c2 += m2 ? t : 0.f; t = __shfl_down(c3, 2); c3 += m2 ? t : 0.f;
-                        t = __shfl_down(c0, 4); c0 += m4 ? t : 0.f; t = __shfl_down(c1, 4); c1 += m4 ? t : 0.f;
-                        t = __shfl_down(c2, 4); c2 += m4 ? t : 0.f; t = __shfl_down(c3, 4); c3 += m4 ? t : 0.f;
-                        t = __shfl_down(c0, 8); c0 += m8 ? t : 0.f; t = __shfl_down(c1, 8); c1 += m8 ? t : 0.f;
-                        t = __shfl_down(c2, 8); c2 += m8 ? t : 0.f; t = __shfl_down(c3, 8); c3 += m8 ? t : 0.f;
+                        // c += f_o * row_shl:o(c), o = 1, 2, 4[, 8]: one v_fmac_f32_dpp each.  hipcc emits
+                        // v_mov_b32_dpp + v_fmac (+ s_nop) for the builtin form, so this is hand-written; the four
+                        // independent chains are interleaved so that a DPP read of c_k is >= 3 VALU ops after its
+                        // write (DPP needs 2 wait states), and the leading s_nop covers the compiler's last write.
+                        if (REDUCE_STEPS == 2) {
+                            asm volatile("s_nop 1\n"
+                                SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5")
+                                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2));
+                        } else if (REDUCE_STEPS == 3) {
+                            asm volatile("s_nop 1\n"
+                                SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") SPK_FMAC_DPP("4", "%6")
+                                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4));
+                        } else {
+                            asm volatile("s_nop 1\n"
+                                SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") SPK_FMAC_DPP("4", "%6") SPK_FMAC_DPP("8", "%7")
+                                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4), "v"(f8));
+                        }
                         if (live && head) {
                             const int n = base + sx + TILE_W * sy + TILE_W * TILE_W * sz;
-                            atomicAdd(&tile[0][n], c0);
-                            atomicAdd(&tile[1][n], c1);
-                            atomicAdd(&tile[2][n], c2);
-                            atomicAdd(&tile[3][n], c3);
+                            atomicAdd(&tile[0][n], (double)c0);
+                            atomicAdd(&tile[1][n], (double)c1);
+                            atomicAdd(&tile[2][n], (double)c2);
+                            atomicAdd(&tile[3][n], (double)c3);
                         }
                     }
         } else if (live) {
@@ -227,16 +256,16 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
                     for (int sx = 0; sx < 3; ++sx) {
                         const float w = wgt[0][sx] * wgt[1][sy] * wgt[2][sz];
                         const int n = base + sx + TILE_W * sy + TILE_W * TILE_W * sz;
-                        atomicAdd(&tile[0][n], w * val_m);
-                        atomicAdd(&tile[1][n], w * (qv[0] + sx * A.m[0] + sy * A.m[3] + sz * A.m[6]));
-                        atomicAdd(&tile[2][n], w * (qv[1] + sx * A.m[1] + sy * A.m[4] + sz * A.m[7]));
-                        atomicAdd(&tile[3][n], w * (qv[2] + sx * A.m[2] + sy * A.m[5] + sz * A.m[8]));
+                        atomicAdd(&tile[0][n], (double)(w * val_m));
+                        atomicAdd(&tile[1][n], (double)(w * (qv[0] + sx * A.m[0] + sy * A.m[3] + sz * A.m[6])));
+                        atomicAdd(&tile[2][n], (double)(w * (qv[1] + sx * A.m[1] + sy * A.m[4] + sz * A.m[7])));
+                        atomicAdd(&tile[3][n], (double)(w * (qv[2] + sx * A.m[2] + sy * A.m[5] + sz * A.m[8])));
                     }
         }
     }
     __syncthreads();
     float4* out = G.tiles + (size_t)pb * TILE_N;
-    for (int n = tid; n < TILE_N; n += BLK_THREADS) out[n] = make_float4(tile[0][n], tile[1][n], tile[2][n], tile[3][n]);
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) out[n] = make_float4((float)tile[0][n], (float)tile[1][n], (float)tile[2][n], (float)tile[3][n]);
 }
 
 // ----------------------------------------------------------------------------------- grid update
@@ -389,46 +418,70 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p(ParticleArrays P, GridArray
     const int4 org = G.blk_origin[b];
     const int pfirst = G.blk_pfirst[b], pcount = G.blk_pcount[b];
     __syncthreads();
-    const float h = S.h, dt = S.dt;
+    const float h = S.h, dt = S.dt, inv_h = 1.0f / S.h;
     bool want_sort = false;
     for (int li = tid; li < pcount; li += BLK_THREADS) {
         const int i = pfirst + li;
         const float4 q0 = P.q[0][i], kk = P.k[i];
         uint32_t flags = __float_as_uint(kk.w);
         if (flags & FLAG_INVALID) continue;
-        const float4 q1 = P.q[1][i], q2 = P.q[2][i], dd = P.d[i];
-        const DevModel mo = models[flags >> FLAG_MODEL_SHIFT];
+        const DevModel& mo = models[flags >> FLAG_MODEL_SHIFT];
         float px[3] = {q0.x, q0.y, q0.z};
         float d0[3], wgt[3][3];
         int lc[3];
         const int orgv[3] = {org.x, org.y, org.z};
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const float r = roundf(px[a] / h);
+            const float r = round_cell(px[a], h, inv_h);
             d0[a] = (r - 1.0f) * h - px[a];
-            eval_all(-d0[a] / h, wgt[a]);
+            eval_all(-d0[a] * inv_h, wgt[a]);
             lc[a] = (int)r - 1 - orgv[a] + 1;
         }
         const int base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
-        float vel[3] = {0.f, 0.f, 0.f};
-        M3 C = m3_zero();
-        float div = 0.f;
+        // APIC gather in separable form (grid_to_particle.rs:47-60):
+        //   v = sum w v_n ;  C = inv_d * sum w v_n (d0 + s h)^T = inv_d * (v d0^T + h [Vx Vy Vz]),  V_a = sum w s_a v_n
+        //   velocity_gradient_det = sum w (v_n . dpt) inv_d = trace(C)
+        float V0[3] = {0.f, 0.f, 0.f}, Vx[3] = {0.f, 0.f, 0.f}, Vy[3] = {0.f, 0.f, 0.f}, Vz[3] = {0.f, 0.f, 0.f};
+        const float wx0 = wgt[0][0], wx1 = wgt[0][1], wx2 = wgt[0][2], wx2d = 2.f * wgt[0][2];
+#pragma unroll 1
+        for (int sz = 0; sz < 3; ++sz) {
+            const float wz = sz == 0 ? wgt[2][0] : (sz == 1 ? wgt[2][1] : wgt[2][2]);  // no dynamic register indexing
+            float Rz[3] = {0.f, 0.f, 0.f}, Rzx[3] = {0.f, 0.f, 0.f}, Rzy[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int sz = 0; sz < 3; ++sz)
+            for (int sy = 0; sy < 3; ++sy) {
+                const float4* row = vt + base + TILE_W * sy + TILE_W * TILE_W * sz;
+                const float4 c0 = row[0], c1 = row[1], c2 = row[2];
+                const float wy = wgt[1][sy];
+                const float a1x = wx1 * c1.x, a1y = wx1 * c1.y, a1z = wx1 * c1.z;
+                const float R[3] = {wx0 * c0.x + a1x + wx2 * c2.x, wx0 * c0.y + a1y + wx2 * c2.y, wx0 * c0.z + a1z + wx2 * c2.z};
+                const float Rx[3] = {a1x + wx2d * c2.x, a1y + wx2d * c2.y, a1z + wx2d * c2.z};
 #pragma unroll
-            for (int sy = 0; sy < 3; ++sy)
-#pragma unroll
-                for (int sx = 0; sx < 3; ++sx) {
-                    const float4 cv = vt[base + sx + TILE_W * sy + TILE_W * TILE_W * sz];
-                    const float w = wgt[0][sx] * wgt[1][sy] * wgt[2][sz];
-                    const float dpt[3] = {d0[0] + sx * h, d0[1] + sy * h, d0[2] + sz * h};
-                    vel[0] += w * cv.x; vel[1] += w * cv.y; vel[2] += w * cv.z;
-                    const float wi = w * S.inv_d;
-                    const float a0 = wi * cv.x, a1 = wi * cv.y, a2 = wi * cv.z;
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) { C.m[3 * j] += a0 * dpt[j]; C.m[3 * j + 1] += a1 * dpt[j]; C.m[3 * j + 2] += a2 * dpt[j]; }
-                    div += w * (cv.x * dpt[0] + cv.y * dpt[1] + cv.z * dpt[2]) * S.inv_d;
+                for (int e = 0; e < 3; ++e) {
+                    Rz[e] += wy * R[e];
+                    Rzx[e] += wy * Rx[e];
+                    if (sy > 0) Rzy[e] += (wy * (float)sy) * R[e];
                 }
+            }
+            const float wzs = wz * (float)sz;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                V0[e] += wz * Rz[e];
+                Vx[e] += wz * Rzx[e];
+                Vy[e] += wz * Rzy[e];
+                Vz[e] += wzs * Rz[e];
+            }
+        }
+        float vel[3] = {V0[0], V0[1], V0[2]};
+        M3 C;
+        const float hid = h * S.inv_d;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            C.m[e] = (S.inv_d * V0[e]) * d0[0] + hid * Vx[e];
+            C.m[3 + e] = (S.inv_d * V0[e]) * d0[1] + hid * Vy[e];
+            C.m[6 + e] = (S.inv_d * V0[e]) * d0[2] + hid * Vz[e];
+        }
+        const float div = C.m[0] + C.m[4] + C.m[8];
+        const float4 q1 = P.q[1][i], q2 = P.q[2][i], dd = P.d[i];
         // kinematic override, advection (grid_to_particle.rs:82-86)
         if (flags & FLAG_KINEMATIC) { const float4 kv = P.kinvel[i]; vel[0] = kv.x; vel[1] = kv.y; vel[2] = kv.z; }
         px[0] += vel[0] * dt; px[1] += vel[1] * dt; px[2] += vel[2] * dt;
@@ -447,14 +500,15 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p(ParticleArrays P, GridArray
         float q = dd.x, lvg = dd.y, Jp = dd.z, psi = dd.w;
         const float eh = kk.z;
         const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.phase[i] : 1.f;
-        float sv[3];
+        float sv[3] = {1.f, 1.f, 1.f};
         bool sv_valid = false;
         if (mo.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER) dp_update(mo, phase, F, Jp, q, lvg, sv, sv_valid);
         if (flags & FLAG_STATIC) { vel[0] = vel[1] = vel[2] = 0.f; C = m3_zero(); }
         // fail guards (:111-121)
-        const float density = (kk.x / kk.y) / m3_det(F);
+        // density_def_grad() == 0  <=>  mass/volume0 == 0 or det(F) overflowed (grid_to_particle.rs:111)
+        const bool zero_density = (kk.x == 0.f) || !(fabsf(m3_det(F)) < 1.0e30f);
         bool newly_failed = false;
-        if (density == 0.f || (flags & FLAG_FAILED) || (!mo.is_fluid && fabsf(F.m[0]) > 1.0e4f)) {
+        if (zero_density || (flags & FLAG_FAILED) || (!mo.is_fluid && fabsf(F.m[0]) > 1.0e4f)) {
             newly_failed = !(flags & FLAG_FAILED);
             flags |= FLAG_FAILED;
             F = m3_identity();
@@ -462,13 +516,13 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p(ParticleArrays P, GridArray
             sv_valid = false;
         }
         // positive energy bookkeeping (:127-132)
-        psi = fmaxf(psi, model_pos_energy(mo, phase, eh, F, sv_valid ? sv : nullptr));
+        psi = fmaxf(psi, model_pos_energy(mo, phase, eh, F, sv, sv_valid));
 
         // does the particle still sit inside its home block's tile, and inside the domain?
         bool invalid = false;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const float r = roundf(px[a] / h);
+            const float r = round_cell(px[a], h, inv_h);
             const bool ok = (r >= 1.0f) && (r < (float)(S.dom - 4));   // 0 <= assoc, assoc + 5 < dom
             if (!ok) invalid = true;
             else {

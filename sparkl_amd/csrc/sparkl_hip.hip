@@ -295,8 +295,8 @@ static StepParams make_params(const SparklPipeline* p, const SparklSolverParams*
     return S;
 }
 
-#ifndef SPK_P2G_WAVE_REDUCE
-#define SPK_P2G_WAVE_REDUCE 1
+#ifndef SPK_P2G_REDUCE_STEPS
+#define SPK_P2G_REDUCE_STEPS 3
 #endif
 
 static int enqueue_fluid_volumes(SparklPipeline* p, const StepParams& S) {
@@ -319,7 +319,7 @@ static int enqueue_substep(SparklPipeline* p, const SparklSolverParams* sp, cons
     if (sp->force_fluids_volume_recomputation && p->any_fluid) CHK(enqueue_fluid_volumes(p, S));
     size_t t0 = 0, t1 = 0, t2 = 0;
     CHK(clock_begin(p, SPAN_P2G, &t0));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g<SPK_P2G_WAVE_REDUCE != 0>), dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, P, G, p->d_models.p, p->d_ctl, S);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g<SPK_P2G_REDUCE_STEPS>), dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, P, G, p->d_models.p, p->d_ctl, S);
     CHK(clock_end(p, t0));
     CHK(clock_begin(p, SPAN_GRID, &t1));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false>), dim3((p->num_blocks + 3) / 4), dim3(BLK_THREADS), 0, st, G, p->d_cuboids.p, p->d_ctl, S);
