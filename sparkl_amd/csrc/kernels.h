@@ -56,6 +56,7 @@ struct GridArrays {
     const int* blk_pcount;
     const int* blk_nbr;        // [B][27], index of neighbour block or -1
     const int* pblk;           // [PB] block index of each tile owner
+    const int4* pb_info;       // [PB][2]: (origin.xyz, block index), (pfirst, pcount, -, -): one hop instead of three
     float4* tiles;             // [PB][512] (mass, px, py, pz)
     float4* node_vel;          // [B][64]  (vx, vy, vz, mass)
     float4* node_mom;          // [B][64]  (px, py, pz, -) debug capture or NULL
@@ -132,18 +133,27 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
     const int tid = threadIdx.x;
     const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
     for (int n = tid; n < TILE_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
-    const int b = G.pblk[pb];
-    const int4 org = G.blk_origin[b];
-    const int pfirst = G.blk_pfirst[b], pcount = G.blk_pcount[b];
-    __syncthreads();
-
+    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int pfirst = rng.x, pcount = rng.y;
     const float h = S.h, inv_h = 1.0f / S.h;
     const int niter = (pcount + BLK_THREADS - 1) / BLK_THREADS;
+    // software pipeline: the 7 x 16 B of the next batch are in flight while this batch computes
+    float4 n0, n1, n2, n3, n4, n5, nk;
+    {
+        const int i0 = pfirst + min(tid, pcount - 1);
+        n0 = P.q[0][i0]; n1 = P.q[1][i0]; n2 = P.q[2][i0]; n3 = P.q[3][i0]; n4 = P.q[4][i0]; n5 = P.q[5][i0]; nk = P.k[i0];
+    }
+    __syncthreads();
+
     for (int it = 0; it < niter; ++it) {
         const int li = it * BLK_THREADS + tid;
         const bool active = li < pcount;
         const int i = pfirst + (active ? li : 0);
-        const float4 q0 = P.q[0][i], kk = P.k[i];
+        const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3, q4 = n4, q5 = n5, kk = nk;
+        if (it + 1 < niter) {
+            const int inx = pfirst + min(li + BLK_THREADS, pcount - 1);
+            n0 = P.q[0][inx]; n1 = P.q[1][inx]; n2 = P.q[2][inx]; n3 = P.q[3][inx]; n4 = P.q[4][inx]; n5 = P.q[5][inx]; nk = P.k[inx];
+        }
         const uint32_t flags = __float_as_uint(kk.w);
         const bool live = active && !(flags & FLAG_INVALID);
         int cell_key = -1;
@@ -154,7 +164,6 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
         M3 A = m3_zero();               // affine * h
         int base = 0;
         if (live) {
-            const float4 q1 = P.q[1][i], q2 = P.q[2][i], q3 = P.q[3][i], q4 = P.q[4][i], q5 = P.q[5][i];
             const float px[3] = {q0.x, q0.y, q0.z};
             int lc[3];
             const int orgv[3] = {org.x, org.y, org.z};
@@ -412,17 +421,27 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p(ParticleArrays P, GridArray
     }
     __shared__ float4 vt[TILE_N];
     const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
-    const int b = G.pblk[pb];
+    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int b = org.w, pfirst = rng.x, pcount = rng.y;
+    // first batch of particle data goes in flight before the tile is staged
+    int li = tid;
+    bool have = li < pcount;
+    float4 n0, n1, n2, nd, nk;
+    {
+        const int i0 = pfirst + min(li, pcount - 1);
+        n0 = P.q[0][i0]; n1 = P.q[1][i0]; n2 = P.q[2][i0]; nd = P.d[i0]; nk = P.k[i0];
+    }
     load_vel_tile(vt, G, b, tid);
     if (blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
-    const int4 org = G.blk_origin[b];
-    const int pfirst = G.blk_pfirst[b], pcount = G.blk_pcount[b];
     __syncthreads();
     const float h = S.h, dt = S.dt, inv_h = 1.0f / S.h;
     bool want_sort = false;
-    for (int li = tid; li < pcount; li += BLK_THREADS) {
+    while (have) {
         const int i = pfirst + li;
-        const float4 q0 = P.q[0][i], kk = P.k[i];
+        const float4 q0 = n0, q1 = n1, q2 = n2, dd = nd, kk = nk;
+        li += BLK_THREADS;
+        have = li < pcount;
+        if (have) { const int inx = pfirst + li; n0 = P.q[0][inx]; n1 = P.q[1][inx]; n2 = P.q[2][inx]; nd = P.d[inx]; nk = P.k[inx]; }
         uint32_t flags = __float_as_uint(kk.w);
         if (flags & FLAG_INVALID) continue;
         const DevModel& mo = models[flags >> FLAG_MODEL_SHIFT];
@@ -481,7 +500,6 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p(ParticleArrays P, GridArray
             C.m[6 + e] = (S.inv_d * V0[e]) * d0[2] + hid * Vz[e];
         }
         const float div = C.m[0] + C.m[4] + C.m[8];
-        const float4 q1 = P.q[1][i], q2 = P.q[2][i], dd = P.d[i];
         // kinematic override, advection (grid_to_particle.rs:82-86)
         if (flags & FLAG_KINEMATIC) { const float4 kv = P.kinvel[i]; vel[0] = kv.x; vel[1] = kv.y; vel[2] = kv.z; }
         px[0] += vel[0] * dt; px[1] += vel[1] * dt; px[2] += vel[2] * dt;
@@ -558,9 +576,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_mass(ParticleArrays P, Grid
     const int tid = threadIdx.x;
     const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
     for (int n = tid; n < TILE_N; n += BLK_THREADS) tile[n] = 0.f;
-    const int b = G.pblk[pb];
-    const int4 org = G.blk_origin[b];
-    const int pfirst = G.blk_pfirst[b], pcount = G.blk_pcount[b];
+    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int pfirst = rng.x, pcount = rng.y;
     __syncthreads();
     const float h = S.h;
     for (int li = tid; li < pcount; li += BLK_THREADS) {
@@ -598,10 +615,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p_volume(ParticleArrays P, Gr
     __shared__ float4 vt[TILE_N];
     const int tid = threadIdx.x;
     const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
-    const int b = G.pblk[pb];
+    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int b = org.w, pfirst = rng.x, pcount = rng.y;
     load_vel_tile(vt, G, b, tid);
-    const int4 org = G.blk_origin[b];
-    const int pfirst = G.blk_pfirst[b], pcount = G.blk_pcount[b];
     __syncthreads();
     const float h = S.h;
     for (int li = tid; li < pcount; li += BLK_THREADS) {
@@ -780,7 +796,7 @@ __global__ void k_setup_blocks(const uint32_t* __restrict__ blk_keys, int nb, in
     hash_insert(H, (uint64_t)k, (uint32_t)b);
 }
 __global__ void k_link_pblocks(const uint64_t* __restrict__ pb_keys, const uint32_t* __restrict__ pb_counts, const uint32_t* __restrict__ pb_first,
-                               int npb, HashTable H, int4* origin, int* pfirst, int* pcount, int* pblk) {
+                               int npb, HashTable H, int4* origin, int* pfirst, int* pcount, int* pblk, int4* pb_info) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= npb) return;
     const int b = hash_lookup(H, pb_keys[j]);
@@ -788,6 +804,9 @@ __global__ void k_link_pblocks(const uint64_t* __restrict__ pb_keys, const uint3
     origin[b].w = j;
     pfirst[b] = (int)pb_first[j];
     pcount[b] = (int)pb_counts[j];
+    const int4 o = origin[b];
+    pb_info[2 * j] = make_int4(o.x, o.y, o.z, b);
+    pb_info[2 * j + 1] = make_int4((int)pb_first[j], (int)pb_counts[j], 0, 0);
 }
 __global__ void k_link_nbrs(const uint32_t* __restrict__ blk_keys, int nb, HashTable H, int* nbr) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
