@@ -276,7 +276,9 @@ int sparkl_hip_pipeline_sync(SparklPipeline* p);
 typedef struct {
     double p2g_ms, grid_update_ms, g2p_ms, sort_ms, dt_ms, halo_ms;
     uint64_t substeps, resorts;
+    uint64_t sampled_substeps;   /* substeps whose kernels carried event spans (the *_ms sums cover these) */
 } SparklKernelClock;
+/* enable: 0 = off, 1 = spans on every substep, N > 1 = spans on every N-th substep */
 int sparkl_hip_pipeline_clock_enable(SparklPipeline* p, int enable);
 int sparkl_hip_pipeline_clock_read(SparklPipeline* p, SparklKernelClock* out, int reset);
 

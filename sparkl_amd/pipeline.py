@@ -133,8 +133,9 @@ class MpmPipeline:
     def sync(self):
         check(self.L.sparkl_hip_pipeline_sync(self.h))
 
-    def clock_enable(self, on=True):
-        check(self.L.sparkl_hip_pipeline_clock_enable(self.h, int(on)))
+    def clock_enable(self, on=True, stride=1):
+        """Per-kernel hipEvent spans; stride N > 1 samples every N-th substep."""
+        check(self.L.sparkl_hip_pipeline_clock_enable(self.h, (int(stride) if stride > 1 else 1) if on else 0))
 
     def clock_read(self, reset=True):
         k = abi.KernelClockC()
