@@ -296,6 +296,45 @@ uint64_t sparkl_hip_grid_num_particle_blocks(SparklPipeline* p);
 int sparkl_hip_grid_debug_capture(SparklPipeline* p, int enable);
 int sparkl_hip_grid_read_nodes(SparklPipeline* p, SparklGridNode* out, uint64_t cap, uint64_t* n_out);
 
+/* ---- multi-GPU slabs: one process per GPU, the exchange itself is the host's (RCCL over xGMI) ----
+ * A slab owns the particles whose HOME BLOCK index along `axis` is in [block_lo, block_hi)
+ * (INT32_MIN / INT32_MAX = open side).  A particle of the last owned block plane writes nodes of the
+ * block planes cut-1 and cut, and so does the neighbour's first plane: per substep each side packs its
+ * partial (mass, momentum) of the node blocks in those two planes (halo_pack), the host swaps the
+ * buffers with the neighbour rank (ncclSend/ncclRecv) and hands the received one back (halo_merge);
+ * a + b is bit-identical on both sides, so both run the same grid update and no second exchange is
+ * needed.  The re-bin is collective: the per-substep request flag is exported, all-reduced (max) by
+ * the host and imported, so every rank skips the same substeps; at a re-bin, particles whose home
+ * block left the slab are packed for the neighbour (emigrants) and appended there (immigrants).
+ * The reference's scheme for contrast: src/cuda/cuda_sparse_grid.rs:255-322,
+ * src/cuda/cuda_mpm_pipeline.rs:407-533 (disabled: testbed_plugin.rs:182-189).  See DESIGN.md. */
+typedef struct {
+    int32_t axis;           /* 0, 1, 2 */
+    int32_t block_lo;       /* first owned block index along axis (INT32_MIN: open) */
+    int32_t block_hi;       /* one past the last owned block (INT32_MAX: open) */
+    uint32_t _pad0;
+    uint64_t id_offset;     /* global id of this rank's first uploaded particle */
+} SparklSlab;
+int sparkl_hip_slab_set(SparklPipeline* p, const SparklSlab* slab);   /* before particles_upload */
+uint64_t sparkl_hip_halo_record_bytes(void);        /* key + 64 x (mass, px, py, pz) */
+uint64_t sparkl_hip_migration_record_bytes(void);   /* full particle state */
+/* (re-)bin the particles now; afterwards emigrant/halo counts are valid.  Collective by convention. */
+int sparkl_hip_rebin(SparklPipeline* p);
+int sparkl_hip_slab_emigrant_count(SparklPipeline* p, int side, uint64_t* n);          /* side 0 = low cut, 1 = high */
+int sparkl_hip_slab_emigrants_pack(SparklPipeline* p, int side, void* dev_out);        /* removes them locally */
+int sparkl_hip_slab_immigrants_add(SparklPipeline* p, const void* dev_in, uint64_t n);  /* needs a re-bin afterwards */
+/* re-bin request flag of the UPCOMING substep <-> a device u32 the host all-reduces (max) */
+int sparkl_hip_flags_export(SparklPipeline* p, void* dev_u32);
+int sparkl_hip_flags_import(SparklPipeline* p, const void* dev_u32);
+/* split-phase substep: begin = P2G; [halo_pack -> exchange -> halo_merge] per side; finish = grid update + G2P */
+int sparkl_hip_substep_begin(SparklPipeline* p, const SparklSolverParams* params, const float gravity[3], float dt);
+int sparkl_hip_halo_count(SparklPipeline* p, int side, uint64_t* n);
+int sparkl_hip_halo_pack(SparklPipeline* p, int side, void* dev_out);
+int sparkl_hip_halo_merge(SparklPipeline* p, int side, const void* dev_in, uint64_t n);
+int sparkl_hip_substep_finish(SparklPipeline* p);
+/* synchronises; steps_done counts substeps whose G2P really ran, need_rebin != 0 when a re-bin is due */
+int sparkl_hip_substep_status(SparklPipeline* p, uint32_t* steps_done, uint32_t* need_rebin);
+
 const char* sparkl_hip_last_error_string(void);
 /* "sparkl_hip <version> gfx950" */
 const char* sparkl_hip_version(void);

@@ -35,7 +35,7 @@ def lib():
             getattr(L, name).restype = C.c_double
         for name in ("oracle_num_particles", "oracle_get_nodes", "oracle_num_regions", "oracle_num_particle_regions", "oracle_num_bins",
                      "oracle_pack", "oracle_packed_add", "oracle_morton_encode3", "oracle_packed_nbh_shift",
-                     "oracle_packed_region_shift", "oracle_check_pack_roundtrip", "oracle_check_packed_add"):
+                     "oracle_packed_region_shift", "oracle_check_pack_roundtrip", "oracle_check_packed_add", "oracle_get_region_ids"):
             getattr(L, name).restype = C.c_uint64
         L.oracle_pack.argtypes = [C.c_uint32] * 3
         L.oracle_morton_encode3.argtypes = [C.c_uint32] * 3
@@ -153,6 +153,24 @@ class Oracle:
         out = np.zeros(n, abi.GRID_NODE_DTYPE)
         self.L.oracle_get_nodes(self.h, abi.ptr(out, abi.GRID_NODE_DTYPE), C.c_uint64(n))
         return out
+
+    def region_ids(self):
+        n = int(self.L.oracle_get_region_ids(self.h, None, C.c_uint64(0)))
+        out = np.zeros(n, np.uint64)
+        self.L.oracle_get_region_ids(self.h, out.ctypes.data_as(C.c_void_p), C.c_uint64(n))
+        return out
+
+    def get_block_nodes(self, region_id):
+        out = np.zeros((64, 4), np.float32)
+        self.L.oracle_get_block_nodes(self.h, C.c_uint64(int(region_id)), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def add_block_nodes(self, region_id, nodes):
+        nodes = np.ascontiguousarray(nodes, dtype=np.float32)
+        return int(self.L.oracle_add_block_nodes(self.h, C.c_uint64(int(region_id)), nodes.ctypes.data_as(C.c_void_p)))
+
+    def refresh_velocities(self, dt, gravity):
+        self.L.oracle_refresh_velocities(self.h, C.c_double(dt), _g(gravity))
 
     def num_regions(self):
         return int(self.L.oracle_num_regions(self.h))

@@ -114,6 +114,7 @@ template <class R> static void stress_impl(const SparklConstitutiveModel* cm, do
     }
     for (int i = 0; i < 9; ++i) out[i] = (double)s.m[i];
 }
+template <class R> static bool region_active(Oracle<R>& o, uint64_t id) { for (auto& r : o.regions) if (r.id == id) return true; return false; }
 }  // namespace
 
 #define DISPATCH(h, expr_f, expr_d) (((Handle*)(h))->f64 ? (expr_d) : (expr_f))
@@ -209,6 +210,49 @@ void oracle_get_grid_indices(void* hv, uint64_t* out) {
     Handle* h = (Handle*)hv;
     if (h->f64) { for (size_t i = 0; i < h->od->particles.size(); ++i) out[i] = h->od->particles[i].grid_index; }
     else { for (size_t i = 0; i < h->of->particles.size(); ++i) out[i] = h->of->particles[i].grid_index; }
+}
+
+// ---- slab-decomposition checker hooks (tests/test_slab_gloo.py): region-wise access to (mass, momentum)
+uint64_t oracle_get_region_ids(void* hv, uint64_t* out, uint64_t cap) {
+    Handle* h = (Handle*)hv;
+    uint64_t n = 0;
+    auto put = [&](uint64_t id) { if (out && n < cap) out[n] = id; ++n; };
+    if (h->f64) { for (auto& r : h->od->regions) put(r.id); } else { for (auto& r : h->of->regions) put(r.id); }
+    return n;
+}
+// nodes[64][4] = (mass, px, py, pz), node i at region_id | (i << 6)
+int oracle_get_block_nodes(void* hv, uint64_t region_id, float* nodes) {
+    Handle* h = (Handle*)hv;
+    for (uint64_t i = 0; i < 64; ++i) {
+        uint64_t id = region_id | (i << PACK_ALIGN);
+        if (h->f64) { auto& g = h->od->node(id); nodes[4 * i] = (float)g.mass; for (int a = 0; a < 3; ++a) nodes[4 * i + 1 + a] = (float)g.momentum[a]; }
+        else { auto& g = h->of->node(id); nodes[4 * i] = g.mass; for (int a = 0; a < 3; ++a) nodes[4 * i + 1 + a] = g.momentum[a]; }
+    }
+    return 1;
+}
+int oracle_add_block_nodes(void* hv, uint64_t region_id, const float* nodes) {
+    Handle* h = (Handle*)hv;
+    if (h->f64 ? !region_active(*h->od, region_id) : !region_active(*h->of, region_id)) return 0;  // no local particle touches it
+    for (uint64_t i = 0; i < 64; ++i) {
+        uint64_t id = region_id | (i << PACK_ALIGN);
+        if (h->f64) { auto& g = h->od->node(id); g.mass += nodes[4 * i]; for (int a = 0; a < 3; ++a) g.momentum[a] += nodes[4 * i + 1 + a]; }
+        else { auto& g = h->of->node(id); g.mass += nodes[4 * i]; for (int a = 0; a < 3; ++a) g.momentum[a] += nodes[4 * i + 1 + a]; }
+    }
+    return 1;
+}
+// velocity = (momentum + mass g dt) inv_exact(mass) on every active node (particle_to_grid.rs:88-89)
+void oracle_refresh_velocities(void* hv, double dt, const float g[3]) {
+    Handle* h = (Handle*)hv;
+    auto go = [&](auto& o) {
+        using R = decltype(o.h);
+        for (auto& r : o.regions)
+            for (uint64_t i = 0; i < 64; ++i) {
+                auto& c = o.node(r.id | (i << PACK_ALIGN));
+                R im = inv_exact(c.mass);
+                for (int a = 0; a < 3; ++a) c.velocity[a] = (c.momentum[a] + c.mass * (R)g[a] * (R)dt) * im;
+            }
+    };
+    if (h->f64) go(*h->od); else go(*h->of);
 }
 
 // ---- SPGrid addressing (pinned by the reference's own tests, sp_grid.rs:411-555)

@@ -29,6 +29,7 @@ enum : uint32_t {
     FLAG_KINEMATIC = 1u << 2,
     FLAG_INVALID = 1u << 3,       // outside the SPGrid domain: frozen, scatters nothing
     FLAG_PHASE_NOT_ONE = 1u << 4, // phase lives in the side array
+    FLAG_REMOVED = 1u << 5,       // migrated to a neighbour slab; dropped at the next re-bin
     FLAG_MODEL_SHIFT = 8
 };
 
@@ -46,9 +47,9 @@ struct ParticleArrays {
     float4* d;
     float4* k;
     float4* kinvel;   // (kx, ky, kz, -)
-    float* phase;
-    uint32_t* orig_id;
+    float4* aux;      // (phase, radius0, nacc_alpha, bits of the particle's caller/global id): cold, only moved by re-bins
 };
+SPK_DEV uint32_t particle_id(const ParticleArrays& P, int i) { return reinterpret_cast<const uint32_t*>(&P.aux[i])[3]; }
 
 struct GridArrays {
     const int4* blk_origin;    // cell coordinate of node (0,0,0) of the block, w = tile index or -1
@@ -60,6 +61,7 @@ struct GridArrays {
     float4* tiles;             // [PB][512] (mass, px, py, pz)
     float4* node_vel;          // [B][64]  (vx, vy, vz, mass)
     float4* node_mom;          // [B][64]  (px, py, pz, -) debug capture or NULL
+    const float4* halo_in;     // [B][64]  (mass, px, py, pz) received from neighbour slabs, or NULL
     int num_blocks;
     int num_pblocks;
 };
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
             const DevModel mo = models[flags >> FLAG_MODEL_SHIFT];
             M3 tau = m3_zero();
             if (!(flags & FLAG_FAILED)) {
-                const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.phase[i] : 1.f;
+                const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
                 if (mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR) tau = corotated_kirchhoff(mo, phase, eh, F);
                 else if (mo.ctag == SPARKL_CONSTITUTIVE_NEO_HOOKEAN) tau = neo_hookean_kirchhoff(mo, phase, eh, F);
                 else if (mo.ctag == SPARKL_CONSTITUTIVE_EOS_MONAGHAN_SPH) tau = monaghan_kirchhoff(mo, mass, vol0, F.m[0], P.d[i].z, C);
@@ -349,6 +351,10 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
                 const float4 v = G.tiles[(size_t)t * TILE_N + tx + TILE_W * ty + TILE_W * TILE_W * tz];
                 m += v.x; px += v.y; py += v.z; pz += v.w;
             }
+    if (G.halo_in) {  // partial sums of the neighbour slab(s): a + b is bit-identical on both sides of a cut
+        const float4 hv = G.halo_in[(size_t)b * 64 + lane];
+        m += hv.x; px += hv.y; py += hv.z; pz += hv.w;
+    }
     if (MASS_ONLY) {
         G.node_vel[(size_t)b * 64 + lane] = make_float4(0.f, 0.f, 0.f, m);
         return;
@@ -517,7 +523,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p(ParticleArrays P, GridArray
         }
         float q = dd.x, lvg = dd.y, Jp = dd.z, psi = dd.w;
         const float eh = kk.z;
-        const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.phase[i] : 1.f;
+        const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
         float sv[3] = {1.f, 1.f, 1.f};
         bool sv_valid = false;
         if (mo.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER) dp_update(mo, phase, F, Jp, q, lvg, sv, sv_valid);
@@ -700,9 +706,13 @@ SPK_DEV uint32_t compact10(uint32_t x) {
 // block key = Morton code of the block coordinate biased by +1 (blocks at -1 are legal node blocks)
 SPK_DEV uint32_t block_key(int bx, int by, int bz) { return spread10(bx + 1) | (spread10(by + 1) << 1) | (spread10(bz + 1) << 2); }
 
-constexpr uint64_t KEY_INVALID = ~0ull;
+// tail classes of the sort: every valid key is < 2^36, these have all high bits set and sort after them
+constexpr uint64_t KEY_EMIG_LO = ~0ull - 3;      // home block below the slab's low cut
+constexpr uint64_t KEY_EMIG_HI = ~0ull - 2;      // home block beyond the slab's high cut
+constexpr uint64_t KEY_INVALID = ~0ull - 1;      // outside the SPGrid domain (frozen, failed)
+constexpr uint64_t KEY_REMOVED = ~0ull;          // already handed to a neighbour slab: dropped by this re-bin
 
-__global__ void k_compute_keys(ParticleArrays P, uint64_t* keys, uint32_t* idx, int n, float h, int dom) {
+__global__ void k_compute_keys(ParticleArrays P, uint64_t* keys, uint32_t* idx, int n, float h, int dom, int slab_axis, int slab_lo, int slab_hi) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 q0 = P.q[0][i];
@@ -717,10 +727,15 @@ __global__ void k_compute_keys(ParticleArrays P, uint64_t* keys, uint32_t* idx, 
         c[a] = ok ? (int)r - 1 : 0;
     }
     uint64_t key = KEY_INVALID;
-    if (ok) {
+    if (flags & FLAG_REMOVED) {
+        key = KEY_REMOVED;
+    } else if (ok) {
         const uint32_t bk = block_key(c[0] >> 2, c[1] >> 2, c[2] >> 2);
         key = ((uint64_t)bk << 6) | (uint64_t)((c[0] & 3) | ((c[1] & 3) << 2) | ((c[2] & 3) << 4));
         if (flags & FLAG_INVALID) { flags &= ~FLAG_INVALID; reinterpret_cast<uint32_t*>(&P.k[i])[3] = flags; }
+        const int bs = c[slab_axis] >> 2;
+        if (bs < slab_lo) key = KEY_EMIG_LO;
+        else if (bs >= slab_hi) key = KEY_EMIG_HI;
     } else if ((flags & (FLAG_INVALID | FLAG_FAILED)) != (FLAG_INVALID | FLAG_FAILED)) {
         flags |= FLAG_INVALID | FLAG_FAILED;  // particle_set.rs:132-135
         reinterpret_cast<uint32_t*>(&P.k[i])[3] = flags;
@@ -743,8 +758,7 @@ __global__ void k_permute(ParticleArrays src, ParticleArrays dst, const uint32_t
     dst.d[i] = src.d[s];
     dst.k[i] = src.k[s];
     dst.kinvel[i] = src.kinvel[s];
-    dst.phase[i] = src.phase[s];
-    dst.orig_id[i] = src.orig_id[s];
+    dst.aux[i] = src.aux[s];
 }
 
 // 27 candidate node blocks around every particle block
@@ -820,40 +834,145 @@ __global__ void k_link_nbrs(const uint32_t* __restrict__ blk_keys, int nb, HashT
 }
 
 // --------------------------------------------------------------------------------------- readback
-// scatter a component back to caller order: out[orig_id[i]] = value(i)
-__global__ void k_read_positions(ParticleArrays P, float* out, int n) {
+// scatter a component back to caller order: out[id - id_base] = value(i); id_base < 0 keeps device order
+SPK_DEV size_t out_slot(const ParticleArrays& P, int i, long long id_base) { return id_base < 0 ? (size_t)i : (size_t)((long long)particle_id(P, i) - id_base); }
+__global__ void k_read_positions(ParticleArrays P, float* out, int n, long long id_base) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 q0 = P.q[0][i];
-    float* o = out + 3 * (size_t)P.orig_id[i];
+    float* o = out + 3 * out_slot(P, i, id_base);
     o[0] = q0.x; o[1] = q0.y; o[2] = q0.z;
 }
-__global__ void k_read_velocities(ParticleArrays P, float* out, int n) {
+__global__ void k_read_velocities(ParticleArrays P, float* out, int n, long long id_base) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 q3 = P.q[3][i];
-    float* o = out + 3 * (size_t)P.orig_id[i];
+    float* o = out + 3 * out_slot(P, i, id_base);
     o[0] = q3.x; o[1] = q3.y; o[2] = q3.z;
 }
-// 16 floats per particle: F[9], Jp, q, lvg, psi, flags(bits), mass, volume0
-__global__ void k_read_state(ParticleArrays P, float* out, int n) {
+// 24 floats per particle: F[9], Jp, q, lvg | psi, flags(bits), mass, volume0 | eh, phase, radius0, nacc_alpha | kin[3], id(bits)
+__global__ void k_read_state(ParticleArrays P, float* out, int n, long long id_base) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float4 q0 = P.q[0][i], q1 = P.q[1][i], q2 = P.q[2][i], dd = P.d[i], kk = P.k[i];
-    float4* o = reinterpret_cast<float4*>(out + 16 * (size_t)P.orig_id[i]);
+    const float4 q0 = P.q[0][i], q1 = P.q[1][i], q2 = P.q[2][i], dd = P.d[i], kk = P.k[i], ax = P.aux[i], kv = P.kinvel[i];
+    float4* o = reinterpret_cast<float4*>(out + 24 * out_slot(P, i, id_base));
     o[0] = make_float4(q0.w, q1.x, q1.y, q1.z);
     o[1] = make_float4(q1.w, q2.x, q2.y, q2.z);
     o[2] = make_float4(q2.w, dd.z, dd.x, dd.y);
     o[3] = make_float4(dd.w, kk.w, kk.x, kk.y);
+    o[4] = make_float4(kk.z, ax.x, ax.y, ax.z);
+    o[5] = make_float4(kv.x, kv.y, kv.z, ax.w);
 }
-__global__ void k_read_velgrad(ParticleArrays P, float* out, int n) {
+__global__ void k_read_velgrad(ParticleArrays P, float* out, int n, long long id_base) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 q3 = P.q[3][i], q4 = P.q[4][i], q5 = P.q[5][i];
-    float* o = out + 9 * (size_t)P.orig_id[i];
+    float* o = out + 9 * out_slot(P, i, id_base);
     o[0] = q3.w; o[1] = q4.x; o[2] = q4.y; o[3] = q4.z; o[4] = q4.w; o[5] = q5.x; o[6] = q5.y; o[7] = q5.z; o[8] = q5.w;
 }
+__global__ void k_read_ids(ParticleArrays P, uint32_t* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = particle_id(P, i);
+}
 
+// ------------------------------------------------------------------------------ slabs (multi-GPU)
+// a rank that owns no particle block still has to take part in the step counting / abort chain
+__global__ void k_bump_steps(Ctl* ctl, int parity) {
+    if (ctl->abort_flag[parity]) ctl->abort_flag[(parity + 1) & 1] = 1u;
+    else atomicAdd(&ctl->steps_done, 1u);
+}
+// Migration record: the ten float4 of one particle (160 B).
+constexpr int MIG_F4 = 10;
+__global__ void k_pack_particles(ParticleArrays P, int first, int count, float4* out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const int i = first + t;
+    float4* o = out + (size_t)t * MIG_F4;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) o[a] = P.q[a][i];
+    o[6] = P.d[i]; o[7] = P.k[i]; o[8] = P.kinvel[i]; o[9] = P.aux[i];
+    reinterpret_cast<uint32_t*>(&P.k[i])[3] |= FLAG_REMOVED;
+}
+__global__ void k_unpack_particles(ParticleArrays P, int first, int count, const float4* in) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const int i = first + t;
+    const float4* o = in + (size_t)t * MIG_F4;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) P.q[a][i] = o[a];
+    P.d[i] = o[6]; P.k[i] = o[7]; P.kinvel[i] = o[8]; P.aux[i] = o[9];
+}
+// first index of every tail class in the sorted key array: out[k] = first i with class(i) >= k,
+// classes 0..3 = EMIG_LO, EMIG_HI, INVALID, REMOVED (out[] preset to n)
+__global__ void k_tail_bounds(const uint64_t* __restrict__ keys, int n, int* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t M = (1ull << 37) - 1;   // the sort only looked at these bits
+    const uint64_t a = keys[i] & M, b = i ? (keys[i - 1] & M) : 0ull;
+    const uint64_t T[4] = {KEY_EMIG_LO & M, KEY_EMIG_HI & M, KEY_INVALID & M, KEY_REMOVED & M};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (a >= T[k] && (i == 0 || b < T[k])) atomicMin(&out[k], i);
+}
+
+// Halo record: key + 64 x (mass, px, py, pz) of one node block (1040 B, 16-B aligned payload)
+struct HaloRecord {
+    unsigned long long key;
+    unsigned long long pad;
+    float4 nodes[64];
+};
+// node blocks in the two block planes adjacent to a cut (plane indices cut-1 and cut along slab_axis)
+__global__ void k_halo_list(const int4* __restrict__ blk_origin, int nb, int axis, int cut, int* list, int* count) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const int4 o = blk_origin[b];
+    const int bs = (axis == 0 ? o.x : (axis == 1 ? o.y : o.z)) >> 2;
+    if (bs == cut - 1 || bs == cut) list[atomicAdd(count, 1)] = b;
+}
+// one wave per listed block: this slab's partial (mass, momentum) of its 64 nodes, gathered from own tiles
+__global__ __launch_bounds__(BLK_THREADS) void k_halo_pack(GridArrays G, const uint32_t* __restrict__ blk_keys, const int* __restrict__ list, int n,
+                                                            HaloRecord* out, const Ctl* __restrict__ ctl, int parity) {
+    if (ctl->abort_flag[parity]) return;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int b = list[r];
+    const int lane = threadIdx.x & 63;
+    const int cx = lane & 3, cy = (lane >> 2) & 3, cz = lane >> 4;
+    const int dx0 = cx <= 2 ? -1 : 0, dy0 = cy <= 2 ? -1 : 0, dz0 = cz <= 2 ? -1 : 0;
+    float m = 0.f, px = 0.f, py = 0.f, pz = 0.f;
+#pragma unroll
+    for (int iz = 0; iz < 2; ++iz)
+#pragma unroll
+        for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+            for (int ix = 0; ix < 2; ++ix) {
+                const int dx = dx0 + ix, dy = dy0 + iy, dz = dz0 + iz;
+                const int nb = G.blk_nbr[b * 27 + (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1)];
+                if (nb < 0) continue;
+                const int t = G.blk_origin[nb].w;
+                if (t < 0) continue;
+                const int tx = cx - 4 * dx + 1, ty = cy - 4 * dy + 1, tz = cz - 4 * dz + 1;
+                const float4 v = G.tiles[(size_t)t * TILE_N + tx + TILE_W * ty + TILE_W * TILE_W * tz];
+                m += v.x; px += v.y; py += v.z; pz += v.w;
+            }
+    out[r].nodes[lane] = make_float4(m, px, py, pz);
+    if (lane == 0) { out[r].key = (unsigned long long)blk_keys[b]; out[r].pad = 0ull; }
+}
+// add the neighbour's partial sums into halo_in (zeroed every substep); unknown blocks are ignored: no local
+// particle touches them
+__global__ __launch_bounds__(BLK_THREADS) void k_halo_merge(const HaloRecord* __restrict__ in, int n, HashTable H, float4* halo_in,
+                                                             const Ctl* __restrict__ ctl, int parity) {
+    if (ctl->abort_flag[parity]) return;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int b = hash_lookup(H, (uint64_t)in[r].key);
+    if (b < 0) return;
+    float4 v = halo_in[(size_t)b * 64 + lane];
+    const float4 a = in[r].nodes[lane];
+    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    halo_in[(size_t)b * 64 + lane] = v;
+}
 // compact the nodes with mass != 0 for grid_read_nodes
 __global__ void k_dump_nodes(GridArrays G, SparklGridNode* out, unsigned long long cap, unsigned long long* count) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -63,21 +63,19 @@ struct DevBuf {
 };
 
 struct ParticleStore {
-    DevBuf<float4> q[6], d, k, kinvel;
-    DevBuf<float> phase;
-    DevBuf<uint32_t> orig_id;
-    int reserve(size_t n) {
-        for (auto& b : q) CHK(b.reserve(n));
-        CHK(d.reserve(n)); CHK(k.reserve(n)); CHK(kinvel.reserve(n)); CHK(phase.reserve(n)); CHK(orig_id.reserve(n));
+    DevBuf<float4> q[6], d, k, kinvel, aux;
+    int reserve(size_t n, bool keep = false, hipStream_t st = nullptr) {
+        for (auto& b : q) CHK(b.reserve(n, keep, st));
+        CHK(d.reserve(n, keep, st)); CHK(k.reserve(n, keep, st)); CHK(kinvel.reserve(n, keep, st)); CHK(aux.reserve(n, keep, st));
         return SPARKL_OK;
     }
     ParticleArrays arrays() const {
         ParticleArrays a;
         for (int i = 0; i < 6; ++i) a.q[i] = q[i].p;
-        a.d = d.p; a.k = k.p; a.kinvel = kinvel.p; a.phase = phase.p; a.orig_id = orig_id.p;
+        a.d = d.p; a.k = k.p; a.kinvel = kinvel.p; a.aux = aux.p;
         return a;
     }
-    void release() { for (auto& b : q) b.release(); d.release(); k.release(); kinvel.release(); phase.release(); orig_id.release(); }
+    void release() { for (auto& b : q) b.release(); d.release(); k.release(); kinvel.release(); aux.release(); }
 };
 
 struct EventPair { hipEvent_t a, b; int kind; };
@@ -93,9 +91,18 @@ struct SparklPipeline {
     // particles
     uint64_t n = 0;
     ParticleStore cur, alt;
-    // host copies of the constant / caller-order fields
-    std::vector<SparklParticleStatus> h_status;
-    std::vector<float> h_radius0, h_nacc_alpha, h_phase;
+    uint32_t max_model_index = 0;
+    // slab decomposition (multi-GPU): owned home blocks along `slab_axis` are [slab_lo, slab_hi)
+    bool slab_on = false;
+    int slab_axis = 0, slab_lo = INT32_MIN, slab_hi = INT32_MAX;
+    uint64_t id_offset = 0;
+    int n_emig[2] = {0, 0}, emig_first[2] = {0, 0};   // emigrant ranges after the last re-bin (low, high)
+    DevBuf<int> halo_list[2];
+    int halo_count[2] = {0, 0};
+    DevBuf<float4> halo_in;
+    DevBuf<int> d_tail;
+    StepParams pending{};          // split-phase substep state
+    bool in_substep = false;
 
     // models / colliders
     DevBuf<DevModel> d_models;
@@ -188,6 +195,7 @@ static GridArrays grid_arrays(const SparklPipeline* p) {
     GridArrays g;
     g.blk_origin = p->blk_origin.p; g.blk_pfirst = p->blk_pfirst.p; g.blk_pcount = p->blk_pcount.p; g.blk_nbr = p->blk_nbr.p;
     g.pblk = p->pblk.p; g.pb_info = p->pb_info.p; g.tiles = p->tiles.p; g.node_vel = p->node_vel.p; g.node_mom = p->capture_mom ? p->node_mom.p : nullptr;
+    g.halo_in = (p->slab_on && p->num_blocks) ? p->halo_in.p : nullptr;
     g.num_blocks = p->num_blocks; g.num_pblocks = p->num_pblocks;
     return g;
 }
@@ -208,7 +216,8 @@ static int resort(SparklPipeline* p) {
         CHK(p->bkeys.reserve(n)); CHK(p->pb_keys.reserve(n)); CHK(p->pb_counts.reserve(n)); CHK(p->pb_first.reserve(n));
         CHK(p->d_scalars.reserve(4));
         CHK(p->alt.reserve(p->cur.q[0].cap));
-        hipLaunchKernelGGL(k_compute_keys, dim3(grid_for(n, 256)), dim3(256), 0, st, p->cur.arrays(), p->keys_a.p, p->idx_a.p, n, p->h, p->dom);
+        hipLaunchKernelGGL(k_compute_keys, dim3(grid_for(n, 256)), dim3(256), 0, st, p->cur.arrays(), p->keys_a.p, p->idx_a.p, n, p->h, p->dom, p->slab_axis,
+                           p->slab_on ? p->slab_lo : INT32_MIN, p->slab_on ? p->slab_hi : INT32_MAX);
         // key bits: 3 * (block bits + 1 for the -1 bias) + 6 cell bits; invalid keys are all ones => sort all 64 if any
         int end_bit = 64;
         size_t tb = 0;
@@ -229,14 +238,27 @@ static int resort(SparklPipeline* p) {
         HIPCHK(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb2, p->bkeys.p, p->pb_keys.p, p->pb_counts.p, p->d_scalars.p, n, st));
         CHK(cub_reserve(p, tb2));
         HIPCHK(hipcub::DeviceRunLengthEncode::Encode(p->cub_temp.p, tb2, p->bkeys.p, p->pb_keys.p, p->pb_counts.p, p->d_scalars.p, n, st));
-        int h_runs = 0;
+        // tail classes (removed | emigrants low | emigrants high | out of domain) sit after the valid keys
+        CHK(p->d_tail.reserve(4));
+        {
+            int init[4] = {n, n, n, n};
+            HIPCHK(hipMemcpyAsync(p->d_tail.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_tail_bounds, dim3(grid_for(n, 256)), dim3(256), 0, st, p->keys_b.p, n, p->d_tail.p);
+        }
+        int h_runs = 0, tail[4] = {n, n, n, n};
         HIPCHK(hipMemcpyAsync(&h_runs, p->d_scalars.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(tail, p->d_tail.p, sizeof(tail), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        // tail[k] = first index with class >= k; a missing class keeps the bound of the next one
+        for (int k = 2; k >= 0; --k) tail[k] = std::min(tail[k], tail[k + 1]);
         uint64_t last_key = 0;
         if (h_runs > 0) {
             HIPCHK(hipMemcpy(&last_key, p->pb_keys.p + (h_runs - 1), sizeof(uint64_t), hipMemcpyDeviceToHost));
-            if (last_key == (KEY_INVALID >> 6)) --h_runs;  // the out-of-domain bucket is not a block
+            if (last_key == (KEY_INVALID >> 6)) --h_runs;  // every tail class shares this block key: not a block
         }
+        p->emig_first[0] = tail[0]; p->n_emig[0] = tail[1] - tail[0];
+        p->emig_first[1] = tail[1]; p->n_emig[1] = tail[2] - tail[1];
+        p->n = (uint64_t)tail[3];   // particles already handed to a neighbour slab are dropped here
         const int npb = h_runs;
         if (npb > 0) {
             size_t tb3 = 0;
@@ -276,6 +298,20 @@ static int resort(SparklPipeline* p) {
             HIPCHK(hipMemsetAsync(p->node_vel.p, 0, (size_t)nb * 64 * sizeof(float4), st));
             p->num_blocks = nb;
             p->num_pblocks = npb;
+            p->halo_count[0] = p->halo_count[1] = 0;
+            if (p->slab_on) {
+                CHK(p->halo_in.reserve((size_t)nb * 64));
+                HIPCHK(hipMemsetAsync(p->halo_in.p, 0, (size_t)nb * 64 * sizeof(float4), st));
+                for (int side = 0; side < 2; ++side) {
+                    const int cut = side == 0 ? p->slab_lo : p->slab_hi;
+                    if (cut == INT32_MIN || cut == INT32_MAX) continue;
+                    CHK(p->halo_list[side].reserve(nb));
+                    HIPCHK(hipMemsetAsync(p->d_scalars.p + 2 + side, 0, sizeof(int), st));
+                    hipLaunchKernelGGL(k_halo_list, dim3(grid_for(nb, 256)), dim3(256), 0, st, p->blk_origin.p, nb, p->slab_axis, cut, p->halo_list[side].p, p->d_scalars.p + 2 + side);
+                    HIPCHK(hipMemcpyAsync(&p->halo_count[side], p->d_scalars.p + 2 + side, sizeof(int), hipMemcpyDeviceToHost, st));
+                }
+                HIPCHK(hipStreamSynchronize(st));
+            }
         }
     }
     // clear the abort chain; the substep counter restarts so parity 0 is clean
@@ -346,10 +382,8 @@ static int read_ctl(SparklPipeline* p) {
 }
 
 static int validate_models(const SparklPipeline* p) {
-    for (uint64_t i = 0; i < p->n; ++i)
-        if (p->h_status[i].model_index >= p->h_models.size())
-            return set_error(SPARKL_ERR_INVALID_ARGUMENT, "particle %llu uses model %llu but only %zu models are set", (unsigned long long)i,
-                             (unsigned long long)p->h_status[i].model_index, p->h_models.size());
+    if (p->n && p->max_model_index >= p->h_models.size())
+        return set_error(SPARKL_ERR_INVALID_ARGUMENT, "a particle uses model %u but only %zu models are set", p->max_model_index, p->h_models.size());
     return SPARKL_OK;
 }
 
@@ -485,9 +519,7 @@ static int upload_range(SparklPipeline* p, uint64_t first, uint64_t n, const Spa
                         const SparklParticleVelocity* vel, const SparklParticleVolume* volume, const SparklParticlePhase* phase,
                         const SparklParticleData* data, const SparklVelocityGradient* vg) {
     // pack the caller's SoA into the eight float4 streams (host), then one H2D per stream
-    std::vector<float4> hq[6], hd(n), hk(n), hkin(n);
-    std::vector<float> hphase(n);
-    std::vector<uint32_t> hid(n);
+    std::vector<float4> hq[6], hd(n), hk(n), hkin(n), haux(n);
     for (auto& v : hq) v.resize(n);
     for (uint64_t i = 0; i < n; ++i) {
         const float* F = volume[i].deformation_gradient;
@@ -509,16 +541,18 @@ static int upload_range(SparklPipeline* p, uint64_t first, uint64_t n, const Spa
         memcpy(&fl, &flags, 4);
         hk[i] = make_float4(volume[i].mass, volume[i].volume0, data[i].elastic_hardening, fl);
         hkin[i] = make_float4(status[i].kinematic_vel[0], status[i].kinematic_vel[1], status[i].kinematic_vel[2], 0.f);
-        hphase[i] = phase[i].phase;
-        hid[i] = (uint32_t)(first + i);
+        const uint32_t gid = (uint32_t)(p->id_offset + first + i);
+        float gidf;
+        memcpy(&gidf, &gid, 4);
+        haux[i] = make_float4(phase[i].phase, volume[i].radius0, data[i].nacc_alpha, gidf);
+        p->max_model_index = std::max(p->max_model_index, (uint32_t)status[i].model_index);
     }
     hipStream_t st = p->stream;
     for (int a = 0; a < 6; ++a) HIPCHK(hipMemcpyAsync(p->cur.q[a].p + first, hq[a].data(), n * sizeof(float4), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(p->cur.d.p + first, hd.data(), n * sizeof(float4), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(p->cur.k.p + first, hk.data(), n * sizeof(float4), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(p->cur.kinvel.p + first, hkin.data(), n * sizeof(float4), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(p->cur.phase.p + first, hphase.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(p->cur.orig_id.p + first, hid.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(p->cur.aux.p + first, haux.data(), n * sizeof(float4), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
     return SPARKL_OK;
 }
@@ -528,16 +562,14 @@ int sparkl_hip_particles_upload(SparklPipeline* p, uint64_t n, const SparklParti
                                 const SparklParticleData* data, const SparklVelocityGradient* vg) {
     if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
     if (n && (!status || !pos || !vel || !volume || !phase || !data)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null particle array");
-    if (n >= (1ull << 31)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "at most 2^31 - 1 particles per device");
+    if (n >= (1ull << 31) || p->id_offset + n > 0xFFFFFFFFull) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "at most 2^31 - 1 particles per device, 2^32 ids per job");
     for (uint64_t i = 0; i < n; ++i)
         if (status[i].model_index >= (1ull << 24)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "model_index too large");
     HIPCHK(hipSetDevice(p->device));
     HIPCHK(hipStreamSynchronize(p->stream));
     CHK(p->cur.reserve(std::max<uint64_t>(n, 1)));
     p->n = n;
-    p->h_status.assign(status, status + n);
-    p->h_radius0.resize(n); p->h_nacc_alpha.resize(n); p->h_phase.resize(n);
-    for (uint64_t i = 0; i < n; ++i) { p->h_radius0[i] = volume[i].radius0; p->h_nacc_alpha[i] = data[i].nacc_alpha; p->h_phase[i] = phase[i].phase; }
+    p->max_model_index = 0;
     if (n) CHK(upload_range(p, 0, n, status, pos, vel, volume, phase, data, vg));
     p->sorted = false;
     return SPARKL_OK;
@@ -545,20 +577,22 @@ int sparkl_hip_particles_upload(SparklPipeline* p, uint64_t n, const SparklParti
 
 uint64_t sparkl_hip_particles_len(const SparklPipeline* p) { return p ? p->n : 0; }
 
-static int launch_read(SparklPipeline* p, int what, size_t floats_per) {
+// id_base >= 0: scatter to out[id - id_base] (caller order); id_base < 0: device (sorted) order
+static int launch_read(SparklPipeline* p, int what, size_t floats_per, long long id_base) {
     const int n = (int)p->n;
     CHK(p->staging.reserve(std::max<size_t>((size_t)n * floats_per, 1)));
     const ParticleArrays P = p->cur.arrays();
     hipStream_t st = p->stream;
     const dim3 g(grid_for(n, 256)), b(256);
     switch (what) {
-        case 0: hipLaunchKernelGGL(k_read_positions, g, b, 0, st, P, p->staging.p, n); break;
-        case 1: hipLaunchKernelGGL(k_read_velocities, g, b, 0, st, P, p->staging.p, n); break;
-        case 2: hipLaunchKernelGGL(k_read_state, g, b, 0, st, P, p->staging.p, n); break;
-        default: hipLaunchKernelGGL(k_read_velgrad, g, b, 0, st, P, p->staging.p, n); break;
+        case 0: hipLaunchKernelGGL(k_read_positions, g, b, 0, st, P, p->staging.p, n, id_base); break;
+        case 1: hipLaunchKernelGGL(k_read_velocities, g, b, 0, st, P, p->staging.p, n, id_base); break;
+        case 2: hipLaunchKernelGGL(k_read_state, g, b, 0, st, P, p->staging.p, n, id_base); break;
+        default: hipLaunchKernelGGL(k_read_velgrad, g, b, 0, st, P, p->staging.p, n, id_base); break;
     }
     return SPARKL_OK;
 }
+static long long read_base(const SparklPipeline* p) { return p->slab_on ? -1ll : (long long)p->id_offset; }
 #define READ_PROLOGUE                                                                                      \
     if (!p || (n && !out)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");                 \
     if (n != p->n) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "n (%llu) != particle count (%llu)", (unsigned long long)n, (unsigned long long)p->n); \
@@ -567,21 +601,21 @@ static int launch_read(SparklPipeline* p, int what, size_t floats_per) {
 
 int sparkl_hip_particles_read_positions(SparklPipeline* p, SparklParticlePosition* out, uint64_t n) {
     READ_PROLOGUE
-    CHK(launch_read(p, 0, 3));
+    CHK(launch_read(p, 0, 3, read_base(p)));
     HIPCHK(hipMemcpyAsync(out, p->staging.p, n * 12, hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     return SPARKL_OK;
 }
 int sparkl_hip_particles_read_velocities(SparklPipeline* p, SparklParticleVelocity* out, uint64_t n) {
     READ_PROLOGUE
-    CHK(launch_read(p, 1, 3));
+    CHK(launch_read(p, 1, 3, read_base(p)));
     HIPCHK(hipMemcpyAsync(out, p->staging.p, n * 12, hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     return SPARKL_OK;
 }
 static int read_state(SparklPipeline* p, std::vector<float>& st) {
-    CHK(launch_read(p, 2, 16));
-    st.resize((size_t)p->n * 16);
+    CHK(launch_read(p, 2, 24, read_base(p)));
+    st.resize((size_t)p->n * 24);
     HIPCHK(hipMemcpyAsync(st.data(), p->staging.p, st.size() * sizeof(float), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     return SPARKL_OK;
@@ -591,8 +625,8 @@ int sparkl_hip_particles_read_volumes(SparklPipeline* p, SparklParticleVolume* o
     std::vector<float> st;
     CHK(read_state(p, st));
     for (uint64_t i = 0; i < n; ++i) {
-        const float* s = &st[16 * i];
-        out[i].mass = s[14]; out[i].volume0 = s[15]; out[i].radius0 = p->h_radius0[i];
+        const float* s = &st[24 * i];
+        out[i].mass = s[14]; out[i].volume0 = s[15]; out[i].radius0 = s[18];
         for (int k = 0; k < 9; ++k) out[i].deformation_gradient[k] = s[k];
         out[i].plastic_deformation_gradient_det = s[9];
     }
@@ -603,10 +637,15 @@ int sparkl_hip_particles_read_statuses(SparklPipeline* p, SparklParticleStatus* 
     std::vector<float> st;
     CHK(read_state(p, st));
     for (uint64_t i = 0; i < n; ++i) {
+        const float* s = &st[24 * i];
         uint32_t flags;
-        memcpy(&flags, &st[16 * i + 13], 4);
-        out[i] = p->h_status[i];
+        memcpy(&flags, &s[13], 4);
+        memset(&out[i], 0, sizeof(out[i]));
         out[i].failed = (flags & FLAG_FAILED) ? 1 : 0;
+        out[i].is_static = (flags & FLAG_STATIC) ? 1 : 0;
+        out[i].kinematic_vel_enabled = (flags & FLAG_KINEMATIC) ? 1 : 0;
+        out[i].kinematic_vel[0] = s[20]; out[i].kinematic_vel[1] = s[21]; out[i].kinematic_vel[2] = s[22];
+        out[i].model_index = flags >> FLAG_MODEL_SHIFT;
     }
     return SPARKL_OK;
 }
@@ -614,37 +653,32 @@ int sparkl_hip_particles_read_phases(SparklPipeline* p, SparklParticlePhase* out
     READ_PROLOGUE
     std::vector<float> st;
     CHK(read_state(p, st));
-    for (uint64_t i = 0; i < n; ++i) { out[i].phase = p->h_phase[i]; out[i].psi_pos = st[16 * i + 12]; }
+    for (uint64_t i = 0; i < n; ++i) { out[i].phase = st[24 * i + 17]; out[i].psi_pos = st[24 * i + 12]; }
     return SPARKL_OK;
 }
 int sparkl_hip_particles_read_data(SparklPipeline* p, SparklParticleData* out, uint64_t n) {
     READ_PROLOGUE
     std::vector<float> st;
     CHK(read_state(p, st));
-    std::vector<float4> hk(n);
-    // elastic_hardening lives in K (sorted order): fetch through orig_id on the host
-    std::vector<uint32_t> ids(n);
-    HIPCHK(hipMemcpy(hk.data(), p->cur.k.p, n * sizeof(float4), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ids.data(), p->cur.orig_id.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    for (uint64_t s = 0; s < n; ++s) out[ids[s]].elastic_hardening = hk[s].z;
     for (uint64_t i = 0; i < n; ++i) {
-        out[i].nacc_alpha = p->h_nacc_alpha[i];
-        out[i].plastic_hardening = st[16 * i + 10];
-        out[i].log_vol_gain = st[16 * i + 11];
+        const float* s = &st[24 * i];
+        out[i].nacc_alpha = s[19]; out[i].plastic_hardening = s[10]; out[i].elastic_hardening = s[16]; out[i].log_vol_gain = s[11];
     }
     return SPARKL_OK;
 }
 int sparkl_hip_particles_read_velocity_gradients(SparklPipeline* p, SparklVelocityGradient* out, uint64_t n) {
     READ_PROLOGUE
-    CHK(launch_read(p, 3, 9));
+    CHK(launch_read(p, 3, 9, read_base(p)));
     HIPCHK(hipMemcpyAsync(out, p->staging.p, n * 36, hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     return SPARKL_OK;
 }
 int sparkl_hip_particles_read_sorted_ids(SparklPipeline* p, uint32_t* out, uint64_t n) {
     READ_PROLOGUE
+    CHK(p->staging.reserve(n));
+    hipLaunchKernelGGL(k_read_ids, dim3(grid_for(n, 256)), dim3(256), 0, p->stream, p->cur.arrays(), (uint32_t*)p->staging.p, (int)n);
+    HIPCHK(hipMemcpyAsync(out, p->staging.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
-    HIPCHK(hipMemcpy(out, p->cur.orig_id.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return SPARKL_OK;
 }
 
@@ -702,6 +736,8 @@ static int ensure_ready(SparklPipeline* p) {
 
 int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* params, const float gravity[3], float dt, uint32_t nsubsteps) {
     if (!p || !params || !gravity) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    if (p->slab_on && (p->slab_lo != INT32_MIN || p->slab_hi != INT32_MAX))
+        return set_error(SPARKL_ERR_INVALID_ARGUMENT, "a slab with finite cuts must be stepped through substep_begin/halo_*/substep_finish");
     if (p->n == 0 || nsubsteps == 0) return SPARKL_OK;
     CHK(ensure_ready(p));
     CHK(read_ctl(p));
@@ -803,6 +839,147 @@ int sparkl_hip_pipeline_clock_read(SparklPipeline* p, SparklKernelClock* out, in
     *out = p->clock;
     out->sampled_substeps = p->clock_sampled;
     if (reset) { memset(&p->clock, 0, sizeof(p->clock)); p->clock_sampled = 0; }
+    return SPARKL_OK;
+}
+
+// ------------------------------------------------------------------------------ slabs (multi-GPU)
+int sparkl_hip_slab_set(SparklPipeline* p, const SparklSlab* slab) {
+    if (!p || !slab) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    if (slab->axis < 0 || slab->axis > 2 || slab->block_lo >= slab->block_hi) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "bad slab");
+    if (p->n) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "set the slab before uploading particles");
+    p->slab_on = true;
+    p->slab_axis = slab->axis; p->slab_lo = slab->block_lo; p->slab_hi = slab->block_hi; p->id_offset = slab->id_offset;
+    return SPARKL_OK;
+}
+uint64_t sparkl_hip_halo_record_bytes(void) { return sizeof(HaloRecord); }
+uint64_t sparkl_hip_migration_record_bytes(void) { return MIG_F4 * sizeof(float4); }
+
+int sparkl_hip_rebin(SparklPipeline* p) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    HIPCHK(hipSetDevice(p->device));
+    CHK(validate_models(p));
+    return resort(p);
+}
+int sparkl_hip_flags_export(SparklPipeline* p, void* dev_u32) {
+    if (!p || !dev_u32) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    HIPCHK(hipMemcpyAsync(dev_u32, &p->d_ctl->abort_flag[p->substep_index & 1u], 4, hipMemcpyDeviceToDevice, p->stream));
+    return SPARKL_OK;
+}
+int sparkl_hip_flags_import(SparklPipeline* p, const void* dev_u32) {
+    if (!p || !dev_u32) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    HIPCHK(hipMemcpyAsync(&p->d_ctl->abort_flag[p->substep_index & 1u], dev_u32, 4, hipMemcpyDeviceToDevice, p->stream));
+    return SPARKL_OK;
+}
+int sparkl_hip_substep_status(SparklPipeline* p, uint32_t* steps_done, uint32_t* need_rebin) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    HIPCHK(hipSetDevice(p->device));
+    CHK(read_ctl(p));
+    if (p->clock_on) CHK(clock_collect(p));
+    if (steps_done) *steps_done = p->h_ctl->steps_done;
+    if (need_rebin) *need_rebin = (p->h_ctl->abort_flag[0] | p->h_ctl->abort_flag[1]) ? 1u : 0u;
+    return SPARKL_OK;
+}
+
+int sparkl_hip_substep_begin(SparklPipeline* p, const SparklSolverParams* params, const float gravity[3], float dt) {
+    if (!p || !params || !gravity) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    if (p->in_substep) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "substep_begin called twice");
+    if (params->force_fluids_volume_recomputation && p->any_fluid && p->slab_on && (p->slab_lo != INT32_MIN || p->slab_hi != INT32_MAX))
+        return set_error(SPARKL_ERR_UNSUPPORTED, "fluid volume recomputation across slab cuts is not implemented");
+    HIPCHK(hipSetDevice(p->device));
+    if (!p->sorted) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "particles are not binned: call sparkl_hip_rebin (collectively) first");
+    p->pending = make_params(p, params, gravity, dt);
+    p->in_substep = true;
+    if (p->num_pblocks == 0) return SPARKL_OK;
+    hipStream_t st = p->stream;
+    const GridArrays G = grid_arrays(p);
+    if (G.halo_in) HIPCHK(hipMemsetAsync(p->halo_in.p, 0, (size_t)p->num_blocks * 64 * sizeof(float4), st));
+    if (params->force_fluids_volume_recomputation && p->any_fluid) CHK(enqueue_fluid_volumes(p, p->pending));
+    size_t t0 = 0;
+    CHK(clock_begin(p, SPAN_P2G, &t0));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g<SPK_P2G_REDUCE_STEPS>), dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, p->cur.arrays(), G, p->d_models.p, p->d_ctl, p->pending);
+    CHK(clock_end(p, t0));
+    return SPARKL_OK;
+}
+int sparkl_hip_halo_count(SparklPipeline* p, int side, uint64_t* n) {
+    if (!p || !n || side < 0 || side > 1) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "bad argument");
+    *n = (uint64_t)p->halo_count[side];
+    return SPARKL_OK;
+}
+int sparkl_hip_halo_pack(SparklPipeline* p, int side, void* dev_out) {
+    if (!p || side < 0 || side > 1) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "bad argument");
+    if (!p->in_substep) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "halo_pack outside substep_begin/finish");
+    const int n = p->halo_count[side];
+    if (n == 0) return SPARKL_OK;
+    if (!dev_out) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null buffer");
+    size_t tok = 0;
+    CHK(clock_begin(p, SPAN_HALO, &tok));
+    hipLaunchKernelGGL(k_halo_pack, dim3((n + 3) / 4), dim3(BLK_THREADS), 0, p->stream, grid_arrays(p), p->blk_keys.p, p->halo_list[side].p, n, (HaloRecord*)dev_out,
+                       p->d_ctl, p->pending.parity);
+    CHK(clock_end(p, tok));
+    return SPARKL_OK;
+}
+int sparkl_hip_halo_merge(SparklPipeline* p, int side, const void* dev_in, uint64_t n) {
+    if (!p || side < 0 || side > 1) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "bad argument");
+    if (!p->in_substep) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "halo_merge outside substep_begin/finish");
+    if (n == 0 || p->num_blocks == 0) return SPARKL_OK;
+    if (!dev_in) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null buffer");
+    HashTable H{p->hash_keys.p, p->hash_vals.p, p->hash_mask};
+    size_t tok = 0;
+    CHK(clock_begin(p, SPAN_HALO, &tok));
+    hipLaunchKernelGGL(k_halo_merge, dim3((unsigned)((n + 3) / 4)), dim3(BLK_THREADS), 0, p->stream, (const HaloRecord*)dev_in, (int)n, H, p->halo_in.p, p->d_ctl,
+                       p->pending.parity);
+    CHK(clock_end(p, tok));
+    return SPARKL_OK;
+}
+int sparkl_hip_substep_finish(SparklPipeline* p) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    if (!p->in_substep) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "substep_finish without substep_begin");
+    p->in_substep = false;
+    if (p->num_pblocks == 0) {
+        hipLaunchKernelGGL(k_bump_steps, dim3(1), dim3(1), 0, p->stream, p->d_ctl, p->pending.parity);
+        p->substep_index++;
+        return SPARKL_OK;
+    }
+    hipStream_t st = p->stream;
+    const GridArrays G = grid_arrays(p);
+    size_t t1 = 0, t2 = 0;
+    CHK(clock_begin(p, SPAN_GRID, &t1));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false>), dim3((p->num_blocks + 3) / 4), dim3(BLK_THREADS), 0, st, G, p->d_cuboids.p, p->d_ctl, p->pending);
+    CHK(clock_end(p, t1));
+    CHK(clock_begin(p, SPAN_G2P, &t2));
+    hipLaunchKernelGGL(k_g2p, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, p->cur.arrays(), G, p->d_models.p, p->d_ctl, p->pending);
+    CHK(clock_end(p, t2));
+    p->substep_index++;
+    p->clock.substeps++;
+    return SPARKL_OK;
+}
+
+int sparkl_hip_slab_emigrant_count(SparklPipeline* p, int side, uint64_t* n) {
+    if (!p || !n || side < 0 || side > 1) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "bad argument");
+    *n = (uint64_t)p->n_emig[side];
+    return SPARKL_OK;
+}
+int sparkl_hip_slab_emigrants_pack(SparklPipeline* p, int side, void* dev_out) {
+    if (!p || side < 0 || side > 1) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "bad argument");
+    const int n = p->n_emig[side];
+    if (n == 0) return SPARKL_OK;
+    if (!dev_out) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null buffer");
+    HIPCHK(hipSetDevice(p->device));
+    hipLaunchKernelGGL(k_pack_particles, dim3(grid_for(n, 256)), dim3(256), 0, p->stream, p->cur.arrays(), p->emig_first[side], n, (float4*)dev_out);
+    p->n_emig[side] = 0;
+    p->sorted = false;   // the FLAG_REMOVED particles are dropped by the next re-bin
+    return SPARKL_OK;
+}
+int sparkl_hip_slab_immigrants_add(SparklPipeline* p, const void* dev_in, uint64_t n) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    if (n == 0) return SPARKL_OK;
+    if (!dev_in) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null buffer");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    CHK(p->cur.reserve(p->n + n, true, p->stream));
+    hipLaunchKernelGGL(k_unpack_particles, dim3(grid_for(n, 256)), dim3(256), 0, p->stream, p->cur.arrays(), (int)p->n, (int)n, (const float4*)dev_in);
+    p->n += n;
+    p->sorted = false;
     return SPARKL_OK;
 }
 

@@ -44,6 +44,14 @@ class MpmPipeline:
     def __exit__(self, *a):
         self.close()
 
+    # ---- multi-GPU slabs (see sparkl_amd/slab.py)
+    def set_slab(self, axis, block_lo, block_hi, id_offset=0):
+        """Own the home blocks [block_lo, block_hi) along `axis`; call before upload_particles.
+        In slab mode the read_* methods return device order; read_sorted_particle_ids() gives the global ids."""
+        from .slab import SlabC
+        s = SlabC(axis, block_lo, block_hi, 0, id_offset)
+        check(self.L.sparkl_hip_slab_set(self.h, C.byref(s)))
+
     # ---- CudaParticleModelSet / CudaColliderSet
     def set_models(self, model_set):
         check(self.L.sparkl_hip_models_set(self.h, C.c_uint32(len(model_set)), model_set.to_c_array()))
