@@ -771,8 +771,9 @@ __global__ void k_candidates(const uint64_t* __restrict__ pb_keys, int npb, uint
     cand[t] = block_key(bx + (d % 3) - 1, by + ((d / 3) % 3) - 1, bz + (d / 9) - 1);
 }
 
+constexpr uint64_t HASH_EMPTY = ~0ull;   // what hipMemset(0xFF) leaves in a slot
 struct HashTable {
-    uint64_t* keys;   // KEY_INVALID = empty
+    uint64_t* keys;   // HASH_EMPTY = free slot
     uint32_t* vals;
     uint32_t mask;    // capacity - 1 (power of two, load <= 50 %)
 };
@@ -784,8 +785,8 @@ SPK_DEV uint64_t hash64(uint64_t key) {
 SPK_DEV void hash_insert(const HashTable& H, uint64_t key, uint32_t val) {
     uint32_t slot = (uint32_t)hash64(key) & H.mask;
     for (uint32_t probe = 0; probe <= H.mask; ++probe) {
-        const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&H.keys[slot]), (unsigned long long)KEY_INVALID, (unsigned long long)key);
-        if (prev == KEY_INVALID || prev == key) { H.vals[slot] = val; return; }
+        const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&H.keys[slot]), (unsigned long long)HASH_EMPTY, (unsigned long long)key);
+        if (prev == HASH_EMPTY || prev == key) { H.vals[slot] = val; return; }
         slot = (slot + 1) & H.mask;
     }
 }
@@ -794,7 +795,7 @@ SPK_DEV int hash_lookup(const HashTable& H, uint64_t key) {
     for (uint32_t probe = 0; probe <= H.mask; ++probe) {
         const uint64_t k = H.keys[slot];
         if (k == key) return (int)H.vals[slot];
-        if (k == KEY_INVALID) return -1;
+        if (k == HASH_EMPTY) return -1;
         slot = (slot + 1) & H.mask;
     }
     return -1;

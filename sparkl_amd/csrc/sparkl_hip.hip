@@ -241,8 +241,7 @@ static int resort(SparklPipeline* p) {
         // tail classes (removed | emigrants low | emigrants high | out of domain) sit after the valid keys
         CHK(p->d_tail.reserve(4));
         {
-            int init[4] = {n, n, n, n};
-            HIPCHK(hipMemcpyAsync(p->d_tail.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)p->d_tail.p, n, 4, st));   // no host staging buffer to outlive
             hipLaunchKernelGGL(k_tail_bounds, dim3(grid_for(n, 256)), dim3(256), 0, st, p->keys_b.p, n, p->d_tail.p);
         }
         int h_runs = 0, tail[4] = {n, n, n, n};
@@ -750,6 +749,9 @@ int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* pa
         for (uint32_t i = 0; i < batch; ++i) CHK(enqueue_substep(p, params, gravity, dt));
         CHK(read_ctl(p));
         if (p->clock_on) CHK(clock_collect(p));
+        if (getenv("SPARKL_HIP_DEBUG"))
+            fprintf(stderr, "[sparkl_hip] batch %u: steps_done %u (base %u) abort %u %u invalid %u n %llu pblocks %d blocks %d parity-next %u\n", batch, p->h_ctl->steps_done,
+                    base_done, p->h_ctl->abort_flag[0], p->h_ctl->abort_flag[1], p->h_ctl->num_invalid, (unsigned long long)p->n, p->num_pblocks, p->num_blocks, p->substep_index & 1u);
         const uint32_t now_done = p->num_pblocks ? (p->h_ctl->steps_done - base_done) : done + batch;
         const bool aborted = now_done < done + batch;
         done = now_done;
