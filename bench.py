@@ -67,27 +67,56 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # test hook: SPARKL_BENCH_BACKEND=gloo + SPARKL_BENCH_ONE_DEVICE=1 runs the N-rank slab path on a single GPU
+    backend = os.environ.get("SPARKL_BENCH_BACKEND", "nccl")
+    device_id = 0 if os.environ.get("SPARKL_BENCH_ONE_DEVICE") else local_rank
+    torch.cuda.set_device(device_id)
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_id))
+        else:
+            dist.init_process_group(backend)
 
     from sparkl_amd import scenes
     from sparkl_amd.pipeline import MpmPipeline
+    from sparkl_amd.slab import INT32_MAX, INT32_MIN, HipSlabBackend, SlabStepper
 
-    # weak scaling: every rank advances its own column of `particles` (replicas until slab halo lands)
+    # weak scaling: rank k owns the k-th x-slab of a column `world` times longer (config 5's decomposition);
+    # each slab holds `particles` particles, cut on block planes, ghost node-block planes swapped every substep
     nx, ny, nz = column_dims(args.particles)
+    mode = os.environ.get("SPARKL_BENCH_MODE", "slabs" if world > 1 else "single")
+    if mode == "slabs":
+        nx = max(8, int(round(nx / 8.0)) * 8)          # whole 4-cell blocks per slab (200 at the 10M default)
     t0 = time.time()
-    sc = scenes.sand_column(nx, ny, nz, name="config3_drucker_prager_column")
+    sc = scenes.sand_column(nx, ny, nz, name="config3_drucker_prager_column", x_slab=(rank, world) if mode == "slabs" else (0, 1))
     n_particles = len(sc.particles)
     gen_s = time.time() - t0
-    pipe = MpmPipeline(sc.cell_width, device_id=local_rank, domain_log2_bytes=sc.domain_log2_bytes)
+    dt = sc.fixed_dt
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    pipe = MpmPipeline(sc.cell_width, device_id=device_id, domain_log2_bytes=sc.domain_log2_bytes, stream=stream.cuda_stream)
+    stepper = None
+    if mode == "slabs":
+        cells_per_rank = nx // 2                       # lattice spacing h/2
+        assert cells_per_rank % 4 == 0, "slab width must be a whole number of 4-cell blocks"
+        first_block = 1                                # the column starts at cell 4
+        lo = INT32_MIN if rank == 0 else first_block + rank * (cells_per_rank // 4)
+        hi = INT32_MAX if rank == world - 1 else first_block + (rank + 1) * (cells_per_rank // 4)
+        pipe.set_slab(0, lo, hi, id_offset=rank * n_particles)
     t0 = time.time()
     pipe.load_scene(sc)
     upload_s = time.time() - t0
-    dt = sc.fixed_dt
+    if mode == "slabs":
+        stepper = SlabStepper(HipSlabBackend(pipe, torch.device("cuda", device_id)), rank, world, chunk=16)
+
+    def run(n):
+        if stepper is not None:
+            stepper.substeps(sc.params, sc.gravity, dt, n)
+        else:
+            pipe.substeps(sc.params, sc.gravity, dt, n)
 
     def barrier():
         if world > 1:
@@ -95,17 +124,17 @@ def main():
         torch.cuda.synchronize()
         pipe.sync()
 
-    pipe.substeps(sc.params, sc.gravity, dt, args.warmup)
+    run(args.warmup)
     if not args.no_kernel_clock:
         pipe.clock_enable(True, stride=4)   # event spans on every 4th substep: <1 % perturbation of the timed region
         pipe.clock_read(reset=True)
     barrier()
     t0 = time.perf_counter()
-    pipe.substeps(sc.params, sc.gravity, dt, args.steps)   # EXACTLY K substeps; synchronises at the end
+    run(args.steps)   # EXACTLY K substeps; synchronises at the end
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     clock = None if args.no_kernel_clock else pipe.clock_read(reset=False)
@@ -130,7 +159,9 @@ def main():
             "config": {"workload": f"3D Drucker-Prager sand column collapse, {n_particles} particles/GPU ({nx}x{ny}x{nz} lattice, 8 ppc, h=0.2, "
                                    f"E=1e7 nu=0.2 rho=2700, cuboid friction floor), fixed dt={dt}", "particles_per_gpu": n_particles,
                        "active_node_blocks": n_blocks, "particle_blocks": n_pblocks,
-                       "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (slab halo exchange not enabled)"},
+                       "parallelism": "single GPU" if world == 1 else (
+                           f"{world} x-slabs of one {world * nx}x{ny}x{nz} column, ghost node-block planes swapped with both neighbours every substep "
+                           f"({backend} send/recv), re-bin flag all-reduce" if mode == "slabs" else f"{world} independent replicas")},
             "step_gbs": step_bytes * world / (elapsed / args.steps) / 1e9,
             "step_frac_of_hbm_peak": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
             "setup_s": {"generate": gen_s, "upload_and_pack": upload_s},
@@ -148,6 +179,8 @@ def main():
             out["kernel_clock_sampled_launches"] = launches
             out["kernels_gbs"] = {name: per_kernel_bytes[name] / (avg_ms[name] * 1e-3) / 1e9 for name in avg_ms if avg_ms[name] > 0}
             out["resort"] = {"count": int(clock.resorts), "ms_total": clock.sort_ms}
+            if mode == "slabs":
+                out["halo_ms_per_step"] = clock.halo_ms / launches
         if not args.no_cpu_baseline:
             threads = len(os.sched_getaffinity(0))
             out["cpu_baseline"] = cpu_baseline(threads)

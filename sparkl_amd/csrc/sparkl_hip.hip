@@ -103,6 +103,7 @@ struct SparklPipeline {
     DevBuf<int> d_tail;
     StepParams pending{};          // split-phase substep state
     bool in_substep = false;
+    bool pending_clock_saved = false;
 
     // models / colliders
     DevBuf<DevModel> d_models;
@@ -891,6 +892,9 @@ int sparkl_hip_substep_begin(SparklPipeline* p, const SparklSolverParams* params
     if (!p->sorted) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "particles are not binned: call sparkl_hip_rebin (collectively) first");
     p->pending = make_params(p, params, gravity, dt);
     p->in_substep = true;
+    p->pending_clock_saved = p->clock_on;   // sample the spans of this substep or not (restored by substep_finish)
+    if (p->clock_on && (p->substep_index % p->clock_stride) != 0) p->clock_on = false;
+    if (p->clock_on) p->clock_sampled++;
     if (p->num_pblocks == 0) return SPARKL_OK;
     hipStream_t st = p->stream;
     const GridArrays G = grid_arrays(p);
@@ -939,6 +943,7 @@ int sparkl_hip_substep_finish(SparklPipeline* p) {
     p->in_substep = false;
     if (p->num_pblocks == 0) {
         hipLaunchKernelGGL(k_bump_steps, dim3(1), dim3(1), 0, p->stream, p->d_ctl, p->pending.parity);
+        p->clock_on = p->pending_clock_saved;
         p->substep_index++;
         return SPARKL_OK;
     }
@@ -951,6 +956,7 @@ int sparkl_hip_substep_finish(SparklPipeline* p) {
     CHK(clock_begin(p, SPAN_G2P, &t2));
     hipLaunchKernelGGL(k_g2p, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, p->cur.arrays(), G, p->d_models.p, p->d_ctl, p->pending);
     CHK(clock_end(p, t2));
+    p->clock_on = p->pending_clock_saved;
     p->substep_index++;
     p->clock.substeps++;
     return SPARKL_OK;

@@ -81,16 +81,18 @@ def _domain_bits_for(max_cell):
     raise ValueError("scene does not fit the largest virtual grid")
 
 
-def sand_column(nx, ny, nz, h=0.2, with_block=False, jitter=True, name=None):
+def sand_column(nx, ny, nz, h=0.2, with_block=False, jitter=True, name=None, x_slab=(0, 1)):
     """Configs 1/3: Drucker-Prager sand (corotated, E=1e7, nu=0.2, rho=2700) on a friction floor.
 
     with_block=True stacks the sand on an elastic block of the same size (config 1, examples3d/sand3.rs:39-78).
+    x_slab=(k, K): generate only the k-th of K x-slabs of a column K*nx particles long (multi-GPU weak scaling).
     """
     E, NU = 1.0e7, 0.2
     models = ParticleModelSet()
     sand = models.insert(ParticleModel.with_plasticity(CorotatedLinearElasticity(E, NU), DruckerPragerPlasticity(E, NU)))
     r = h / 4.0
     origin = np.array([4 * h, 4 * h, 4 * h], dtype=f32) + f32(r)  # >= 2 cells inside the domain (SURVEY F5)
+    origin[0] += f32(x_slab[0] * nx) * f32(2 * r)
     parts = []
     y0 = origin[1]
     if with_block:
@@ -99,11 +101,11 @@ def sand_column(nx, ny, nz, h=0.2, with_block=False, jitter=True, name=None):
         y0 = origin[1] + f32(ny) * f32(2 * r)
         parts.append(new_particles(sand, cube_positions([origin[0], y0, origin[2]], nx, ny, nz, r, jitter, rng_offset=nx * ny * nz), r, 2700.0))
     else:
-        parts.append(new_particles(sand, cube_positions(origin, nx, ny, nz, r, jitter), r, 2700.0))
+        parts.append(new_particles(sand, cube_positions(origin, nx, ny, nz, r, jitter, seed=42 + x_slab[0]), r, 2700.0))
     comps = ParticleComponents.concatenate(parts)
     floor = floor_cuboid(top_y=4 * h - 0.5 * h + 0.0, friction=0.5)
     params = abi.SolverParameters()
-    max_cell = int(np.ceil(comps.position["point"].max() / h)) + 2
+    max_cell = int(np.ceil(max(comps.position["point"].max(), (4 * h + x_slab[1] * nx * 2 * r)) / h)) + 2
     return Scene(name or f"sand_column_{nx}x{ny}x{nz}", h, models, comps, [floor], params, (0.0, -9.81, 0.0), 2.5e-4,
                  _domain_bits_for(max_cell))
 
