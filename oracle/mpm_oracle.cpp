@@ -18,7 +18,8 @@ void set_particles(Oracle<R>& o, uint64_t n, const SparklParticleStatus* st, con
                    const SparklParticleVelocity* vel, const SparklParticleVolume* vol, const SparklParticlePhase* ph,
                    const SparklParticleData* data, const SparklVelocityGradient* vg) {
     o.particles.resize(n);
-    o.order.clear();
+    o.order.resize(n);   // ParticleSet::set_particles: order = (0..n).collect() (particle_set.rs:48-51)
+    for (uint64_t i = 0; i < n; ++i) o.order[i] = i;
     for (uint64_t i = 0; i < n; ++i) {
         Particle<R>& p = o.particles[i];
         p.model = st[i].model_index;

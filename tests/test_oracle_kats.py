@@ -1,0 +1,247 @@
+"""Analytic known-answer tests of the oracle (SURVEY 8(c) "What pins the oracle instead").
+
+The reference has no dynamics test, so these closed-form cases pin the restated math: B-spline weights, SVD, the three
+constitutive laws, the Drucker-Prager return map, the dt bound, the cuboid projection and the APIC transfer properties."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from sparkl_amd import abi, scenes
+from sparkl_amd.models import (CorotatedLinearElasticity, DruckerPragerPlasticity, MonaghanSphEos, NeoHookeanElasticity, ParticleModel,
+                               ParticleModelSet, lame_lambda_mu)
+from sparkl_amd.particles import new_particles
+
+RNG = np.random.default_rng(12345)
+
+
+def test_quadratic_kernel_moments():
+    # kernel.rs:15-21: partition of unity, first moment 0, second moment h^2/4 (= 1/inv_d) for any x in [0.5, 1.5]
+    for x in np.linspace(0.5, 1.5, 41):
+        w = oracle.eval_all(x, f64=True)
+        nodes = np.array([0.0, 1.0, 2.0])
+        assert abs(w.sum() - 1.0) < 1e-14
+        assert abs((w * (nodes - x)).sum()) < 1e-14
+        assert abs((w * (nodes - x) ** 2).sum() - 0.25) < 1e-14
+    assert np.allclose(oracle.eval_all(1.0), [0.125, 0.75, 0.125])
+
+
+def test_svd_against_numpy():
+    for trial in range(2000):
+        A = RNG.normal(size=(3, 3))
+        if trial % 5 == 0:
+            A = np.eye(3) + 1e-3 * A                      # near identity: repeated singular values
+        if trial % 7 == 0:
+            A[:, 2] = A[:, 0] * 1e-9 + A[:, 1]            # nearly rank deficient
+        U, S, V = oracle.svd3(A)
+        assert np.allclose(U @ np.diag(S) @ V.T, A, atol=1e-12 * max(1.0, np.abs(A).max()))
+        assert np.allclose(U.T @ U, np.eye(3), atol=1e-10) and np.allclose(V.T @ V, np.eye(3), atol=1e-10)
+        assert (S >= 0).all()
+        assert np.allclose(np.sort(S), np.sort(np.linalg.svd(A, compute_uv=False)), atol=1e-12 * max(1.0, S.max()))
+    U, S, V = oracle.svd3(np.diag([2.0, 2.0, 2.0]))
+    assert np.allclose(S, 2.0)
+    R = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1.0]])
+    U, S, V = oracle.svd3(R)
+    assert np.allclose(S, 1.0) and np.allclose(U @ V.T, R)
+
+
+def _rot(axis, ang):
+    axis = np.asarray(axis, float) / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * K @ K
+
+
+def test_elastic_stress_closed_forms():
+    E, nu = 1.0e7, 0.2
+    lam, mu = lame_lambda_mu(E, nu)
+    co = CorotatedLinearElasticity(E, nu).to_core_model()
+    nh = NeoHookeanElasticity(E, nu).to_core_model()
+    I = np.eye(3)
+    for cm in (co, nh):
+        assert np.abs(oracle.kirchhoff_stress(cm, I, f64=True)).max() == 0.0          # F = I  =>  tau = 0
+        assert np.abs(oracle.kirchhoff_stress(cm, _rot([1, 2, 3], 0.7), f64=True)).max() < 1e-7   # rigid rotation
+    # corotated, diagonal F: tau = 2 mu (S - I) S + lam (J - 1) J I
+    s = np.array([1.1, 0.9, 1.05])
+    J = s.prod()
+    want = np.diag(2 * mu * (s - 1) * s + lam * (J - 1) * J)
+    assert np.allclose(oracle.kirchhoff_stress(co, np.diag(s), f64=True), want, rtol=1e-12)
+    assert np.allclose(oracle.kirchhoff_stress(co, np.diag(s), f64=False), want, rtol=2e-5)
+    # ... and objectivity: tau(R F) = R tau(F) R^T
+    R = _rot([0.3, -1, 2], 1.1)
+    assert np.allclose(oracle.kirchhoff_stress(co, R @ np.diag(s), f64=True), R @ want @ R.T, atol=1e-5)
+    # neo-Hookean, F = s I: tau = kappa/2 (s^6 - 1) I, kappa = 2/3 mu + lam  
+    for sc in (1.05, 0.93):
+        kappa = 2.0 / 3.0 * mu + lam
+        got = oracle.kirchhoff_stress(nh, sc * I, f64=True)
+        assert np.allclose(got, kappa / 2 * (sc ** 6 - 1) * I, rtol=1e-12, atol=1e-6)
+    # hardening scales the stress linearly
+    assert np.allclose(oracle.kirchhoff_stress(co, np.diag(s), hardening=2.0, f64=True), 2 * want, rtol=1e-12)
+
+
+def test_monaghan_eos():
+    cm = MonaghanSphEos(1.0e6, 7, 1.01e-3).to_core_model()
+    I = np.eye(3)
+    # J = F00 = 1: p = 0
+    assert np.abs(oracle.kirchhoff_stress(cm, I, mass=1.0, volume0=1.0e-3, fluid_j=1.0, f64=True)).max() == 0.0
+    # compression F00 = 0.98: p = p0 ((1/F00)^7 - 1), tau = -p * fluid_j * I
+    F = I.copy(); F[0, 0] = 0.98
+    p = 1.0e6 * ((1 / 0.98) ** 7 - 1)
+    assert np.allclose(oracle.kirchhoff_stress(cm, F, mass=2.0, volume0=2.0e-3, fluid_j=1.0, f64=True), -p * I, rtol=1e-12)
+    # expansion clamps at -max_neg_pressure = -1
+    F[0, 0] = 1.5
+    assert np.allclose(oracle.kirchhoff_stress(cm, F, mass=2.0, volume0=2.0e-3, fluid_j=1.0, f64=True), 1.0 * I)
+    # viscous part: 2 nu fluid_j dev(sym C)
+    F[0, 0] = 1.0
+    Cm = np.array([[0.0, 2.0, 0], [0, 0, 0], [0, 0, 0]])
+    tau = oracle.kirchhoff_stress(cm, F, mass=1.0, volume0=1.0e-3, fluid_j=1.0, Cmat=Cm, f64=True)
+    want = 2 * 1.01e-3 * np.array([[0, 1.0, 0], [1.0, 0, 0], [0, 0, 0]])
+    assert np.allclose(tau, want, atol=1e-15)
+
+
+def test_drucker_prager_return_map():
+    dp = DruckerPragerPlasticity(1.0e7, 0.2).to_core_model().u.drucker_prager
+    lam, mu = dp.lambda_, dp.mu
+    # alpha(q) with the defaults (35, 9, 0.2, 10 degrees)
+    q = 1.0
+    ang = math.radians(35) + (math.radians(9) * q - math.radians(10)) * math.exp(-0.2 * q)
+    assert oracle.dp_alpha(dp, q, f64=True) == pytest.approx(math.sqrt(2 / 3) * 2 * math.sin(ang) / (3 - math.sin(ang)), rel=1e-6)
+    alpha = oracle.dp_alpha(dp, q, f64=True)
+    # sigma = (1,1,1): zero strain -> "dev == 0" branch: sigma' = 1, dq = 0
+    sv, dq = oracle.dp_project(dp, [1, 1, 1], 0.0, alpha, f64=True)
+    assert np.allclose(sv, 1.0) and dq == 0.0
+    # isotropic expansion: tr > 0 -> sigma' = 1, dq = |eps|
+    sv, dq = oracle.dp_project(dp, [1.02, 1.02, 1.02], 0.0, alpha, f64=True)
+    assert np.allclose(sv, 1.0) and dq == pytest.approx(math.sqrt(3) * math.log(1.02))
+    # compressed + sheared, inside the cone -> None ; outside -> hand-computed gamma
+    k = (3 * lam + 2 * mu) / (2 * mu)
+    for s in ([0.95, 0.951, 0.949], [1.05, 0.85, 1.0]):
+        eps = np.log(s)
+        tr = eps.sum()
+        dev = eps - tr / 3
+        gamma = np.linalg.norm(dev) + k * tr * alpha
+        res = oracle.dp_project(dp, s, 0.0, alpha, f64=True)
+        if gamma <= 0:
+            assert res is None
+        else:
+            H = eps - gamma * dev / np.linalg.norm(dev)
+            assert np.allclose(res[0], np.exp(H), rtol=1e-12) and res[1] == pytest.approx(gamma)
+    assert oracle.dp_project(dp, [0.95, 0.951, 0.949], 0.0, alpha, f64=True) is None
+    assert oracle.dp_project(dp, [1.05, 0.85, 1.0], 0.0, alpha, f64=True) is not None
+    # update_particle on a rotated F keeps U, V and projects S; Jp and log_vol_gain follow the determinants
+    R1, R2 = _rot([1, 0, 2], 0.4), _rot([0, 1, 1], -0.9)
+    s = np.array([1.05, 0.85, 1.0])
+    F = R1 @ np.diag(s) @ R2.T
+    F2, Jp, q2, lvg = oracle.dp_update(dp, F, Jp=1.0, q=1.0, lvg=0.0, f64=True)
+    s2, dq = oracle.dp_project(dp, s, 0.0, alpha, f64=True)
+    assert np.allclose(np.sort(np.linalg.svd(F2, compute_uv=False)), np.sort(s2), rtol=1e-10)
+    assert np.allclose(F2, R1 @ np.diag(s2) @ R2.T, atol=1e-10)
+    assert Jp == pytest.approx(s.prod() / s2.prod()) and lvg == pytest.approx(math.log(s.prod()) - math.log(s2.prod()))
+    assert q2 == pytest.approx(1.0 + dq)
+
+
+def test_pos_energy():
+    co = CorotatedLinearElasticity(1.0e7, 0.2).to_core_model()
+    lam, mu = lame_lambda_mu(1.0e7, 0.2)
+    s = np.array([1.1, 0.9, 1.05])
+    J = s.prod()
+    want = mu * ((s - 1).clip(min=0) ** 2).sum() + (lam / 2 * (J - 1) ** 2 if J >= 1 else 0.0)
+    assert oracle.pos_energy(co, np.diag(s), f64=True) == pytest.approx(want, rel=1e-12)
+    assert oracle.pos_energy(co, np.eye(3), f64=True) == 0.0
+
+
+def test_timestep_bound_matches_survey_number():
+    # E = 1e7, nu = 0.2, rho = 2700, h = 0.2: c = sqrt((K + 4G/3)/rho) ~ 64.15 m/s, dt = 0.9 h / c ~ 2.806e-3
+    sc = scenes.sand_column(4, 4, 4)
+    o = oracle.Oracle(sc.cell_width, f64=True)
+    o.load_scene(sc)
+    K, G = 1.0e7 / (3 * (1 - 0.4)), 1.0e7 / (2 * 1.2)
+    c = math.sqrt((K + 4 * G / 3) / 2700.0)
+    assert c == pytest.approx(64.15, abs=0.01)
+    assert o.estimate_dt(1.0) == pytest.approx(0.9 * 0.2 / c, rel=1e-5)
+    assert o.estimate_dt(1.0) == pytest.approx(2.806e-3, rel=1e-3)
+    assert o.estimate_dt(1.0e-3) == 1.0e-3   # max_dt caps it (timestep_estimator.rs:25)
+
+
+def test_cuboid_projection():
+    c = abi.CuboidColliderC()
+    c.half_extents[:] = [1.0, 2.0, 3.0]
+    c.rotation[:] = [0, 0, 0, 1]
+    c.translation[:] = [10.0, 0, 0]
+    pt, inside = oracle.cuboid_project(c, [12.5, 0.5, 0.0])       # outside: clamp
+    assert not inside and np.allclose(pt, [11.0, 0.5, 0.0])
+    pt, inside = oracle.cuboid_project(c, [10.9, 0.0, 0.0])       # inside: closest face (solid = false)
+    assert inside and np.allclose(pt, [11.0, 0.0, 0.0])
+    pt, inside = oracle.cuboid_project(c, [10.0, -1.9, 0.0])
+    assert inside and np.allclose(pt, [10.0, -2.0, 0.0])
+    # rotated 90 degrees about z: local x extent maps to world y
+    c.rotation[:] = [0, 0, math.sin(math.pi / 4), math.cos(math.pi / 4)]
+    pt, inside = oracle.cuboid_project(c, [10.0, 1.5, 0.0])
+    assert not inside and np.allclose(pt, [10.0, 1.0, 0.0], atol=1e-6)
+
+
+def _elastic_cloud(n=14):
+    models = ParticleModelSet()
+    mid = models.insert(ParticleModel.new(NeoHookeanElasticity(1.0e6, 0.3)))
+    h, r = 0.2, 0.05
+    pos = scenes.cube_positions([1.0, 1.0, 1.0], n, n, n, r, jitter=True)
+    return h, models, new_particles(mid, pos, r, 1000.0)
+
+
+def test_p2g_conserves_mass_and_momentum_and_apic_reproduces_affine_fields():
+    h, models, comps = _elastic_cloud()
+    x = comps.position["point"].astype(np.float64)
+    c = x.mean(0)
+    A = np.array([[0.1, -0.3, 0.2], [0.4, 0.05, -0.1], [-0.2, 0.3, -0.15]])   # uniform affine velocity field
+    v0 = np.array([0.3, -0.2, 0.5])
+    comps.velocity["vector"] = (v0 + (x - c) @ A.T).astype(np.float32)
+    comps.velocity_gradient["m"] = np.tile(A.T.reshape(9), (len(comps), 1)).astype(np.float32)  # column-major
+    o = oracle.Oracle(h, f64=True)
+    o.set_models(models); o.set_cuboids([]); o.set_particles(comps)
+    o.sort(); o.p2g(1.0e-4, (0, 0, 0))
+    nodes = o.nodes()
+    m = comps.volume["mass"].astype(np.float64)
+    assert nodes["mass"].astype(np.float64).sum() == pytest.approx(m.sum(), rel=1e-6)
+    pmom = (m[:, None] * comps.velocity["vector"].astype(np.float64)).sum(0)
+    assert np.allclose(nodes["momentum"].astype(np.float64).sum(0), pmom, rtol=1e-5, atol=1e-7)
+    # APIC: the grid carries the affine field exactly, so interior nodes have v(x_n) = v0 + A (x_n - c) ...
+    xn = nodes["cell"].astype(np.float64) * h
+    vn = v0 + (xn - c) @ A.T
+    heavy = nodes["mass"] > 0.5 * nodes["mass"].max()
+    assert np.allclose(nodes["velocity"][heavy], vn[heavy], atol=2e-5)
+    # ... and G2P returns v and C of interior particles unchanged (F = I: no stress)
+    o.grid_update(1.0e-4, abi.BOUNDARY_NONE, 0)
+    o.g2p(1.0e-4)
+    got = o.get_particles()
+    lo, hi = x.min(0) + 1.2 * h, x.max(0) - 1.2 * h
+    interior = ((x > lo) & (x < hi)).all(1)
+    assert interior.sum() > 10
+    assert np.allclose(got.velocity["vector"][interior], comps.velocity["vector"][interior], atol=3e-5)
+    assert np.allclose(got.velocity_gradient["m"][interior], comps.velocity_gradient["m"][interior], atol=3e-4)
+
+
+def test_rigid_translation_is_exact_to_rounding():
+    h, models, comps = _elastic_cloud(5)
+    comps.velocity["vector"][:] = np.array([0.5, -0.25, 0.125], np.float32)
+    o = oracle.Oracle(h)
+    o.set_models(models); o.set_cuboids([]); o.set_particles(comps)
+    params = abi.SolverParameters(boundary_handling=abi.BOUNDARY_NONE)
+    for _ in range(5):
+        o.substep_fixed(params, (0, 0, 0), 1.0e-3)
+    got = o.get_particles()
+    assert np.allclose(got.velocity["vector"], [0.5, -0.25, 0.125], atol=2e-6)
+    assert np.allclose(got.position["point"], comps.position["point"] + 5.0e-3 * np.array([0.5, -0.25, 0.125]), atol=2e-6)
+    assert np.abs(got.volume["deformation_gradient"] - np.eye(3).reshape(9)).max() < 2e-6
+
+
+def test_step_driver_substep_rule():
+    # mls_solver.rs:33-59,125: dt clamped up to dt/max_num_substeps while more than that remains; frame of 1/60 s -> 6 substeps
+    sc = scenes.sand_column(6, 6, 6)
+    o = oracle.Oracle(sc.cell_width)
+    o.load_scene(sc)
+    t = o.step(sc.params, sc.gravity)
+    dts = o.last_dts()
+    assert t == pytest.approx(1 / 60, rel=1e-6) and len(dts) == 6
+    assert dts[:5] == pytest.approx([2.806e-3] * 5, rel=1e-3) and dts.sum() == pytest.approx(1 / 60, rel=1e-5)
+    p = abi.SolverParameters(stop_after_one_substep=1)
+    assert o.step(p, sc.gravity) == pytest.approx(dts[0], rel=1e-3)

@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 for lib in "$@"; do
   export SPARKL_HIP_LIB=$PWD/sparkl_amd/lib/$lib
   echo "=== $lib"
-  python tools_diag_p2g.py 2>&1 | head -1
+  python tools/tools_diag_p2g.py 2>&1 | head -1
   python bench.py --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())

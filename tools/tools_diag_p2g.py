@@ -1,6 +1,6 @@
 import os, sys, json
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sparkl_amd import scenes
 from sparkl_amd.pipeline import MpmPipeline
 from oracle import Oracle

@@ -1,7 +1,7 @@
 """Quick GPU-vs-oracle check used while optimising kernels (not part of the test suite)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sparkl_amd import scenes
 from sparkl_amd.pipeline import MpmPipeline
 from oracle import Oracle
