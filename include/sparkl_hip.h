@@ -277,6 +277,9 @@ typedef struct {
     double p2g_ms, grid_update_ms, g2p_ms, sort_ms, dt_ms, halo_ms;
     uint64_t substeps, resorts;
     uint64_t sampled_substeps;   /* substeps whose kernels carried event spans (the *_ms sums cover these) */
+    /* fixed-dt runs fuse G2P of substep s with P2G of substep s+1 (k_g2p2g); launches counted per kernel */
+    double g2p2g_ms;
+    uint64_t p2g_launches, grid_update_launches, g2p_launches, g2p2g_launches;
 } SparklKernelClock;
 /* enable: 0 = off, 1 = spans on every substep, N > 1 = spans on every N-th substep */
 int sparkl_hip_pipeline_clock_enable(SparklPipeline* p, int enable);

@@ -122,15 +122,131 @@ SPK_DEV int dpp_shr1_i(int v, int fill) { return __builtin_amdgcn_update_dpp(fil
     "v_fmac_f32_dpp %2, %2, " M " row_shl:" SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"    \
     "v_fmac_f32_dpp %3, %3, " M " row_shl:" SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
 
-// REDUCE_STEPS = log2 of the lane-group size over which same-cell particles are pre-summed with DPP
-// before the LDS atomics (0: none, 2: groups of 4, 3: of 8, 4: of 16).
+// What one particle scatters: node s of its 3x3x3 support receives  w_s * (mass ; qv + sx A0 + sy A1 + sz A2).
+struct Scatter {
+    float wgt[3][3];
+    float val_m;
+    float qv[3];   // affine * d0 + m v
+    M3 A;          // affine * h
+    int base;      // tile index of the associated cell (also the cell key of the lane)
+};
+
+// particle_to_grid.rs:42-59: stress, affine, weights.  `org` = cell origin of the home block.
+SPK_DEV Scatter p2g_prepare(const DevModel& mo, uint32_t flags, const float px[3], const float v[3], const M3& C, const M3& F, float mass, float vol0, float eh,
+                            float phase, float fluid_jp, const int4& org, float h, float inv_h, float inv_d, float dt) {
+    Scatter sc;
+    float d0[3];
+    int lc[3];
+    const int orgv[3] = {org.x, org.y, org.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float r = round_cell(px[a], h, inv_h);
+        d0[a] = (r - 1.0f) * h - px[a];
+        eval_all(-d0[a] * inv_h, sc.wgt[a]);
+        lc[a] = (int)r - 1 - orgv[a] + 1;  // tile coordinate of the associated cell, in [0, 5]
+    }
+    sc.base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
+    M3 tau = m3_zero();
+    if (!(flags & FLAG_FAILED)) {
+        if (mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR) tau = corotated_kirchhoff(mo, phase, eh, F);
+        else if (mo.ctag == SPARKL_CONSTITUTIVE_NEO_HOOKEAN) tau = neo_hookean_kirchhoff(mo, phase, eh, F);
+        else if (mo.ctag == SPARKL_CONSTITUTIVE_EOS_MONAGHAN_SPH) tau = monaghan_kirchhoff(mo, mass, vol0, F.m[0], fluid_jp, C);
+    }
+    // affine = m C - (V0 inv_d dt) tau   (particle_to_grid.rs:58-59)
+    const float ks = vol0 * inv_d * dt;
+    M3 aff;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) aff.m[e] = mass * C.m[e] - ks * tau.m[e];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) sc.qv[r] = aff.m[r] * d0[0] + aff.m[r + 3] * d0[1] + aff.m[r + 6] * d0[2] + mass * v[r];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) sc.A.m[e] = aff.m[e] * h;
+    sc.val_m = mass;
+    return sc;
+}
+SPK_DEV void scatter_clear(Scatter& sc) {
+    sc.val_m = 0.f; sc.qv[0] = sc.qv[1] = sc.qv[2] = 0.f; sc.A = m3_zero(); sc.base = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) sc.wgt[a][0] = sc.wgt[a][1] = sc.wgt[a][2] = 0.f;
+}
+
+// Accumulate one batch of scatters (one per lane; every lane of the wave must call this) into the f64 LDS tile.
+//
+// Measured on gfx950: ds_add_f32 retires ~1 lane per 2.6 cycles (169 cycles for a full wave), ds_add_f64 is pipelined
+// (7.6 cycles per wave instruction) -- so the tile is f64: 20x cheaper atomics *and* one rounding to f32 at write-out.
+// REDUCE_STEPS = log2 of the lane-group size over which same-cell particles are pre-summed with DPP before the LDS
+// atomics (0: none, 2: groups of 4, 3: of 8, 4: of 16).  Particles are cell-sorted inside a block, so runs of lanes
+// share a cell key: segmented suffix sums over runs inside aligned groups of G lanes, all VALU, then one atomic per
+// run head.  Cross-lane ops are hoisted out of every `&&` / `||`: they must execute with all lanes enabled.
+template <int REDUCE_STEPS>
+SPK_DEV void p2g_scatter(double (*tile)[TILE_N], const Scatter& sc, bool live, int tid) {
+    if (REDUCE_STEPS > 0) {
+        constexpr int G = 1 << REDUCE_STEPS;
+        const int lane = tid & 63;
+        const int r = lane & (G - 1);
+        const int cell_key = live ? sc.base : -1;
+        const int key_prev = dpp_shr1_i(cell_key, -2), key_next = dpp_shl_i<1>(cell_key);
+        const bool head = (r == 0) | (key_prev != cell_key);
+        // f_o = 1.0 when lanes L .. L+o form one contiguous same-key run inside the group
+        const int i1 = ((r + 1 < G) & (key_next == cell_key)) ? 1 : 0;
+        const int i2 = (REDUCE_STEPS >= 2) ? (i1 & dpp_shl_i<1>(i1) & (r + 2 < G ? 1 : 0)) : 0;
+        const int i4 = (REDUCE_STEPS >= 3) ? (i2 & dpp_shl_i<2>(i2) & (r + 4 < G ? 1 : 0)) : 0;
+        const int i8 = (REDUCE_STEPS >= 4) ? (i4 & dpp_shl_i<4>(i4) & (r + 8 < G ? 1 : 0)) : 0;
+        const float f1 = (float)i1, f2 = (float)i2, f4 = (float)i4, f8 = (float)i8;
+#pragma unroll
+        for (int sz = 0; sz < 3; ++sz)
+#pragma unroll
+            for (int sy = 0; sy < 3; ++sy)
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) {
+                    const float w = sc.wgt[0][sx] * sc.wgt[1][sy] * sc.wgt[2][sz];
+                    float c0 = w * sc.val_m;
+                    float c1 = w * (sc.qv[0] + sx * sc.A.m[0] + sy * sc.A.m[3] + sz * sc.A.m[6]);
+                    float c2 = w * (sc.qv[1] + sx * sc.A.m[1] + sy * sc.A.m[4] + sz * sc.A.m[7]);
+                    float c3 = w * (sc.qv[2] + sx * sc.A.m[2] + sy * sc.A.m[5] + sz * sc.A.m[8]);
+                    // c += f_o * row_shl:o(c), o = 1, 2, 4[, 8]: one v_fmac_f32_dpp each.  hipcc emits v_mov_b32_dpp +
+                    // v_fmac (+ s_nop) for the builtin form, so this is hand-written; the four independent chains are
+                    // interleaved so that a DPP read of c_k is >= 3 VALU ops after its write (DPP needs 2 wait states),
+                    // and the leading s_nop covers the compiler's last write.
+                    if (REDUCE_STEPS == 2) {
+                        asm volatile("s_nop 1\n" SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2));
+                    } else if (REDUCE_STEPS == 3) {
+                        asm volatile("s_nop 1\n" SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") SPK_FMAC_DPP("4", "%6")
+                                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4));
+                    } else {
+                        asm volatile("s_nop 1\n" SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") SPK_FMAC_DPP("4", "%6") SPK_FMAC_DPP("8", "%7")
+                                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4), "v"(f8));
+                    }
+                    if (live && head) {
+                        const int n = sc.base + sx + TILE_W * sy + TILE_W * TILE_W * sz;
+                        atomicAdd(&tile[0][n], (double)c0);
+                        atomicAdd(&tile[1][n], (double)c1);
+                        atomicAdd(&tile[2][n], (double)c2);
+                        atomicAdd(&tile[3][n], (double)c3);
+                    }
+                }
+    } else if (live) {
+#pragma unroll
+        for (int sz = 0; sz < 3; ++sz)
+#pragma unroll
+            for (int sy = 0; sy < 3; ++sy)
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) {
+                    const float w = sc.wgt[0][sx] * sc.wgt[1][sy] * sc.wgt[2][sz];
+                    const int n = sc.base + sx + TILE_W * sy + TILE_W * TILE_W * sz;
+                    atomicAdd(&tile[0][n], (double)(w * sc.val_m));
+                    atomicAdd(&tile[1][n], (double)(w * (sc.qv[0] + sx * sc.A.m[0] + sy * sc.A.m[3] + sz * sc.A.m[6])));
+                    atomicAdd(&tile[2][n], (double)(w * (sc.qv[1] + sx * sc.A.m[1] + sy * sc.A.m[4] + sz * sc.A.m[7])));
+                    atomicAdd(&tile[3][n], (double)(w * (sc.qv[2] + sx * sc.A.m[2] + sy * sc.A.m[5] + sz * sc.A.m[8])));
+                }
+    }
+}
+
+// One workgroup per particle block: scatter its particles into the LDS tile, write the tile once.
 template <int REDUCE_STEPS>
 __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models,
                                                      const Ctl* __restrict__ ctl, StepParams S) {
     if (ctl->abort_flag[S.parity]) return;
-    // Measured on gfx950: ds_add_f32 retires ~1 lane per 2.6 cycles (169 cycles for a full wave), while
-    // ds_add_f64 is pipelined (7.6 cycles per wave instruction).  So the tile is accumulated in f64 --
-    // 20x cheaper *and* more accurate (sums are rounded to f32 once, at write-out).
     __shared__ double tile[4][TILE_N];
     const int tid = threadIdx.x;
     const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
@@ -158,121 +274,18 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
         }
         const uint32_t flags = __float_as_uint(kk.w);
         const bool live = active && !(flags & FLAG_INVALID);
-        int cell_key = -1;
-        float wgt[3][3];
-        float d0[3];
-        float val_m = 0.f;
-        float qv[3] = {0.f, 0.f, 0.f};  // A*d0 + m v
-        M3 A = m3_zero();               // affine * h
-        int base = 0;
+        Scatter sc;
+        scatter_clear(sc);
         if (live) {
-            const float px[3] = {q0.x, q0.y, q0.z};
-            int lc[3];
-            const int orgv[3] = {org.x, org.y, org.z};
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float r = round_cell(px[a], h, inv_h);
-                d0[a] = (r - 1.0f) * h - px[a];
-                eval_all(-d0[a] * inv_h, wgt[a]);
-                lc[a] = (int)r - 1 - orgv[a] + 1;  // tile coordinate of the associated cell, in [0, 5]
-            }
-            base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
-            cell_key = base;
+            const float px[3] = {q0.x, q0.y, q0.z}, v[3] = {q3.x, q3.y, q3.z};
             const M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
             const M3 C = {{q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
-            const float mass = kk.x, vol0 = kk.y, eh = kk.z;
-            const DevModel mo = models[flags >> FLAG_MODEL_SHIFT];
-            M3 tau = m3_zero();
-            if (!(flags & FLAG_FAILED)) {
-                const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
-                if (mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR) tau = corotated_kirchhoff(mo, phase, eh, F);
-                else if (mo.ctag == SPARKL_CONSTITUTIVE_NEO_HOOKEAN) tau = neo_hookean_kirchhoff(mo, phase, eh, F);
-                else if (mo.ctag == SPARKL_CONSTITUTIVE_EOS_MONAGHAN_SPH) tau = monaghan_kirchhoff(mo, mass, vol0, F.m[0], P.d[i].z, C);
-            }
-            // affine = m C - (V0 inv_d dt) tau   (particle_to_grid.rs:58-59)
-            const float ks = vol0 * S.inv_d * S.dt;
-            M3 aff;
-#pragma unroll
-            for (int e = 0; e < 9; ++e) aff.m[e] = mass * C.m[e] - ks * tau.m[e];
-            // contribution to node s: w * (aff * (d0 + s h) + m v) = w * (qv + sx A0 + sy A1 + sz A2), A = aff * h
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                qv[r] = aff.m[r] * d0[0] + aff.m[r + 3] * d0[1] + aff.m[r + 6] * d0[2];
-            }
-            qv[0] += mass * q3.x; qv[1] += mass * q3.y; qv[2] += mass * q3.z;
-#pragma unroll
-            for (int e = 0; e < 9; ++e) A.m[e] = aff.m[e] * h;
-            val_m = mass;
+            const DevModel& mo = models[flags >> FLAG_MODEL_SHIFT];
+            const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
+            const float jp = mo.is_fluid ? P.d[i].z : 1.f;
+            sc = p2g_prepare(mo, flags, px, v, C, F, kk.x, kk.y, kk.z, phase, jp, org, h, inv_h, S.inv_d, S.dt);
         }
-
-        if (REDUCE_STEPS > 0) {
-            // Particles are cell-sorted inside a block, so runs of lanes share `cell_key`.  Segmented suffix
-            // sums over runs inside aligned groups of G = 2^REDUCE_STEPS lanes, all in DPP (VALU, no LDS
-            // traffic), then one LDS atomic per run head.  Every lane executes every DPP (no divergence).
-            constexpr int G = 1 << REDUCE_STEPS;
-            const int lane = tid & 63;
-            const int r = lane & (G - 1);
-            // (cross-lane ops are hoisted out of every `&&` / `||`: they must run with all lanes enabled)
-            const int key_prev = dpp_shr1_i(cell_key, -2), key_next = dpp_shl_i<1>(cell_key);
-            const bool head = (r == 0) | (key_prev != cell_key);
-            // f_o = 1.0 when lanes L .. L+o form one contiguous same-key run inside the group
-            const int i1 = ((r + 1 < G) & (key_next == cell_key)) ? 1 : 0;
-            const int i2 = (REDUCE_STEPS >= 2) ? (i1 & dpp_shl_i<1>(i1) & (r + 2 < G ? 1 : 0)) : 0;
-            const int i4 = (REDUCE_STEPS >= 3) ? (i2 & dpp_shl_i<2>(i2) & (r + 4 < G ? 1 : 0)) : 0;
-            const int i8 = (REDUCE_STEPS >= 4) ? (i4 & dpp_shl_i<4>(i4) & (r + 8 < G ? 1 : 0)) : 0;
-            const float f1 = (float)i1, f2 = (float)i2, f4 = (float)i4, f8 = (float)i8;
-            if (!live) { val_m = 0.f; qv[0] = qv[1] = qv[2] = 0.f; A = m3_zero(); wgt[0][0] = wgt[0][1] = wgt[0][2] = 0.f; wgt[1][0] = wgt[1][1] = wgt[1][2] = 0.f; wgt[2][0] = wgt[2][1] = wgt[2][2] = 0.f; }
-#pragma unroll
-            for (int sz = 0; sz < 3; ++sz)
-#pragma unroll
-                for (int sy = 0; sy < 3; ++sy)
-#pragma unroll
-                    for (int sx = 0; sx < 3; ++sx) {
-                        const float w = wgt[0][sx] * wgt[1][sy] * wgt[2][sz];
-                        float c0 = w * val_m;
-                        float c1 = w * (qv[0] + sx * A.m[0] + sy * A.m[3] + sz * A.m[6]);
-                        float c2 = w * (qv[1] + sx * A.m[1] + sy * A.m[4] + sz * A.m[7]);
-                        float c3 = w * (qv[2] + sx * A.m[2] + sy * A.m[5] + sz * A.m[8]);
-                        // c += f_o * row_shl:o(c), o = 1, 2, 4[, 8]: one v_fmac_f32_dpp each.  hipcc emits
-                        // v_mov_b32_dpp + v_fmac (+ s_nop) for the builtin form, so this is hand-written; the four
-                        // independent chains are interleaved so that a DPP read of c_k is >= 3 VALU ops after its
-                        // write (DPP needs 2 wait states), and the leading s_nop covers the compiler's last write.
-                        if (REDUCE_STEPS == 2) {
-                            asm volatile("s_nop 1\n"
-                                SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5")
-                                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2));
-                        } else if (REDUCE_STEPS == 3) {
-                            asm volatile("s_nop 1\n"
-                                SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") SPK_FMAC_DPP("4", "%6")
-                                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4));
-                        } else {
-                            asm volatile("s_nop 1\n"
-                                SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") SPK_FMAC_DPP("4", "%6") SPK_FMAC_DPP("8", "%7")
-                                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4), "v"(f8));
-                        }
-                        if (live && head) {
-                            const int n = base + sx + TILE_W * sy + TILE_W * TILE_W * sz;
-                            atomicAdd(&tile[0][n], (double)c0);
-                            atomicAdd(&tile[1][n], (double)c1);
-                            atomicAdd(&tile[2][n], (double)c2);
-                            atomicAdd(&tile[3][n], (double)c3);
-                        }
-                    }
-        } else if (live) {
-#pragma unroll
-            for (int sz = 0; sz < 3; ++sz)
-#pragma unroll
-                for (int sy = 0; sy < 3; ++sy)
-#pragma unroll
-                    for (int sx = 0; sx < 3; ++sx) {
-                        const float w = wgt[0][sx] * wgt[1][sy] * wgt[2][sz];
-                        const int n = base + sx + TILE_W * sy + TILE_W * TILE_W * sz;
-                        atomicAdd(&tile[0][n], (double)(w * val_m));
-                        atomicAdd(&tile[1][n], (double)(w * (qv[0] + sx * A.m[0] + sy * A.m[3] + sz * A.m[6])));
-                        atomicAdd(&tile[2][n], (double)(w * (qv[1] + sx * A.m[1] + sy * A.m[4] + sz * A.m[7])));
-                        atomicAdd(&tile[3][n], (double)(w * (qv[2] + sx * A.m[2] + sy * A.m[5] + sz * A.m[8])));
-                    }
-        }
+        p2g_scatter<REDUCE_STEPS>(tile, sc, live, tid);
     }
     __syncthreads();
     float4* out = G.tiles + (size_t)pb * TILE_N;
@@ -418,6 +431,142 @@ SPK_DEV void load_vel_tile(float4* vt, const GridArrays& G, int b, int tid) {
     }
 }
 
+// State of one particle after grid_to_particle.rs:62-164 (gather .. psi_pos), before it is written back.
+struct Advected {
+    float px[3], vel[3];
+    M3 C, F;
+    float q, lvg, Jp, psi;
+    uint32_t flags;
+    bool newly_failed;   // flags word must be stored
+    bool in_tile;        // the NEW position still scatters inside the home block's tile (and inside the domain)
+};
+
+SPK_DEV Advected g2p_update(const float4* vt, const DevModel& mo, uint32_t flags, const float4& q0, const float4& q1, const float4& q2, const float4& dd,
+                            const float4& kk, const float4* kinvel_i, float phase, const int4& org, const StepParams& S, float inv_h, unsigned* num_invalid) {
+    Advected o;
+    const float h = S.h, dt = S.dt;
+    float px[3] = {q0.x, q0.y, q0.z};
+    float d0[3], wgt[3][3];
+    int lc[3];
+    const int orgv[3] = {org.x, org.y, org.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float r = round_cell(px[a], h, inv_h);
+        d0[a] = (r - 1.0f) * h - px[a];
+        eval_all(-d0[a] * inv_h, wgt[a]);
+        lc[a] = (int)r - 1 - orgv[a] + 1;
+    }
+    const int base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
+    // APIC gather in separable form (grid_to_particle.rs:47-60):
+    //   v = sum w v_n ;  C = inv_d * sum w v_n (d0 + s h)^T = inv_d * (v d0^T + h [Vx Vy Vz]),  V_a = sum w s_a v_n
+    //   velocity_gradient_det = sum w (v_n . dpt) inv_d = trace(C)
+    float V0[3] = {0.f, 0.f, 0.f}, Vx[3] = {0.f, 0.f, 0.f}, Vy[3] = {0.f, 0.f, 0.f}, Vz[3] = {0.f, 0.f, 0.f};
+    const float wx0 = wgt[0][0], wx1 = wgt[0][1], wx2 = wgt[0][2], wx2d = 2.f * wgt[0][2];
+#pragma unroll 1
+    for (int sz = 0; sz < 3; ++sz) {
+        const float wz = sz == 0 ? wgt[2][0] : (sz == 1 ? wgt[2][1] : wgt[2][2]);  // no dynamic register indexing
+        float Rz[3] = {0.f, 0.f, 0.f}, Rzx[3] = {0.f, 0.f, 0.f}, Rzy[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sy = 0; sy < 3; ++sy) {
+            const float4* row = vt + base + TILE_W * sy + TILE_W * TILE_W * sz;
+            const float4 c0 = row[0], c1 = row[1], c2 = row[2];
+            const float wy = wgt[1][sy];
+            const float a1x = wx1 * c1.x, a1y = wx1 * c1.y, a1z = wx1 * c1.z;
+            const float R[3] = {wx0 * c0.x + a1x + wx2 * c2.x, wx0 * c0.y + a1y + wx2 * c2.y, wx0 * c0.z + a1z + wx2 * c2.z};
+            const float Rx[3] = {a1x + wx2d * c2.x, a1y + wx2d * c2.y, a1z + wx2d * c2.z};
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                Rz[e] += wy * R[e];
+                Rzx[e] += wy * Rx[e];
+                if (sy > 0) Rzy[e] += (wy * (float)sy) * R[e];
+            }
+        }
+        const float wzs = wz * (float)sz;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            V0[e] += wz * Rz[e];
+            Vx[e] += wz * Rzx[e];
+            Vy[e] += wz * Rzy[e];
+            Vz[e] += wzs * Rz[e];
+        }
+    }
+    float vel[3] = {V0[0], V0[1], V0[2]};
+    M3 C;
+    const float hid = h * S.inv_d;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        C.m[e] = (S.inv_d * V0[e]) * d0[0] + hid * Vx[e];
+        C.m[3 + e] = (S.inv_d * V0[e]) * d0[1] + hid * Vy[e];
+        C.m[6 + e] = (S.inv_d * V0[e]) * d0[2] + hid * Vz[e];
+    }
+    const float div = C.m[0] + C.m[4] + C.m[8];
+    // kinematic override, advection (grid_to_particle.rs:82-86)
+    if (flags & FLAG_KINEMATIC) { const float4 kv = *kinvel_i; vel[0] = kv.x; vel[1] = kv.y; vel[2] = kv.z; }
+    px[0] += vel[0] * dt; px[1] += vel[1] * dt; px[2] += vel[2] * dt;
+    // deformation gradient update (:91-100)
+    M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
+    if (!mo.is_fluid) {
+        M3 Cdt;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Cdt.m[e] = C.m[e] * dt;
+        const M3 dF = m3_mul(Cdt, F);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) F.m[e] += dF.m[e];
+    } else {
+        F.m[0] += (div * dt) * F.m[0];
+    }
+    float q = dd.x, lvg = dd.y, Jp = dd.z, psi = dd.w;
+    const float eh = kk.z;
+    float sv[3] = {1.f, 1.f, 1.f};
+    bool sv_valid = false;
+    if (mo.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER) dp_update(mo, phase, F, Jp, q, lvg, sv, sv_valid);
+    if (flags & FLAG_STATIC) { vel[0] = vel[1] = vel[2] = 0.f; C = m3_zero(); }
+    // fail guards (:111-121); density_def_grad() == 0  <=>  mass/volume0 == 0 or det(F) overflowed
+    const bool zero_density = (kk.x == 0.f) || !(fabsf(m3_det(F)) < 1.0e30f);
+    bool newly_failed = false;
+    if (zero_density || (flags & FLAG_FAILED) || (!mo.is_fluid && fabsf(F.m[0]) > 1.0e4f)) {
+        newly_failed = !(flags & FLAG_FAILED);
+        flags |= FLAG_FAILED;
+        F = m3_identity();
+        C = m3_zero();
+        sv_valid = false;
+    }
+    // positive energy bookkeeping (:127-132)
+    psi = fmaxf(psi, model_pos_energy(mo, phase, eh, F, sv, sv_valid));
+    // does the particle still sit inside its home block's tile, and inside the domain?
+    bool invalid = false, in_tile = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float r = round_cell(px[a], h, inv_h);
+        const bool ok = (r >= 1.0f) && (r < (float)(S.dom - 4));   // 0 <= assoc, assoc + 5 < dom
+        if (!ok) invalid = true;
+        else {
+            const int nl = (int)r - 1 - orgv[a];
+            if (nl < -1 || nl > 4) in_tile = false;
+        }
+    }
+    if (invalid) {  // what the next ParticleSet::sort would do (particle_set.rs:129-136)
+        newly_failed = true;
+        flags |= FLAG_FAILED | FLAG_INVALID;
+        in_tile = false;
+        atomicAdd(num_invalid, 1u);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { o.px[a] = px[a]; o.vel[a] = vel[a]; }
+    o.C = C; o.F = F; o.q = q; o.lvg = lvg; o.Jp = Jp; o.psi = psi; o.flags = flags; o.newly_failed = newly_failed; o.in_tile = in_tile;
+    return o;
+}
+SPK_DEV void g2p_store(const ParticleArrays& P, int i, const Advected& o) {
+    P.q[0][i] = make_float4(o.px[0], o.px[1], o.px[2], o.F.m[0]);
+    P.q[1][i] = make_float4(o.F.m[1], o.F.m[2], o.F.m[3], o.F.m[4]);
+    P.q[2][i] = make_float4(o.F.m[5], o.F.m[6], o.F.m[7], o.F.m[8]);
+    P.q[3][i] = make_float4(o.vel[0], o.vel[1], o.vel[2], o.C.m[0]);
+    P.q[4][i] = make_float4(o.C.m[1], o.C.m[2], o.C.m[3], o.C.m[4]);
+    P.q[5][i] = make_float4(o.C.m[5], o.C.m[6], o.C.m[7], o.C.m[8]);
+    P.d[i] = make_float4(o.q, o.lvg, o.Jp, o.psi);
+    if (o.newly_failed) reinterpret_cast<uint32_t*>(&P.k[i])[3] = o.flags;
+}
+
 __global__ __launch_bounds__(BLK_THREADS) void k_g2p(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
     const int tid = threadIdx.x;
     if (ctl->abort_flag[S.parity]) {
@@ -440,7 +589,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p(ParticleArrays P, GridArray
     load_vel_tile(vt, G, b, tid);
     if (blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
     __syncthreads();
-    const float h = S.h, dt = S.dt, inv_h = 1.0f / S.h;
+    const float inv_h = 1.0f / S.h;
     bool want_sort = false;
     while (have) {
         const int i = pfirst + li;
@@ -448,127 +597,75 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p(ParticleArrays P, GridArray
         li += BLK_THREADS;
         have = li < pcount;
         if (have) { const int inx = pfirst + li; n0 = P.q[0][inx]; n1 = P.q[1][inx]; n2 = P.q[2][inx]; nd = P.d[inx]; nk = P.k[inx]; }
-        uint32_t flags = __float_as_uint(kk.w);
+        const uint32_t flags = __float_as_uint(kk.w);
         if (flags & FLAG_INVALID) continue;
         const DevModel& mo = models[flags >> FLAG_MODEL_SHIFT];
-        float px[3] = {q0.x, q0.y, q0.z};
-        float d0[3], wgt[3][3];
-        int lc[3];
-        const int orgv[3] = {org.x, org.y, org.z};
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float r = round_cell(px[a], h, inv_h);
-            d0[a] = (r - 1.0f) * h - px[a];
-            eval_all(-d0[a] * inv_h, wgt[a]);
-            lc[a] = (int)r - 1 - orgv[a] + 1;
-        }
-        const int base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
-        // APIC gather in separable form (grid_to_particle.rs:47-60):
-        //   v = sum w v_n ;  C = inv_d * sum w v_n (d0 + s h)^T = inv_d * (v d0^T + h [Vx Vy Vz]),  V_a = sum w s_a v_n
-        //   velocity_gradient_det = sum w (v_n . dpt) inv_d = trace(C)
-        float V0[3] = {0.f, 0.f, 0.f}, Vx[3] = {0.f, 0.f, 0.f}, Vy[3] = {0.f, 0.f, 0.f}, Vz[3] = {0.f, 0.f, 0.f};
-        const float wx0 = wgt[0][0], wx1 = wgt[0][1], wx2 = wgt[0][2], wx2d = 2.f * wgt[0][2];
-#pragma unroll 1
-        for (int sz = 0; sz < 3; ++sz) {
-            const float wz = sz == 0 ? wgt[2][0] : (sz == 1 ? wgt[2][1] : wgt[2][2]);  // no dynamic register indexing
-            float Rz[3] = {0.f, 0.f, 0.f}, Rzx[3] = {0.f, 0.f, 0.f}, Rzy[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-            for (int sy = 0; sy < 3; ++sy) {
-                const float4* row = vt + base + TILE_W * sy + TILE_W * TILE_W * sz;
-                const float4 c0 = row[0], c1 = row[1], c2 = row[2];
-                const float wy = wgt[1][sy];
-                const float a1x = wx1 * c1.x, a1y = wx1 * c1.y, a1z = wx1 * c1.z;
-                const float R[3] = {wx0 * c0.x + a1x + wx2 * c2.x, wx0 * c0.y + a1y + wx2 * c2.y, wx0 * c0.z + a1z + wx2 * c2.z};
-                const float Rx[3] = {a1x + wx2d * c2.x, a1y + wx2d * c2.y, a1z + wx2d * c2.z};
-#pragma unroll
-                for (int e = 0; e < 3; ++e) {
-                    Rz[e] += wy * R[e];
-                    Rzx[e] += wy * Rx[e];
-                    if (sy > 0) Rzy[e] += (wy * (float)sy) * R[e];
-                }
-            }
-            const float wzs = wz * (float)sz;
-#pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                V0[e] += wz * Rz[e];
-                Vx[e] += wz * Rzx[e];
-                Vy[e] += wz * Rzy[e];
-                Vz[e] += wzs * Rz[e];
-            }
-        }
-        float vel[3] = {V0[0], V0[1], V0[2]};
-        M3 C;
-        const float hid = h * S.inv_d;
-#pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            C.m[e] = (S.inv_d * V0[e]) * d0[0] + hid * Vx[e];
-            C.m[3 + e] = (S.inv_d * V0[e]) * d0[1] + hid * Vy[e];
-            C.m[6 + e] = (S.inv_d * V0[e]) * d0[2] + hid * Vz[e];
-        }
-        const float div = C.m[0] + C.m[4] + C.m[8];
-        // kinematic override, advection (grid_to_particle.rs:82-86)
-        if (flags & FLAG_KINEMATIC) { const float4 kv = P.kinvel[i]; vel[0] = kv.x; vel[1] = kv.y; vel[2] = kv.z; }
-        px[0] += vel[0] * dt; px[1] += vel[1] * dt; px[2] += vel[2] * dt;
-        // deformation gradient update (:91-100)
-        M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
-        if (!mo.is_fluid) {
-            M3 Cdt;
-#pragma unroll
-            for (int e = 0; e < 9; ++e) Cdt.m[e] = C.m[e] * dt;
-            const M3 dF = m3_mul(Cdt, F);
-#pragma unroll
-            for (int e = 0; e < 9; ++e) F.m[e] += dF.m[e];
-        } else {
-            F.m[0] += (div * dt) * F.m[0];
-        }
-        float q = dd.x, lvg = dd.y, Jp = dd.z, psi = dd.w;
-        const float eh = kk.z;
         const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
-        float sv[3] = {1.f, 1.f, 1.f};
-        bool sv_valid = false;
-        if (mo.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER) dp_update(mo, phase, F, Jp, q, lvg, sv, sv_valid);
-        if (flags & FLAG_STATIC) { vel[0] = vel[1] = vel[2] = 0.f; C = m3_zero(); }
-        // fail guards (:111-121)
-        // density_def_grad() == 0  <=>  mass/volume0 == 0 or det(F) overflowed (grid_to_particle.rs:111)
-        const bool zero_density = (kk.x == 0.f) || !(fabsf(m3_det(F)) < 1.0e30f);
-        bool newly_failed = false;
-        if (zero_density || (flags & FLAG_FAILED) || (!mo.is_fluid && fabsf(F.m[0]) > 1.0e4f)) {
-            newly_failed = !(flags & FLAG_FAILED);
-            flags |= FLAG_FAILED;
-            F = m3_identity();
-            C = m3_zero();
-            sv_valid = false;
-        }
-        // positive energy bookkeeping (:127-132)
-        psi = fmaxf(psi, model_pos_energy(mo, phase, eh, F, sv, sv_valid));
-
-        // does the particle still sit inside its home block's tile, and inside the domain?
-        bool invalid = false;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float r = round_cell(px[a], h, inv_h);
-            const bool ok = (r >= 1.0f) && (r < (float)(S.dom - 4));   // 0 <= assoc, assoc + 5 < dom
-            if (!ok) invalid = true;
-            else {
-                const int nl = (int)r - 1 - orgv[a];
-                if (nl < -1 || nl > 4) want_sort = true;
-            }
-        }
-        if (invalid) {  // what the next ParticleSet::sort would do (particle_set.rs:129-136)
-            newly_failed = true;
-            flags |= FLAG_FAILED | FLAG_INVALID;
-            want_sort = true;
-            atomicAdd(&ctl->num_invalid, 1u);
-        }
-        P.q[0][i] = make_float4(px[0], px[1], px[2], F.m[0]);
-        P.q[1][i] = make_float4(F.m[1], F.m[2], F.m[3], F.m[4]);
-        P.q[2][i] = make_float4(F.m[5], F.m[6], F.m[7], F.m[8]);
-        P.q[3][i] = make_float4(vel[0], vel[1], vel[2], C.m[0]);
-        P.q[4][i] = make_float4(C.m[1], C.m[2], C.m[3], C.m[4]);
-        P.q[5][i] = make_float4(C.m[5], C.m[6], C.m[7], C.m[8]);
-        P.d[i] = make_float4(q, lvg, Jp, psi);
-        if (newly_failed) reinterpret_cast<uint32_t*>(&P.k[i])[3] = flags;
+        const Advected o = g2p_update(vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, phase, org, S, inv_h, &ctl->num_invalid);
+        g2p_store(P, i, o);
+        want_sort |= !o.in_tile;
     }
+    if (__any(want_sort)) {
+        if ((tid & 63) == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
+    }
+}
+
+// Fused G2P(substep s) -> P2G(substep s+1) for fixed-dt runs: the advected particle is scattered straight from
+// registers, so v / C / F are not re-read (192 instead of 304 B per particle-substep; SURVEY 8(d) "fused schedule").
+// `S` carries substep s (parity, dt); the scatter uses the same dt (fixed) and writes the tiles of substep s+1.
+// The G2P half is always valid.  The P2G half is only valid if no particle left its tile margin; otherwise the
+// re-bin flag is raised, every later kernel is a no-op and the host re-bins and restarts with a standalone k_p2g.
+template <int REDUCE_STEPS>
+__global__ __launch_bounds__(BLK_THREADS) void k_g2p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
+    const int tid = threadIdx.x;
+    if (ctl->abort_flag[S.parity]) {
+        if (blockIdx.x == 0 && tid == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
+        return;
+    }
+    __shared__ float4 vt[TILE_N];
+    __shared__ double tile[4][TILE_N];
+    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int b = org.w, pfirst = rng.x, pcount = rng.y;
+    const int niter = (pcount + BLK_THREADS - 1) / BLK_THREADS;
+    float4 n0, n1, n2, nd, nk;
+    {
+        const int i0 = pfirst + min(tid, pcount - 1);
+        n0 = P.q[0][i0]; n1 = P.q[1][i0]; n2 = P.q[2][i0]; nd = P.d[i0]; nk = P.k[i0];
+    }
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
+    load_vel_tile(vt, G, b, tid);
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
+    __syncthreads();
+    const float h = S.h, inv_h = 1.0f / S.h;
+    bool want_sort = false;
+    for (int it = 0; it < niter; ++it) {
+        const int li = it * BLK_THREADS + tid;
+        const bool active = li < pcount;
+        const int i = pfirst + (active ? li : 0);
+        const float4 q0 = n0, q1 = n1, q2 = n2, dd = nd, kk = nk;
+        if (it + 1 < niter) {
+            const int inx = pfirst + min(li + BLK_THREADS, pcount - 1);
+            n0 = P.q[0][inx]; n1 = P.q[1][inx]; n2 = P.q[2][inx]; nd = P.d[inx]; nk = P.k[inx];
+        }
+        const uint32_t flags = __float_as_uint(kk.w);
+        bool live = active && !(flags & FLAG_INVALID);
+        Scatter sc;
+        scatter_clear(sc);
+        if (live) {
+            const DevModel& mo = models[flags >> FLAG_MODEL_SHIFT];
+            const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
+            const Advected o = g2p_update(vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, phase, org, S, inv_h, &ctl->num_invalid);
+            g2p_store(P, i, o);
+            want_sort |= !o.in_tile;
+            live = o.in_tile;
+            if (live) sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.F, kk.x, kk.y, kk.z, phase, o.Jp, org, h, inv_h, S.inv_d, S.dt);
+        }
+        p2g_scatter<REDUCE_STEPS>(tile, sc, live, tid);
+    }
+    __syncthreads();
+    float4* out = G.tiles + (size_t)pb * TILE_N;
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) out[n] = make_float4((float)tile[0][n], (float)tile[1][n], (float)tile[2][n], (float)tile[3][n]);
     if (__any(want_sort)) {
         if ((tid & 63) == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
     }

@@ -140,6 +140,7 @@ struct SparklPipeline {
     DevBuf<unsigned long long> d_count;
 
     // clock: per-kernel hipEvent spans on every clock_stride-th substep (events cost ~2 % when on every launch)
+    bool fuse_fixed_dt = true;     // SPARKL_HIP_NO_FUSE=1 in the environment turns the fused schedule off (A/B)
     bool clock_on = false;
     uint32_t clock_stride = 1;
     uint64_t clock_sampled = 0;
@@ -151,7 +152,7 @@ struct SparklPipeline {
     uint64_t total_resorts = 0;
 };
 
-enum { SPAN_P2G = 0, SPAN_GRID = 1, SPAN_G2P = 2, SPAN_SORT = 3, SPAN_DT = 4, SPAN_HALO = 5 };
+enum { SPAN_P2G = 0, SPAN_GRID = 1, SPAN_G2P = 2, SPAN_SORT = 3, SPAN_DT = 4, SPAN_HALO = 5, SPAN_FUSED = 6 };
 
 static int clock_begin(SparklPipeline* p, int kind, size_t* tok) {
     if (!p->clock_on) return SPARKL_OK;
@@ -177,9 +178,10 @@ static int clock_collect(SparklPipeline* p) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, p->ev_pool[s.a], p->ev_pool[s.b]));
         switch (s.kind) {
-            case SPAN_P2G: p->clock.p2g_ms += ms; break;
-            case SPAN_GRID: p->clock.grid_update_ms += ms; break;
-            case SPAN_G2P: p->clock.g2p_ms += ms; break;
+            case SPAN_P2G: p->clock.p2g_ms += ms; p->clock.p2g_launches++; break;
+            case SPAN_GRID: p->clock.grid_update_ms += ms; p->clock.grid_update_launches++; break;
+            case SPAN_G2P: p->clock.g2p_ms += ms; p->clock.g2p_launches++; break;
+            case SPAN_FUSED: p->clock.g2p2g_ms += ms; p->clock.g2p2g_launches++; break;
             case SPAN_SORT: p->clock.sort_ms += ms; break;
             case SPAN_DT: p->clock.dt_ms += ms; break;
             default: p->clock.halo_ms += ms; break;
@@ -374,6 +376,45 @@ static int enqueue_substep(SparklPipeline* p, const SparklSolverParams* sp, cons
     return SPARKL_OK;
 }
 
+// Fixed-dt batch with the fused schedule:  P2G_s ; { GU ; G2P+P2G } x (n-1) ; GU ; G2P.  Same arithmetic as the
+// unfused order (the scatter of substep s+1 starts from the registers G2P of substep s just produced).
+static int enqueue_fused_batch(SparklPipeline* p, const SparklSolverParams* sp, const float g[3], float dt, uint32_t n) {
+    if (p->num_pblocks == 0) { p->substep_index += n; return SPARKL_OK; }
+    hipStream_t st = p->stream;
+    const GridArrays G = grid_arrays(p);
+    const ParticleArrays P = p->cur.arrays();
+    const bool was_on = p->clock_on;
+    size_t tk = 0;
+    {
+        const StepParams S = make_params(p, sp, g, dt);
+        if (was_on && (p->substep_index % p->clock_stride) != 0) p->clock_on = false;
+        CHK(clock_begin(p, SPAN_P2G, &tk));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g<SPK_P2G_REDUCE_STEPS>), dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, P, G, p->d_models.p, p->d_ctl, S);
+        CHK(clock_end(p, tk));
+        p->clock_on = was_on;
+    }
+    for (uint32_t j = 0; j < n; ++j) {
+        const StepParams S = make_params(p, sp, g, dt);
+        if (was_on && (p->substep_index % p->clock_stride) != 0) p->clock_on = false;
+        if (p->clock_on) p->clock_sampled++;
+        CHK(clock_begin(p, SPAN_GRID, &tk));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false>), dim3((p->num_blocks + 3) / 4), dim3(BLK_THREADS), 0, st, G, p->d_cuboids.p, p->d_ctl, S);
+        CHK(clock_end(p, tk));
+        if (j + 1 < n) {
+            CHK(clock_begin(p, SPAN_FUSED, &tk));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<SPK_P2G_REDUCE_STEPS>), dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, P, G, p->d_models.p, p->d_ctl, S);
+            CHK(clock_end(p, tk));
+        } else {
+            CHK(clock_begin(p, SPAN_G2P, &tk));
+            hipLaunchKernelGGL(k_g2p, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, P, G, p->d_models.p, p->d_ctl, S);
+            CHK(clock_end(p, tk));
+        }
+        p->clock_on = was_on;
+        p->substep_index++;
+    }
+    return SPARKL_OK;
+}
+
 static int read_ctl(SparklPipeline* p) {
     HIPCHK(hipMemcpyAsync(p->h_ctl, p->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
@@ -404,6 +445,7 @@ int sparkl_hip_pipeline_create(const SparklPipelineDesc* desc, SparklPipeline** 
     if (desc->device_id < 0 || desc->device_id >= ndev) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "device_id %d out of range (%d devices)", desc->device_id, ndev);
     if (hipSetDevice(desc->device_id) != hipSuccess) return set_error(SPARKL_ERR_NO_DEVICE, "hipSetDevice(%d) failed", desc->device_id);
     SparklPipeline* p = new SparklPipeline;
+    p->fuse_fixed_dt = getenv("SPARKL_HIP_NO_FUSE") == nullptr;
     p->device = desc->device_id;
     p->h = desc->cell_width;
     p->domain_log2 = bits;
@@ -747,7 +789,10 @@ int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* pa
     int guard = 0;
     while (done < nsubsteps) {
         const uint32_t batch = std::min(CHUNK, nsubsteps - done);
-        for (uint32_t i = 0; i < batch; ++i) CHK(enqueue_substep(p, params, gravity, dt));
+        // fixed dt: G2P of substep s and P2G of substep s+1 run as one kernel (see k_g2p2g)
+        const bool fuse = p->fuse_fixed_dt && !(params->force_fluids_volume_recomputation && p->any_fluid);
+        if (fuse) CHK(enqueue_fused_batch(p, params, gravity, dt, batch));
+        else for (uint32_t i = 0; i < batch; ++i) CHK(enqueue_substep(p, params, gravity, dt));
         CHK(read_ctl(p));
         if (p->clock_on) CHK(clock_collect(p));
         if (getenv("SPARKL_HIP_DEBUG"))
