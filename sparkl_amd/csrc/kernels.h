@@ -616,7 +616,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p(ParticleArrays P, GridArray
 // The G2P half is always valid.  The P2G half is only valid if no particle left its tile margin; otherwise the
 // re-bin flag is raised, every later kernel is a no-op and the host re-bins and restarts with a standalone k_p2g.
 template <int REDUCE_STEPS>
-__global__ __launch_bounds__(BLK_THREADS) void k_g2p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
+__global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
     const int tid = threadIdx.x;
     if (ctl->abort_flag[S.parity]) {
         if (blockIdx.x == 0 && tid == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;

@@ -785,12 +785,13 @@ int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* pa
     CHK(read_ctl(p));
     const uint32_t base_done = p->h_ctl->steps_done;
     uint32_t done = 0;
-    const uint32_t CHUNK = 32;
+    // fixed dt: G2P of substep s and P2G of substep s+1 run as one kernel (see k_g2p2g); a batch pays one standalone
+    // P2G + G2P, so fused batches are longer.  After a re-bin request the rest of a batch is no-op launches (~3 us each).
+    const bool fuse = p->fuse_fixed_dt && !(params->force_fluids_volume_recomputation && p->any_fluid);
+    const uint32_t CHUNK = fuse ? 128 : 32;
     int guard = 0;
     while (done < nsubsteps) {
         const uint32_t batch = std::min(CHUNK, nsubsteps - done);
-        // fixed dt: G2P of substep s and P2G of substep s+1 run as one kernel (see k_g2p2g)
-        const bool fuse = p->fuse_fixed_dt && !(params->force_fluids_volume_recomputation && p->any_fluid);
         if (fuse) CHK(enqueue_fused_batch(p, params, gravity, dt, batch));
         else for (uint32_t i = 0; i < batch; ++i) CHK(enqueue_substep(p, params, gravity, dt));
         CHK(read_ctl(p));
