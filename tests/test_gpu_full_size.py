@@ -1,0 +1,106 @@
+"""Size-independent properties at BASELINE.json's full sizes (the oracle cannot run these in seconds):
+configs[2] 10 M-particle Drucker-Prager column, configs[1] 1 M neo-Hookean cube, a 2 M-particle slice of configs[3]."""
+import numpy as np
+import pytest
+
+from sparkl_amd import abi, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Pipeline():
+    from sparkl_amd.pipeline import MpmPipeline
+    return MpmPipeline
+
+
+def _home_block_ok(pipe, sc):
+    """sortedness: after a re-bin, device order is sorted by (block Morton key, cell) -> block coordinates of consecutive
+    particles change only at run boundaries, and every caller id appears exactly once"""
+    ids = pipe.read_sorted_particle_ids()
+    assert len(ids) == len(sc.particles)
+    seen = np.zeros(len(ids), bool)
+    seen[ids] = True
+    assert seen.all()
+    pos = pipe.read_positions()["point"][ids]            # device order
+    cell = np.round(pos / np.float32(sc.cell_width)).astype(np.int64) - 1
+    blk = cell >> 2
+    key = (blk[:, 0] << 42) | (blk[:, 1] << 21) | blk[:, 2]
+    change = np.nonzero(key[1:] != key[:-1])[0]
+    runs = len(change) + 1
+    return runs, len(np.unique(key))
+
+
+def test_config3_10M_drucker_prager_properties(Pipeline):
+    sc = scenes.baseline_config(2)
+    n = len(sc.particles)
+    assert n == 10_000_000
+    m = sc.particles.volume["mass"].astype(np.float64)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.grid_debug_capture(True)
+        p.load_scene(sc)
+        p.substeps(sc.params, (0.0, 0.0, 0.0), sc.fixed_dt, 1)          # no gravity: momentum stays zero
+        nodes = p.read_grid_nodes()
+        # P2G conserves mass; with v = 0, F = I the grid momentum is exactly zero
+        assert abs(nodes["mass"].astype(np.float64).sum() - m.sum()) / m.sum() < 1e-5
+        assert np.abs(nodes["momentum"]).max() == 0.0
+        runs, blocks = _home_block_ok(p, sc)
+        assert runs == blocks == p.num_particle_blocks(), "each particle block is one contiguous run of the device order"
+        # column under gravity: 50 substeps; nothing fails, nothing leaves the domain, free fall above the floor
+        p.substeps(sc.params, sc.gravity, sc.fixed_dt, 50)
+        st = p.read_statuses()
+        assert st["failed"].sum() == 0
+        vel = p.read_velocities()["vector"]
+        assert np.isfinite(vel).all()
+        t = 50 * sc.fixed_dt
+        top = sc.particles.position["point"][:, 1] > sc.particles.position["point"][:, 1].max() - 1.0
+        # the top metre has not been reached by the elastic wave from the floor (c ~ 64 m/s, 50 m column): v_y = -g t
+        assert np.allclose(vel[top, 1], -9.81 * t, rtol=2e-3)
+        # linear momentum in x and z stays zero by symmetry of the forces (floor is frictional but nothing slides yet)
+        px = (m * vel[:, 0].astype(np.float64)).sum() / (m.sum() * 9.81 * t)
+        assert abs(px) < 1e-5
+
+
+def test_config2_1M_neo_hookean_angular_momentum(Pipeline):
+    """No gravity, no collider: linear and angular momentum of the spinning cube are conserved by APIC/MLS-MPM."""
+    sc = scenes.baseline_config(1)
+    assert len(sc.particles) == 1_000_000
+    m = sc.particles.volume["mass"].astype(np.float64)[:, None]
+    x0 = sc.particles.position["point"].astype(np.float64)
+    v0 = sc.particles.velocity["vector"].astype(np.float64)
+    c0 = (m * x0).sum(0) / m.sum()
+    L0 = (m * np.cross(x0 - c0, v0)).sum(0)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, sc.fixed_dt, 100)
+        x = p.read_positions()["point"].astype(np.float64)
+        v = p.read_velocities()["vector"].astype(np.float64)
+        C = p.read_velocity_gradients()["m"].astype(np.float64)
+    P0, P1 = (m * v0).sum(0), (m * v).sum(0)
+    scale = (m * np.abs(v0)).sum()
+    assert np.abs(P1 - P0).max() / scale < 1e-5
+    c1 = (m * x).sum(0) / m.sum()
+    # APIC angular momentum = sum m x ^ v + the affine part (m D C^T - C m D), D = h^2/4 I  ->  antisymmetric part of C
+    h = sc.cell_width
+    Cm = C.reshape(-1, 3, 3).transpose(0, 2, 1)       # column-major -> C[i, j]
+    spin = np.stack([Cm[:, 2, 1] - Cm[:, 1, 2], Cm[:, 0, 2] - Cm[:, 2, 0], Cm[:, 1, 0] - Cm[:, 0, 1]], 1)
+    L1 = (m * np.cross(x - c1, v)).sum(0) + (m * (h * h / 4.0) * spin).sum(0)
+    assert np.abs(L1 - L0).max() / np.abs(L0).max() < 2e-3
+
+
+def test_config4_fluid_slice_mass_and_volume(Pipeline):
+    """64 particles per cell (fluids3): the volume recomputation pass leaves F00 = rho0 / rho_grid near 1 in the bulk."""
+    sc = scenes.fluid_dam(160, 112, 112)              # 2.0 M particles of the 20 M config
+    assert len(sc.particles) > 2_000_000
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, sc.fixed_dt, 5)
+        vol = p.read_volumes()
+        st = p.read_statuses()
+        pos = p.read_positions()["point"]
+    assert st["failed"].sum() == 0
+    J = vol["deformation_gradient"][:, 0]
+    lo, hi = pos.min(0) + 1.5 * sc.cell_width, pos.max(0) - 1.5 * sc.cell_width
+    bulk = ((pos > lo) & (pos < hi)).all(1)
+    assert bulk.sum() > 1_000_000
+    assert abs(float(np.median(J[bulk])) - 1.0) < 0.02 and np.isfinite(J).all()
