@@ -76,6 +76,7 @@ struct StepParams {
     int parity;
     int dom;          // valid cell coords: 0 <= c, c + 5 < dom
     int num_cuboids;
+    int want_dt;      // G2P also reduces the next substep's dt bound into ctl->dt_bits (adaptive stepping)
 };
 
 struct DevCuboid {
@@ -431,6 +432,16 @@ SPK_DEV void load_vel_tile(float4* vt, const GridArrays& G, int b, int tid) {
     }
 }
 
+// timestep_estimator.rs:21-44: velocity (APIC) bound and constitutive-model bound of one particle
+SPK_DEV float particle_dt_bound(const DevModel& mo, uint32_t flags, const float v[3], const M3& C, float mass, float vol0, float eh, float f00, float h) {
+    const float d = (h * h) / 4.f;
+    const float apic_v = (d * m3_frob(C)) * 6.f * sqrtf(3.f) / h;
+    const float vn = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) + apic_v;
+    float dt = fminf(3.402823466e+38f, h / vn);
+    if (!(flags & FLAG_FAILED)) dt = fminf(dt, model_timestep_bound(mo, mass, vol0, eh, mo.is_fluid ? f00 : 1.f, v[0], v[1], v[2], h));
+    return dt;
+}
+
 // State of one particle after grid_to_particle.rs:62-164 (gather .. psi_pos), before it is written back.
 struct Advected {
     float px[3], vel[3];
@@ -567,7 +578,7 @@ SPK_DEV void g2p_store(const ParticleArrays& P, int i, const Advected& o) {
     if (o.newly_failed) reinterpret_cast<uint32_t*>(&P.k[i])[3] = o.flags;
 }
 
-__global__ __launch_bounds__(BLK_THREADS) void k_g2p(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
+__global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
     const int tid = threadIdx.x;
     if (ctl->abort_flag[S.parity]) {
         // sticky abort: keep every later substep a no-op until the host re-bins
@@ -591,6 +602,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p(ParticleArrays P, GridArray
     __syncthreads();
     const float inv_h = 1.0f / S.h;
     bool want_sort = false;
+    float dt_bound = 3.402823466e+38f;
+    bool dt_nan = false;
     while (have) {
         const int i = pfirst + li;
         const float4 q0 = n0, q1 = n1, q2 = n2, dd = nd, kk = nk;
@@ -604,9 +617,21 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p(ParticleArrays P, GridArray
         const Advected o = g2p_update(vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, phase, org, S, inv_h, &ctl->num_invalid);
         g2p_store(P, i, o);
         want_sort |= !o.in_tile;
+        if (S.want_dt) {  // the bound the next substep's estimator would compute from this state
+            const float b = particle_dt_bound(mo, o.flags, o.vel, o.C, kk.x, kk.y, kk.z, o.F.m[0], S.h);
+            dt_nan |= b != b;
+            dt_bound = fminf(dt_bound, b);
+        }
     }
     if (__any(want_sort)) {
         if ((tid & 63) == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
+    }
+    if (S.want_dt) {
+        if (dt_nan) dt_bound = 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dt_bound = fminf(dt_bound, __shfl_xor(dt_bound, off));
+        if ((tid & 63) == 0) atomicMin(&ctl->dt_bits, __float_as_uint(dt_bound));
+        if (__any(dt_nan) && (tid & 63) == 0) ctl->dt_nan = 1u;
     }
 }
 
@@ -764,16 +789,10 @@ __global__ __launch_bounds__(BLK_THREADS) void k_estimate_dt(ParticleArrays P, c
     if (i < n) {
         const float4 q3 = P.q[3][i], q4 = P.q[4][i], q5 = P.q[5][i], kk = P.k[i];
         const uint32_t flags = __float_as_uint(kk.w);
-        const float d = (h * h) / 4.f;
-        const float cn = sqrtf(q3.w * q3.w + q4.x * q4.x + q4.y * q4.y + q4.z * q4.z + q4.w * q4.w + q5.x * q5.x + q5.y * q5.y + q5.z * q5.z + q5.w * q5.w);
-        const float apic_v = (d * cn) * 6.f * sqrtf(3.f) / h;
-        const float v = sqrtf(q3.x * q3.x + q3.y * q3.y + q3.z * q3.z) + apic_v;
-        dt = fminf(dt, h / v);
-        if (!(flags & FLAG_FAILED)) {
-            const DevModel mo = models[flags >> FLAG_MODEL_SHIFT];
-            const float f00 = mo.is_fluid ? P.q[0][i].w : 1.f;
-            dt = fminf(dt, model_timestep_bound(mo, kk.x, kk.y, kk.z, f00, q3.x, q3.y, q3.z, h));
-        }
+        const DevModel& mo = models[flags >> FLAG_MODEL_SHIFT];
+        const float v[3] = {q3.x, q3.y, q3.z};
+        const M3 C = {{q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
+        dt = particle_dt_bound(mo, flags, v, C, kk.x, kk.y, kk.z, mo.is_fluid ? P.q[0][i].w : 1.f, h);
         nan = dt != dt;
     }
     if (nan) dt = 0.f;

@@ -332,7 +332,7 @@ static StepParams make_params(const SparklPipeline* p, const SparklSolverParams*
     S.h = p->h; S.inv_d = 4.0f / (p->h * p->h); S.dt = dt;
     S.gx = g[0]; S.gy = g[1]; S.gz = g[2];
     S.boundary_handling = sp->boundary_handling; S.dofs = sp->simulation_dofs;
-    S.parity = (int)(p->substep_index & 1u); S.dom = p->dom; S.num_cuboids = p->num_cuboids;
+    S.parity = (int)(p->substep_index & 1u); S.dom = p->dom; S.num_cuboids = p->num_cuboids; S.want_dt = 0;
     return S;
 }
 
@@ -351,10 +351,11 @@ static int enqueue_fluid_volumes(SparklPipeline* p, const StepParams& S) {
 }
 
 // enqueue P2G -> grid update -> G2P for the current substep index (no host sync)
-static int enqueue_substep(SparklPipeline* p, const SparklSolverParams* sp, const float g[3], float dt) {
+static int enqueue_substep(SparklPipeline* p, const SparklSolverParams* sp, const float g[3], float dt, bool want_dt = false) {
     if (p->num_pblocks == 0) { p->substep_index++; return SPARKL_OK; }
     hipStream_t st = p->stream;
-    const StepParams S = make_params(p, sp, g, dt);
+    StepParams S = make_params(p, sp, g, dt);
+    S.want_dt = want_dt ? 1 : 0;
     const GridArrays G = grid_arrays(p);
     const ParticleArrays P = p->cur.arrays();
     if (sp->force_fluids_volume_recomputation && p->any_fluid) CHK(enqueue_fluid_volumes(p, S));
@@ -528,6 +529,7 @@ int sparkl_hip_models_set(SparklPipeline* p, uint32_t n, const SparklParticleMod
             d.ptag = SPARKL_PLASTIC_DRUCKER_PRAGER;
             d.h0 = dp.h0; d.h1 = dp.h1; d.h2 = dp.h2; d.h3 = dp.h3; d.p_lambda = dp.lambda; d.p_mu = dp.mu;
             d.volume_correction = dp.volume_correction; d.only_active_when_failed = dp.only_active_when_failed;
+            d.p_k = (3.0f * dp.lambda + 2.0f * dp.mu) / (2.0f * dp.mu);
         }
         if (m.has_failure_model) return set_error(SPARKL_ERR_UNSUPPORTED, "model %u: failure models are not implemented", i);
         dm[i] = d;
@@ -827,16 +829,19 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
     uint32_t nsub = 0;
     float result = params->dt;
     int rc = SPARKL_OK;
+    bool have_bound = false;   // after the first substep, G2P leaves the next bound in ctl->dt_bits (no extra pass over the particles)
+    const float fmax = std::numeric_limits<float>::max();
+    uint32_t init_bits;
+    memcpy(&init_bits, &fmax, 4);
     while (remaining > 0.0f) {
-        // particle bound first (order independent), one host sync per substep as in the reference
-        size_t tok = 0;
-        uint32_t init_bits;
-        const float fmax = std::numeric_limits<float>::max();
-        memcpy(&init_bits, &fmax, 4);
-        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dt_bits, (int)init_bits, 1, p->stream));
-        CHK(clock_begin(p, SPAN_DT, &tok));
-        hipLaunchKernelGGL(k_estimate_dt, dim3(grid_for(p->n, BLK_THREADS)), dim3(BLK_THREADS), 0, p->stream, p->cur.arrays(), p->d_models.p, p->d_ctl, (int)p->n, p->h);
-        CHK(clock_end(p, tok));
+        // one host sync per substep, as in the reference (cuda_mpm_pipeline.rs:393-398)
+        if (!have_bound) {
+            size_t tok = 0;
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dt_bits, (int)init_bits, 1, p->stream));
+            CHK(clock_begin(p, SPAN_DT, &tok));
+            hipLaunchKernelGGL(k_estimate_dt, dim3(grid_for(p->n, BLK_THREADS)), dim3(BLK_THREADS), 0, p->stream, p->cur.arrays(), p->d_models.p, p->d_ctl, (int)p->n, p->h);
+            CHK(clock_end(p, tok));
+        }
         CHK(read_ctl(p));
         if (p->h_ctl->abort_flag[0] || p->h_ctl->abort_flag[1]) CHK(resort(p));
         if (p->h_ctl->dt_nan) { rc = set_error(SPARKL_ERR_NAN_TIMESTEP, "NaN timestep bound (the reference panics: timestep_estimator.rs:46)"); break; }
@@ -844,7 +849,9 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
         memcpy(&bound, &p->h_ctl->dt_bits, 4);
         float dt = std::fmin(std::fmin(remaining, params->max_substep_dt), bound);  // timestep_estimator.rs:25,35,44
         if (dt < min_dt && remaining > min_dt) dt = min_dt;                           // mls_solver.rs:57-59
-        CHK(enqueue_substep(p, params, gravity, dt));
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dt_bits, (int)init_bits, 1, p->stream));
+        CHK(enqueue_substep(p, params, gravity, dt, /*want_dt=*/true));
+        have_bound = p->num_pblocks > 0;
         ++nsub;
         remaining -= dt;
         if (params->stop_after_one_substep) { result = dt; break; }
