@@ -85,16 +85,20 @@ SPK_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 SPK_DEV float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 SPK_DEV float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
-// returns |t| (tangent of the rotation): ~ size of the remaining off-diagonal coupling
-// (a variant with two v_rsq_f32 and no v_rcp/v_sqrt was tried: not faster, and 6x worse parity on the sand case)
-SPK_DEV float jacobi_pair(float* wp, float* wq, float* vp, float* vq) {
+// Orthogonalises columns p and q; returns true when their coupling |wp.wq| / (|wp||wq|) was above 3e-4 BEFORE the
+// rotation (one more sweep is then needed: couplings shrink quadratically, 3e-4 -> 1e-7).  The rotation tangent is NOT a
+// convergence measure: for (nearly) equal singular values -- F = I, the common case -- it is O(1) however small the
+// coupling, which kept the first version of this loop spinning for ~5 sweeps on undeformed particles.
+// (a rotation with two v_rsq_f32 and no v_rcp/v_sqrt was also tried: not faster, and 6x worse parity on the sand case)
+SPK_DEV bool jacobi_pair(float* wp, float* wq, float* vp, float* vq) {
     const float alpha = wp[0] * wp[0] + wp[1] * wp[1] + wp[2] * wp[2];
     const float beta = wq[0] * wq[0] + wq[1] * wq[1] + wq[2] * wq[2];
     const float gamma = wp[0] * wq[0] + wp[1] * wq[1] + wp[2] * wq[2];
-    float c = 1.f, s = 0.f, t = 0.f;
-    if (gamma * gamma > 1.0e-18f * (alpha * beta)) {
+    const float g2 = gamma * gamma, ab = alpha * beta;
+    float c = 1.f, s = 0.f;
+    if (g2 > 1.0e-18f * ab) {
         const float zeta = (beta - alpha) * fast_rcp(2.f * gamma);
-        t = copysignf(1.f, zeta) * fast_rcp(fabsf(zeta) + fast_sqrt(1.f + zeta * zeta));
+        const float t = copysignf(1.f, zeta) * fast_rcp(fabsf(zeta) + fast_sqrt(1.f + zeta * zeta));
         c = fast_rsq(1.f + t * t);
         s = c * t;
     }
@@ -107,21 +111,21 @@ SPK_DEV float jacobi_pair(float* wp, float* wq, float* vp, float* vq) {
         vp[i] = c * va - s * vb;
         vq[i] = s * va + c * vb;
     }
-    return fabsf(t);
+    return g2 > 1.0e-7f * ab;
 }
 
-// Cyclic one-sided Jacobi with a wave-uniform early exit: a sweep whose largest rotation tangent is
-// below 2e-4 leaves couplings ~ t^2 < 1e-7, i.e. converged in f32.  F near identity needs 2-3 sweeps.
+// Cyclic one-sided Jacobi: one unconditional sweep, then more while any lane of the wave still had a coupling above
+// 3e-4 in the sweep just done (wave-uniform branch).  Undeformed particles take 1 sweep, MPM-sized strains 2-3.
 template <int MAX_SWEEPS>
 SPK_DEV Svd3 svd3(const M3& a) {
     Svd3 r;
     r.w = a;
     r.v = m3_identity();
     for (int sweep = 0; sweep < MAX_SWEEPS; ++sweep) {
-        float t = jacobi_pair(r.w.m + 0, r.w.m + 3, r.v.m + 0, r.v.m + 3);
-        t = fmaxf(t, jacobi_pair(r.w.m + 0, r.w.m + 6, r.v.m + 0, r.v.m + 6));
-        t = fmaxf(t, jacobi_pair(r.w.m + 3, r.w.m + 6, r.v.m + 3, r.v.m + 6));
-        if (!__any(t > 2.0e-4f)) break;
+        bool more = jacobi_pair(r.w.m + 0, r.w.m + 3, r.v.m + 0, r.v.m + 3);
+        more |= jacobi_pair(r.w.m + 0, r.w.m + 6, r.v.m + 0, r.v.m + 6);
+        more |= jacobi_pair(r.w.m + 3, r.w.m + 6, r.v.m + 3, r.v.m + 6);
+        if (!__any(more)) break;
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) r.s[j] = fast_sqrt(r.w.m[3 * j] * r.w.m[3 * j] + r.w.m[3 * j + 1] * r.w.m[3 * j + 1] + r.w.m[3 * j + 2] * r.w.m[3 * j + 2]);
