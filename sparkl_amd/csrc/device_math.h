@@ -85,10 +85,13 @@ SPK_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 SPK_DEV float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 SPK_DEV float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
-// Orthogonalises columns p and q; returns true when their coupling |wp.wq| / (|wp||wq|) was above 3e-4 BEFORE the
-// rotation (one more sweep is then needed: couplings shrink quadratically, 3e-4 -> 1e-7).  The rotation tangent is NOT a
-// convergence measure: for (nearly) equal singular values -- F = I, the common case -- it is O(1) however small the
-// coupling, which kept the first version of this loop spinning for ~5 sweeps on undeformed particles.
+// Orthogonalises columns p and q; returns true when their coupling |wp.wq| / (|wp||wq|) was above 1e-6 BEFORE the
+// rotation, i.e. one more sweep is needed.  Why 1e-6 and not sqrt(eps): with (nearly) equal singular values -- F ~ I,
+// the common case -- the rotation angle is O(1) however small the coupling, so a later rotation of the sweep carries
+// couplings over linearly, and a residual coupling r shifts a near-degenerate singular value by O(r), not O(r^2).
+// Measured in f32 (tools/svd_threshold_scan.py): threshold 3e-4 leaves sigma errors up to 7.5e-5 for |F - I| ~ 1e-4,
+// 1e-6 keeps them <= 5e-7 at every scale for 1 (undeformed) to ~3.5 (strained) sweeps.  The rotation tangent itself is
+// NOT a convergence measure (the first version used it and spun ~5 sweeps on undeformed particles).
 // (a rotation with two v_rsq_f32 and no v_rcp/v_sqrt was also tried: not faster, and 6x worse parity on the sand case)
 SPK_DEV bool jacobi_pair(float* wp, float* wq, float* vp, float* vq) {
     const float alpha = wp[0] * wp[0] + wp[1] * wp[1] + wp[2] * wp[2];
@@ -111,11 +114,11 @@ SPK_DEV bool jacobi_pair(float* wp, float* wq, float* vp, float* vq) {
         vp[i] = c * va - s * vb;
         vq[i] = s * va + c * vb;
     }
-    return g2 > 1.0e-7f * ab;
+    return g2 > 1.0e-12f * ab;
 }
 
-// Cyclic one-sided Jacobi: one unconditional sweep, then more while any lane of the wave still had a coupling above
-// 3e-4 in the sweep just done (wave-uniform branch).  Undeformed particles take 1 sweep, MPM-sized strains 2-3.
+// Cyclic one-sided Jacobi: sweep until a sweep starts with every coupling of every lane below 1e-6 (wave-uniform
+// branch).  Undeformed particles take 1 sweep, MPM-sized strains 3-4.
 template <int MAX_SWEEPS>
 SPK_DEV Svd3 svd3(const M3& a) {
     Svd3 r;
