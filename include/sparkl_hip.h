@@ -335,6 +335,9 @@ int sparkl_hip_halo_count(SparklPipeline* p, int side, uint64_t* n);
 int sparkl_hip_halo_pack(SparklPipeline* p, int side, void* dev_out);
 int sparkl_hip_halo_merge(SparklPipeline* p, int side, const void* dev_in, uint64_t n);
 int sparkl_hip_substep_finish(SparklPipeline* p);
+/* same, but G2P also scatters the NEXT substep's tiles (k_g2p2g): valid only if the next substep_begin uses the same dt,
+ * gravity and parameters and no particle data is touched in between; that begin then launches nothing. */
+int sparkl_hip_substep_finish_fused(SparklPipeline* p);
 /* synchronises; steps_done counts substeps whose G2P really ran, need_rebin != 0 when a re-bin is due */
 int sparkl_hip_substep_status(SparklPipeline* p, uint32_t* steps_done, uint32_t* need_rebin);
 

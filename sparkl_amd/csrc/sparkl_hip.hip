@@ -104,6 +104,7 @@ struct SparklPipeline {
     StepParams pending{};          // split-phase substep state
     bool in_substep = false;
     bool pending_clock_saved = false;
+    bool tiles_ready = false;      // the previous substep_finish_fused already scattered this substep's tiles
 
     // models / colliders
     DevBuf<DevModel> d_models;
@@ -321,6 +322,7 @@ static int resort(SparklPipeline* p) {
     HIPCHK(hipGetLastError());
     CHK(clock_end(p, tok));
     p->sorted = true;
+    p->tiles_ready = false;
     p->clock.resorts++;
     p->total_resorts++;
     return SPARKL_OK;
@@ -952,6 +954,7 @@ int sparkl_hip_substep_begin(SparklPipeline* p, const SparklSolverParams* params
     hipStream_t st = p->stream;
     const GridArrays G = grid_arrays(p);
     if (G.halo_in) HIPCHK(hipMemsetAsync(p->halo_in.p, 0, (size_t)p->num_blocks * 64 * sizeof(float4), st));
+    if (p->tiles_ready) { p->tiles_ready = false; return SPARKL_OK; }   // scattered by the fused kernel of the previous substep
     if (params->force_fluids_volume_recomputation && p->any_fluid) CHK(enqueue_fluid_volumes(p, p->pending));
     size_t t0 = 0;
     CHK(clock_begin(p, SPAN_P2G, &t0));
@@ -990,10 +993,11 @@ int sparkl_hip_halo_merge(SparklPipeline* p, int side, const void* dev_in, uint6
     CHK(clock_end(p, tok));
     return SPARKL_OK;
 }
-int sparkl_hip_substep_finish(SparklPipeline* p) {
+static int substep_finish_impl(SparklPipeline* p, bool fuse_next) {
     if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
     if (!p->in_substep) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "substep_finish without substep_begin");
     p->in_substep = false;
+    p->tiles_ready = false;
     if (p->num_pblocks == 0) {
         hipLaunchKernelGGL(k_bump_steps, dim3(1), dim3(1), 0, p->stream, p->d_ctl, p->pending.parity);
         p->clock_on = p->pending_clock_saved;
@@ -1006,14 +1010,25 @@ int sparkl_hip_substep_finish(SparklPipeline* p) {
     CHK(clock_begin(p, SPAN_GRID, &t1));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false>), dim3((p->num_blocks + 3) / 4), dim3(BLK_THREADS), 0, st, G, p->d_cuboids.p, p->d_ctl, p->pending);
     CHK(clock_end(p, t1));
-    CHK(clock_begin(p, SPAN_G2P, &t2));
-    hipLaunchKernelGGL(k_g2p, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, p->cur.arrays(), G, p->d_models.p, p->d_ctl, p->pending);
-    CHK(clock_end(p, t2));
+    if (fuse_next && p->fuse_fixed_dt) {
+        // G2P of this substep + P2G of the next one (same dt) in one kernel; the next substep_begin is then free
+        CHK(clock_begin(p, SPAN_FUSED, &t2));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<SPK_P2G_REDUCE_STEPS>), dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, p->cur.arrays(), G, p->d_models.p, p->d_ctl,
+                           p->pending);
+        CHK(clock_end(p, t2));
+        p->tiles_ready = true;
+    } else {
+        CHK(clock_begin(p, SPAN_G2P, &t2));
+        hipLaunchKernelGGL(k_g2p, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, p->cur.arrays(), G, p->d_models.p, p->d_ctl, p->pending);
+        CHK(clock_end(p, t2));
+    }
     p->clock_on = p->pending_clock_saved;
     p->substep_index++;
     p->clock.substeps++;
     return SPARKL_OK;
 }
+int sparkl_hip_substep_finish(SparklPipeline* p) { return substep_finish_impl(p, false); }
+int sparkl_hip_substep_finish_fused(SparklPipeline* p) { return substep_finish_impl(p, true); }
 
 int sparkl_hip_slab_emigrant_count(SparklPipeline* p, int side, uint64_t* n) {
     if (!p || !n || side < 0 || side > 1) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "bad argument");

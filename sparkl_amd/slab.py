@@ -101,8 +101,9 @@ class HipSlabBackend:
         g = (C.c_float * 3)(*[float(x) for x in gravity])
         check(self.L.sparkl_hip_substep_begin(self.h, C.byref(params), g, C.c_float(dt)))
 
-    def substep_finish(self):
-        check(self.L.sparkl_hip_substep_finish(self.h))
+    def substep_finish(self, fuse_next=False):
+        """fuse_next: G2P also scatters the next substep's tiles (fixed dt); the next substep_begin is then a no-op."""
+        check((self.L.sparkl_hip_substep_finish_fused if fuse_next else self.L.sparkl_hip_substep_finish)(self.h))
 
     def status(self):
         done, need = C.c_uint32(0), C.c_uint32(0)
@@ -221,7 +222,7 @@ class SlabStepper:
         self.num_rebins += 1
 
     # ---- substeps
-    def _one_substep(self, params, gravity, dt):
+    def _one_substep(self, params, gravity, dt, fuse_next=False):
         b, hb = self.b, self.b.halo_record_bytes
         b.flags_export(self.flag)
         self._allreduce_max_i32(self.flag)
@@ -235,7 +236,7 @@ class SlabStepper:
         for side in (0, 1):
             if self.n_recv[side]:
                 b.halo_merge(side, self.recv[side], self.n_recv[side])
-        b.substep_finish()
+        b.substep_finish(fuse_next)
 
     def substeps(self, params, gravity, dt, n):
         """n fixed-length substeps; re-bins (collectively) whenever any rank's particles leave their tile margin."""
@@ -246,8 +247,9 @@ class SlabStepper:
         guard = 0
         while done < n:
             batch = min(self.chunk, n - done)
-            for _ in range(batch):
-                self._one_substep(params, gravity, dt)
+            for j in range(batch):
+                # all substeps of a batch share dt/params, so G2P can scatter the next substep's tiles right away
+                self._one_substep(params, gravity, dt, fuse_next=(j + 1 < batch))
             now, need = self.b.status()
             ran = now - base
             # the flag is global, so every rank ran the same substeps

@@ -138,7 +138,7 @@ class OracleSlabBackend:
         for r in rec:
             self.o.add_block_nodes(r["key"], r["nodes"])
 
-    def substep_finish(self):
+    def substep_finish(self, fuse_next=False):
         if self.cur_flag:
             self.next_flag = 1
             return
