@@ -104,3 +104,33 @@ def test_config4_fluid_slice_mass_and_volume(Pipeline):
     bulk = ((pos > lo) & (pos < hi)).all(1)
     assert bulk.sum() > 1_000_000
     assert abs(float(np.median(J[bulk])) - 1.0) < 0.02 and np.isfinite(J).all()
+
+
+def test_long_collapse_stays_sane(Pipeline):
+    """2000 substeps (0.5 s) of a 0.5 M-particle sand column collapsing: re-bins happen, nothing blows up, mass is where it should be."""
+    sc = scenes.sand_column(64, 128, 64)
+    n = len(sc.particles)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.clock_enable(True, stride=64)
+        p.substeps(sc.params, sc.gravity, sc.fixed_dt, 2000)
+        k = p.clock_read()
+        pos = p.read_positions()["point"]
+        vel = p.read_velocities()["vector"]
+        st = p.read_statuses()
+        vol = p.read_volumes()
+        ids = p.read_sorted_particle_ids()
+    assert np.isfinite(pos).all() and np.isfinite(vel).all()
+    assert st["failed"].sum() == 0
+    assert sorted(ids.tolist()) == list(range(n))
+    assert k.resorts >= 2, "a collapsing column must have been re-binned"
+    floor_y = 4 * sc.cell_width - 0.5 * sc.cell_width
+    assert pos[:, 1].min() > floor_y - 0.6 * sc.cell_width, "particles do not tunnel through the floor"
+    # the column has slumped: lower and wider than it started, and nowhere near free-fall speed any more
+    y0 = sc.particles.position["point"][:, 1]
+    x0 = sc.particles.position["point"][:, 0]
+    assert pos[:, 1].max() < y0.max() - 0.05
+    assert pos[:, 0].max() - pos[:, 0].min() > (x0.max() - x0.min()) + 0.1
+    assert np.abs(vel).max() <= 9.81 * 0.5 * 1.01, "nothing moves faster than free fall"
+    J = np.linalg.det(vol["deformation_gradient"].reshape(-1, 3, 3))
+    assert (J > 0.5).all() and (J < 1.5).all()
