@@ -174,6 +174,23 @@ typedef struct {
     float friction;         /* collider.friction(), grid_update.rs:113 */
 } SparklCuboidCollider;
 
+/* Heightfield (rapier `ColliderBuilder::heightfield(heights, scale)`, examples3d/sand3.rs:23-37): parry3d 0.13 layout --
+ * heights is an nrows x ncols nalgebra DMatrix (column-major: (i, j) at i + nrows * j), rows run along local z, columns
+ * along local x, both spanning [-0.5, 0.5] * scale; every cell is split into the triangles (p00, p10, p01) and
+ * (p10, p11, p01).  The CPU path projects on the triangle soup and never reports `is_inside`
+ * (grid_update.rs:78-86); `below_is_solid` != 0 selects the CUDA path's rule instead
+ * (src_kernels/gpu_collider.rs:69-91: inside = within the x-z extent and not above the surface). */
+typedef struct {
+    uint32_t nrows, ncols;
+    const float* heights;
+    float scale[3];
+    float rotation[4];      /* (i, j, k, w) */
+    float translation[3];
+    float friction;
+    uint8_t below_is_solid;
+    uint8_t _pad[3];
+} SparklHeightFieldCollider;
+
 /* ------------------------------------------------------------------- timings
  * reference: CudaTimestepTimings / CudaSubstepTimings / CudaDeviceTimings
  * (src/cuda/cuda_mpm_pipeline.rs:28-85).  Milliseconds from hipEvents, summed over the
@@ -253,6 +270,8 @@ int sparkl_hip_particles_read_sorted_ids(SparklPipeline* p, uint32_t* out, uint6
 int sparkl_hip_models_set(SparklPipeline* p, uint32_t n, const SparklParticleModel* models);
 /* CudaColliderSet::from_collider_set (cuboids) */
 int sparkl_hip_colliders_set_cuboids(SparklPipeline* p, uint32_t n, const SparklCuboidCollider* colliders);
+/* CudaColliderSet::from_collider_set (heightfields); applied after the cuboids.  Heights are copied. */
+int sparkl_hip_colliders_set_heightfields(SparklPipeline* p, uint32_t n, const SparklHeightFieldCollider* colliders);
 
 /* MpmPipeline::step / CudaMpmPipeline::step
  * (src/pipelines/mpm_pipeline.rs:15-42, src/cuda/cuda_mpm_pipeline.rs:262-271):

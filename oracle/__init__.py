@@ -109,9 +109,15 @@ class Oracle:
         arr = (abi.CuboidColliderC * max(len(cuboids), 1))(*cuboids)
         self.L.oracle_set_cuboids(self.h, C.c_uint32(len(cuboids)), arr)
 
+    def set_heightfields(self, heightfields):
+        arr = (abi.HeightFieldColliderC * max(len(heightfields), 1))(*heightfields)
+        self._keep.append(heightfields)
+        self.L.oracle_set_heightfields(self.h, C.c_uint32(len(heightfields)), arr)
+
     def load_scene(self, scene):
         self.set_models(scene.models)
         self.set_cuboids(scene.colliders)
+        self.set_heightfields(getattr(scene, "heightfields", []))
         self.set_particles(scene.particles)
 
     # ---- stepping
@@ -240,6 +246,14 @@ def eval_all(x, f64=False):
     out = np.zeros(3)
     lib().oracle_eval_all(int(f64), C.c_double(x), out.ctypes.data_as(C.c_void_p))
     return out
+
+
+def heightfield_project(hf, pt):
+    _, pp = _d(pt, 3)
+    out = np.zeros(3)
+    inside = C.c_int(0)
+    lib().oracle_heightfield_project(C.byref(hf), pp, out.ctypes.data_as(C.c_void_p), C.byref(inside))
+    return out, bool(inside.value)
 
 
 def cuboid_project(cuboid, pt):

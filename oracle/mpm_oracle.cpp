@@ -84,6 +84,19 @@ void set_cuboids(Oracle<R>& o, uint32_t n, const SparklCuboidCollider* c) {
 }
 
 template <class R>
+void set_heightfields(Oracle<R>& o, uint32_t n, const SparklHeightFieldCollider* c) {
+    o.heightfields.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        auto& h = o.heightfields[i];
+        h.nrows = (int)c[i].nrows; h.ncols = (int)c[i].ncols;
+        h.heights.assign(c[i].heights, c[i].heights + (size_t)c[i].nrows * c[i].ncols);
+        for (int a = 0; a < 3; ++a) { h.scale[a] = c[i].scale[a]; h.t[a] = c[i].translation[a]; }
+        for (int a = 0; a < 4; ++a) h.q[a] = c[i].rotation[a];
+        h.friction = c[i].friction; h.below_is_solid = c[i].below_is_solid != 0;
+    }
+}
+
+template <class R>
 uint64_t get_nodes(Oracle<R>& o, SparklGridNode* out, uint64_t cap) {
     uint64_t n = 0;
     for (const auto& reg : o.regions)
@@ -156,6 +169,23 @@ void oracle_set_models(void* hv, uint32_t n, const SparklParticleModel* m) {
 void oracle_set_cuboids(void* hv, uint32_t n, const SparklCuboidCollider* c) {
     Handle* h = (Handle*)hv;
     if (h->f64) set_cuboids(*h->od, n, c); else set_cuboids(*h->of, n, c);
+}
+
+void oracle_set_heightfields(void* hv, uint32_t n, const SparklHeightFieldCollider* c) {
+    Handle* h = (Handle*)hv;
+    if (h->f64) set_heightfields(*h->od, n, c); else set_heightfields(*h->of, n, c);
+}
+void oracle_heightfield_project(const SparklHeightFieldCollider* c, const double pt[3], double out[3], int* is_inside) {
+    Oracle<double>* dummy = nullptr; (void)dummy;
+    HeightField<double> h;
+    h.nrows = (int)c->nrows; h.ncols = (int)c->ncols;
+    h.heights.assign(c->heights, c->heights + (size_t)c->nrows * c->ncols);
+    for (int a = 0; a < 3; ++a) { h.scale[a] = c->scale[a]; h.t[a] = c->translation[a]; }
+    for (int a = 0; a < 4; ++a) h.q[a] = c->rotation[a];
+    h.friction = c->friction; h.below_is_solid = c->below_is_solid != 0;
+    Projection<double> p = heightfield_project_point(h, Vec3<double>{{pt[0], pt[1], pt[2]}});
+    for (int a = 0; a < 3; ++a) out[a] = p.point[a];
+    *is_inside = p.is_inside;
 }
 
 double oracle_step(void* hv, const SparklSolverParams* params, const float g[3]) {

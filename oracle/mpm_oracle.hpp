@@ -469,6 +469,59 @@ template <class R> Projection<R> cuboid_project_point(const Cuboid<R>& c, const 
     return Projection<R>{inside, Vec3<R>{{w[0] + c.t[0], w[1] + c.t[1], w[2] + c.t[2]}}};
 }
 
+// parry3d 0.13 Triangle::project_local_point = Ericson's closest point on a triangle (unpinned third party)
+template <class R> Vec3<R> closest_on_triangle(const Vec3<R>& p, const Vec3<R>& a, const Vec3<R>& b, const Vec3<R>& c) {
+    auto sub = [](const Vec3<R>& x, const Vec3<R>& y) { return Vec3<R>{{x[0] - y[0], x[1] - y[1], x[2] - y[2]}}; };
+    auto lin = [](const Vec3<R>& x, const Vec3<R>& d, R t) { return Vec3<R>{{x[0] + t * d[0], x[1] + t * d[1], x[2] + t * d[2]}}; };
+    Vec3<R> ab = sub(b, a), ac = sub(c, a), ap = sub(p, a);
+    R d1 = dot(ab, ap), d2 = dot(ac, ap);
+    if (d1 <= 0 && d2 <= 0) return a;
+    Vec3<R> bp = sub(p, b);
+    R d3 = dot(ab, bp), d4 = dot(ac, bp);
+    if (d3 >= 0 && d4 <= d3) return b;
+    R vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) return lin(a, ab, d1 / (d1 - d3));
+    Vec3<R> cp = sub(p, c);
+    R d5 = dot(ab, cp), d6 = dot(ac, cp);
+    if (d6 >= 0 && d5 <= d6) return c;
+    R vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) return lin(a, ac, d2 / (d2 - d6));
+    R va = d3 * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) return lin(b, sub(c, b), (d4 - d3) / ((d4 - d3) + (d5 - d6)));
+    R denom = R(1) / (va + vb + vc), v = vb * denom, w = vc * denom;
+    return Vec3<R>{{a[0] + ab[0] * v + ac[0] * w, a[1] + ab[1] * v + ac[1] * w, a[2] + ab[2] * v + ac[2] * w}};
+}
+// parry3d 0.13 HeightField (rows along z, columns along x, cell = triangles (p00,p10,p01) + (p10,p11,p01));
+// project_local_point brute-forces every triangle; is_inside is never set on the CPU path.  `below_is_solid` adds the
+// CUDA path's rule (src_kernels/gpu_collider.rs:69-91).
+template <class R> struct HeightField { int nrows, ncols; std::vector<R> heights; Vec3<R> scale; R q[4]; Vec3<R> t; R friction; bool below_is_solid; };
+template <class R> Projection<R> heightfield_project_point(const HeightField<R>& hf, const Vec3<R>& pt_world) {
+    Vec3<R> rel{{pt_world[0] - hf.t[0], pt_world[1] - hf.t[1], pt_world[2] - hf.t[2]}};
+    Vec3<R> lp = quat_rotate(hf.q, rel, true);
+    R cw = R(1) / R(hf.ncols - 1), ch = R(1) / R(hf.nrows - 1);
+    R best = std::numeric_limits<R>::max();
+    Vec3<R> bp = lp;
+    for (int i = 0; i + 1 < hf.nrows; ++i)
+        for (int j = 0; j + 1 < hf.ncols; ++j) {
+            R z0 = (R(-0.5) + ch * R(i)) * hf.scale[2], z1 = (R(-0.5) + ch * R(i + 1)) * hf.scale[2];
+            R x0 = (R(-0.5) + cw * R(j)) * hf.scale[0], x1 = (R(-0.5) + cw * R(j + 1)) * hf.scale[0];
+            Vec3<R> p00{{x0, hf.heights[i + hf.nrows * j] * hf.scale[1], z0}}, p10{{x0, hf.heights[i + 1 + hf.nrows * j] * hf.scale[1], z1}};
+            Vec3<R> p01{{x1, hf.heights[i + hf.nrows * (j + 1)] * hf.scale[1], z0}}, p11{{x1, hf.heights[i + 1 + hf.nrows * (j + 1)] * hf.scale[1], z1}};
+            for (int tri = 0; tri < 2; ++tri) {
+                Vec3<R> c = tri == 0 ? closest_on_triangle(lp, p00, p10, p01) : closest_on_triangle(lp, p10, p11, p01);
+                R d = (c[0] - lp[0]) * (c[0] - lp[0]) + (c[1] - lp[1]) * (c[1] - lp[1]) + (c[2] - lp[2]) * (c[2] - lp[2]);
+                if (d < best) { best = d; bp = c; }
+            }
+        }
+    bool inside = false;
+    if (hf.below_is_solid) {
+        R ux = lp[0] / hf.scale[0] + R(0.5), uz = lp[2] / hf.scale[2] + R(0.5);
+        inside = ux >= 0 && ux <= 1 && uz >= 0 && uz <= 1 && lp[1] <= bp[1];
+    }
+    Vec3<R> w = quat_rotate(hf.q, bp, false);
+    return Projection<R>{inside, Vec3<R>{{w[0] + hf.t[0], w[1] + hf.t[1], w[2] + hf.t[2]}}};
+}
+
 // ---------------------------------------------------------------------------------------- solver
 struct Region { uint64_t id; size_t begin, end; };
 
@@ -486,6 +539,7 @@ struct Oracle {
     std::vector<std::array<size_t, 5>> bins;
     std::vector<SparklParticleModel> models;
     std::vector<Cuboid<R>> cuboids;
+    std::vector<HeightField<R>> heightfields;
     int last_num_substeps = 0;
     std::vector<double> last_dts;
     int num_threads = 1;
@@ -683,17 +737,16 @@ struct Oracle {
                 GridNode<R>& cell = node(cell_id);
                 for (int a = 0; a < 3; ++a)
                     if (dofs & (1u << a)) { cell.momentum[a] = 0; cell.velocity[a] = 0; }
-                for (const auto& col : cuboids) {
-                    Projection<R> proj = cuboid_project_point(col, cell_pos);
+                auto apply = [&](const Projection<R>& proj, R friction) {
                     if (!(cell.flags & 2u) && proj.is_inside) cell.flags |= 2u;
-                    if (boundary_handling == SPARKL_BOUNDARY_NONE) continue;
+                    if (boundary_handling == SPARKL_BOUNDARY_NONE) return;
                     if (boundary_handling == SPARKL_BOUNDARY_STICK) {
                         if (proj.is_inside) cell.velocity[0] = cell.velocity[1] = cell.velocity[2] = 0;
-                        continue;
+                        return;
                     }
                     Vec3<R> dv{{cell_pos[0] - proj.point[0], cell_pos[1] - proj.point[1], cell_pos[2] - proj.point[2]}};
                     R dist = norm(dv);
-                    if (!(dist > R(1.0e-5))) continue;  // Unit::try_new_and_get(.., 1e-5)
+                    if (!(dist > R(1.0e-5))) return;  // Unit::try_new_and_get(.., 1e-5)
                     Vec3<R> normal{{dv[0] / dist, dv[1] / dist, dv[2] / dist}};
                     if (proj.is_inside) for (int a = 0; a < 3; ++a) normal[a] = -normal[a];
                     Vec3<R> vel{{cell.velocity[0], cell.velocity[1], cell.velocity[2]}};
@@ -705,7 +758,7 @@ struct Oracle {
                             R tvn = norm(tv);
                             for (int a = 0; a < 3; ++a) cell.velocity[a] = tv[a];
                             if (tvn > R(1.0e-10)) {
-                                R f = std::max(tvn + normal_vel * col.friction, R(0));
+                                R f = std::max(tvn + normal_vel * friction, R(0));
                                 for (int a = 0; a < 3; ++a) cell.velocity[a] = tv[a] / tvn * f;
                             }
                         } else if (-normal_vel * dt > dist_with_margin) {
@@ -713,7 +766,9 @@ struct Oracle {
                             for (int a = 0; a < 3; ++a) cell.velocity[a] -= k * normal[a];
                         }
                     }
-                }
+                };
+                for (const auto& col : cuboids) apply(cuboid_project_point(col, cell_pos), col.friction);
+                for (const auto& hf : heightfields) apply(heightfield_project_point(hf, cell_pos), hf.friction);
             }
         }
     }

@@ -16,7 +16,7 @@ SYMBOLS = [
     "sparkl_hip_particles_read_positions", "sparkl_hip_particles_read_velocities", "sparkl_hip_particles_read_volumes",
     "sparkl_hip_particles_read_statuses", "sparkl_hip_particles_read_phases", "sparkl_hip_particles_read_data",
     "sparkl_hip_particles_read_velocity_gradients", "sparkl_hip_particles_read_sorted_ids", "sparkl_hip_models_set",
-    "sparkl_hip_colliders_set_cuboids", "sparkl_hip_pipeline_step", "sparkl_hip_pipeline_substeps", "sparkl_hip_pipeline_sync",
+    "sparkl_hip_colliders_set_cuboids", "sparkl_hip_colliders_set_heightfields", "sparkl_hip_pipeline_step", "sparkl_hip_pipeline_substeps", "sparkl_hip_pipeline_sync",
     "sparkl_hip_pipeline_clock_enable", "sparkl_hip_pipeline_clock_read", "sparkl_hip_grid_num_active_blocks",
     "sparkl_hip_grid_num_particle_blocks", "sparkl_hip_grid_debug_capture", "sparkl_hip_grid_read_nodes",
     "sparkl_hip_last_error_string", "sparkl_hip_version",

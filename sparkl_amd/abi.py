@@ -134,6 +134,27 @@ class CuboidColliderC(C.Structure):
                 ("translation", C.c_float * 3), ("friction", C.c_float)]
 
 
+class HeightFieldColliderC(C.Structure):
+    _fields_ = [("nrows", C.c_uint32), ("ncols", C.c_uint32), ("heights", C.POINTER(C.c_float)), ("scale", C.c_float * 3),
+                ("rotation", C.c_float * 4), ("translation", C.c_float * 3), ("friction", C.c_float),
+                ("below_is_solid", C.c_uint8), ("_pad", C.c_uint8 * 3)]
+
+
+def heightfield(heights, scale, translation=(0.0, 0.0, 0.0), rotation=(0.0, 0.0, 0.0, 1.0), friction=0.5, below_is_solid=False):
+    """`ColliderBuilder::heightfield(heights, scale).translation(..)`: heights[i, j], rows along z, columns along x."""
+    hts = np.asfortranarray(np.asarray(heights, dtype=np.float32))      # nalgebra DMatrix is column-major
+    c = HeightFieldColliderC()
+    c.nrows, c.ncols = hts.shape
+    c._keep = hts                                                       # keep the buffer alive
+    c.heights = hts.ctypes.data_as(C.POINTER(C.c_float))
+    c.scale[:] = [float(x) for x in scale]
+    c.rotation[:] = [float(x) for x in rotation]
+    c.translation[:] = [float(x) for x in translation]
+    c.friction = friction
+    c.below_is_solid = int(below_is_solid)
+    return c
+
+
 class TimingsC(C.Structure):
     _fields_ = [("dt", C.c_float), ("num_substeps", C.c_uint32), ("num_resorts", C.c_uint32),
                 ("grid_resize_and_sort_ms", C.c_float), ("reset_grid_ms", C.c_float),

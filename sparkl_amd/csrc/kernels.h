@@ -77,6 +77,7 @@ struct StepParams {
     int parity;
     int dom;          // valid cell coords: 0 <= c, c + 5 < dom
     int num_cuboids;
+    int num_heightfields;
     int want_dt;      // G2P also reduces the next substep's dt bound into ctl->dt_bits (adaptive stepping)
 };
 
@@ -85,6 +86,15 @@ struct DevCuboid {
     float q[4];
     float t[3];
     float friction;
+};
+struct DevHeightField {
+    const float* heights;   // nrows x ncols, column-major
+    int nrows, ncols;
+    float scale[3];
+    float q[4];
+    float t[3];
+    float friction;
+    int below_is_solid;
 };
 
 // Observed placement is workgroup b -> XCD b % 8: give each XCD a contiguous run of Morton-ordered
@@ -363,10 +373,110 @@ SPK_DEV bool cuboid_project(const DevCuboid& c, const float ptw[3], float projw[
     return inside;
 }
 
+// closest point on triangle (a, b, c) to p (Ericson, Real-Time Collision Detection 5.1.5 -- the algorithm of parry's
+// Triangle::project_local_point)
+SPK_DEV void closest_on_triangle(const float p[3], const float a[3], const float b[3], const float c[3], float out[3]) {
+    float ab[3], ac[3], ap[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; }
+    const float d1 = ab[0] * ap[0] + ab[1] * ap[1] + ab[2] * ap[2], d2 = ac[0] * ap[0] + ac[1] * ap[1] + ac[2] * ap[2];
+    if (d1 <= 0.f && d2 <= 0.f) { out[0] = a[0]; out[1] = a[1]; out[2] = a[2]; return; }
+    float bp[3] = {p[0] - b[0], p[1] - b[1], p[2] - b[2]};
+    const float d3 = ab[0] * bp[0] + ab[1] * bp[1] + ab[2] * bp[2], d4 = ac[0] * bp[0] + ac[1] * bp[1] + ac[2] * bp[2];
+    if (d3 >= 0.f && d4 <= d3) { out[0] = b[0]; out[1] = b[1]; out[2] = b[2]; return; }
+    const float vc = d1 * d4 - d3 * d2;
+    if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { const float v = d1 / (d1 - d3); out[0] = a[0] + v * ab[0]; out[1] = a[1] + v * ab[1]; out[2] = a[2] + v * ab[2]; return; }
+    float cp[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
+    const float d5 = ab[0] * cp[0] + ab[1] * cp[1] + ab[2] * cp[2], d6 = ac[0] * cp[0] + ac[1] * cp[1] + ac[2] * cp[2];
+    if (d6 >= 0.f && d5 <= d6) { out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; return; }
+    const float vb = d5 * d2 - d1 * d6;
+    if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { const float w = d2 / (d2 - d6); out[0] = a[0] + w * ac[0]; out[1] = a[1] + w * ac[1]; out[2] = a[2] + w * ac[2]; return; }
+    const float va = d3 * d6 - d5 * d4;
+    if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
+        const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        out[0] = b[0] + w * (c[0] - b[0]); out[1] = b[1] + w * (c[1] - b[1]); out[2] = b[2] + w * (c[2] - b[2]);
+        return;
+    }
+    const float denom = 1.f / (va + vb + vc), v = vb * denom, w = vc * denom;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[i] = a[i] + ab[i] * v + ac[i] * w;
+}
+
+// Closest point of a heightfield to a world point, searching only the cells within `reach` (world units) of the point
+// horizontally: the boundary rule never needs a projection farther than a couple of cells (grid_update.rs:103-127).
+// Returns false when no triangle is in reach.  The CPU reference brute-forces every triangle (parry HeightField::
+// project_local_point); the results agree whenever the true distance is below `reach`.
+SPK_DEV bool heightfield_project(const DevHeightField& hf, const float ptw[3], float reach, float projw[3], bool& inside) {
+    float rel[3] = {ptw[0] - hf.t[0], ptw[1] - hf.t[1], ptw[2] - hf.t[2]};
+    float lp[3];
+    quat_rot(hf.q, rel, -1.f, lp);
+    const float cw = 1.f / (float)(hf.ncols - 1), ch = 1.f / (float)(hf.nrows - 1);
+    const float ux = lp[0] / hf.scale[0] + 0.5f, uz = lp[2] / hf.scale[2] + 0.5f;
+    const float rx = reach / fabsf(hf.scale[0]), rz = reach / fabsf(hf.scale[2]);
+    int j0 = (int)floorf((ux - rx) / cw), j1 = (int)floorf((ux + rx) / cw), i0 = (int)floorf((uz - rz) / ch), i1 = (int)floorf((uz + rz) / ch);
+    j0 = max(j0, 0); i0 = max(i0, 0); j1 = min(j1, hf.ncols - 2); i1 = min(i1, hf.nrows - 2);
+    // bounded work even for heightfield cells much finer than the MPM grid: an 8 x 8 window centred on the point
+    if (j1 - j0 > 7) { j0 = min(max((int)floorf(ux / cw) - 3, 0), max(hf.ncols - 9, 0)); j1 = min(j0 + 7, hf.ncols - 2); }
+    if (i1 - i0 > 7) { i0 = min(max((int)floorf(uz / ch) - 3, 0), max(hf.nrows - 9, 0)); i1 = min(i0 + 7, hf.nrows - 2); }
+    float best = 3.402823466e+38f, bp[3] = {0.f, 0.f, 0.f};
+    for (int i = i0; i <= i1; ++i)
+        for (int j = j0; j <= j1; ++j) {
+            const float z0 = (-0.5f + ch * (float)i) * hf.scale[2], z1 = (-0.5f + ch * (float)(i + 1)) * hf.scale[2];
+            const float x0 = (-0.5f + cw * (float)j) * hf.scale[0], x1 = (-0.5f + cw * (float)(j + 1)) * hf.scale[0];
+            const float p00[3] = {x0, hf.heights[i + hf.nrows * j] * hf.scale[1], z0};
+            const float p10[3] = {x0, hf.heights[i + 1 + hf.nrows * j] * hf.scale[1], z1};
+            const float p01[3] = {x1, hf.heights[i + hf.nrows * (j + 1)] * hf.scale[1], z0};
+            const float p11[3] = {x1, hf.heights[i + 1 + hf.nrows * (j + 1)] * hf.scale[1], z1};
+            float c[3];
+            closest_on_triangle(lp, p00, p10, p01, c);
+            float d = (c[0] - lp[0]) * (c[0] - lp[0]) + (c[1] - lp[1]) * (c[1] - lp[1]) + (c[2] - lp[2]) * (c[2] - lp[2]);
+            if (d < best) { best = d; bp[0] = c[0]; bp[1] = c[1]; bp[2] = c[2]; }
+            closest_on_triangle(lp, p10, p11, p01, c);
+            d = (c[0] - lp[0]) * (c[0] - lp[0]) + (c[1] - lp[1]) * (c[1] - lp[1]) + (c[2] - lp[2]) * (c[2] - lp[2]);
+            if (d < best) { best = d; bp[0] = c[0]; bp[1] = c[1]; bp[2] = c[2]; }
+        }
+    if (best > reach * reach) return false;
+    inside = false;
+    if (hf.below_is_solid) inside = (ux >= 0.f) && (ux <= 1.f) && (uz >= 0.f) && (uz <= 1.f) && (lp[1] <= bp[1]);
+    quat_rot(hf.q, bp, 1.f, projw);
+    projw[0] += hf.t[0]; projw[1] += hf.t[1]; projw[2] += hf.t[2];
+    return true;
+}
+
+// grid_update.rs:84-128 for one collider: `proj` = projection of the node position, `inside` = proj.is_inside
+SPK_DEV void boundary_rule(float v[3], const float cpos[3], const float proj[3], bool inside, float friction, int boundary_handling, float h, float dt) {
+    if (boundary_handling == SPARKL_BOUNDARY_STICK) {
+        if (inside) { v[0] = v[1] = v[2] = 0.f; }
+        return;
+    }
+    float dv[3] = {cpos[0] - proj[0], cpos[1] - proj[1], cpos[2] - proj[2]};
+    const float dist = sqrtf(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+    if (!(dist > 1.0e-5f)) return;
+    float nrm[3] = {dv[0] / dist, dv[1] / dist, dv[2] / dist};
+    if (inside) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
+    const float nv = v[0] * nrm[0] + v[1] * nrm[1] + v[2] * nrm[2];
+    if (nv < 0.f) {
+        const float dwm = dist - h;
+        if (inside || dwm <= 0.f) {
+            const float tv[3] = {v[0] - nv * nrm[0], v[1] - nv * nrm[1], v[2] - nv * nrm[2]};
+            const float tvn = sqrtf(tv[0] * tv[0] + tv[1] * tv[1] + tv[2] * tv[2]);
+            v[0] = tv[0]; v[1] = tv[1]; v[2] = tv[2];
+            if (tvn > 1.0e-10f) {
+                const float f = fmaxf(tvn + nv * friction, 0.f);
+                v[0] = tv[0] / tvn * f; v[1] = tv[1] / tvn * f; v[2] = tv[2] / tvn * f;
+            }
+        } else if (-nv * dt > dwm) {
+            const float kq = dwm / dt + nv;
+            v[0] -= kq * nrm[0]; v[1] -= kq * nrm[1]; v[2] -= kq * nrm[2];
+        }
+    }
+}
+
 // One wave per node block, 4 blocks per workgroup.  MASS_ONLY: fluid volume recompute (fluids_volume.rs).
-template <bool MASS_ONLY>
-__global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const DevCuboid* __restrict__ cuboids, const Ctl* __restrict__ ctl,
-                                                             StepParams S) {
+// HEIGHTFIELDS keeps the triangle search out of the kernel every scene without a heightfield runs.
+template <bool MASS_ONLY, bool HEIGHTFIELDS = false>
+__global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const DevCuboid* __restrict__ cuboids, const DevHeightField* __restrict__ heightfields,
+                                                             const Ctl* __restrict__ ctl, StepParams S) {
     if (ctl->abort_flag[S.parity]) return;
     const int nb_total = G.num_blocks;
     const int b = xcd_remap(blockIdx.x, (nb_total + 3) / 4) * 4 + (threadIdx.x >> 6);
@@ -405,38 +515,20 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
     if (S.dofs & 1u) { px = 0.f; v[0] = 0.f; }
     if (S.dofs & 2u) { py = 0.f; v[1] = 0.f; }
     if (S.dofs & 4u) { pz = 0.f; v[2] = 0.f; }
-    if (S.num_cuboids > 0 && S.boundary_handling != SPARKL_BOUNDARY_NONE) {
+    if ((S.num_cuboids > 0 || HEIGHTFIELDS) && S.boundary_handling != SPARKL_BOUNDARY_NONE) {
         const int4 org = G.blk_origin[b];
         const float cpos[3] = {(float)(org.x + cx) * S.h, (float)(org.y + cy) * S.h, (float)(org.z + cz) * S.h};
         for (int ci = 0; ci < S.num_cuboids; ++ci) {
             const DevCuboid col = cuboids[ci];
             float proj[3];
             const bool inside = cuboid_project(col, cpos, proj);
-            if (S.boundary_handling == SPARKL_BOUNDARY_STICK) {
-                if (inside) { v[0] = v[1] = v[2] = 0.f; }
-                continue;
-            }
-            float dv[3] = {cpos[0] - proj[0], cpos[1] - proj[1], cpos[2] - proj[2]};
-            const float dist = sqrtf(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
-            if (!(dist > 1.0e-5f)) continue;
-            float nrm[3] = {dv[0] / dist, dv[1] / dist, dv[2] / dist};
-            if (inside) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
-            const float nv = v[0] * nrm[0] + v[1] * nrm[1] + v[2] * nrm[2];
-            if (nv < 0.f) {
-                const float dwm = dist - S.h;
-                if (inside || dwm <= 0.f) {
-                    const float tv[3] = {v[0] - nv * nrm[0], v[1] - nv * nrm[1], v[2] - nv * nrm[2]};
-                    const float tvn = sqrtf(tv[0] * tv[0] + tv[1] * tv[1] + tv[2] * tv[2]);
-                    v[0] = tv[0]; v[1] = tv[1]; v[2] = tv[2];
-                    if (tvn > 1.0e-10f) {
-                        const float f = fmaxf(tvn + nv * col.friction, 0.f);
-                        v[0] = tv[0] / tvn * f; v[1] = tv[1] / tvn * f; v[2] = tv[2] / tvn * f;
-                    }
-                } else if (-nv * S.dt > dwm) {
-                    const float kq = dwm / S.dt + nv;
-                    v[0] -= kq * nrm[0]; v[1] -= kq * nrm[1]; v[2] -= kq * nrm[2];
-                }
-            }
+            boundary_rule(v, cpos, proj, inside, col.friction, S.boundary_handling, S.h, S.dt);
+        }
+        if (HEIGHTFIELDS) for (int hi = 0; hi < S.num_heightfields; ++hi) {
+            const DevHeightField hf = heightfields[hi];
+            float proj[3];
+            bool inside = false;
+            if (heightfield_project(hf, cpos, 4.0f * S.h, proj, inside)) boundary_rule(v, cpos, proj, inside, hf.friction, S.boundary_handling, S.h, S.dt);
         }
     }
     G.node_vel[(size_t)b * 64 + lane] = make_float4(v[0], v[1], v[2], m);

@@ -112,6 +112,9 @@ struct SparklPipeline {
     bool any_fluid = false;
     DevBuf<DevCuboid> d_cuboids;
     int num_cuboids = 0;
+    DevBuf<DevHeightField> d_heightfields;
+    std::vector<float*> d_heights;   // one device array per heightfield
+    int num_heightfields = 0;
 
     // control block
     Ctl* d_ctl = nullptr;
@@ -334,7 +337,7 @@ static StepParams make_params(const SparklPipeline* p, const SparklSolverParams*
     S.h = p->h; S.inv_d = 4.0f / (p->h * p->h); S.dt = dt;
     S.gx = g[0]; S.gy = g[1]; S.gz = g[2];
     S.boundary_handling = sp->boundary_handling; S.dofs = sp->simulation_dofs;
-    S.parity = (int)(p->substep_index & 1u); S.dom = p->dom; S.num_cuboids = p->num_cuboids; S.want_dt = 0;
+    S.parity = (int)(p->substep_index & 1u); S.dom = p->dom; S.num_cuboids = p->num_cuboids; S.num_heightfields = p->num_heightfields; S.want_dt = 0;
     return S;
 }
 
@@ -342,12 +345,20 @@ static StepParams make_params(const SparklPipeline* p, const SparklSolverParams*
 #define SPK_P2G_REDUCE_STEPS 3
 #endif
 
+static void launch_grid_update(SparklPipeline* p, const GridArrays& G, const StepParams& S, hipStream_t st) {
+    const dim3 grid((p->num_blocks + 3) / 4), block(BLK_THREADS);
+    if (p->num_heightfields > 0)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, true>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_ctl, S);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, false>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_ctl, S);
+}
+
 static int enqueue_fluid_volumes(SparklPipeline* p, const StepParams& S) {
     hipStream_t st = p->stream;
     GridArrays G = grid_arrays(p);
     G.node_mom = nullptr;
     hipLaunchKernelGGL(k_p2g_mass, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, p->cur.arrays(), G, p->d_ctl, S);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<true>), dim3((p->num_blocks + 3) / 4), dim3(BLK_THREADS), 0, st, G, p->d_cuboids.p, p->d_ctl, S);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<true>), dim3((p->num_blocks + 3) / 4), dim3(BLK_THREADS), 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_ctl, S);
     hipLaunchKernelGGL(k_g2p_volume, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, p->cur.arrays(), G, p->d_models.p, p->d_ctl, S);
     return SPARKL_OK;
 }
@@ -369,7 +380,7 @@ static int enqueue_substep(SparklPipeline* p, const SparklSolverParams* sp, cons
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g<SPK_P2G_REDUCE_STEPS>), dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, P, G, p->d_models.p, p->d_ctl, S);
     CHK(clock_end(p, t0));
     CHK(clock_begin(p, SPAN_GRID, &t1));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false>), dim3((p->num_blocks + 3) / 4), dim3(BLK_THREADS), 0, st, G, p->d_cuboids.p, p->d_ctl, S);
+    launch_grid_update(p, G, S, st);
     CHK(clock_end(p, t1));
     CHK(clock_begin(p, SPAN_G2P, &t2));
     hipLaunchKernelGGL(k_g2p, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, P, G, p->d_models.p, p->d_ctl, S);
@@ -401,7 +412,7 @@ static int enqueue_fused_batch(SparklPipeline* p, const SparklSolverParams* sp, 
         if (was_on && (p->substep_index % p->clock_stride) != 0) p->clock_on = false;
         if (p->clock_on) p->clock_sampled++;
         CHK(clock_begin(p, SPAN_GRID, &tk));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false>), dim3((p->num_blocks + 3) / 4), dim3(BLK_THREADS), 0, st, G, p->d_cuboids.p, p->d_ctl, S);
+        launch_grid_update(p, G, S, st);
         CHK(clock_end(p, tk));
         if (j + 1 < n) {
             CHK(clock_begin(p, SPAN_FUSED, &tk));
@@ -473,7 +484,8 @@ void sparkl_hip_pipeline_destroy(SparklPipeline* p) {
     (void)hipSetDevice(p->device);
     (void)hipStreamSynchronize(p->stream);
     p->cur.release(); p->alt.release();
-    p->d_models.release(); p->d_cuboids.release();
+    p->d_models.release(); p->d_cuboids.release(); p->d_heightfields.release();
+    for (float* d : p->d_heights) (void)hipFree(d);
     p->blk_origin.release(); p->blk_pfirst.release(); p->blk_pcount.release(); p->blk_nbr.release(); p->pblk.release(); p->pb_info.release(); p->tile_mode.release(); p->blk_keys.release();
     p->tiles.release(); p->node_vel.release(); p->node_mom.release(); p->hash_keys.release(); p->hash_vals.release();
     p->keys_a.release(); p->keys_b.release(); p->pb_keys.release(); p->bkeys.release(); p->idx_a.release(); p->idx_b.release();
@@ -557,6 +569,33 @@ int sparkl_hip_colliders_set_cuboids(SparklPipeline* p, uint32_t n, const Sparkl
     if (n) HIPCHK(hipMemcpyAsync(p->d_cuboids.p, dc.data(), n * sizeof(DevCuboid), hipMemcpyHostToDevice, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     p->num_cuboids = (int)n;
+    return SPARKL_OK;
+}
+
+int sparkl_hip_colliders_set_heightfields(SparklPipeline* p, uint32_t n, const SparklHeightFieldCollider* c) {
+    if (!p || (n && !c)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    for (uint32_t i = 0; i < n; ++i)
+        if (c[i].nrows < 2 || c[i].ncols < 2 || !c[i].heights || c[i].scale[0] == 0.f || c[i].scale[2] == 0.f)
+            return set_error(SPARKL_ERR_INVALID_ARGUMENT, "heightfield %u: needs >= 2x2 heights and a non-zero x/z scale", i);
+    for (float* d : p->d_heights) (void)hipFree(d);
+    p->d_heights.clear();
+    std::vector<DevHeightField> dh(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const size_t cnt = (size_t)c[i].nrows * c[i].ncols;
+        float* d = nullptr;
+        HIPCHK(hipMalloc((void**)&d, cnt * sizeof(float)));
+        p->d_heights.push_back(d);
+        HIPCHK(hipMemcpy(d, c[i].heights, cnt * sizeof(float), hipMemcpyHostToDevice));
+        dh[i].heights = d; dh[i].nrows = (int)c[i].nrows; dh[i].ncols = (int)c[i].ncols;
+        for (int a = 0; a < 3; ++a) { dh[i].scale[a] = c[i].scale[a]; dh[i].t[a] = c[i].translation[a]; }
+        for (int a = 0; a < 4; ++a) dh[i].q[a] = c[i].rotation[a];
+        dh[i].friction = c[i].friction; dh[i].below_is_solid = c[i].below_is_solid;
+    }
+    CHK(p->d_heightfields.reserve(std::max<uint32_t>(n, 1)));
+    if (n) HIPCHK(hipMemcpy(p->d_heightfields.p, dh.data(), n * sizeof(DevHeightField), hipMemcpyHostToDevice));
+    p->num_heightfields = (int)n;
     return SPARKL_OK;
 }
 
@@ -1008,7 +1047,7 @@ static int substep_finish_impl(SparklPipeline* p, bool fuse_next) {
     const GridArrays G = grid_arrays(p);
     size_t t1 = 0, t2 = 0;
     CHK(clock_begin(p, SPAN_GRID, &t1));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false>), dim3((p->num_blocks + 3) / 4), dim3(BLK_THREADS), 0, st, G, p->d_cuboids.p, p->d_ctl, p->pending);
+    launch_grid_update(p, G, p->pending, st);
     CHK(clock_end(p, t1));
     if (fuse_next && p->fuse_fixed_dt) {
         // G2P of this substep + P2G of the next one (same dt) in one kernel; the next substep_begin is then free

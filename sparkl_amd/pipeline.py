@@ -60,6 +60,11 @@ class MpmPipeline:
         arr = (abi.CuboidColliderC * max(len(cuboids), 1))(*cuboids)
         check(self.L.sparkl_hip_colliders_set_cuboids(self.h, C.c_uint32(len(cuboids)), arr))
 
+    def set_heightfields(self, heightfields):
+        """`CudaColliderSet::from_collider_set` for heightfield colliders (abi.heightfield(..)); applied after the cuboids."""
+        arr = (abi.HeightFieldColliderC * max(len(heightfields), 1))(*heightfields)
+        check(self.L.sparkl_hip_colliders_set_heightfields(self.h, C.c_uint32(len(heightfields)), arr))
+
     # ---- CudaParticleSet
     def _args(self, c):
         return (C.c_uint64(len(c)), abi.ptr(c.status, abi.STATUS_DTYPE), abi.ptr(c.position, abi.POSITION_DTYPE),
@@ -122,6 +127,7 @@ class MpmPipeline:
     def load_scene(self, scene):
         self.set_models(scene.models)
         self.set_colliders(scene.colliders)
+        self.set_heightfields(getattr(scene, "heightfields", []))
         self.upload_particles(scene.particles)
 
     # ---- stepping

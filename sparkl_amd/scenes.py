@@ -72,6 +72,7 @@ class Scene:
         self.name, self.cell_width, self.models, self.particles = name, cell_width, models, particles
         self.colliders, self.params, self.gravity, self.fixed_dt = colliders, params, gravity, fixed_dt
         self.domain_log2_bytes = domain_log2_bytes
+        self.heightfields = []
 
 
 def _domain_bits_for(max_cell):
@@ -157,6 +158,24 @@ def cube_through_sand(nx, ny, nz, cube_n=25, h=0.2, jitter=True, name=None):
     sc.name = name or f"cube_through_sand_{nx}x{ny}x{nz}"
     max_cell = int(np.ceil(sc.particles.position["point"].max() / h)) + 2
     sc.domain_log2_bytes = _domain_bits_for(max_cell)
+    return sc
+
+
+def sand_on_heightfield(nx, ny, nz, h=0.2, jitter=True, below_is_solid=False):
+    """sand3-like scene with its real ground (examples3d/sand3.rs:23-37): a 41 x 41 sinusoidal heightfield instead of the
+    cuboid floor.  Scaled down so that the particle cloud sits over the middle of one valley."""
+    sc = sand_column(nx, ny, nz, h=h, jitter=jitter, name=f"sand_on_heightfield_{nx}x{ny}x{nz}")
+    n = 40
+    i = np.arange(n + 1, dtype=f32)
+    heights = np.repeat((-np.sin(i * f32(np.pi) / f32(n)))[:, None], n + 1, axis=1).astype(f32)   # heights[(i, j)] = -sin(i pi / n)
+    side = 16.0
+    lo = sc.particles.position["point"].min(0)
+    cx = float(sc.particles.position["point"][:, 0].mean())
+    cz = float(sc.particles.position["point"][:, 2].mean())
+    # surface y = ty + scale_y * height ; put the valley bottom (height -1) two cells under the cloud
+    ty = float(lo[1]) - 2.0 * h + 1.5
+    sc.colliders = []
+    sc.heightfields = [abi.heightfield(heights, (side, 1.5, side), translation=(cx, ty, cz), friction=0.5, below_is_solid=below_is_solid)]
     return sc
 
 

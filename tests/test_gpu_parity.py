@@ -114,6 +114,42 @@ def test_particle_state_parity_100_substeps(Pipeline, name, builder, dt):
             assert np.isfinite(got.position["point"]).all()
 
 
+@pytest.mark.parametrize("below_is_solid", [False, True])
+def test_heightfield_ground_parity(Pipeline, below_is_solid):
+    """sand3's real ground (examples3d/sand3.rs:23-37): a heightfield.  Node velocities after one substep and particle
+    state after 100 against the oracle's brute-force triangle projection."""
+    sc = scenes.sand_on_heightfield(16, 8, 12, below_is_solid=below_is_solid)
+    sc.particles.velocity["vector"][:, 1] = -3.0                    # hits the surface within the 100 substeps
+    sc.particles.velocity["vector"][:, 0] = 0.7
+    dt = 2.5e-4
+    o = _oracle(sc)
+    o.sort(); o.p2g(dt, sc.gravity); o.grid_update(dt, sc.params.boundary_handling, 0)
+    ref = o.nodes()
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.grid_debug_capture(True)
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, dt, 1)
+        e = node_errors(p.read_grid_nodes(), ref)
+    _report(f"heightfield_nodes_solid{int(below_is_solid)}", e)
+    assert e["n_got"] == e["n_ref"] == e["n_common"]
+    assert e["velocity_rel"] < 2e-5
+    o32, o64 = _oracle(sc), _oracle(sc, f64=True)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        for _ in range(100):
+            o32.substep_fixed(sc.params, sc.gravity, dt)
+            o64.substep_fixed(sc.params, sc.gravity, dt)
+        p.substeps(sc.params, sc.gravity, dt, 100)
+        got, r32, r64 = p.read_particles(), o32.get_particles(), o64.get_particles()
+    e = particle_errors(got, r32, sc.cell_width)
+    floor = particle_errors(r32, r64, sc.cell_width)
+    _report(f"heightfield_k100_solid{int(below_is_solid)}", {"vs_f32": e, "oracle_f32_vs_f64": floor})
+    touched = (np.abs(r32.velocity["vector"][:, 1] - (-3.0 + sc.gravity[1] * dt * 100)) > 0.05).sum()
+    assert touched > 100, "the scene must actually exercise the collider"
+    assert e["failed_mismatch"] == 0 and e["eps_x"] <= TOL
+    assert e["eps_v"] <= TOL or e["eps_v"] <= 3 * floor["eps_v"], (e, floor)
+
+
 def test_adaptive_step_matches_oracle(Pipeline):
     """`MpmPipeline::step` with dt = 1/60: same substep count and lengths as the CPU path (mls_solver.rs:33-59)."""
     sc = scenes.sand_column(16, 10, 12, with_block=True)

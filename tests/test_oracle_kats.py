@@ -180,6 +180,52 @@ def test_cuboid_projection():
     assert not inside and np.allclose(pt, [10.0, 1.0, 0.0], atol=1e-6)
 
 
+def test_heightfield_projection():
+    """parry HeightField::project_local_point: brute force over the triangles (p00,p10,p01),(p10,p11,p01) of every cell."""
+    # a tilted plane y = 0.25 x' + 0.5 z' (x', z' in [0, 1]) -> every triangle is coplanar, so the answer is the plane projection
+    n = 9
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")   # i: row (z), j: column (x)
+    heights = 0.25 * j / (n - 1) + 0.5 * i / (n - 1)
+    hf = abi.heightfield(heights, (4.0, 2.0, 8.0), translation=(1.0, -1.0, 3.0))
+    # local surface: y = 2 (0.25 (x/4 + 0.5) + 0.5 (z/8 + 0.5)) = 0.125 x + 0.125 z + 0.75
+    nrm = np.array([-0.125, 1.0, -0.125]); nrm /= np.linalg.norm(nrm)
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        lp = rng.uniform([-1.5, -1.0, -3.0], [1.5, 3.0, 3.0])
+        d = (lp[1] - (0.125 * lp[0] + 0.125 * lp[2] + 0.75)) * nrm[1]
+        want = lp - d * nrm
+        if abs(want[0]) > 2.0 or abs(want[2]) > 4.0:
+            continue
+        pt, inside = oracle.heightfield_project(hf, lp + [1.0, -1.0, 3.0])
+        assert not inside                                          # CPU path: a heightfield has no inside
+        assert np.allclose(pt, want + [1.0, -1.0, 3.0], atol=1e-5)
+    # off the side: closest point is on the border edge
+    pt, _ = oracle.heightfield_project(hf, [1.0 + 5.0, 0.0, 3.0])
+    assert pt[0] == pytest.approx(3.0, abs=1e-6)
+    # the triangle split matters on a saddle cell: h00 = h11 = 0, h10 = h01 = 1 ; diagonal (p10, p01) is the ridge
+    sad = abi.heightfield([[0.0, 1.0], [1.0, 0.0]], (1.0, 1.0, 1.0))
+    pt, _ = oracle.heightfield_project(sad, [0.0, 5.0, 0.0])       # straight above the centre -> ridge at y = 1
+    assert np.allclose(pt, [0.0, 1.0, 0.0], atol=1e-6)
+    # below_is_solid (CUDA path rule): under the surface and inside the footprint
+    hs = abi.heightfield(heights, (4.0, 2.0, 8.0), translation=(1.0, -1.0, 3.0), below_is_solid=True)
+    assert oracle.heightfield_project(hs, [1.0, -3.0, 3.0])[1] and not oracle.heightfield_project(hs, [1.0, 3.0, 3.0])[1]
+    assert not oracle.heightfield_project(hs, [9.0, -3.0, 3.0])[1]
+
+
+def test_heightfield_scene_sand_comes_to_rest_on_the_surface():
+    sc = scenes.sand_on_heightfield(6, 4, 6)
+    o = oracle.Oracle(sc.cell_width)
+    o.load_scene(sc)
+    y0 = sc.particles.position["point"][:, 1].min()
+    for _ in range(600):
+        o.substep_fixed(sc.params, sc.gravity, 5.0e-4)
+    c = o.get_particles()
+    surf = oracle.heightfield_project(sc.heightfields[0], [float(c.position["point"][:, 0].mean()), 0.0, float(c.position["point"][:, 2].mean())])[0][1]
+    assert c.position["point"][:, 1].min() < y0 - 0.05           # it fell (contact starts one cell above the surface) ...
+    assert c.position["point"][:, 1].min() > surf - 0.5 * sc.cell_width   # ... and did not go through
+    assert c.status["failed"].sum() == 0
+
+
 def _elastic_cloud(n=14):
     models = ParticleModelSet()
     mid = models.insert(ParticleModel.new(NeoHookeanElasticity(1.0e6, 0.3)))
