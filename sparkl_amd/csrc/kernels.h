@@ -56,6 +56,7 @@ struct GridArrays {
     const int* blk_pfirst;
     const int* blk_pcount;
     const int* blk_nbr;        // [B][27], index of neighbour block or -1
+    const int* blk_tnbr;       // [B][27], tile (= particle block) of that neighbour block or -1
     const int* pblk;           // [PB] block index of each tile owner
     const int4* pb_info;       // [PB][2]: (origin.xyz, block index), (pfirst, pcount, -, -): one hop instead of three
     float4* tiles;             // [PB][512] (mass, px, py, pz); a core-only tile keeps its 6^3 inner nodes compactly in front
@@ -123,6 +124,7 @@ SPK_DEV float dpp_shl(float v) {
 }
 template <int N>
 SPK_DEV int dpp_shl_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xF, 0xF, true); }
+typedef float f2v __attribute__((ext_vector_type(2)));
 SPK_DEV int dpp_shr1_i(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xF, 0xF, false); }
 
 // ------------------------------------------------------------------------------------------- P2G
@@ -161,7 +163,11 @@ SPK_DEV Scatter p2g_prepare(const DevModel& mo, uint32_t flags, const float px[3
     sc.base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
     sc.shell = ((lc[0] < 1) | (lc[0] > 4) | (lc[1] < 1) | (lc[1] > 4) | (lc[2] < 1) | (lc[2] > 4)) ? 1 : 0;
     M3 tau = m3_zero();
+#ifdef SPK_EXP_NO_STRESS
+    if (mass == 123.456f) {
+#else
     if (!(flags & FLAG_FAILED)) {
+#endif
         if (mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR) tau = corotated_kirchhoff(mo, phase, eh, F);
         else if (mo.ctag == SPARKL_CONSTITUTIVE_NEO_HOOKEAN) tau = neo_hookean_kirchhoff(mo, phase, eh, F);
         else if (mo.ctag == SPARKL_CONSTITUTIVE_EOS_MONAGHAN_SPH) tau = monaghan_kirchhoff(mo, mass, vol0, F.m[0], fluid_jp, C);
@@ -207,31 +213,48 @@ SPK_DEV void p2g_scatter(double (*tile)[TILE_N], const Scatter& sc, bool live, i
         const int i4 = (REDUCE_STEPS >= 3) ? (i2 & dpp_shl_i<2>(i2) & (r + 4 < G ? 1 : 0)) : 0;
         const int i8 = (REDUCE_STEPS >= 4) ? (i4 & dpp_shl_i<4>(i4) & (r + 8 < G ? 1 : 0)) : 0;
         const float f1 = (float)i1, f2 = (float)i2, f4 = (float)i4, f8 = (float)i8;
+        // Node values as two packed pairs (m, px), (py, pz): v_pk_mul/add_f32 retire two f32 per lane at ~1.15x the cost of
+        // one (tools/microbench/pkfma.hip), and this kernel is VALU-bound.
+        const f2v X01 = {0.f, sc.A.m[0]}, X23 = {sc.A.m[1], sc.A.m[2]};
 #pragma unroll
         for (int sz = 0; sz < 3; ++sz)
 #pragma unroll
-            for (int sy = 0; sy < 3; ++sy)
+            for (int sy = 0; sy < 3; ++sy) {
+                const float wyz = sc.wgt[1][sy] * sc.wgt[2][sz];
+                f2v P01 = {sc.val_m, sc.qv[0] + sy * sc.A.m[3] + sz * sc.A.m[6]};
+                f2v P23 = {sc.qv[1] + sy * sc.A.m[4] + sz * sc.A.m[7], sc.qv[2] + sy * sc.A.m[5] + sz * sc.A.m[8]};
 #pragma unroll
                 for (int sx = 0; sx < 3; ++sx) {
-                    const float w = sc.wgt[0][sx] * sc.wgt[1][sy] * sc.wgt[2][sz];
-                    float c0 = w * sc.val_m;
-                    float c1 = w * (sc.qv[0] + sx * sc.A.m[0] + sy * sc.A.m[3] + sz * sc.A.m[6]);
-                    float c2 = w * (sc.qv[1] + sx * sc.A.m[1] + sy * sc.A.m[4] + sz * sc.A.m[7]);
-                    float c3 = w * (sc.qv[2] + sx * sc.A.m[2] + sy * sc.A.m[5] + sz * sc.A.m[8]);
+                    if (sx > 0) { P01 += X01; P23 += X23; }
+                    const float w = sc.wgt[0][sx] * wyz;
+                    const f2v c01 = P01 * w, c23 = P23 * w;
+                    float c0 = c01.x, c1 = c01.y, c2 = c23.x, c3 = c23.y;
                     // c += f_o * row_shl:o(c), o = 1, 2, 4[, 8]: one v_fmac_f32_dpp each.  hipcc emits v_mov_b32_dpp +
                     // v_fmac (+ s_nop) for the builtin form, so this is hand-written; the four independent chains are
                     // interleaved so that a DPP read of c_k is >= 3 VALU ops after its write (DPP needs 2 wait states),
                     // and the leading s_nop covers the compiler's last write.
+#ifdef SPK_EXP_NO_DPP
+                    if (false) {
+#else
                     if (REDUCE_STEPS == 2) {
+#endif
                         asm volatile("s_nop 1\n" SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2));
+#ifdef SPK_EXP_NO_DPP
+                    } else if (false) {
+#else
                     } else if (REDUCE_STEPS == 3) {
+#endif
                         asm volatile("s_nop 1\n" SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") SPK_FMAC_DPP("4", "%6")
                                      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4));
-                    } else {
+                    } else if (REDUCE_STEPS == 4) {
                         asm volatile("s_nop 1\n" SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") SPK_FMAC_DPP("4", "%6") SPK_FMAC_DPP("8", "%7")
                                      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4), "v"(f8));
                     }
+#ifdef SPK_EXP_NO_ATOMICS
+                    if (live && head && c0 == 123.456f) {
+#else
                     if (live && head) {
+#endif
                         const int n = sc.base + sx + TILE_W * sy + TILE_W * TILE_W * sz;
                         atomicAdd(&tile[0][n], (double)c0);
                         atomicAdd(&tile[1][n], (double)c1);
@@ -239,6 +262,7 @@ SPK_DEV void p2g_scatter(double (*tile)[TILE_N], const Scatter& sc, bool live, i
                         atomicAdd(&tile[3][n], (double)c3);
                     }
                 }
+            }
     } else if (live) {
 #pragma unroll
         for (int sz = 0; sz < 3; ++sz)
@@ -477,33 +501,43 @@ SPK_DEV void boundary_rule(float v[3], const float cpos[3], const float proj[3],
 template <bool MASS_ONLY, bool HEIGHTFIELDS = false>
 __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const DevCuboid* __restrict__ cuboids, const DevHeightField* __restrict__ heightfields,
                                                              const Ctl* __restrict__ ctl, StepParams S) {
-    if (ctl->abort_flag[S.parity]) return;
+    // The abort flag is only consulted before the store: the topology arrays stay valid (stale) after an abort, and
+    // this keeps the dependent-load chain at  blk_tnbr -> tile_mode -> tile  (3 hops; it used to be 5).
+    const int aborted = ctl->abort_flag[S.parity];
     const int nb_total = G.num_blocks;
     const int b = xcd_remap(blockIdx.x, (nb_total + 3) / 4) * 4 + (threadIdx.x >> 6);
     if (b >= nb_total) return;
     const int lane = threadIdx.x & 63;
     const int cx = lane & 3, cy = (lane >> 2) & 3, cz = lane >> 4;
     const int dx0 = cx <= 2 ? -1 : 0, dy0 = cy <= 2 ? -1 : 0, dz0 = cz <= 2 ? -1 : 0;
+    int tl[8], off_full[8], off_core[8];
+    bool shell[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int dx = dx0 + (i & 1), dy = dy0 + ((i >> 1) & 1), dz = dz0 + (i >> 2);
+        tl[i] = G.blk_tnbr[b * 27 + (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1)];
+        const int tx = cx - 4 * dx + 1, ty = cy - 4 * dy + 1, tz = cz - 4 * dz + 1;
+        off_full[i] = tx + TILE_W * ty + TILE_W * TILE_W * tz;
+        off_core[i] = (tx - 1) + 6 * (ty - 1) + 36 * (tz - 1);
+        shell[i] = (tx == 0) | (tx == 7) | (ty == 0) | (ty == 7) | (tz == 0) | (tz == 7);
+    }
+    int mode[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mode[i] = G.tile_mode[max(tl[i], 0)];
     float m = 0.f, px = 0.f, py = 0.f, pz = 0.f;
 #pragma unroll
-    for (int iz = 0; iz < 2; ++iz)
-#pragma unroll
-        for (int iy = 0; iy < 2; ++iy)
-#pragma unroll
-            for (int ix = 0; ix < 2; ++ix) {
-                const int dx = dx0 + ix, dy = dy0 + iy, dz = dz0 + iz;
-                const int nb = G.blk_nbr[b * 27 + (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1)];
-                if (nb < 0) continue;
-                const int t = G.blk_origin[nb].w;
-                if (t < 0) continue;
-                const int tx = cx - 4 * dx + 1, ty = cy - 4 * dy + 1, tz = cz - 4 * dz + 1;
-                const float4 v = tile_read(G, t, tx, ty, tz);
-                m += v.x; px += v.y; py += v.z; pz += v.w;
-            }
+    for (int i = 0; i < 8; ++i) {
+        const bool use = (tl[i] >= 0) & ((mode[i] != 0) | !shell[i]);
+        if (use) {
+            const float4 v = G.tiles[(size_t)tl[i] * TILE_N + (mode[i] ? off_full[i] : off_core[i])];
+            m += v.x; px += v.y; py += v.z; pz += v.w;
+        }
+    }
     if (G.halo_in) {  // partial sums of the neighbour slab(s): a + b is bit-identical on both sides of a cut
         const float4 hv = G.halo_in[(size_t)b * 64 + lane];
         m += hv.x; px += hv.y; py += hv.z; pz += hv.w;
     }
+    if (aborted) return;
     if (MASS_ONLY) {
         G.node_vel[(size_t)b * 64 + lane] = make_float4(0.f, 0.f, 0.f, m);
         return;
@@ -647,7 +681,12 @@ SPK_DEV Advected g2p_update(const float4* vt, const DevModel& mo, uint32_t flags
     const float eh = kk.z;
     float sv[3] = {1.f, 1.f, 1.f};
     bool sv_valid = false;
-    if (mo.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER) dp_update(mo, phase, F, Jp, q, lvg, sv, sv_valid);
+#ifdef SPK_EXP_NO_PLASTICITY
+    if (mo.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER && Jp == 123.456f) dp_update(
+#else
+    if (mo.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER) dp_update(
+#endif
+mo, phase, F, Jp, q, lvg, sv, sv_valid);
     if (flags & FLAG_STATIC) { vel[0] = vel[1] = vel[2] = 0.f; C = m3_zero(); }
     // fail guards (:111-121); density_def_grad() == 0  <=>  mass/volume0 == 0 or det(F) overflowed
     const bool zero_density = (kk.x == 0.f) || !(fabsf(m3_det(F)) < 1.0e30f);
@@ -1064,6 +1103,12 @@ __global__ void k_link_nbrs(const uint32_t* __restrict__ blk_keys, int nb, HashT
     int r = -1;
     if (bx >= -1 && by >= -1 && bz >= -1 && bx < 1022 && by < 1022 && bz < 1022) r = hash_lookup(H, (uint64_t)block_key(bx, by, bz));
     nbr[t] = r;
+}
+__global__ void k_link_tile_nbrs(const int* __restrict__ nbr, const int4* __restrict__ origin, int n, int* tnbr) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int b = nbr[t];
+    tnbr[t] = b < 0 ? -1 : origin[b].w;
 }
 
 // --------------------------------------------------------------------------------------- readback

@@ -125,7 +125,7 @@ struct SparklPipeline {
     // sparse grid
     int num_blocks = 0, num_pblocks = 0;
     DevBuf<int4> blk_origin;
-    DevBuf<int> blk_pfirst, blk_pcount, blk_nbr, pblk, tile_mode;
+    DevBuf<int> blk_pfirst, blk_pcount, blk_nbr, blk_tnbr, pblk, tile_mode;
     DevBuf<int4> pb_info;
     DevBuf<uint32_t> blk_keys;
     DevBuf<float4> tiles, node_vel, node_mom;
@@ -200,7 +200,7 @@ static inline int grid_for(size_t n, int threads) { return (int)((n + threads - 
 
 static GridArrays grid_arrays(const SparklPipeline* p) {
     GridArrays g;
-    g.blk_origin = p->blk_origin.p; g.blk_pfirst = p->blk_pfirst.p; g.blk_pcount = p->blk_pcount.p; g.blk_nbr = p->blk_nbr.p;
+    g.blk_origin = p->blk_origin.p; g.blk_pfirst = p->blk_pfirst.p; g.blk_pcount = p->blk_pcount.p; g.blk_nbr = p->blk_nbr.p; g.blk_tnbr = p->blk_tnbr.p;
     g.pblk = p->pblk.p; g.pb_info = p->pb_info.p; g.tile_mode = p->tile_mode.p; g.tiles = p->tiles.p; g.node_vel = p->node_vel.p; g.node_mom = p->capture_mom ? p->node_mom.p : nullptr;
     g.halo_in = (p->slab_on && p->num_blocks) ? p->halo_in.p : nullptr;
     g.num_blocks = p->num_blocks; g.num_pblocks = p->num_pblocks;
@@ -293,7 +293,7 @@ static int resort(SparklPipeline* p) {
             p->hash_mask = hcap - 1;
             HIPCHK(hipMemsetAsync(p->hash_keys.p, 0xFF, (size_t)hcap * sizeof(uint64_t), st));
             CHK(p->blk_origin.reserve(nb)); CHK(p->blk_pfirst.reserve(nb)); CHK(p->blk_pcount.reserve(nb));
-            CHK(p->blk_nbr.reserve((size_t)nb * 27)); CHK(p->pblk.reserve(npb)); CHK(p->pb_info.reserve((size_t)npb * 2)); CHK(p->tile_mode.reserve(npb));
+            CHK(p->blk_nbr.reserve((size_t)nb * 27)); CHK(p->blk_tnbr.reserve((size_t)nb * 27)); CHK(p->pblk.reserve(npb)); CHK(p->pb_info.reserve((size_t)npb * 2)); CHK(p->tile_mode.reserve(npb));
             CHK(p->tiles.reserve((size_t)npb * TILE_N)); CHK(p->node_vel.reserve((size_t)nb * 64));
             if (p->capture_mom) CHK(p->node_mom.reserve((size_t)nb * 64));
             HashTable H{p->hash_keys.p, p->hash_vals.p, p->hash_mask};
@@ -301,6 +301,7 @@ static int resort(SparklPipeline* p) {
             hipLaunchKernelGGL(k_link_pblocks, dim3(grid_for(npb, 256)), dim3(256), 0, st, p->pb_keys.p, p->pb_counts.p, p->pb_first.p, npb, H,
                                p->blk_origin.p, p->blk_pfirst.p, p->blk_pcount.p, p->pblk.p, p->pb_info.p);
             hipLaunchKernelGGL(k_link_nbrs, dim3(grid_for((size_t)nb * 27, 256)), dim3(256), 0, st, p->blk_keys.p, nb, H, p->blk_nbr.p);
+            hipLaunchKernelGGL(k_link_tile_nbrs, dim3(grid_for((size_t)nb * 27, 256)), dim3(256), 0, st, p->blk_nbr.p, p->blk_origin.p, nb * 27, p->blk_tnbr.p);
             HIPCHK(hipMemsetAsync(p->node_vel.p, 0, (size_t)nb * 64 * sizeof(float4), st));
             p->num_blocks = nb;
             p->num_pblocks = npb;
@@ -486,7 +487,7 @@ void sparkl_hip_pipeline_destroy(SparklPipeline* p) {
     p->cur.release(); p->alt.release();
     p->d_models.release(); p->d_cuboids.release(); p->d_heightfields.release();
     for (float* d : p->d_heights) (void)hipFree(d);
-    p->blk_origin.release(); p->blk_pfirst.release(); p->blk_pcount.release(); p->blk_nbr.release(); p->pblk.release(); p->pb_info.release(); p->tile_mode.release(); p->blk_keys.release();
+    p->blk_origin.release(); p->blk_pfirst.release(); p->blk_pcount.release(); p->blk_nbr.release(); p->blk_tnbr.release(); p->pblk.release(); p->pb_info.release(); p->tile_mode.release(); p->blk_keys.release();
     p->tiles.release(); p->node_vel.release(); p->node_mom.release(); p->hash_keys.release(); p->hash_vals.release();
     p->keys_a.release(); p->keys_b.release(); p->pb_keys.release(); p->bkeys.release(); p->idx_a.release(); p->idx_b.release();
     p->pb_counts.release(); p->pb_first.release(); p->cand_a.release(); p->cand_b.release(); p->cub_temp.release(); p->d_scalars.release();
