@@ -265,6 +265,18 @@ int sparkl_hip_particles_read_velocity_gradients(SparklPipeline* p, SparklVeloci
 /* read_sorted_particle_ids: caller index of the particle stored in each sorted slot */
 int sparkl_hip_particles_read_sorted_ids(SparklPipeline* p, uint32_t* out, uint64_t n);
 
+/* Per-frame readback for rendering (testbed_plugin.rs:533-588: positions, velocities and phases are copied into
+ * `LockedBuffer`s every frame).  `sparkl_hip_host_alloc` = LockedBuffer::uninitialized (page-locked host memory).
+ * `readback_begin` snapshots the state after everything enqueued so far, in caller order, and returns at once:
+ * the device-to-host copies run on their own stream, so the next `pipeline_step` overlaps them
+ * (10 M particles x 32 B = 320 MB per frame).  Any of pos / vel / phase may be NULL.  The host arrays may be read
+ * after `readback_wait`; a second `readback_begin` queues behind the first.  Pageable host pointers work too
+ * (the copy then degrades to a staged one). */
+int sparkl_hip_host_alloc(void** out, uint64_t bytes);
+int sparkl_hip_host_free(void* ptr);
+int sparkl_hip_readback_begin(SparklPipeline* p, SparklParticlePosition* pos, SparklParticleVelocity* vel, SparklParticlePhase* phase, uint64_t n);
+int sparkl_hip_readback_wait(SparklPipeline* p);
+
 /* CudaParticleModelSet::from_model_set / ensure_models_are_uploaded
  * (cuda_particle_model_set.rs:37-84): call again whenever a model changed. */
 int sparkl_hip_models_set(SparklPipeline* p, uint32_t n, const SparklParticleModel* models);
@@ -290,6 +302,22 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
 int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* params,
                                  const float gravity[3], float dt, uint32_t nsubsteps);
 int sparkl_hip_pipeline_sync(SparklPipeline* p);
+
+/* Re-order policy.  Particles keep their memory slots between re-bins, so lanes that shared a cell drift apart and the
+ * scatter's lane pre-reduction degrades (k_g2p2g: 0.57 -> 1.0 ms over ~300 substeps of the collapsing 10M column).
+ * Every scatter counts its run heads; the heads in excess of the count right after the last re-bin are summed over
+ * the substeps since, and
+ *   - past `reorder_limit` every particle block is re-sorted by current cell in place (device only, ~0.6 ms at 10M),
+ *   - past `rebin_limit` a full re-bin is requested through the same abort chain a margin violation uses.
+ * Limits are in run heads (the cost of the remedy / the cost of one excess head).  0 = off, < 0 = built-in default
+ * (reorder: scaled with the particle count; full re-bin: off).  Physical results do not depend on the policy beyond
+ * f32 summation order. */
+int sparkl_hip_reorder_policy_set(SparklPipeline* p, float reorder_limit, float rebin_limit);
+typedef struct {
+    uint32_t last_heads, base_heads;      /* run heads of the last scatter / right after the last re-bin */
+    uint32_t reorders, policy_rebins;     /* in-place reorders and full re-bins the policy has triggered */
+} SparklReorderStats;
+int sparkl_hip_reorder_policy_stats(SparklPipeline* p, SparklReorderStats* out);
 /* Elapsed GPU time (ms, hipEvents on the pipeline's stream) and launch count of the
  * p2g / grid_update / g2p kernels accumulated since the last reset. */
 typedef struct {
@@ -299,6 +327,8 @@ typedef struct {
     /* fixed-dt runs fuse G2P of substep s with P2G of substep s+1 (k_g2p2g); launches counted per kernel */
     double g2p2g_ms;
     uint64_t p2g_launches, grid_update_launches, g2p_launches, g2p2g_launches;
+    double reorder_ms;           /* k_block_reorder launches (most return at once: see sparkl_hip_reorder_policy_set) */
+    uint64_t reorder_launches;
 } SparklKernelClock;
 /* enable: 0 = off, 1 = spans on every substep, N > 1 = spans on every N-th substep */
 int sparkl_hip_pipeline_clock_enable(SparklPipeline* p, int enable);

@@ -15,7 +15,8 @@ SYMBOLS = [
     "sparkl_hip_particles_remove_range", "sparkl_hip_particles_truncate", "sparkl_hip_particles_len",
     "sparkl_hip_particles_read_positions", "sparkl_hip_particles_read_velocities", "sparkl_hip_particles_read_volumes",
     "sparkl_hip_particles_read_statuses", "sparkl_hip_particles_read_phases", "sparkl_hip_particles_read_data",
-    "sparkl_hip_particles_read_velocity_gradients", "sparkl_hip_particles_read_sorted_ids", "sparkl_hip_models_set",
+    "sparkl_hip_particles_read_velocity_gradients", "sparkl_hip_particles_read_sorted_ids", "sparkl_hip_host_alloc", "sparkl_hip_host_free",
+    "sparkl_hip_readback_begin", "sparkl_hip_readback_wait", "sparkl_hip_reorder_policy_set", "sparkl_hip_reorder_policy_stats", "sparkl_hip_models_set",
     "sparkl_hip_colliders_set_cuboids", "sparkl_hip_colliders_set_heightfields", "sparkl_hip_pipeline_step", "sparkl_hip_pipeline_substeps", "sparkl_hip_pipeline_sync",
     "sparkl_hip_pipeline_clock_enable", "sparkl_hip_pipeline_clock_read", "sparkl_hip_grid_num_active_blocks",
     "sparkl_hip_grid_num_particle_blocks", "sparkl_hip_grid_debug_capture", "sparkl_hip_grid_read_nodes",
@@ -46,7 +47,8 @@ def lib():
                                "(hipcc --offload-arch=gfx950). sparkl_amd has no CPU fallback.")
         L = C.CDLL(LIB_PATH)
         for s in SYMBOLS:
-            getattr(L, s)  # AttributeError if the library does not export it
+            if not os.environ.get("SPARKL_HIP_LIB_AB"):   # A/B runs against libraries of older revisions (tools/tools_ab3.sh)
+                getattr(L, s)  # AttributeError if the library does not export it
         L.sparkl_hip_last_error_string.restype = C.c_char_p
         L.sparkl_hip_version.restype = C.c_char_p
         L.sparkl_hip_particles_len.restype = C.c_uint64
@@ -56,6 +58,8 @@ def lib():
         L.sparkl_hip_grid_num_active_blocks.argtypes = [C.c_void_p]
         L.sparkl_hip_grid_num_particle_blocks.argtypes = [C.c_void_p]
         L.sparkl_hip_halo_record_bytes.restype = C.c_uint64
+        if hasattr(L, "sparkl_hip_host_free"):
+            L.sparkl_hip_host_free.argtypes = [C.c_void_p]
         L.sparkl_hip_migration_record_bytes.restype = C.c_uint64
         L.sparkl_hip_pipeline_destroy.argtypes = [C.c_void_p]
         L.sparkl_hip_pipeline_destroy.restype = None

@@ -166,7 +166,12 @@ class KernelClockC(C.Structure):
     _fields_ = [("p2g_ms", C.c_double), ("grid_update_ms", C.c_double), ("g2p_ms", C.c_double),
                 ("sort_ms", C.c_double), ("dt_ms", C.c_double), ("halo_ms", C.c_double),
                 ("substeps", C.c_uint64), ("resorts", C.c_uint64), ("sampled_substeps", C.c_uint64), ("g2p2g_ms", C.c_double),
-                ("p2g_launches", C.c_uint64), ("grid_update_launches", C.c_uint64), ("g2p_launches", C.c_uint64), ("g2p2g_launches", C.c_uint64)]
+                ("p2g_launches", C.c_uint64), ("grid_update_launches", C.c_uint64), ("g2p_launches", C.c_uint64), ("g2p2g_launches", C.c_uint64),
+                ("reorder_ms", C.c_double), ("reorder_launches", C.c_uint64)]
+
+
+class ReorderStatsC(C.Structure):
+    _fields_ = [("last_heads", C.c_uint32), ("base_heads", C.c_uint32), ("reorders", C.c_uint32), ("policy_rebins", C.c_uint32)]
 
 
 class PipelineDescC(C.Structure):

@@ -39,7 +39,22 @@ struct Ctl {
     uint32_t dt_bits;        // atomicMin target of the dt estimator (float bits, dt >= 0)
     uint32_t dt_nan;
     uint32_t num_invalid;    // particles that left the domain since the last re-bin
-    uint32_t pad[2];
+    // Re-bin-on-disorder policy.  Between re-bins particles keep their slots, so lanes that used to share a cell drift
+    // apart, the scatter's DPP pre-reduction finds shorter runs and the LDS atomics multiply (k_g2p2g went 0.57 -> 1.0 ms
+    // over ~300 substeps of the collapsing column).  Every scatter counts its run heads; once the heads in excess of the
+    // count right after the last re-bin, summed over the substeps since, pass `excess_limit` (= the cost of a re-bin in
+    // heads), the abort chain is raised exactly like for a margin violation and the host re-bins.
+    uint32_t heads[2];       // run heads of the scatter of substep t, at [t & 1]
+    uint32_t heads_base;     // heads of the first scatter after the last re-bin (0 = not measured yet)
+    float excess_acc;
+    float excess_limit;      // 0 = policy off
+    uint32_t disorder_aborts;
+    uint32_t last_heads;
+    // cheaper remedy, tried first: k_block_reorder re-sorts every particle block by current cell in place (no host
+    // round trip, block membership unchanged).  Requested once the excess passes `reorder_limit`.
+    float reorder_limit;     // 0 = off
+    uint32_t reorder_request;
+    uint32_t reorders;
 };
 
 struct ParticleArrays {
@@ -198,8 +213,11 @@ SPK_DEV void scatter_clear(Scatter& sc) {
 // atomics (0: none, 2: groups of 4, 3: of 8, 4: of 16).  Particles are cell-sorted inside a block, so runs of lanes
 // share a cell key: segmented suffix sums over runs inside aligned groups of G lanes, all VALU, then one atomic per
 // run head.  Cross-lane ops are hoisted out of every `&&` / `||`: they must execute with all lanes enabled.
+// Returns the number of run heads of the wave (wave-uniform): the disorder measure of the re-bin policy.
 template <int REDUCE_STEPS>
-SPK_DEV void p2g_scatter(double (*tile)[TILE_N], const Scatter& sc, bool live, int tid) {
+SPK_DEV int p2g_scatter(double (*tile)[TILE_N], const Scatter& sc, bool live, int tid) {
+    int nheads = 0;
+    if (!__any(live)) return 0;   // wave-uniform: the tail waves of a partly filled batch skip the ~650 instructions below
     if (REDUCE_STEPS > 0) {
         constexpr int G = 1 << REDUCE_STEPS;
         const int lane = tid & 63;
@@ -207,6 +225,7 @@ SPK_DEV void p2g_scatter(double (*tile)[TILE_N], const Scatter& sc, bool live, i
         const int cell_key = live ? sc.base : -1;
         const int key_prev = dpp_shr1_i(cell_key, -2), key_next = dpp_shl_i<1>(cell_key);
         const bool head = (r == 0) | (key_prev != cell_key);
+        nheads = (int)__popcll(__ballot(live & head));
         // f_o = 1.0 when lanes L .. L+o form one contiguous same-key run inside the group
         const int i1 = ((r + 1 < G) & (key_next == cell_key)) ? 1 : 0;
         const int i2 = (REDUCE_STEPS >= 2) ? (i1 & dpp_shl_i<1>(i1) & (r + 2 < G ? 1 : 0)) : 0;
@@ -278,6 +297,7 @@ SPK_DEV void p2g_scatter(double (*tile)[TILE_N], const Scatter& sc, bool live, i
                     atomicAdd(&tile[3][n], (double)(w * (sc.qv[2] + sx * sc.A.m[2] + sy * sc.A.m[5] + sz * sc.A.m[8])));
                 }
     }
+    return nheads;
 }
 
 // Tile write-out (ends with the workgroup barrier the caller needs anyway).  Most blocks have no particle in the drift
@@ -302,13 +322,36 @@ SPK_DEV float4 tile_read(const GridArrays& G, int t, int tx, int ty, int tz) {
     return G.tiles[(size_t)t * TILE_N + (tx - 1) + 6 * (ty - 1) + 36 * (tz - 1)];
 }
 
+// One thread per launch: account for the heads of the previous scatter (index `prev`), arm the counter, maybe abort.
+// `parity` is the launch's substep parity: like a margin violation, the abort takes effect from the next substep.
+SPK_DEV void disorder_policy(Ctl* ctl, int prev, int parity) {
+    const uint32_t hcount = ctl->heads[prev];
+    ctl->heads[prev] = 0u;
+    if (hcount == 0u) return;
+    ctl->last_heads = hcount;
+    const uint32_t base = ctl->heads_base;
+    if (base == 0u) { ctl->heads_base = hcount; return; }
+    if (hcount > base) {
+        const float acc = ctl->excess_acc + (float)(hcount - base);
+        ctl->excess_acc = acc;
+        if (ctl->reorder_limit > 0.f && acc > ctl->reorder_limit) ctl->reorder_request = 1u;
+        if (ctl->excess_limit > 0.f && acc > ctl->excess_limit && !ctl->abort_flag[(parity + 1) & 1]) {
+            ctl->abort_flag[(parity + 1) & 1] = 1u;
+            ctl->disorder_aborts += 1u;
+        }
+    }
+}
+
 // One workgroup per particle block: scatter its particles into the LDS tile, write the tile once.
 template <int REDUCE_STEPS>
 __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models,
-                                                     const Ctl* __restrict__ ctl, StepParams S) {
+                                                     Ctl* __restrict__ ctl, StepParams S) {
     if (ctl->abort_flag[S.parity]) return;
     __shared__ double tile[4][TILE_N];
+    __shared__ int s_heads;
     const int tid = threadIdx.x;
+    if (tid == 0) s_heads = 0;
+    if (blockIdx.x == 0 && tid == 0) disorder_policy(ctl, (S.parity + 1) & 1, S.parity);
     const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
     for (int n = tid; n < TILE_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
@@ -324,6 +367,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
     __syncthreads();
 
     bool shell_used = false;
+    int wave_heads = 0;
     for (int it = 0; it < niter; ++it) {
         const int li = it * BLK_THREADS + tid;
         const bool active = li < pcount;
@@ -347,9 +391,11 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
             sc = p2g_prepare(mo, flags, px, v, C, F, kk.x, kk.y, kk.z, phase, jp, org, h, inv_h, S.inv_d, S.dt);
             shell_used |= sc.shell != 0;
         }
-        p2g_scatter<REDUCE_STEPS>(tile, sc, live, tid);
+        wave_heads += p2g_scatter<REDUCE_STEPS>(tile, sc, live, tid);
     }
+    if ((tid & 63) == 0) atomicAdd(&s_heads, wave_heads);
     tile_write(tile, G, pb, tid, shell_used);
+    if (tid == 0) atomicAdd(&ctl->heads[S.parity], (uint32_t)s_heads);
 }
 
 // ----------------------------------------------------------------------------------- grid update
@@ -805,6 +851,10 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p2g(ParticleArrays P, Grid
     }
     __shared__ float4 vt[TILE_N];
     __shared__ double tile[4][TILE_N];
+    __shared__ int s_heads;
+    if (tid == 0) s_heads = 0;
+    // this launch scatters for substep s + 1: its heads go to [(parity + 1) & 1], the previous scatter's are at [parity]
+    if (blockIdx.x == 0 && tid == 0) disorder_policy(ctl, S.parity, S.parity);
     const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int b = org.w, pfirst = rng.x, pcount = rng.y;
@@ -820,6 +870,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p2g(ParticleArrays P, Grid
     __syncthreads();
     const float h = S.h, inv_h = 1.0f / S.h;
     bool want_sort = false, shell_used = false;
+    int wave_heads = 0;
     for (int it = 0; it < niter; ++it) {
         const int li = it * BLK_THREADS + tid;
         const bool active = li < pcount;
@@ -842,12 +893,99 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p2g(ParticleArrays P, Grid
             live = o.in_tile;
             if (live) { sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.F, kk.x, kk.y, kk.z, phase, o.Jp, org, h, inv_h, S.inv_d, S.dt); shell_used |= sc.shell != 0; }
         }
-        p2g_scatter<REDUCE_STEPS>(tile, sc, live, tid);
+        wave_heads += p2g_scatter<REDUCE_STEPS>(tile, sc, live, tid);
     }
+    if ((tid & 63) == 0) atomicAdd(&s_heads, wave_heads);
     tile_write(tile, G, pb, tid, shell_used);
+    if (tid == 0) atomicAdd(&ctl->heads[(S.parity + 1) & 1], (uint32_t)s_heads);
     if (__any(want_sort)) {
         if ((tid & 63) == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
     }
+}
+
+// ------------------------------------------------------------------- in-place block reorder
+// Re-sorts the particles of every particle block by their *current* cell, inside the block's own slot range: a stable
+// counting sort over the 512 tile cells, one chunk of 512 particles at a time, the ten float4 of both particles of a
+// thread held in registers between the read and the write.  Restores the same-cell lane runs the scatter's pre-reduction
+// needs (see Ctl) for one pass over the particle data (~0.6 ms at 10M) instead of a full re-bin with its host round trip.
+// Launched blindly every few substeps; does nothing unless the policy asked for it.
+__global__ __launch_bounds__(BLK_THREADS) void k_block_reorder(ParticleArrays P, GridArrays G, const Ctl* __restrict__ ctl, float h, int parity) {
+    if (ctl->abort_flag[parity] || !ctl->reorder_request) return;
+    __shared__ int hist[8][TILE_N];   // [slot-order segment = iteration * 4 + wave][cell]: count, then start offset
+    __shared__ int wave_sum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int pfirst = rng.x, pcount = rng.y;
+    const float inv_h = 1.0f / h;
+    const int orgv[3] = {org.x, org.y, org.z};
+    for (int c0 = 0; c0 < pcount; c0 += 2 * BLK_THREADS) {
+        const int cnt = min(2 * BLK_THREADS, pcount - c0);
+        for (int n = tid; n < 8 * TILE_N; n += BLK_THREADS) (&hist[0][0])[n] = 0;
+        __syncthreads();
+        float4 r[2][10];
+        int key[2], rank[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int li = k * BLK_THREADS + tid;
+            const bool valid = li < cnt;
+            const int i = pfirst + c0 + (valid ? li : 0);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) r[k][a] = P.q[a][i];
+            r[k][6] = P.d[i]; r[k][7] = P.k[i]; r[k][8] = P.kinvel[i]; r[k][9] = P.aux[i];
+            const float px[3] = {r[k][0].x, r[k][0].y, r[k][0].z};
+            int kk = 0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float rc = round_cell(px[a], h, inv_h);
+                const int lc = min(max((rc == rc ? (int)rc : 0) - orgv[a], 0), TILE_W - 1);   // tile coordinate of the associated cell
+                kk += lc << (3 * a);
+            }
+            key[k] = kk;
+            rank[k] = valid ? atomicAdd(&hist[4 * k + wv][kk], 1) : 0;
+        }
+        __syncthreads();
+        // exclusive scan over the 512 cells (two per thread), then per-segment start offsets
+        int t0 = 0, t1 = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { t0 += hist[w][2 * tid]; t1 += hist[w][2 * tid + 1]; }
+        const int both = t0 + t1;
+        int incl = both;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            incl += (lane >= d) ? up : 0;
+        }
+        if (lane == 63) wave_sum[wv] = incl;
+        __syncthreads();
+        int start0 = incl - both;
+        for (int j = 0; j < wv; ++j) start0 += wave_sum[j];
+        int start1 = start0 + t0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const int a0 = hist[w][2 * tid], a1 = hist[w][2 * tid + 1];
+            hist[w][2 * tid] = start0; hist[w][2 * tid + 1] = start1;
+            start0 += a0; start1 += a1;
+        }
+        __syncthreads();   // also: every read of this chunk has completed (workgroup fence) before the first write
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int li = k * BLK_THREADS + tid;
+            if (li < cnt) {
+                const int dst = pfirst + c0 + hist[4 * k + wv][key[k]] + rank[k];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) P.q[a][dst] = r[k][a];
+                P.d[dst] = r[k][6]; P.k[dst] = r[k][7]; P.kinvel[dst] = r[k][8]; P.aux[dst] = r[k][9];
+            }
+        }
+        __syncthreads();
+    }
+}
+__global__ void k_reorder_done(Ctl* ctl, int parity) {
+    if (ctl->abort_flag[parity] || !ctl->reorder_request) return;
+    ctl->reorder_request = 0u;
+    ctl->excess_acc = 0.f;
+    ctl->reorders += 1u;
 }
 
 // ------------------------------------------------------------- fluid volume recompute (config 4)
@@ -1147,6 +1285,15 @@ __global__ void k_read_velgrad(ParticleArrays P, float* out, int n, long long id
     const float4 q3 = P.q[3][i], q4 = P.q[4][i], q5 = P.q[5][i];
     float* o = out + 9 * out_slot(P, i, id_base);
     o[0] = q3.w; o[1] = q4.x; o[2] = q4.y; o[3] = q4.z; o[4] = q4.w; o[5] = q5.x; o[6] = q5.y; o[7] = q5.z; o[8] = q5.w;
+}
+// the three per-frame render components in one pass (any output may be null)
+__global__ void k_read_render(ParticleArrays P, float* pos, float* vel, float* phase, int n, long long id_base) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t o = out_slot(P, i, id_base);
+    if (pos) { const float4 q0 = P.q[0][i]; pos[3 * o] = q0.x; pos[3 * o + 1] = q0.y; pos[3 * o + 2] = q0.z; }
+    if (vel) { const float4 q3 = P.q[3][i]; vel[3 * o] = q3.x; vel[3 * o + 1] = q3.y; vel[3 * o + 2] = q3.z; }
+    if (phase) { phase[2 * o] = P.aux[i].x; phase[2 * o + 1] = P.d[i].w; }
 }
 __global__ void k_read_ids(ParticleArrays P, uint32_t* out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -140,6 +140,11 @@ struct SparklPipeline {
     DevBuf<uint8_t> cub_temp;
     DevBuf<int> d_scalars;  // [0] num_runs, [1] num_unique
     DevBuf<float> staging;
+    float reorder_limit = -1.f, rebin_limit = 0.f;   // sparkl_hip_reorder_policy_set: < 0 = default, 0 = off
+    DevBuf<float> rb_staging;               // asynchronous render readback: 8 floats per particle, own copy stream
+    hipStream_t rb_stream = nullptr;
+    hipEvent_t rb_gathered = nullptr, rb_done = nullptr;
+    bool rb_pending = false;
     DevBuf<SparklGridNode> node_staging;
     DevBuf<unsigned long long> d_count;
 
@@ -156,7 +161,7 @@ struct SparklPipeline {
     uint64_t total_resorts = 0;
 };
 
-enum { SPAN_P2G = 0, SPAN_GRID = 1, SPAN_G2P = 2, SPAN_SORT = 3, SPAN_DT = 4, SPAN_HALO = 5, SPAN_FUSED = 6 };
+enum { SPAN_P2G = 0, SPAN_GRID = 1, SPAN_G2P = 2, SPAN_SORT = 3, SPAN_DT = 4, SPAN_HALO = 5, SPAN_FUSED = 6, SPAN_REORDER = 7 };
 
 static int clock_begin(SparklPipeline* p, int kind, size_t* tok) {
     if (!p->clock_on) return SPARKL_OK;
@@ -187,6 +192,7 @@ static int clock_collect(SparklPipeline* p) {
             case SPAN_G2P: p->clock.g2p_ms += ms; p->clock.g2p_launches++; break;
             case SPAN_FUSED: p->clock.g2p2g_ms += ms; p->clock.g2p2g_launches++; break;
             case SPAN_SORT: p->clock.sort_ms += ms; break;
+            case SPAN_REORDER: p->clock.reorder_ms += ms; p->clock.reorder_launches++; break;
             case SPAN_DT: p->clock.dt_ms += ms; break;
             default: p->clock.halo_ms += ms; break;
         }
@@ -197,6 +203,11 @@ static int clock_collect(SparklPipeline* p) {
 }
 
 static inline int grid_for(size_t n, int threads) { return (int)((n + threads - 1) / threads); }
+
+// Default reorder budget (see Ctl): an in-place block reorder costs about as much as this many excess run heads per
+// particle (~0.1 ns per excess head, ~0.6 ms per reorder at 10M: tools/long_run_probe.py, profiles/r01_reorder_policy.txt).
+static constexpr float DEFAULT_REORDER_HEADS_PER_PARTICLE = 0.6f;
+static constexpr uint32_t REORDER_PERIOD = 16;   // substeps between (mostly no-op) k_block_reorder launches
 
 static GridArrays grid_arrays(const SparklPipeline* p) {
     GridArrays g;
@@ -212,6 +223,26 @@ static int cub_reserve(SparklPipeline* p, size_t bytes) { return p->cub_temp.res
 // --------------------------------------------------------------------------------- re-bin (resort)
 // Sort particles by (block Morton key, cell in block), move the data, rebuild the node-block list,
 // its hash and neighbour tables.  Host-orchestrated; runs only when a particle left its tile margin.
+static float effective_reorder_limit(const SparklPipeline* p) { return p->reorder_limit < 0.f ? DEFAULT_REORDER_HEADS_PER_PARTICLE * (float)p->n : p->reorder_limit; }
+static int upload_policy(SparklPipeline* p) {
+    const float lim[2] = {effective_reorder_limit(p), p->rebin_limit < 0.f ? 0.f : p->rebin_limit};
+    uint32_t bits[2];
+    memcpy(bits, lim, 8);
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->reorder_limit, (int)bits[0], 1, p->stream));
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->excess_limit, (int)bits[1], 1, p->stream));
+    return SPARKL_OK;
+}
+// every REORDER_PERIOD substeps: the in-place block reorder, which returns at once unless the policy asked for it
+static int maybe_reorder(SparklPipeline* p, int parity) {
+    if (p->num_pblocks == 0 || (p->substep_index % REORDER_PERIOD) != 0 || !(effective_reorder_limit(p) > 0.f)) return SPARKL_OK;
+    size_t tok = 0;
+    CHK(clock_begin(p, SPAN_REORDER, &tok));
+    hipLaunchKernelGGL(k_block_reorder, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, p->stream, p->cur.arrays(), grid_arrays(p), p->d_ctl, p->h, parity);
+    hipLaunchKernelGGL(k_reorder_done, dim3(1), dim3(1), 0, p->stream, p->d_ctl, parity);
+    CHK(clock_end(p, tok));
+    return SPARKL_OK;
+}
+
 static int resort(SparklPipeline* p) {
     hipStream_t st = p->stream;
     const int n = (int)p->n;
@@ -323,6 +354,9 @@ static int resort(SparklPipeline* p) {
     }
     // clear the abort chain; the substep counter restarts so parity 0 is clean
     HIPCHK(hipMemsetAsync(p->d_ctl, 0, 2 * sizeof(uint32_t), st));
+    HIPCHK(hipMemsetAsync(&p->d_ctl->heads[0], 0, 4 * sizeof(uint32_t), st));   // heads[2], heads_base, excess_acc
+    HIPCHK(hipMemsetAsync(&p->d_ctl->reorder_request, 0, sizeof(uint32_t), st));
+    CHK(upload_policy(p));
     HIPCHK(hipGetLastError());
     CHK(clock_end(p, tok));
     p->sorted = true;
@@ -377,6 +411,7 @@ static int enqueue_substep(SparklPipeline* p, const SparklSolverParams* sp, cons
     const bool was_on = p->clock_on;
     if (was_on && (p->substep_index % p->clock_stride) != 0) p->clock_on = false;  // sample this substep or not
     if (p->clock_on) p->clock_sampled++;
+    CHK(maybe_reorder(p, S.parity));
     CHK(clock_begin(p, SPAN_P2G, &t0));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g<SPK_P2G_REDUCE_STEPS>), dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, P, G, p->d_models.p, p->d_ctl, S);
     CHK(clock_end(p, t0));
@@ -412,6 +447,7 @@ static int enqueue_fused_batch(SparklPipeline* p, const SparklSolverParams* sp, 
         const StepParams S = make_params(p, sp, g, dt);
         if (was_on && (p->substep_index % p->clock_stride) != 0) p->clock_on = false;
         if (p->clock_on) p->clock_sampled++;
+        if (j > 0) CHK(maybe_reorder(p, S.parity));   // between two fused kernels: the tiles of this substep are already scattered
         CHK(clock_begin(p, SPAN_GRID, &tk));
         launch_grid_update(p, G, S, st);
         CHK(clock_end(p, tk));
@@ -492,11 +528,30 @@ void sparkl_hip_pipeline_destroy(SparklPipeline* p) {
     p->keys_a.release(); p->keys_b.release(); p->pb_keys.release(); p->bkeys.release(); p->idx_a.release(); p->idx_b.release();
     p->pb_counts.release(); p->pb_first.release(); p->cand_a.release(); p->cand_b.release(); p->cub_temp.release(); p->d_scalars.release();
     p->staging.release(); p->node_staging.release(); p->d_count.release();
+    if (p->rb_stream) { (void)hipStreamSynchronize(p->rb_stream); (void)hipStreamDestroy(p->rb_stream); (void)hipEventDestroy(p->rb_gathered); (void)hipEventDestroy(p->rb_done); }
+    p->rb_staging.release();
     for (auto e : p->ev_pool) (void)hipEventDestroy(e);
     if (p->d_ctl) (void)hipFree(p->d_ctl);
     if (p->h_ctl) (void)hipHostFree(p->h_ctl);
     if (p->own_stream) (void)hipStreamDestroy(p->stream);
     delete p;
+}
+
+int sparkl_hip_reorder_policy_set(SparklPipeline* p, float reorder_limit, float rebin_limit) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    if (reorder_limit != reorder_limit || rebin_limit != rebin_limit) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "NaN limit");
+    HIPCHK(hipSetDevice(p->device));
+    p->reorder_limit = reorder_limit;
+    p->rebin_limit = rebin_limit;
+    return upload_policy(p);
+}
+int sparkl_hip_reorder_policy_stats(SparklPipeline* p, SparklReorderStats* out) {
+    if (!p || !out) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    HIPCHK(hipSetDevice(p->device));
+    CHK(read_ctl(p));
+    out->last_heads = p->h_ctl->last_heads; out->base_heads = p->h_ctl->heads_base;
+    out->reorders = p->h_ctl->reorders; out->policy_rebins = p->h_ctl->disorder_aborts;
+    return SPARKL_OK;
 }
 
 int sparkl_hip_pipeline_sync(SparklPipeline* p) {
@@ -737,9 +792,10 @@ int sparkl_hip_particles_read_statuses(SparklPipeline* p, SparklParticleStatus* 
 }
 int sparkl_hip_particles_read_phases(SparklPipeline* p, SparklParticlePhase* out, uint64_t n) {
     READ_PROLOGUE
-    std::vector<float> st;
-    CHK(read_state(p, st));
-    for (uint64_t i = 0; i < n; ++i) { out[i].phase = st[24 * i + 17]; out[i].psi_pos = st[24 * i + 12]; }
+    CHK(p->staging.reserve(n * 2));
+    hipLaunchKernelGGL(k_read_render, dim3(grid_for(n, 256)), dim3(256), 0, p->stream, p->cur.arrays(), (float*)nullptr, (float*)nullptr, p->staging.p, (int)n, read_base(p));
+    HIPCHK(hipMemcpyAsync(out, p->staging.p, n * sizeof(SparklParticlePhase), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
     return SPARKL_OK;
 }
 int sparkl_hip_particles_read_data(SparklPipeline* p, SparklParticleData* out, uint64_t n) {
@@ -773,6 +829,52 @@ struct HostAll {
     std::vector<SparklParticleStatus> st; std::vector<SparklParticlePosition> pos; std::vector<SparklParticleVelocity> vel;
     std::vector<SparklParticleVolume> vol; std::vector<SparklParticlePhase> ph; std::vector<SparklParticleData> da; std::vector<SparklVelocityGradient> vg;
 };
+// ---- asynchronous render readback (testbed_plugin.rs:533-588)
+int sparkl_hip_host_alloc(void** out, uint64_t bytes) {
+    if (!out) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    HIPCHK(hipHostMalloc(out, std::max<uint64_t>(bytes, 1), hipHostMallocDefault));
+    return SPARKL_OK;
+}
+int sparkl_hip_host_free(void* ptr) {
+    if (ptr) HIPCHK(hipHostFree(ptr));
+    return SPARKL_OK;
+}
+int sparkl_hip_readback_begin(SparklPipeline* p, SparklParticlePosition* pos, SparklParticleVelocity* vel, SparklParticlePhase* phase, uint64_t n) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    if (n != p->n) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "n (%llu) != particle count (%llu)", (unsigned long long)n, (unsigned long long)p->n);
+    HIPCHK(hipSetDevice(p->device));
+    if (n == 0 || (!pos && !vel && !phase)) return SPARKL_OK;
+    if (!p->rb_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&p->rb_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&p->rb_gathered, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&p->rb_done, hipEventDisableTiming));
+    }
+    // the gather may not overwrite the staging area while an earlier copy still reads it
+    if (p->rb_pending) HIPCHK(hipStreamWaitEvent(p->stream, p->rb_done, 0));
+    if ((size_t)n * 8 > p->rb_staging.cap && p->rb_pending) HIPCHK(hipEventSynchronize(p->rb_done));   // growing frees the old area
+    CHK(p->rb_staging.reserve((size_t)n * 8));
+    float* d_pos = p->rb_staging.p, *d_vel = d_pos + 3 * n, *d_phase = d_vel + 3 * n;
+    hipLaunchKernelGGL(k_read_render, dim3(grid_for(n, 256)), dim3(256), 0, p->stream, p->cur.arrays(), pos ? d_pos : nullptr, vel ? d_vel : nullptr,
+                       phase ? d_phase : nullptr, (int)n, read_base(p));
+    HIPCHK(hipEventRecord(p->rb_gathered, p->stream));
+    HIPCHK(hipStreamWaitEvent(p->rb_stream, p->rb_gathered, 0));
+    if (pos) HIPCHK(hipMemcpyAsync(pos, d_pos, n * sizeof(SparklParticlePosition), hipMemcpyDeviceToHost, p->rb_stream));
+    if (vel) HIPCHK(hipMemcpyAsync(vel, d_vel, n * sizeof(SparklParticleVelocity), hipMemcpyDeviceToHost, p->rb_stream));
+    if (phase) HIPCHK(hipMemcpyAsync(phase, d_phase, n * sizeof(SparklParticlePhase), hipMemcpyDeviceToHost, p->rb_stream));
+    HIPCHK(hipEventRecord(p->rb_done, p->rb_stream));
+    p->rb_pending = true;
+    return SPARKL_OK;
+}
+int sparkl_hip_readback_wait(SparklPipeline* p) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    if (!p->rb_pending) return SPARKL_OK;
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipEventSynchronize(p->rb_done));
+    p->rb_pending = false;
+    return SPARKL_OK;
+}
+
 static int read_all(SparklPipeline* p, HostAll& h) {
     const uint64_t n = p->n;
     h.st.resize(n); h.pos.resize(n); h.vel.resize(n); h.vol.resize(n); h.ph.resize(n); h.da.resize(n); h.vg.resize(n);
@@ -1047,6 +1149,7 @@ static int substep_finish_impl(SparklPipeline* p, bool fuse_next) {
     hipStream_t st = p->stream;
     const GridArrays G = grid_arrays(p);
     size_t t1 = 0, t2 = 0;
+    CHK(maybe_reorder(p, p->pending.parity));
     CHK(clock_begin(p, SPAN_GRID, &t1));
     launch_grid_update(p, G, p->pending, st);
     CHK(clock_end(p, t1));

@@ -16,6 +16,17 @@ from ._lib import check, lib
 from .particles import ParticleComponents
 
 
+class _Pinned:
+    def __init__(self, L, ptr):
+        self.L, self.ptr = L, ptr
+
+    def __del__(self):
+        try:
+            self.L.sparkl_hip_host_free(self.ptr)
+        except Exception:
+            pass
+
+
 class MpmPipeline:
     """One GPU's MPM pipeline (CudaMpmPipeline + SingleGpuMpmContext rolled into an opaque handle)."""
 
@@ -116,6 +127,39 @@ class MpmPipeline:
 
     def read_sorted_particle_ids(self):
         return self._read(self.L.sparkl_hip_particles_read_sorted_ids, np.dtype("<u4"))
+
+    def reorder_policy_set(self, reorder_limit=-1.0, rebin_limit=0.0):
+        """Limits in excess run heads: 0 = off, < 0 = built-in default (see sparkl_hip_reorder_policy_set)."""
+        check(self.L.sparkl_hip_reorder_policy_set(self.h, C.c_float(reorder_limit), C.c_float(rebin_limit)))
+
+    def reorder_policy_stats(self):
+        st = abi.ReorderStatsC()
+        check(self.L.sparkl_hip_reorder_policy_stats(self.h, C.byref(st)))
+        return {"last_heads": st.last_heads, "base_heads": st.base_heads, "reorders": st.reorders, "policy_rebins": st.policy_rebins}
+
+    # ---- per-frame render readback (testbed_plugin.rs:533-588), overlapped with the next step
+    def host_alloc(self, n, dtype):
+        """`LockedBuffer::uninitialized(n)`: a page-locked numpy array of n records (freed with the pipeline)."""
+        dtype = np.dtype(dtype)
+        ptr = C.c_void_p()
+        check(self.L.sparkl_hip_host_alloc(C.byref(ptr), C.c_uint64(max(n * dtype.itemsize, 1))))
+        buf = (C.c_uint8 * max(n * dtype.itemsize, 1)).from_address(ptr.value)
+        buf._owner = _Pinned(self.L, ptr)           # freed when the last numpy view goes away
+        return np.frombuffer(buf, dtype=dtype, count=n)
+
+    def readback_begin(self, pos=None, vel=None, phase=None):
+        """Snapshot positions / velocities / phases (caller order) into the given arrays; returns at once."""
+        def ptr(a, dt):
+            if a is None:
+                return None
+            assert a.dtype == dt and a.flags["C_CONTIGUOUS"] and len(a) == len(self)
+            return C.c_void_p(a.ctypes.data)
+        self._rb_keep = (pos, vel, phase)
+        check(self.L.sparkl_hip_readback_begin(self.h, ptr(pos, abi.POSITION_DTYPE), ptr(vel, abi.VELOCITY_DTYPE), ptr(phase, abi.PHASE_DTYPE),
+                                               C.c_uint64(len(self))))
+
+    def readback_wait(self):
+        check(self.L.sparkl_hip_readback_wait(self.h))
 
     def read_particles(self):
         c = ParticleComponents(0)

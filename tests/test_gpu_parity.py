@@ -191,6 +191,34 @@ def test_rebin_keeps_parity_and_ids(Pipeline):
     assert e["eps_x"] <= TOL and e["eps_v"] <= TOL
 
 
+def test_async_readback_snapshots_the_state_at_the_call(Pipeline):
+    """testbed_plugin.rs:533-588 (pos / vel / phase into LockedBuffers each frame), overlapped with the next step here."""
+    sc = scenes.sand_column(16, 10, 12, with_block=True)
+    dt = 2.5e-4
+    with Pipeline(sc.cell_width) as p:
+        p.load_scene(sc)
+        n = len(p)
+        pos, vel, ph = p.host_alloc(n, abi.POSITION_DTYPE), p.host_alloc(n, abi.VELOCITY_DTYPE), p.host_alloc(n, abi.PHASE_DTYPE)
+        p.substeps(sc.params, sc.gravity, dt, 20)
+        want_pos, want_vel, want_ph = p.read_positions(), p.read_velocities(), p.read_phases()
+        p.readback_begin(pos, vel, ph)
+        p.substeps(sc.params, sc.gravity, dt, 20)          # runs while the copies are in flight
+        p.readback_wait()
+        np.testing.assert_array_equal(pos["point"], want_pos["point"])
+        np.testing.assert_array_equal(vel["vector"], want_vel["vector"])
+        np.testing.assert_array_equal(ph["phase"], want_ph["phase"])
+        np.testing.assert_array_equal(ph["psi_pos"], want_ph["psi_pos"])
+        later = p.read_positions()
+        assert (later["point"] != want_pos["point"]).any()
+        # back-to-back snapshots queue behind each other; partial requests are fine; pageable memory works too
+        p.readback_begin(pos, None, None)
+        plain = np.zeros(n, dtype=abi.VELOCITY_DTYPE)
+        p.readback_begin(None, plain, None)
+        p.readback_wait()
+        np.testing.assert_array_equal(pos["point"], later["point"])
+        np.testing.assert_array_equal(plain["vector"], p.read_velocities()["vector"])
+
+
 def test_append_remove_roundtrip(Pipeline):
     sc = scenes.sand_column(8, 6, 8)
     extra = scenes.sand_column(4, 4, 4).particles

@@ -1,6 +1,7 @@
 #!/bin/bash
 # timing-only A/B over lib variants (results of SPK_EXP_* builds are physically wrong on purpose)
 cd $GRAFT_REPO_ROOT
+export SPARKL_HIP_LIB_AB=1
 for lib in "$@"; do
   export SPARKL_HIP_LIB=$PWD/sparkl_amd/lib/$lib
   echo "=== $lib"
