@@ -67,6 +67,19 @@ def cpu_baseline(max_threads, seconds_budget=20.0):
                       f"best of 8/16/32/64/128 threads on a {max_threads}-thread host"}
 
 
+def recorded_traffic(kernel, n_particles):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (they cannot run inside the timed bench);
+    only reported for the particle count they were recorded at."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None
+    if abs(rec.get("particles_per_gpu", 0) - n_particles) > 0.001 * n_particles or kernel not in rec.get("bytes_per_launch", {}):
+        return None, None
+    return rec["bytes_per_launch"][kernel], rec["source"] + "; " + rec["correction"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,9 +203,10 @@ def main():
             dom = max(total_ms, key=total_ms.get)          # the kernel the timed region spends most of its time in
             achieved = per_kernel_bytes[dom] / (avg_ms[dom] * 1e-3) / 1e9
             kname = {"p2g": "k_p2g", "g2p": "k_g2p", "grid_update": "k_grid_update", "g2p2g": "k_g2p2g"}[dom]
+            traffic, traffic_src = recorded_traffic(kname, n_particles)
             out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                               "traffic": None, "algorithmic_bytes_per_launch": per_kernel_bytes[dom], "avg_launch_ms": avg_ms[dom],
-                               "launches_sampled": int(spans[dom][1])}
+                               "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": per_kernel_bytes[dom],
+                               "avg_launch_ms": avg_ms[dom], "launches_sampled": int(spans[dom][1])}
             out["kernels_avg_launch_ms"] = avg_ms
             out["kernels_gbs"] = {name: per_kernel_bytes[name] / (avg_ms[name] * 1e-3) / 1e9 for name in avg_ms}
             out["kernel_clock_sampled_substeps"] = int(clock.sampled_substeps)

@@ -377,7 +377,7 @@ static StepParams make_params(const SparklPipeline* p, const SparklSolverParams*
 }
 
 #ifndef SPK_P2G_REDUCE_STEPS
-#define SPK_P2G_REDUCE_STEPS 3
+#define SPK_P2G_REDUCE_STEPS 4   // 16-lane groups: same speed as 3 on the aligned initial lattice, 5-8 % faster once cells hold uneven counts
 #endif
 
 static void launch_grid_update(SparklPipeline* p, const GridArrays& G, const StepParams& S, hipStream_t st) {
