@@ -96,6 +96,53 @@ struct DruckerPragerPlasticity {
     }
 };
 
+struct SnowPlasticity {                     // plasticity_snow.rs:18-24
+    Real min_epsilon = 2.5e-2f, max_epsilon = 4.5e-3f, hardening_coeff = 10.0f;
+    SparklPlasticModel to_core_model() const {
+        SparklPlasticModel m{};
+        m.tag = SPARKL_PLASTIC_SNOW;
+        m.u.snow.min_epsilon = min_epsilon; m.u.snow.max_epsilon = max_epsilon; m.u.snow.hardening_coeff = hardening_coeff;
+        return m;
+    }
+};
+struct RankinePlasticity {                  // plasticity_rankine.rs:19-32
+    Real mu = 0, lambda = 0, tensile_strength, softening_rate;
+    RankinePlasticity(Real young_modulus, Real poisson_ratio, Real tensile_strength_, Real softening_rate_)
+        : tensile_strength(tensile_strength_), softening_rate(softening_rate_) { std::tie(lambda, mu) = lame_lambda_mu(young_modulus, poisson_ratio); }
+    SparklPlasticModel to_core_model() const {
+        SparklPlasticModel m{};
+        m.tag = SPARKL_PLASTIC_RANKINE;
+        m.u.rankine.mu = mu; m.u.rankine.lambda = lambda; m.u.rankine.tensile_strength = tensile_strength; m.u.rankine.softening_rate = softening_rate;
+        return m;
+    }
+};
+struct NaccPlasticity {                     // plasticity_nacc.rs:22-43 (dim3: d = 3)
+    Real mu, kappa, hardening_factor, cohesion, friction;
+    bool hardening_enabled;
+    NaccPlasticity(Real young_modulus, Real poisson_ratio, Real cohesion_, bool hardening_enabled_, Real hardening_factor_, Real friction_angle)
+        : mu(young_modulus / (2.0f * (1.0f + poisson_ratio))), kappa(young_modulus / (3.0f * (1.0f - 2.0f * poisson_ratio))),
+          hardening_factor(hardening_factor_), cohesion(cohesion_), hardening_enabled(hardening_enabled_) {
+        const Real sin_f = std::sin(friction_angle), d = 3.0f;
+        friction = std::sqrt(2.0f / 3.0f) * 2.0f * sin_f / (3.0f - sin_f) * d / std::sqrt(2.0f / (6.0f - d));
+    }
+    SparklPlasticModel to_core_model() const {
+        SparklPlasticModel m{};
+        m.tag = SPARKL_PLASTIC_NACC;
+        auto& n = m.u.nacc;
+        n.mu = mu; n.kappa = kappa; n.hardening_enabled = hardening_enabled; n.hardening_factor = hardening_factor; n.cohesion = cohesion; n.friction = friction;
+        return m;
+    }
+};
+struct MaximumStressFailure {               // failure_maximum_stress.rs:13-18
+    Real max_principal_stress, max_shear_stress;
+    SparklFailureModel to_core_model() const {
+        SparklFailureModel m{};
+        m.tag = SPARKL_FAILURE_MAXIMUM_STRESS;
+        m.u.maximum_stress.max_principal_stress = max_principal_stress; m.u.maximum_stress.max_shear_stress = max_shear_stress;
+        return m;
+    }
+};
+
 using ParticleModelHandle = uint64_t;
 struct ParticleModel {
     SparklParticleModel core{};
@@ -108,6 +155,12 @@ struct ParticleModel {
         ParticleModel m = new_(constitutive);
         m.core.has_plastic_model = 1;
         m.core.plastic_model = plasticity.to_core_model();
+        return m;
+    }
+    template <class C, class Fm> static ParticleModel with_failure(const C& constitutive, const Fm& failure) {  // particle_model.rs:104-113
+        ParticleModel m = new_(constitutive);
+        m.core.has_failure_model = 1;
+        m.core.failure_model = failure.to_core_model();
         return m;
     }
 };

@@ -235,6 +235,19 @@ def dp_update(dp, F, Jp=1.0, q=1.0, lvg=0.0, phase=1.0, f64=False):
     return f.reshape(3, 3).T.copy(), st[0], st[1], st[2]
 
 
+def plastic_update(pm, F, Jp=1.0, plastic_hardening=1.0, log_vol_gain=0.0, elastic_hardening=1.0, nacc_alpha=-0.01, phase=1.0, f64=False):
+    """`CorePlasticModel::update_particle` on one particle: returns (F, dict of the updated scalars)."""
+    f, pf = _d(np.asarray(F, dtype=np.float64).T.copy(), 9)
+    st = np.array([Jp, plastic_hardening, log_vol_gain, elastic_hardening, nacc_alpha], dtype=np.float64)
+    lib().oracle_plastic_update(int(f64), C.byref(pm), C.c_double(phase), pf, st.ctypes.data_as(C.c_void_p))
+    return f.reshape(3, 3).T.copy(), {"Jp": st[0], "plastic_hardening": st[1], "log_vol_gain": st[2], "elastic_hardening": st[3], "nacc_alpha": st[4]}
+
+
+def maximum_stress_failed(fm, stress):
+    _, ps = _d(np.asarray(stress, dtype=np.float64).T.copy(), 9)
+    return bool(lib().oracle_maximum_stress_failed(C.byref(fm), ps))
+
+
 def dp_project(dp, sv, lvg, alpha, f64=False):
     _, ps = _d(sv, 3)
     out = np.zeros(4)

@@ -113,6 +113,20 @@ uint64_t get_nodes(Oracle<R>& o, SparklGridNode* out, uint64_t cap) {
         }
     return n;
 }
+// generic plastic update: state = {Jp, plastic_hardening, log_vol_gain, elastic_hardening, nacc_alpha}
+template <class R> void plastic_update_t(const SparklPlasticModel* pm, double phase, double F[9], double st[5]) {
+    Mat3<R> f; for (int i = 0; i < 9; ++i) f.m[i] = (R)F[i];
+    R jp = (R)st[0], q = (R)st[1], lvg = (R)st[2], eh = (R)st[3], al = (R)st[4];
+    switch (pm->tag) {
+        case SPARKL_PLASTIC_DRUCKER_PRAGER: dp_update_particle<R>(pm->u.drucker_prager, (R)phase, f, jp, q, lvg); break;
+        case SPARKL_PLASTIC_SNOW: snow_update_particle<R>(pm->u.snow, f, eh, jp); break;
+        case SPARKL_PLASTIC_RANKINE: rankine_update_particle<R>(pm->u.rankine, f, q); break;
+        case SPARKL_PLASTIC_NACC: nacc_update_particle<R>(pm->u.nacc, f, al); break;
+        default: break;
+    }
+    for (int i = 0; i < 9; ++i) F[i] = f.m[i];
+    st[0] = jp; st[1] = q; st[2] = lvg; st[3] = eh; st[4] = al;
+}
 template <class R> static void stress_impl(const SparklConstitutiveModel* cm, double phase, double hardening, const double* F, double mass,
                                           double volume0, double fluid_j, const double* C, double* out) {
     Mat3<R> f, c; for (int i = 0; i < 9; ++i) { f.m[i] = (R)F[i]; c.m[i] = (R)C[i]; }
@@ -358,6 +372,13 @@ void oracle_dp_update(int f64, const SparklDruckerPragerPlasticity* m, double ph
         for (int i = 0; i < 9; ++i) F[i] = f.m[i];
         state[0] = jp; state[1] = q; state[2] = lvg;
     }
+}
+void oracle_plastic_update(int f64, const SparklPlasticModel* pm, double phase, double F[9], double st[5]) {
+    if (f64) plastic_update_t<double>(pm, phase, F, st); else plastic_update_t<float>(pm, phase, F, st);
+}
+int oracle_maximum_stress_failed(const SparklMaximumStressFailure* m, const double stress[9]) {
+    Mat3<double> t; for (int i = 0; i < 9; ++i) t.m[i] = stress[i];
+    return maximum_stress_failed<double>(*m, t) ? 1 : 0;
 }
 // returns 0 (None) / 1 (Some); out = {s0, s1, s2, dq}
 int oracle_dp_project(int f64, const SparklDruckerPragerPlasticity* m, const double sv[3], double lvg, double alpha, double out[4]) {

@@ -427,6 +427,117 @@ template <class R> void dp_update_particle(const SparklDruckerPragerPlasticity& 
     }
 }
 
+// plasticity_snow.rs:26-48
+template <class R> void snow_update_particle(const SparklSnowPlasticity& m, Mat3<R>& F, R& elastic_hardening, R& Jp) {
+    Svd<R> svd = svd_unordered(F);
+    Vec3<R> nsv;
+    for (int i = 0; i < 3; ++i) nsv[i] = std::fmin(std::fmax(svd.s[i], R(1) - (R)m.min_epsilon), R(1) + (R)m.max_epsilon);
+    Jp *= (svd.s[0] * svd.s[1] * svd.s[2]) / (nsv[0] * nsv[1] * nsv[2]);
+    elastic_hardening = std::exp((R)m.hardening_coeff * (R(1) - Jp));
+    svd.s = nsv;
+    F = recompose(svd);
+}
+// plasticity_rankine.rs:34-78
+template <class R> void rankine_update_particle(const SparklRankinePlasticity& m, Mat3<R>& F, R& plastic_hardening) {
+    const R lambda = m.lambda, mu = m.mu;
+    Svd<R> svd = svd_unordered(F);
+    Vec3<R> eigv, prev;
+    for (int i = 0; i < 3; ++i) eigv[i] = prev[i] = std::log(svd.s[i]);
+    int idx[3] = {0, 1, 2};
+    std::sort(idx, idx + 3, [&](int a, int b) { return eigv[a] < eigv[b]; });
+    const int e3 = idx[0], e2 = idx[1], e1 = idx[2];
+    const R sum = eigv[0] + eigv[1] + eigv[2];
+    const R soft = (R)m.tensile_strength - (plastic_hardening - R(1));
+    if (lambda * sum + R(2) * mu * eigv[e1] <= soft) return;
+    if ((R(2) * mu + lambda) * eigv[e2] + lambda * (sum - eigv[e1]) <= soft) {
+        eigv[e1] = (soft - lambda * (sum - eigv[e1])) / (R(2) * mu + lambda);
+    } else if ((R(2) * mu + R(3) * lambda) * eigv[e3] <= soft) {
+        const R ne = (soft - lambda * (sum - eigv[e1] - eigv[e2])) / (R(2) * mu + R(2) * lambda);
+        eigv[e1] = ne; eigv[e2] = ne;
+    } else {
+        const R ne = soft / (R(2) * mu + R(3) * lambda);
+        eigv[0] = eigv[1] = eigv[2] = ne;
+    }
+    Vec3<R> dd{{prev[0] - eigv[0], prev[1] - eigv[1], prev[2] - eigv[2]}};
+    plastic_hardening += (R)m.softening_rate * norm(dd);
+    plastic_hardening = std::fmin(plastic_hardening, (R)m.tensile_strength);
+    for (int i = 0; i < 3; ++i) svd.s[i] = std::exp(eigv[i]);
+    F = recompose(svd);
+}
+// plasticity_nacc.rs:62-152 (dim3: d = 3)
+template <class R> void nacc_update_particle(const SparklNaccPlasticity& m, Mat3<R>& F, R& alpha) {
+    const R xi = m.hardening_factor, beta = m.cohesion, M = m.friction, d = R(3), mu = m.mu, kappa = m.kappa;
+    Svd<R> svd = svd_unordered(F);
+    Vec3<R> sq{{svd.s[0] * svd.s[0], svd.s[1] * svd.s[1], svd.s[2] * svd.s[2]}};
+    const R sq_tr = sq[0] + sq[1] + sq[2];
+    const R p0 = kappa * (R(1.0e-5) + std::sinh(xi * std::fmax(-alpha, R(0))));
+    const R j_e_tr = svd.s[0] * svd.s[1] * svd.s[2];
+    const R sc = mu * std::pow(j_e_tr, R(-2) / d);
+    Vec3<R> s_tr{{sc * (sq[0] - sq_tr / d), sc * (sq[1] - sq_tr / d), sc * (sq[2] - sq_tr / d)}};
+    const R psi_kappa = kappa / R(2) * (j_e_tr - R(1) / j_e_tr);
+    const R p_tr = -psi_kappa * j_e_tr;
+    if (p_tr > p0) {
+        const R j_e_n1 = std::sqrt(R(-2) * p0 / kappa + R(1));
+        const R v = std::pow(j_e_n1, R(1) / d);
+        svd.s = Vec3<R>{{v, v, v}};
+        if (m.hardening_enabled) alpha += std::log(j_e_tr / j_e_n1);
+        F = recompose(svd);
+        return;
+    }
+    if (p_tr < -beta * p0) {
+        const R j_e_n1 = std::sqrt(R(2) * beta * p0 / kappa + R(1));
+        const R v = std::pow(j_e_n1, R(1) / d);
+        svd.s = Vec3<R>{{v, v, v}};
+        if (m.hardening_enabled) alpha += std::log(j_e_tr / j_e_n1);
+        F = recompose(svd);
+        return;
+    }
+    const R y0 = (R(1) + R(2) * beta) * ((R(6) - d) / R(2));
+    const R y1 = M * M * (p_tr + beta * p0) * (p_tr - p0);
+    const R s_n2 = s_tr[0] * s_tr[0] + s_tr[1] * s_tr[1] + s_tr[2] * s_tr[2];
+    const R y = y0 * s_n2 + y1;
+    if (y < R(1.0e-4)) return;
+    if (m.hardening_enabled && p0 > R(1.0e-4) && p_tr < p0 - R(1.0e-4) && p_tr > -beta * p0 + R(1.0e-4)) {
+        const R p_c = (R(1) - beta) * p0 / R(2);
+        const R q_tr = std::sqrt((R(6) - d) / R(2)) * std::sqrt(s_n2);
+        R dx = p_c - p_tr, dy = R(0) - q_tr;
+        const R dn = std::sqrt(dx * dx + dy * dy);
+        dx /= dn; dy /= dn;
+        const R c = M * M * (p_c + beta * p0) * (p_c - p0);
+        const R b = M * M * dx * (R(2) * p_c - p0 + beta * p0);
+        const R a = M * M * dx * dx + (R(1) + R(2) * beta) * dy * dy;
+        const R discr = std::sqrt(b * b - R(4) * a * c);
+        const R l1 = (-b + discr) / (R(2) * a), l2 = (-b - discr) / (R(2) * a);
+        const R p1 = p_c + l1 * dx, p2 = p_c + l2 * dx;
+        const R p_x = (p_tr - p_c) * (p1 - p_c) > R(0) ? p1 : p2;
+        const R j_e_x = std::sqrt(std::fabs(R(-2) * p_x / kappa + R(1)));
+        if (j_e_x > R(1.0e-4)) alpha += std::log(j_e_tr / j_e_x);
+    }
+    const R sn = std::sqrt(s_n2);
+    const R k = std::sqrt(-y1 / y0) * (std::pow(j_e_tr, R(2) / d) / mu);
+    for (int i = 0; i < 3; ++i) svd.s[i] = std::sqrt(k * (s_tr[i] / sn) + sq_tr / d);
+    F = recompose(svd);
+}
+// failure_maximum_stress.rs:20-28; nalgebra try_symmetric_eigen (third party) -> Jacobi eigenvalues in double here
+template <class R> bool maximum_stress_failed(const SparklMaximumStressFailure& m, const Mat3<R>& stress) {
+    double a[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) a[i][j] = 0.5 * ((double)stress(i, j) + (double)stress(j, i));
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
+            if (a[p][q] == 0.0) continue;
+            const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+            const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+            for (int k = 0; k < 3; ++k) { const double akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - sn * akq; a[k][q] = sn * akp + c * akq; }
+            for (int k = 0; k < 3; ++k) { const double apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - sn * aqk; a[q][k] = sn * apk + c * aqk; }
+        }
+    }
+    const double mn = std::min(a[0][0], std::min(a[1][1], a[2][2])), mx = std::max(a[0][0], std::max(a[1][1], a[2][2]));
+    return mx > (double)m.max_principal_stress || (mx - mn) / 2.0 > (double)m.max_shear_stress;
+}
+
 // --------------------------------------------------------------------------- cuboid projection
 // parry3d 0.13 Cuboid (= local Aabb [-he, he]) project_local_point, restated; unpinned.
 template <class R> struct Projection { bool is_inside; Vec3<R> point; };
@@ -812,9 +923,17 @@ struct Oracle {
                 } else {
                     p.deformation_gradient(0, 0) += (vg_det * dt) * p.deformation_gradient(0, 0);
                 }
-                if (model.has_plastic_model && model.plastic_model.tag == SPARKL_PLASTIC_DRUCKER_PRAGER)
-                    dp_update_particle(model.plastic_model.u.drucker_prager, p.phase, p.deformation_gradient,
-                                       p.plastic_deformation_gradient_det, p.plastic_hardening, p.log_vol_gain);
+                if (model.has_plastic_model) {   // plastic_model.update_particle (src/dynamics/models/plasticity_*.rs glue)
+                    const auto& pm = model.plastic_model;
+                    if (pm.tag == SPARKL_PLASTIC_DRUCKER_PRAGER)
+                        dp_update_particle(pm.u.drucker_prager, p.phase, p.deformation_gradient, p.plastic_deformation_gradient_det, p.plastic_hardening, p.log_vol_gain);
+                    else if (pm.tag == SPARKL_PLASTIC_SNOW)
+                        snow_update_particle(pm.u.snow, p.deformation_gradient, p.elastic_hardening, p.plastic_deformation_gradient_det);
+                    else if (pm.tag == SPARKL_PLASTIC_RANKINE)
+                        rankine_update_particle(pm.u.rankine, p.deformation_gradient, p.plastic_hardening);
+                    else if (pm.tag == SPARKL_PLASTIC_NACC)
+                        nacc_update_particle(pm.u.nacc, p.deformation_gradient, p.nacc_alpha);
+                }
                 if (p.is_static) { p.velocity = Vec3<R>{{0, 0, 0}}; p.velocity_gradient = Mat3<R>::zeros(); }
                 if (p.density_def_grad() == R(0) || p.failed || (!fluid && std::fabs(p.deformation_gradient(0, 0)) > R(1.0e4))) {
                     p.failed = true;
@@ -825,6 +944,10 @@ struct Oracle {
                 p.psi_pos = std::fmax(p.psi_pos, energy);
                 p.parameter1 = p.psi_pos * p.mass;
                 p.parameter2 = p.mass;
+                // grid_to_particle.rs:134-144, failure_maximum_stress.rs (glue): stress of the updated particle
+                if (model.has_failure_model && model.failure_model.tag == SPARKL_FAILURE_MAXIMUM_STRESS &&
+                    maximum_stress_failed(model.failure_model.u.maximum_stress, stress_of(p)))
+                    p.phase = R(0);
             }
         }
     }

@@ -127,6 +127,7 @@ class ParticleModelC(C.Structure):
 
 CONSTITUTIVE_COROTATED_LINEAR, CONSTITUTIVE_NEO_HOOKEAN, CONSTITUTIVE_EOS_MONAGHAN_SPH, CONSTITUTIVE_CUSTOM = 0, 1, 2, 3
 PLASTIC_DRUCKER_PRAGER, PLASTIC_NACC, PLASTIC_RANKINE, PLASTIC_SNOW, PLASTIC_CUSTOM = 0, 1, 2, 3, 4
+FAILURE_MAXIMUM_STRESS, FAILURE_CUSTOM = 0, 1
 
 
 class CuboidColliderC(C.Structure):

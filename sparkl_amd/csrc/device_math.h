@@ -160,6 +160,13 @@ struct DevModel {
     float pressure0, viscosity, max_neg_pressure; int gamma;  // Monaghan
     float h0, h1, h2, h3, p_lambda, p_mu, volume_correction; int only_active_when_failed;  // Drucker-Prager
     float p_k;        // (3 p_lambda + 2 p_mu) / (2 p_mu)
+    // the plastic models the 3-D examples do not use (snow / Rankine / NACC) share one parameter block:
+    //   snow: x0 = min_epsilon, x1 = max_epsilon, x2 = hardening_coeff
+    //   Rankine: x0 = mu, x1 = lambda, x2 = tensile_strength, x3 = softening_rate
+    //   NACC: x0 = mu, x1 = kappa, x2 = hardening_factor, x3 = cohesion, x4 = friction, xi = hardening_enabled
+    float x0, x1, x2, x3, x4; int xi;
+    int has_failure;  // MaximumStressFailure
+    float max_principal_stress, max_shear_stress;
 };
 
 SPK_DEV float powi_f(float x, int n) {
@@ -366,6 +373,127 @@ SPK_DEV void dp_update(const DevModel& mo, float phase, M3& F, float& Jp, float&
     for (int i = 0; i < 3; ++i) g[i] = d.s[i] == 0.f ? 0.f : nsv[i] * fast_rcp(d.s[i]);
     F = svd_compose_scaled(d, g);
     sv[0] = nsv[0]; sv[1] = nsv[1]; sv[2] = nsv[2];
+}
+
+// SnowPlasticity::update_particle (plasticity_snow.rs:26-48)
+SPK_DEV void snow_update(const DevModel& mo, M3& F, float& eh, float& Jp) {
+    const Svd3 d = svd3<SPK_SVD_SWEEPS>(F);
+    float g[3], prod_old = 1.f, prod_new = 1.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float ns = fminf(fmaxf(d.s[i], 1.0f - mo.x0), 1.0f + mo.x1);
+        prod_old *= d.s[i]; prod_new *= ns;
+        g[i] = d.s[i] == 0.f ? 0.f : ns / d.s[i];
+    }
+    Jp *= prod_old / prod_new;
+    eh = expf(mo.x2 * (1.0f - Jp));
+    F = svd_compose_scaled(d, g);
+}
+// RankinePlasticity::update_particle (plasticity_rankine.rs:34-78); q = plastic_hardening
+SPK_DEV void rankine_update(const DevModel& mo, M3& F, float& q) {
+    const float mu = mo.x0, lambda = mo.x1;
+    const Svd3 d = svd3<SPK_SVD_SWEEPS>(F);
+    float e[3] = {logf(d.s[0]), logf(d.s[1]), logf(d.s[2])};
+    const float p0 = e[0], p1 = e[1], p2 = e[2];
+    // indices of the largest / middle / smallest principal strain, without dynamic register indexing
+    const int i1 = (e[0] >= e[1]) ? ((e[0] >= e[2]) ? 0 : 2) : ((e[1] >= e[2]) ? 1 : 2);
+    const int i3 = (e[0] < e[1]) ? ((e[0] < e[2]) ? 0 : 2) : ((e[1] < e[2]) ? 1 : 2);
+    const int i2 = 3 - i1 - i3;
+    const float e1 = i1 == 0 ? e[0] : (i1 == 1 ? e[1] : e[2]), e2 = i2 == 0 ? e[0] : (i2 == 1 ? e[1] : e[2]), e3 = i3 == 0 ? e[0] : (i3 == 1 ? e[1] : e[2]);
+    const float sum = e[0] + e[1] + e[2];
+    const float soft = mo.x2 - (q - 1.0f);
+    if (lambda * sum + 2.0f * mu * e1 <= soft) return;
+    float n1 = e1, n2 = e2, n3 = e3;
+    if ((2.0f * mu + lambda) * e2 + lambda * (sum - e1) <= soft) {
+        n1 = (soft - lambda * (sum - e1)) / (2.0f * mu + lambda);
+    } else if ((2.0f * mu + 3.0f * lambda) * e3 <= soft) {
+        n1 = n2 = (soft - lambda * (sum - e1 - e2)) / (2.0f * mu + 2.0f * lambda);
+    } else {
+        n1 = n2 = n3 = soft / (2.0f * mu + 3.0f * lambda);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) e[i] = (i == i1) ? n1 : ((i == i2) ? n2 : n3);
+    const float d0 = p0 - e[0], d1 = p1 - e[1], d2 = p2 - e[2];
+    q = fminf(q + mo.x3 * sqrtf(d0 * d0 + d1 * d1 + d2 * d2), mo.x2);
+    float g[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g[i] = d.s[i] == 0.f ? 0.f : expf(e[i]) / d.s[i];
+    F = svd_compose_scaled(d, g);
+}
+// NaccPlasticity::project_deformation_gradient (plasticity_nacc.rs:62-152), d = 3
+SPK_DEV void nacc_update(const DevModel& mo, M3& F, float& alpha) {
+    const float mu = mo.x0, kappa = mo.x1, xi = mo.x2, beta = mo.x3, M = mo.x4;
+    const bool hard = mo.xi != 0;
+    const Svd3 d = svd3<SPK_SVD_SWEEPS>(F);
+    const float sq[3] = {d.s[0] * d.s[0], d.s[1] * d.s[1], d.s[2] * d.s[2]};
+    const float sq_tr = sq[0] + sq[1] + sq[2];
+    const float p0 = kappa * (1.0e-5f + sinhf(xi * fmaxf(-alpha, 0.f)));
+    const float j_tr = d.s[0] * d.s[1] * d.s[2];
+    const float sc = mu * powf(j_tr, -2.0f / 3.0f);
+    const float s_tr[3] = {sc * (sq[0] - sq_tr / 3.0f), sc * (sq[1] - sq_tr / 3.0f), sc * (sq[2] - sq_tr / 3.0f)};
+    const float p_tr = -(kappa / 2.0f * (j_tr - 1.0f / j_tr)) * j_tr;
+    float ns[3];
+    const bool tip_a = p_tr > p0, tip_b = !tip_a && p_tr < -beta * p0;
+    if (tip_a || tip_b) {
+        const float j_n1 = sqrtf((tip_a ? -2.0f * p0 : 2.0f * beta * p0) / kappa + 1.0f);
+        ns[0] = ns[1] = ns[2] = powf(j_n1, 1.0f / 3.0f);
+        if (hard) alpha += logf(j_tr / j_n1);
+    } else {
+        const float y0 = (1.0f + 2.0f * beta) * 1.5f;
+        const float y1 = M * M * (p_tr + beta * p0) * (p_tr - p0);
+        const float s_n2 = s_tr[0] * s_tr[0] + s_tr[1] * s_tr[1] + s_tr[2] * s_tr[2];
+        if (y0 * s_n2 + y1 < 1.0e-4f) return;   // inside the yield surface
+        const float sn = sqrtf(s_n2);
+        if (hard && p0 > 1.0e-4f && p_tr < p0 - 1.0e-4f && p_tr > -beta * p0 + 1.0e-4f) {
+            const float p_c = (1.0f - beta) * p0 / 2.0f;
+            const float q_tr = sqrtf(1.5f) * sn;
+            float dx = p_c - p_tr, dy = -q_tr;
+            const float dn = sqrtf(dx * dx + dy * dy);
+            dx /= dn; dy /= dn;
+            const float c = M * M * (p_c + beta * p0) * (p_c - p0);
+            const float b = M * M * dx * (2.0f * p_c - p0 + beta * p0);
+            const float a = M * M * dx * dx + (1.0f + 2.0f * beta) * dy * dy;
+            const float discr = sqrtf(b * b - 4.0f * a * c);
+            const float q1 = p_c + (-b + discr) / (2.0f * a) * dx, q2 = p_c + (-b - discr) / (2.0f * a) * dx;
+            const float p_x = (p_tr - p_c) * (q1 - p_c) > 0.f ? q1 : q2;
+            const float j_x = sqrtf(fabsf(-2.0f * p_x / kappa + 1.0f));
+            if (j_x > 1.0e-4f) alpha += logf(j_tr / j_x);
+        }
+        const float k = sqrtf(-y1 / y0) * (powf(j_tr, 2.0f / 3.0f) / mu);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ns[i] = sqrtf(k * (s_tr[i] / sn) + sq_tr / 3.0f);
+    }
+    float g[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g[i] = d.s[i] == 0.f ? 0.f : ns[i] / d.s[i];
+    F = svd_compose_scaled(d, g);
+}
+// Snow / Rankine / NACC dispatch (only instantiated in the RARE kernels, see g2p_update)
+SPK_DEV void rare_plastic_update(const DevModel& mo, M3& F, float& Jp, float& q, float& eh, float& alpha) {
+    if (mo.ptag == SPARKL_PLASTIC_SNOW) snow_update(mo, F, eh, Jp);
+    else if (mo.ptag == SPARKL_PLASTIC_RANKINE) rankine_update(mo, F, q);
+    else if (mo.ptag == SPARKL_PLASTIC_NACC) nacc_update(mo, F, alpha);
+}
+// MaximumStressFailure::particle_failed (failure_maximum_stress.rs:20-28).  nalgebra's iterative symmetric eigensolver
+// (third party) -> closed-form eigenvalues of the symmetric 3x3 (trigonometric form), evaluated in double.
+SPK_DEV bool maximum_stress_failed(const DevModel& mo, const M3& t) {
+    const double a00 = t.m[0], a11 = t.m[4], a22 = t.m[8];
+    const double a01 = 0.5 * ((double)t.m[3] + t.m[1]), a02 = 0.5 * ((double)t.m[6] + t.m[2]), a12 = 0.5 * ((double)t.m[7] + t.m[5]);
+    const double qm = (a00 + a11 + a22) / 3.0;
+    const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+    const double p2 = (a00 - qm) * (a00 - qm) + (a11 - qm) * (a11 - qm) + (a22 - qm) * (a22 - qm) + 2.0 * p1;
+    double mx, mn;
+    if (p2 <= 0.0) { mx = mn = qm; }
+    else {
+        const double pp = sqrt(p2 / 6.0), ip = 1.0 / pp;
+        const double b00 = (a00 - qm) * ip, b11 = (a11 - qm) * ip, b22 = (a22 - qm) * ip, b01 = a01 * ip, b02 = a02 * ip, b12 = a12 * ip;
+        double r = 0.5 * (b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02));
+        r = fmin(fmax(r, -1.0), 1.0);
+        const double phi = acos(r) / 3.0;
+        mx = qm + 2.0 * pp * cos(phi);
+        mn = qm + 2.0 * pp * cos(phi + 2.0943951023931953);
+    }
+    return mx > (double)mo.max_principal_stress || (mx - mn) * 0.5 > (double)mo.max_shear_stress;
 }
 
 // constitutive_model.pos_energy(particle)

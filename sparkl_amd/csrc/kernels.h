@@ -639,18 +639,37 @@ SPK_DEV float particle_dt_bound(const DevModel& mo, uint32_t flags, const float 
     return dt;
 }
 
+// failure_maximum_stress.rs (glue): the failure model looks at the stress of the updated particle.  Out of line: no 3-D
+// example uses a failure model.
+SPK_DEV bool failure_check(const DevModel& mo, float phase, float eh, const M3& F, float mass, float vol0, float Jp, const M3& C) {
+    M3 tau = m3_zero();
+    if (mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR) tau = corotated_kirchhoff(mo, phase, eh, F);
+    else if (mo.ctag == SPARKL_CONSTITUTIVE_NEO_HOOKEAN) tau = neo_hookean_kirchhoff(mo, phase, eh, F);
+    else if (mo.ctag == SPARKL_CONSTITUTIVE_EOS_MONAGHAN_SPH) tau = monaghan_kirchhoff(mo, mass, vol0, F.m[0], Jp, C);
+    return maximum_stress_failed(mo, tau);
+}
+
 // State of one particle after grid_to_particle.rs:62-164 (gather .. psi_pos), before it is written back.
 struct Advected {
     float px[3], vel[3];
     M3 C, F;
     float q, lvg, Jp, psi;
+    float eh, phase;     // elastic hardening (snow changes it) and phase (a failure model zeroes it) as P2G must see them
     uint32_t flags;
+    bool store_k;        // the K stream changed beyond the flags (elastic hardening)
+    bool store_aux;      // phase and / or nacc_alpha changed (cold stream)
+    float alpha;
     bool newly_failed;   // flags word must be stored
     bool in_tile;        // the NEW position still scatters inside the home block's tile (and inside the domain)
 };
 
+// RARE: the instantiation that also carries snow / Rankine / NACC plasticity and the failure model; launched only when a
+// model of the set needs it, so the elastic / Drucker-Prager kernels keep their register budget (inlining that code,
+// or calling it out of line, cost the hot kernel 35 %).
+template <bool RARE>
 SPK_DEV Advected g2p_update(const float4* vt, const DevModel& mo, uint32_t flags, const float4& q0, const float4& q1, const float4& q2, const float4& dd,
-                            const float4& kk, const float4* kinvel_i, float phase, const int4& org, const StepParams& S, float inv_h, unsigned* num_invalid) {
+                            const float4& kk, const float4* kinvel_i, const float4* aux_i, float phase, const int4& org, const StepParams& S, float inv_h,
+                            unsigned* num_invalid) {
     Advected o;
     const float h = S.h, dt = S.dt;
     float px[3] = {q0.x, q0.y, q0.z};
@@ -724,9 +743,18 @@ SPK_DEV Advected g2p_update(const float4* vt, const DevModel& mo, uint32_t flags
         F.m[0] += (div * dt) * F.m[0];
     }
     float q = dd.x, lvg = dd.y, Jp = dd.z, psi = dd.w;
-    const float eh = kk.z;
+    float eh = kk.z;
     float sv[3] = {1.f, 1.f, 1.f};
     bool sv_valid = false;
+    o.store_k = false; o.store_aux = false; o.alpha = 0.f;
+    if (RARE && mo.ptag > SPARKL_PLASTIC_DRUCKER_PRAGER) {   // snow / Rankine / NACC (plastic_model.update_particle, :102-104)
+        float alpha = mo.ptag == SPARKL_PLASTIC_NACC ? aux_i->z : 0.f;
+        const float eh0 = eh, alpha0 = alpha;
+        rare_plastic_update(mo, F, Jp, q, eh, alpha);
+        o.store_k = eh != eh0;
+        o.store_aux = alpha != alpha0;
+        o.alpha = alpha;
+    }
 #ifdef SPK_EXP_NO_PLASTICITY
     if (mo.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER && Jp == 123.456f) dp_update(
 #else
@@ -746,6 +774,13 @@ mo, phase, F, Jp, q, lvg, sv, sv_valid);
     }
     // positive energy bookkeeping (:127-132)
     psi = fmaxf(psi, model_pos_energy(mo, phase, eh, F, sv, sv_valid));
+    // failure model (:134-144): stress of the updated particle; a failed particle keeps phase = 0 from now on
+    if (RARE && mo.has_failure && phase != 0.f && failure_check(mo, phase, eh, F, kk.x, kk.y, Jp, C)) {
+        phase = 0.f;
+        if (!o.store_aux) o.alpha = aux_i->z;
+        o.store_aux = true;
+        if (!(flags & FLAG_PHASE_NOT_ONE)) { flags |= FLAG_PHASE_NOT_ONE; newly_failed = true; }   // the flags word must be stored
+    }
     // does the particle still sit inside its home block's tile, and inside the domain?
     bool invalid = false, in_tile = true;
 #pragma unroll
@@ -767,6 +802,7 @@ mo, phase, F, Jp, q, lvg, sv, sv_valid);
 #pragma unroll
     for (int a = 0; a < 3; ++a) { o.px[a] = px[a]; o.vel[a] = vel[a]; }
     o.C = C; o.F = F; o.q = q; o.lvg = lvg; o.Jp = Jp; o.psi = psi; o.flags = flags; o.newly_failed = newly_failed; o.in_tile = in_tile;
+    o.eh = eh; o.phase = phase;
     return o;
 }
 SPK_DEV void g2p_store(const ParticleArrays& P, int i, const Advected& o) {
@@ -778,8 +814,11 @@ SPK_DEV void g2p_store(const ParticleArrays& P, int i, const Advected& o) {
     P.q[5][i] = make_float4(o.C.m[5], o.C.m[6], o.C.m[7], o.C.m[8]);
     P.d[i] = make_float4(o.q, o.lvg, o.Jp, o.psi);
     if (o.newly_failed) reinterpret_cast<uint32_t*>(&P.k[i])[3] = o.flags;
+    if (o.store_k) reinterpret_cast<float*>(&P.k[i])[2] = o.eh;
+    if (o.store_aux) { float* a = reinterpret_cast<float*>(&P.aux[i]); a[0] = o.phase; a[2] = o.alpha; }
 }
 
+template <bool RARE>
 __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
     const int tid = threadIdx.x;
     if (ctl->abort_flag[S.parity]) {
@@ -816,11 +855,11 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
         if (flags & FLAG_INVALID) continue;
         const DevModel& mo = models[flags >> FLAG_MODEL_SHIFT];
         const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
-        const Advected o = g2p_update(vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, phase, org, S, inv_h, &ctl->num_invalid);
+        const Advected o = g2p_update<RARE>(vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
         g2p_store(P, i, o);
         want_sort |= !o.in_tile;
         if (S.want_dt) {  // the bound the next substep's estimator would compute from this state
-            const float b = particle_dt_bound(mo, o.flags, o.vel, o.C, kk.x, kk.y, kk.z, o.F.m[0], S.h);
+            const float b = particle_dt_bound(mo, o.flags, o.vel, o.C, kk.x, kk.y, o.eh, o.F.m[0], S.h);
             dt_nan |= b != b;
             dt_bound = fminf(dt_bound, b);
         }
@@ -842,7 +881,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
 // `S` carries substep s (parity, dt); the scatter uses the same dt (fixed) and writes the tiles of substep s+1.
 // The G2P half is always valid.  The P2G half is only valid if no particle left its tile margin; otherwise the
 // re-bin flag is raised, every later kernel is a no-op and the host re-bins and restarts with a standalone k_p2g.
-template <int REDUCE_STEPS>
+template <int REDUCE_STEPS, bool RARE>
 __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
     const int tid = threadIdx.x;
     if (ctl->abort_flag[S.parity]) {
@@ -887,11 +926,11 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p2g(ParticleArrays P, Grid
         if (live) {
             const DevModel& mo = models[flags >> FLAG_MODEL_SHIFT];
             const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
-            const Advected o = g2p_update(vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, phase, org, S, inv_h, &ctl->num_invalid);
+            const Advected o = g2p_update<RARE>(vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
             g2p_store(P, i, o);
             want_sort |= !o.in_tile;
             live = o.in_tile;
-            if (live) { sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.F, kk.x, kk.y, kk.z, phase, o.Jp, org, h, inv_h, S.inv_d, S.dt); shell_used |= sc.shell != 0; }
+            if (live) { sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.F, kk.x, kk.y, o.eh, o.phase, o.Jp, org, h, inv_h, S.inv_d, S.dt); shell_used |= sc.shell != 0; }
         }
         wave_heads += p2g_scatter<REDUCE_STEPS>(tile, sc, live, tid);
     }

@@ -149,6 +149,7 @@ struct SparklPipeline {
     DevBuf<unsigned long long> d_count;
 
     // clock: per-kernel hipEvent spans on every clock_stride-th substep (events cost ~2 % when on every launch)
+    bool rare_models = false;      // some model needs the kernels that carry snow / Rankine / NACC / failure code
     bool fuse_fixed_dt = true;     // SPARKL_HIP_NO_FUSE=1 in the environment turns the fused schedule off (A/B)
     bool clock_on = false;
     uint32_t clock_stride = 1;
@@ -388,6 +389,17 @@ static void launch_grid_update(SparklPipeline* p, const GridArrays& G, const Ste
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, false>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_ctl, S);
 }
 
+static void launch_g2p(SparklPipeline* p, const ParticleArrays& P, const GridArrays& G, const StepParams& S, hipStream_t st) {
+    const dim3 grid(p->num_pblocks), block(BLK_THREADS);
+    if (p->rare_models) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p<true>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p<false>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
+}
+static void launch_g2p2g(SparklPipeline* p, const ParticleArrays& P, const GridArrays& G, const StepParams& S, hipStream_t st) {
+    const dim3 grid(p->num_pblocks), block(BLK_THREADS);
+    if (p->rare_models) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<SPK_P2G_REDUCE_STEPS, true>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<SPK_P2G_REDUCE_STEPS, false>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
+}
+
 static int enqueue_fluid_volumes(SparklPipeline* p, const StepParams& S) {
     hipStream_t st = p->stream;
     GridArrays G = grid_arrays(p);
@@ -419,7 +431,7 @@ static int enqueue_substep(SparklPipeline* p, const SparklSolverParams* sp, cons
     launch_grid_update(p, G, S, st);
     CHK(clock_end(p, t1));
     CHK(clock_begin(p, SPAN_G2P, &t2));
-    hipLaunchKernelGGL(k_g2p, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, P, G, p->d_models.p, p->d_ctl, S);
+    launch_g2p(p, P, G, S, st);
     CHK(clock_end(p, t2));
     p->clock_on = was_on;
     p->substep_index++;
@@ -453,11 +465,11 @@ static int enqueue_fused_batch(SparklPipeline* p, const SparklSolverParams* sp, 
         CHK(clock_end(p, tk));
         if (j + 1 < n) {
             CHK(clock_begin(p, SPAN_FUSED, &tk));
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<SPK_P2G_REDUCE_STEPS>), dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, P, G, p->d_models.p, p->d_ctl, S);
+            launch_g2p2g(p, P, G, S, st);
             CHK(clock_end(p, tk));
         } else {
             CHK(clock_begin(p, SPAN_G2P, &tk));
-            hipLaunchKernelGGL(k_g2p, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, P, G, p->d_models.p, p->d_ctl, S);
+            launch_g2p(p, P, G, S, st);
             CHK(clock_end(p, tk));
         }
         p->clock_on = was_on;
@@ -593,15 +605,41 @@ int sparkl_hip_models_set(SparklPipeline* p, uint32_t n, const SparklParticleMod
                 return set_error(SPARKL_ERR_UNSUPPORTED, "model %u: CoreConstitutiveModel::Custom cannot cross the C ABI", i);
         }
         if (m.has_plastic_model) {
-            if (m.plastic_model.tag != SPARKL_PLASTIC_DRUCKER_PRAGER)
-                return set_error(SPARKL_ERR_UNSUPPORTED, "model %u: plastic model tag %u is not implemented (only DruckerPrager)", i, m.plastic_model.tag);
-            const auto& dp = m.plastic_model.u.drucker_prager;
-            d.ptag = SPARKL_PLASTIC_DRUCKER_PRAGER;
-            d.h0 = dp.h0; d.h1 = dp.h1; d.h2 = dp.h2; d.h3 = dp.h3; d.p_lambda = dp.lambda; d.p_mu = dp.mu;
-            d.volume_correction = dp.volume_correction; d.only_active_when_failed = dp.only_active_when_failed;
-            d.p_k = (3.0f * dp.lambda + 2.0f * dp.mu) / (2.0f * dp.mu);
+            d.ptag = (int)m.plastic_model.tag;
+            switch (m.plastic_model.tag) {
+                case SPARKL_PLASTIC_DRUCKER_PRAGER: {
+                    const auto& dp = m.plastic_model.u.drucker_prager;
+                    d.h0 = dp.h0; d.h1 = dp.h1; d.h2 = dp.h2; d.h3 = dp.h3; d.p_lambda = dp.lambda; d.p_mu = dp.mu;
+                    d.volume_correction = dp.volume_correction; d.only_active_when_failed = dp.only_active_when_failed;
+                    d.p_k = (3.0f * dp.lambda + 2.0f * dp.mu) / (2.0f * dp.mu);
+                    break;
+                }
+                case SPARKL_PLASTIC_SNOW: {
+                    const auto& sn = m.plastic_model.u.snow;
+                    d.x0 = sn.min_epsilon; d.x1 = sn.max_epsilon; d.x2 = sn.hardening_coeff;
+                    break;
+                }
+                case SPARKL_PLASTIC_RANKINE: {
+                    const auto& r = m.plastic_model.u.rankine;
+                    d.x0 = r.mu; d.x1 = r.lambda; d.x2 = r.tensile_strength; d.x3 = r.softening_rate;
+                    break;
+                }
+                case SPARKL_PLASTIC_NACC: {
+                    const auto& na = m.plastic_model.u.nacc;
+                    d.x0 = na.mu; d.x1 = na.kappa; d.x2 = na.hardening_factor; d.x3 = na.cohesion; d.x4 = na.friction; d.xi = na.hardening_enabled;
+                    break;
+                }
+                default:
+                    return set_error(SPARKL_ERR_UNSUPPORTED, "model %u: CorePlasticModel::Custom cannot cross the C ABI", i);
+            }
         }
-        if (m.has_failure_model) return set_error(SPARKL_ERR_UNSUPPORTED, "model %u: failure models are not implemented", i);
+        if (m.has_failure_model) {
+            if (m.failure_model.tag != SPARKL_FAILURE_MAXIMUM_STRESS)
+                return set_error(SPARKL_ERR_UNSUPPORTED, "model %u: CoreFailureModel::Custom cannot cross the C ABI", i);
+            d.has_failure = 1;
+            d.max_principal_stress = m.failure_model.u.maximum_stress.max_principal_stress;
+            d.max_shear_stress = m.failure_model.u.maximum_stress.max_shear_stress;
+        }
         dm[i] = d;
     }
     CHK(p->d_models.reserve(std::max<uint32_t>(n, 1)));
@@ -609,6 +647,8 @@ int sparkl_hip_models_set(SparklPipeline* p, uint32_t n, const SparklParticleMod
     HIPCHK(hipStreamSynchronize(p->stream));
     p->h_models = dm;
     p->any_fluid = any_fluid;
+    p->rare_models = false;
+    for (const DevModel& d : dm) p->rare_models |= d.ptag > SPARKL_PLASTIC_DRUCKER_PRAGER || d.has_failure;
     return SPARKL_OK;
 }
 
@@ -1156,13 +1196,12 @@ static int substep_finish_impl(SparklPipeline* p, bool fuse_next) {
     if (fuse_next && p->fuse_fixed_dt) {
         // G2P of this substep + P2G of the next one (same dt) in one kernel; the next substep_begin is then free
         CHK(clock_begin(p, SPAN_FUSED, &t2));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<SPK_P2G_REDUCE_STEPS>), dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, p->cur.arrays(), G, p->d_models.p, p->d_ctl,
-                           p->pending);
+        launch_g2p2g(p, p->cur.arrays(), G, p->pending, st);
         CHK(clock_end(p, t2));
         p->tiles_ready = true;
     } else {
         CHK(clock_begin(p, SPAN_G2P, &t2));
-        hipLaunchKernelGGL(k_g2p, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, p->cur.arrays(), G, p->d_models.p, p->d_ctl, p->pending);
+        launch_g2p(p, p->cur.arrays(), G, p->pending, st);
         CHK(clock_end(p, t2));
     }
     p->clock_on = p->pending_clock_saved;

@@ -99,6 +99,71 @@ class DruckerPragerPlasticity:
         return m
 
 
+class SnowPlasticity:
+    """`SnowPlasticity::new` (plasticity_snow.rs:18-24): min_epsilon 2.5e-2, max_epsilon 4.5e-3, hardening_coeff 10."""
+
+    def __init__(self):
+        self.min_epsilon, self.max_epsilon, self.hardening_coeff = 2.5e-2, 4.5e-3, 10.0
+
+    def to_core_model(self):
+        m = abi.PlasticModelC()
+        m.tag = abi.PLASTIC_SNOW
+        m.u.snow.min_epsilon, m.u.snow.max_epsilon, m.u.snow.hardening_coeff = self.min_epsilon, self.max_epsilon, self.hardening_coeff
+        return m
+
+
+class RankinePlasticity:
+    """`RankinePlasticity::new(young_modulus, poisson_ratio, tensile_strength, softening_rate)` (plasticity_rankine.rs:19-32)."""
+
+    def __init__(self, young_modulus, poisson_ratio, tensile_strength, softening_rate):
+        self.lambda_, self.mu = lame_lambda_mu(young_modulus, poisson_ratio)
+        self.tensile_strength, self.softening_rate = tensile_strength, softening_rate
+
+    def to_core_model(self):
+        m = abi.PlasticModelC()
+        m.tag = abi.PLASTIC_RANKINE
+        r = m.u.rankine
+        r.mu, r.lambda_, r.tensile_strength, r.softening_rate = self.mu, self.lambda_, self.tensile_strength, self.softening_rate
+        return m
+
+
+class NaccPlasticity:
+    """`NaccPlasticity::new(young_modulus, poisson_ratio, cohesion, hardening_enabled, hardening_factor, friction_angle)`
+    (plasticity_nacc.rs:22-43); `with_m` (:45-60) through the `m=` keyword.  dim3: d = 3."""
+
+    def __init__(self, young_modulus, poisson_ratio, cohesion, hardening_enabled, hardening_factor, friction_angle=None, m=None):
+        e, nu = f32(young_modulus), f32(poisson_ratio)
+        self.mu = float(e / (f32(2.0) * (f32(1.0) + nu)))               # physics.rs:25-27
+        self.kappa = float(e / (f32(3.0) * (f32(1.0) - f32(2.0) * nu)))  # physics.rs:29-31
+        self.hardening_enabled, self.hardening_factor, self.cohesion = bool(hardening_enabled), hardening_factor, cohesion
+        if m is not None:
+            self.friction = m
+        else:
+            sin_f, d = np.sin(f32(friction_angle), dtype=f32), f32(3.0)
+            self.friction = float(np.sqrt(f32(2.0) / f32(3.0), dtype=f32) * f32(2.0) * sin_f / (f32(3.0) - sin_f) * d / np.sqrt(f32(2.0) / (f32(6.0) - d), dtype=f32))
+
+    def to_core_model(self):
+        m = abi.PlasticModelC()
+        m.tag = abi.PLASTIC_NACC
+        n = m.u.nacc
+        n.mu, n.kappa, n.hardening_enabled = self.mu, self.kappa, int(self.hardening_enabled)
+        n.hardening_factor, n.cohesion, n.friction = self.hardening_factor, self.cohesion, self.friction
+        return m
+
+
+class MaximumStressFailure:
+    """`MaximumStressFailure::new(max_principal_stress, max_shear_stress)` (failure_maximum_stress.rs:13-18)."""
+
+    def __init__(self, max_principal_stress, max_shear_stress):
+        self.max_principal_stress, self.max_shear_stress = max_principal_stress, max_shear_stress
+
+    def to_core_model(self):
+        m = abi.FailureModelC()
+        m.tag = abi.FAILURE_MAXIMUM_STRESS
+        m.u.maximum_stress.max_principal_stress, m.u.maximum_stress.max_shear_stress = self.max_principal_stress, self.max_shear_stress
+        return m
+
+
 class ParticleModel:
     """`ParticleModel::{new, with_plasticity}` (src/dynamics/particle_model.rs:85-113)."""
 
@@ -114,6 +179,10 @@ class ParticleModel:
     @classmethod
     def with_plasticity(cls, constitutive_model, plasticity):
         return cls(constitutive_model, plastic_model=plasticity)
+
+    @classmethod
+    def with_failure(cls, constitutive_model, failure):     # particle_model.rs `with_failure`
+        return cls(constitutive_model, failure_model=failure)
 
     def to_c(self):
         m = abi.ParticleModelC()

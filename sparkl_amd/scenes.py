@@ -129,6 +129,27 @@ def elastic_cube(n, h=0.2, jitter=True, name=None):
     return Scene(name or f"elastic_cube_{n}", h, models, comps, [], params, (0.0, 0.0, 0.0), 1.0e-4, _domain_bits_for(max_cell))
 
 
+def block_on_floor(n, constitutive, plasticity=None, failure=None, density=1000.0, v0=(0.0, -3.0, 0.0), expand=0.0, h=0.2, dt=1.0e-4,
+                   gravity=(0.0, -9.81, 0.0), name="block", jitter=True):
+    """An n^3 block one and a half cells above a friction floor, falling at v0 and/or expanding at `expand` 1/s: the small scenes
+    that exercise the plastic / failure models the 3-D examples do not use."""
+    models = ParticleModelSet()
+    mid = models.insert(ParticleModel(constitutive, plastic_model=plasticity, failure_model=failure))
+    r = h / 4.0
+    origin = np.array([4 * h, 5 * h, 4 * h], dtype=f32) + f32(r)
+    pos = cube_positions(origin, n, n, n, r, jitter)
+    comps = new_particles(mid, pos, r, density)
+    c = pos.mean(axis=0, dtype=np.float64).astype(f32)
+    d = pos - c
+    half = f32(0.5 * n * 2 * r)
+    # expansion rate grows linearly from the centre to `expand` at the faces: the strain, hence the yield / failure front, varies in space
+    comps.velocity["vector"] = (np.asarray(v0, dtype=f32)[None, :] + f32(expand) * d * (np.abs(d) / half)).astype(f32)
+    floor = floor_cuboid(top_y=4 * h - 0.5 * h, friction=0.5)
+    params = abi.SolverParameters()
+    max_cell = int(np.ceil(pos.max() / h)) + 6
+    return Scene(f"{name}_{n}", h, models, comps, [floor], params, gravity, dt, _domain_bits_for(max_cell))
+
+
 def fluid_dam(nx, ny, nz, h=0.8, r=0.1, jitter=True, name=None):
     """Config 4: fluids3-like dam break (examples3d/fluids3.rs:17-43), 64 particles per cell."""
     models = ParticleModelSet()

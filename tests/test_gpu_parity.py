@@ -150,6 +150,65 @@ def test_heightfield_ground_parity(Pipeline, below_is_solid):
     assert e["eps_v"] <= TOL or e["eps_v"] <= 3 * floor["eps_v"], (e, floor)
 
 
+def _rare_model_scenes():
+    from sparkl_amd.models import (CorotatedLinearElasticity, MaximumStressFailure, NaccPlasticity, NeoHookeanElasticity, RankinePlasticity,
+                                   SnowPlasticity)
+    return {
+        # snow (plasticity_snow.rs): a soft block hits the floor at 4 m/s -> compaction, Jp < 1, hardening > 1
+        "snow": lambda: scenes.block_on_floor(16, CorotatedLinearElasticity(1.4e5, 0.2), SnowPlasticity(), density=400.0, v0=(0.0, -8.0, 0.0), dt=2.0e-4, name="snow"),
+        # Rankine (plasticity_rankine.rs): a block torn apart by an expanding velocity field; tensile strength 2e3 of E = 1e6
+        "rankine": lambda: scenes.block_on_floor(16, NeoHookeanElasticity(1.0e6, 0.3), RankinePlasticity(1.0e6, 0.3, 5.0e4, 5.0), expand=6.0,
+                                                 v0=(0.0, 0.0, 0.0), gravity=(0.0, 0.0, 0.0), name="rankine"),
+        # NACC (plasticity_nacc.rs): cohesive soil dropped on the floor
+        "nacc": lambda: scenes.block_on_floor(16, NeoHookeanElasticity(2.0e5, 0.3), NaccPlasticity(2.0e5, 0.3, 0.05, True, 1.5, np.deg2rad(35.0)),
+                                              density=1500.0, v0=(0.0, -8.0, 0.0), dt=2.0e-4, name="nacc"),
+        # maximum-stress failure (failure_maximum_stress.rs) with the corotated model's tension split
+        "failure": lambda: scenes.block_on_floor(16, CorotatedLinearElasticity(1.0e6, 0.3), None, MaximumStressFailure(5.0e4, 4.0e4), expand=6.0,
+                                                 v0=(0.0, 0.0, 0.0), gravity=(0.0, 0.0, 0.0), name="failure"),
+    }
+
+
+@pytest.mark.parametrize("name", ["snow", "rankine", "nacc", "failure"])
+def test_rare_material_models_parity(Pipeline, name):
+    """the remaining `ParticleModel` members against the oracle, 100 substeps."""
+    sc = _rare_model_scenes()[name]()
+    dt = sc.fixed_dt
+    o32, o64 = _oracle(sc), _oracle(sc, f64=True)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        for _ in range(100):
+            o32.substep_fixed(sc.params, sc.gravity, dt)
+            o64.substep_fixed(sc.params, sc.gravity, dt)
+        p.substeps(sc.params, sc.gravity, dt, 100)
+        got, r32, r64 = p.read_particles(), o32.get_particles(), o64.get_particles()
+    e = particle_errors(got, r32, sc.cell_width)
+    floor = particle_errors(r32, r64, sc.cell_width)
+    n = len(sc.particles)
+    acted = {
+        "snow": int((r32.volume["plastic_deformation_gradient_det"] < 0.999).sum()),
+        "rankine": int((r32.data["plastic_hardening"] > 1.0).sum()),
+        "nacc": int((np.abs(r32.data["nacc_alpha"] + 0.01) > 1e-6).sum()),
+        "failure": int((r32.phase["phase"] == 0.0).sum()),
+    }[name]
+    extra = {}
+    if name == "snow":
+        extra["eh_rel"] = float(np.abs(got.data["elastic_hardening"] - r32.data["elastic_hardening"]).max() / r32.data["elastic_hardening"].max())
+        extra["jp_abs"] = float(np.abs(got.volume["plastic_deformation_gradient_det"] - r32.volume["plastic_deformation_gradient_det"]).max())
+    if name == "rankine":
+        extra["hard_abs"] = float(np.abs(got.data["plastic_hardening"] - r32.data["plastic_hardening"]).max())
+    if name == "nacc":
+        extra["alpha_abs"] = float(np.abs(got.data["nacc_alpha"] - r32.data["nacc_alpha"]).max())
+    if name == "failure":
+        extra["phase_mismatch"] = int((got.phase["phase"] != r32.phase["phase"]).sum())
+    _report(f"rare_model_{name}", {"vs_f32": e, "oracle_f32_vs_f64": floor, "particles_the_model_acted_on": acted, "n": n, **extra})
+    assert acted > n // 50, "the scene must exercise the model"
+    assert e["failed_mismatch"] == 0 and np.isfinite(got.position["point"]).all()
+    assert e["eps_x"] <= TOL, (e, floor)
+    assert e["eps_v"] <= TOL or e["eps_v"] <= 3 * floor["eps_v"], (e, floor)
+    if name == "failure":   # a threshold decision: particles sitting exactly on it may flip; the bulk must agree
+        assert extra["phase_mismatch"] <= max(2, acted // 100)
+
+
 def test_adaptive_step_matches_oracle(Pipeline):
     """`MpmPipeline::step` with dt = 1/60: same substep count and lengths as the CPU path (mls_solver.rs:33-59)."""
     sc = scenes.sand_column(16, 10, 12, with_block=True)

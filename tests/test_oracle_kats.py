@@ -140,6 +140,135 @@ def test_drucker_prager_return_map():
     assert q2 == pytest.approx(1.0 + dq)
 
 
+def _rot(axis, angle):
+    axis = np.asarray(axis, dtype=np.float64) / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + math.sin(angle) * K + (1 - math.cos(angle)) * K @ K
+
+
+def test_snow_plasticity_clamps_singular_values():
+    """plasticity_snow.rs:26-48: sigma clamped to [1 - 2.5e-2, 1 + 4.5e-3], Jp and the hardening follow."""
+    from sparkl_amd.models import SnowPlasticity
+    pm = SnowPlasticity().to_core_model()
+    U, V = _rot([1, 2, 3], 0.7), _rot([-1, 0.5, 2], -1.1)
+    sig = np.array([1.02, 0.99, 0.95])
+    F, st = oracle.plastic_update(pm, U @ np.diag(sig) @ V.T, Jp=1.0, f64=True)
+    want = np.clip(sig, 1 - float(np.float32(2.5e-2)), 1 + float(np.float32(4.5e-3)))   # the parameters are f32
+    assert np.allclose(np.sort(np.linalg.svd(F, compute_uv=False)), np.sort(want), atol=1e-12)
+    assert np.allclose(F, U @ np.diag(want) @ V.T, atol=1e-12)
+    jp = sig.prod() / want.prod()
+    assert st["Jp"] == pytest.approx(jp, rel=1e-12)
+    assert st["elastic_hardening"] == pytest.approx(math.exp(10.0 * (1.0 - jp)), rel=1e-12)
+    # inside the box: untouched (up to the SVD round trip), hardening = exp(10 (1 - Jp))
+    F2, st2 = oracle.plastic_update(pm, U @ np.diag([1.001, 0.999, 1.0]) @ V.T, Jp=0.98, f64=True)
+    assert np.allclose(F2, U @ np.diag([1.001, 0.999, 1.0]) @ V.T, atol=1e-12) and st2["Jp"] == pytest.approx(0.98, rel=1e-12)
+    assert st2["elastic_hardening"] == pytest.approx(math.exp(10.0 * 0.02), rel=1e-12)
+
+
+def test_rankine_plasticity_branches():
+    """plasticity_rankine.rs:34-78: the four return cases on the principal Hencky strains."""
+    from sparkl_amd.models import RankinePlasticity
+    rp = RankinePlasticity(1.0e4, 0.25, 50.0, 2.0)
+    lam, mu = rp.lambda_, rp.mu
+    pm = rp.to_core_model()
+    U, V = _rot([0.3, 1, -0.5], 0.4), _rot([1, 1, 0], 0.9)
+
+    def run(eps, hard=1.0):
+        F, st = oracle.plastic_update(pm, U @ np.diag(np.exp(eps)) @ V.T, plastic_hardening=hard, f64=True)
+        return np.log(np.linalg.svd(F, compute_uv=False)), st["plastic_hardening"], F
+
+    # 1. below the tensile strength: nothing happens
+    eps = np.array([0.002, 0.0, -0.001])
+    assert lam * eps.sum() + 2 * mu * eps.max() <= 50.0
+    e, h, F = run(eps)
+    assert np.allclose(np.sort(e), np.sort(eps), atol=1e-12) and h == 1.0
+    # 2. only the largest principal stress yields: it is pulled back onto sigma_1 = strength
+    eps = np.array([0.02, 0.0, -0.001])
+    e, h, F = run(eps)
+    e1 = (50.0 - lam * (eps.sum() - eps[0])) / (2 * mu + lam)
+    assert np.allclose(np.sort(e), np.sort([e1, 0.0, -0.001]), atol=1e-12)
+    assert h == pytest.approx(min(1.0 + 2.0 * abs(eps[0] - e1), 50.0), rel=1e-12)
+    assert np.allclose(F, U @ np.diag(np.exp([e1, 0.0, -0.001])) @ V.T, atol=1e-12)
+    # 3. two principal stresses yield
+    eps = np.array([0.02, 0.019, -0.001])
+    e, h, _ = run(eps)
+    ne = (50.0 - lam * eps[2]) / (2 * mu + 2 * lam)
+    assert np.allclose(np.sort(e), np.sort([ne, ne, -0.001]), atol=1e-12)
+    # 4. all three yield: hydrostatic apex
+    eps = np.array([0.02, 0.019, 0.018])
+    e, h, _ = run(eps)
+    assert np.allclose(e, 50.0 / (2 * mu + 3 * lam), atol=1e-12)
+    # softening lowers the effective strength: strength - (hardening - 1)
+    e, h, _ = run(np.array([0.004, 0.0, 0.0]), hard=31.0)     # effective strength 20
+    assert np.sort(e)[-1] == pytest.approx((20.0 - 0.0) / (2 * mu + lam), rel=1e-10)
+
+
+def test_nacc_plasticity_cases():
+    """plasticity_nacc.rs:62-152 against a direct numpy evaluation of the same formulas (d = 3)."""
+    from sparkl_amd.models import NaccPlasticity
+    n = NaccPlasticity(1.0e5, 0.3, cohesion=0.05, hardening_enabled=True, hardening_factor=1.5, friction_angle=math.radians(35.0))
+    pm = n.to_core_model()
+    mu, kappa, xi, beta, M = n.mu, n.kappa, 1.5, float(np.float32(0.05)), float(np.float32(n.friction))
+    # the friction coefficient of `new` in f32 (plasticity_nacc.rs:38-40)
+    sf = math.sin(math.radians(35.0))
+    assert M == pytest.approx(math.sqrt(2 / 3) * 2 * sf / (3 - sf) * 3 / math.sqrt(2 / 3), rel=1e-6)
+    U, V = _rot([1, 0, 1], 0.3), _rot([0, 1, 1], -0.8)
+
+    def ref(sig, alpha):
+        sig = np.asarray(sig, dtype=np.float64)
+        sq, tr = sig ** 2, (sig ** 2).sum()
+        p0 = kappa * (1e-5 + math.sinh(xi * max(-alpha, 0.0)))
+        J = sig.prod()
+        s_tr = mu * J ** (-2 / 3) * (sq - tr / 3)
+        p_tr = -(kappa / 2 * (J - 1 / J)) * J
+        if p_tr > p0:
+            Jn = math.sqrt(-2 * p0 / kappa + 1)
+            return np.full(3, Jn ** (1 / 3)), alpha + math.log(J / Jn), "tipA"
+        if p_tr < -beta * p0:
+            Jn = math.sqrt(2 * beta * p0 / kappa + 1)
+            return np.full(3, Jn ** (1 / 3)), alpha + math.log(J / Jn), "tipB"
+        y0 = (1 + 2 * beta) * 1.5
+        y1 = M * M * (p_tr + beta * p0) * (p_tr - p0)
+        if y0 * (s_tr ** 2).sum() + y1 < 1e-4:
+            return sig, alpha, "inside"
+        if p0 > 1e-4 and p_tr < p0 - 1e-4 and p_tr > -beta * p0 + 1e-4:
+            p_c = (1 - beta) * p0 / 2
+            q_tr = math.sqrt(1.5) * np.linalg.norm(s_tr)
+            d = np.array([p_c - p_tr, -q_tr]); d /= np.linalg.norm(d)
+            c = M * M * (p_c + beta * p0) * (p_c - p0)
+            b = M * M * d[0] * (2 * p_c - p0 + beta * p0)
+            a = M * M * d[0] ** 2 + (1 + 2 * beta) * d[1] ** 2
+            disc = math.sqrt(b * b - 4 * a * c)
+            p1, p2 = p_c + (-b + disc) / (2 * a) * d[0], p_c + (-b - disc) / (2 * a) * d[0]
+            p_x = p1 if (p_tr - p_c) * (p1 - p_c) > 0 else p2
+            Jx = math.sqrt(abs(-2 * p_x / kappa + 1))
+            if Jx > 1e-4:
+                alpha += math.log(J / Jx)
+        b_e = math.sqrt(-y1 / y0) * (J ** (2 / 3) / mu) * s_tr / np.linalg.norm(s_tr) + tr / 3
+        return np.sqrt(b_e), alpha, "surface"
+
+    seen = set()
+    for sig, alpha in [((0.9, 0.9, 0.9), -0.01), ((1.05, 1.05, 1.05), -0.01), ((1.0002, 0.9998, 1.0), -0.5), ((0.96, 0.90, 0.88), -0.05),
+                       ((0.97, 0.94, 0.91), -0.2), ((1.08, 0.96, 0.93), -0.05)]:
+        want, want_alpha, case = ref(sig, alpha)
+        seen.add(case)
+        F, st = oracle.plastic_update(pm, U @ np.diag(sig) @ V.T, nacc_alpha=alpha, f64=True)
+        assert np.allclose(F, U @ np.diag(want) @ V.T, atol=1e-10), case
+        assert st["nacc_alpha"] == pytest.approx(want_alpha, rel=1e-10, abs=1e-12), case
+    assert seen == {"tipA", "tipB", "inside", "surface"}
+
+
+def test_maximum_stress_failure():
+    """failure_maximum_stress.rs:20-28: principal stress and maximum shear criteria on the symmetric eigenvalues."""
+    from sparkl_amd.models import MaximumStressFailure
+    fm = MaximumStressFailure(100.0, 40.0).to_core_model().u.maximum_stress
+    Q = _rot([1, 2, -1], 1.2)
+    assert not oracle.maximum_stress_failed(fm, Q @ np.diag([90.0, 50.0, 20.0]) @ Q.T)       # max 90 <= 100, shear 35 <= 40
+    assert oracle.maximum_stress_failed(fm, Q @ np.diag([101.0, 50.0, 30.0]) @ Q.T)          # principal
+    assert oracle.maximum_stress_failed(fm, Q @ np.diag([90.0, 50.0, 5.0]) @ Q.T)            # shear 42.5
+    assert not oracle.maximum_stress_failed(fm, Q @ np.diag([-500.0, -480.0, -470.0]) @ Q.T)  # compression never fails on max principal
+
+
 def test_pos_energy():
     co = CorotatedLinearElasticity(1.0e7, 0.2).to_core_model()
     lam, mu = lame_lambda_mu(1.0e7, 0.2)
