@@ -65,7 +65,18 @@ class MpmPipeline:
 
     # ---- CudaParticleModelSet / CudaColliderSet
     def set_models(self, model_set):
-        check(self.L.sparkl_hip_models_set(self.h, C.c_uint32(len(model_set)), model_set.to_c_array()))
+        arr = model_set.to_c_array()
+        check(self.L.sparkl_hip_models_set(self.h, C.c_uint32(len(model_set)), arr))
+        self._uploaded_models = bytes(arr)[: len(model_set) * C.sizeof(abi.ParticleModelC)]
+
+    def ensure_models_are_uploaded(self, model_set):
+        """`CudaParticleModelSet::ensure_models_are_uploaded` (cuda_particle_model_set.rs:61-84): the user may have edited a
+        model between two steps; re-upload only when the core models differ from what the device holds.  Returns True if it did."""
+        now = bytes(model_set.to_c_array())[: len(model_set) * C.sizeof(abi.ParticleModelC)]
+        if now == getattr(self, "_uploaded_models", None):
+            return False
+        self.set_models(model_set)
+        return True
 
     def set_colliders(self, cuboids):
         arr = (abi.CuboidColliderC * max(len(cuboids), 1))(*cuboids)

@@ -1,0 +1,122 @@
+"""Serialisation / checkpoint of particle + model state: sparkl_amd/checkpoint.py."""
+import struct
+
+import numpy as np
+import pytest
+
+from sparkl_amd import abi, checkpoint, scenes
+from sparkl_amd.models import (CorotatedLinearElasticity, DruckerPragerPlasticity, MaximumStressFailure, MonaghanSphEos, NaccPlasticity,
+                               NeoHookeanElasticity, ParticleModel, ParticleModelSet, RankinePlasticity, SnowPlasticity)
+from sparkl_amd.particles import ParticleComponents
+
+
+def _all_models():
+    ms = ParticleModelSet()
+    ms.insert(ParticleModel.with_plasticity(CorotatedLinearElasticity(1.0e7, 0.2), DruckerPragerPlasticity(1.0e7, 0.2)))
+    ms.insert(ParticleModel.new(NeoHookeanElasticity(1.0e6, 0.3)))
+    ms.insert(ParticleModel.new(MonaghanSphEos(1.0e6, 7, 1.01e-3)))
+    ms.insert(ParticleModel.with_plasticity(CorotatedLinearElasticity(1.4e5, 0.2), SnowPlasticity()))
+    ms.insert(ParticleModel.with_plasticity(NeoHookeanElasticity(1.0e6, 0.3), RankinePlasticity(1.0e6, 0.3, 5.0e4, 5.0)))
+    ms.insert(ParticleModel.with_plasticity(NeoHookeanElasticity(2.0e5, 0.3), NaccPlasticity(2.0e5, 0.3, 0.05, True, 1.5, 0.6)))
+    ms.insert(ParticleModel.with_failure(CorotatedLinearElasticity(1.0e6, 0.3), MaximumStressFailure(5.0e4, 4.0e4)))
+    return ms
+
+
+def _some_particles():
+    sc = scenes.sand_column(6, 5, 4, with_block=True)
+    c = sc.particles
+    rng = np.random.default_rng(5)
+    n = len(c)
+    c.velocity["vector"] = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    c.velocity_gradient["m"] = rng.normal(0, 1, (n, 9)).astype(np.float32)
+    c.volume["deformation_gradient"] += rng.normal(0, 0.01, (n, 9)).astype(np.float32)
+    c.status["model_index"] = rng.integers(0, 7, n)
+    c.status["kinematic_vel_enabled"][::7] = 1
+    c.status["kinematic_vel"][::7] = [1.0, 2.0, 3.0]
+    c.status["is_static"][3::11] = 1
+    c.status["failed"][5::13] = 1
+    c.phase["psi_pos"] = rng.random(n).astype(np.float32)
+    c.phase["phase"][::5] = 0.0
+    c.data["log_vol_gain"] = rng.normal(0, 0.1, n).astype(np.float32)
+    return c
+
+
+def _same_models(a, b, n):
+    sz = abi.C.sizeof(abi.ParticleModelC)
+    for k in range(n):
+        ma, mb = a[k], b[k]
+        # compare through the serde bytes: union padding in the raw structs is not significant
+        wa, wb = __import__("io").BytesIO(), __import__("io").BytesIO()
+        checkpoint._model_bytes(wa, ma); checkpoint._model_bytes(wb, mb)
+        assert wa.getvalue() == wb.getvalue(), k
+    assert sz == 76
+
+
+def test_native_checkpoint_round_trip(tmp_path):
+    c, ms = _some_particles(), _all_models()
+    params = abi.SolverParameters()
+    params.max_num_substeps = 77
+    path = tmp_path / "ck.npz"
+    checkpoint.save(path, c, ms, 0.2, params=params, simulated_time=1.25, extra={"frame": 12})
+    c2, ms2, header, params2 = checkpoint.load(path)
+    for k in ParticleComponents.__slots__:
+        assert getattr(c, k).tobytes() == getattr(c2, k).tobytes(), k
+    assert len(ms2) == len(ms) == 7
+    assert bytes(ms2.to_c_array()) == bytes(ms.to_c_array())
+    assert header["cell_width"] == pytest.approx(0.2) and header["simulated_time"] == 1.25 and header["extra"] == {"frame": 12}
+    assert params2.max_num_substeps == 77 and bytes(params2) == bytes(params)
+
+
+def test_bincode_layout_round_trip_and_sizes():
+    c, ms = _some_particles(), _all_models()
+    pb, mb = checkpoint.dump_bincode(c, ms)
+    # Vec<Particle>: u64 count, then per particle 236 B (+ 20 B when kinematic_vel is Some)
+    n, nkin = len(c), int(c.status["kinematic_vel_enabled"].sum())
+    per = 8 + 12 + 20 + 20 + 1 + 44 + 44 + 4 + 8 + 1 + 1 + 20 + 20 + 4 + 12 + 20 + 16 + 8 + 4
+    assert struct.unpack_from("<Q", pb)[0] == n and len(pb) == 8 + per * n + 20 * nkin
+    # first particle: arena index + generation, mass
+    assert struct.unpack_from("<II", pb, 8) == (int(c.status["model_index"][0]), 0)
+    assert struct.unpack_from("<f", pb, 16)[0] == c.volume["mass"][0]
+    # Vec<ParticleModel>: model 0 = CorotatedLinearElasticity (variant 0) + Some(DruckerPrager (variant 0)) + None
+    assert struct.unpack_from("<Q", mb)[0] == 7
+    assert struct.unpack_from("<I", mb, 8)[0] == 0 and mb[8 + 4 + 13] == 1 and struct.unpack_from("<I", mb, 8 + 4 + 13 + 1)[0] == 0
+    c2, ms2 = checkpoint.load_bincode(pb, mb)
+    for k in ("position", "velocity", "velocity_gradient", "data"):
+        assert getattr(c, k).tobytes() == getattr(c2, k).tobytes(), k
+    for f in ("mass", "volume0", "radius0", "deformation_gradient", "plastic_deformation_gradient_det"):
+        np.testing.assert_array_equal(c.volume[f], c2.volume[f])
+    for f in ("failed", "is_static", "kinematic_vel_enabled", "model_index"):
+        np.testing.assert_array_equal(c.status[f], c2.status[f])
+    np.testing.assert_array_equal(c.status["kinematic_vel"][c.status["kinematic_vel_enabled"] == 1], c2.status["kinematic_vel"][c2.status["kinematic_vel_enabled"] == 1])
+    np.testing.assert_array_equal(c.phase["phase"], c2.phase["phase"])
+    np.testing.assert_array_equal(c.phase["psi_pos"], c2.phase["psi_pos"])
+    _same_models(ms.to_c_array(), ms2.to_c_array(), 7)
+    assert checkpoint.dump_bincode(c2, ms2) == (pb, mb)
+    with pytest.raises(ValueError):
+        checkpoint.load_bincode(pb + b"\\0", mb)
+
+
+@pytest.mark.gpu
+def test_resume_from_checkpoint_matches_uninterrupted_run(tmp_path):
+    from sparkl_amd.pipeline import MpmPipeline
+    from tests.parity import particle_errors
+    sc = scenes.sand_column(16, 10, 12, with_block=True)
+    dt = 2.5e-4
+    with MpmPipeline(sc.cell_width) as p:
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, dt, 80)
+        ref = p.read_particles()
+    with MpmPipeline(sc.cell_width) as p:
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, dt, 40)
+        checkpoint.save(tmp_path / "mid.npz", p.read_particles(), sc.models, sc.cell_width, params=sc.params, simulated_time=40 * dt)
+    c, models, header, params = checkpoint.load(tmp_path / "mid.npz")
+    with MpmPipeline(header["cell_width"]) as p:
+        p.set_models(models)
+        p.set_colliders(sc.colliders)
+        p.upload_particles(c)
+        p.substeps(params, sc.gravity, dt, 40)
+        got = p.read_particles()
+    e = particle_errors(got, ref, sc.cell_width)
+    # the re-bin after the upload orders particles differently from the uninterrupted run: f32 summation order only
+    assert e["eps_x"] < 1e-5 and e["eps_v"] < 1e-4 and e["failed_mismatch"] == 0, e

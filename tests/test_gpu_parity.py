@@ -278,6 +278,26 @@ def test_async_readback_snapshots_the_state_at_the_call(Pipeline):
         np.testing.assert_array_equal(plain["vector"], p.read_velocities()["vector"])
 
 
+def test_model_hot_reload_is_detected(Pipeline):
+    """cuda_particle_model_set.rs:61-84: an edited model is re-uploaded before the next step, an unchanged set is not."""
+    sc = scenes.elastic_cube(10)
+    with Pipeline(sc.cell_width) as p:
+        p.load_scene(sc)
+        assert p.ensure_models_are_uploaded(sc.models) is False
+        p.substeps(sc.params, sc.gravity, 1.0e-4, 5)
+        sc.models.get(0).constitutive_model.mu *= 4.0          # stiffen the material in place
+        assert p.ensure_models_are_uploaded(sc.models) is True
+        assert p.ensure_models_are_uploaded(sc.models) is False
+        p.substeps(sc.params, sc.gravity, 1.0e-4, 5)
+        edited = p.read_velocities()["vector"].copy()
+    sc2 = scenes.elastic_cube(10)
+    with Pipeline(sc2.cell_width) as p:                         # the same 10 substeps without the edit
+        p.load_scene(sc2)
+        p.substeps(sc2.params, sc2.gravity, 1.0e-4, 10)
+        plain = p.read_velocities()["vector"]
+    assert np.isfinite(edited).all() and np.abs(edited - plain).max() > 1e-3 * np.abs(plain).max()
+
+
 def test_append_remove_roundtrip(Pipeline):
     sc = scenes.sand_column(8, 6, 8)
     extra = scenes.sand_column(4, 4, 4).particles
