@@ -209,6 +209,113 @@ def test_rare_material_models_parity(Pipeline, name):
         assert extra["phase_mismatch"] <= max(2, acted // 100)
 
 
+def _edge_scenes():
+    def kinematic():
+        # config 5 in small: a kinematic cube ploughs through the sand bed (cube_through_sand3.rs:40-81)
+        return scenes.cube_through_sand(20, 6, 14, cube_n=6)
+
+    def static_and_failed():
+        sc = scenes.sand_column(14, 10, 10, with_block=True)
+        c = sc.particles
+        # a static slab at the bottom of the block: velocity and C zeroed after the update (grid_to_particle.rs:106-109)
+        y = c.position["point"][:, 1]
+        c.status["is_static"][y < y.min() + 0.11] = 1
+        c.status["failed"][4::17] = 1                       # no stress, F reset, still scatter mass (particle_to_grid.rs:43-47)
+        c.velocity["vector"][:, 1] = -1.0
+        return sc
+
+    def stick_and_locked_dof():
+        sc = scenes.sand_column(14, 10, 10, with_block=True)
+        sc.params.boundary_handling = abi.BOUNDARY_STICK
+        sc.params.simulation_dofs = abi.LOCK_Z              # grid_update.rs:60-74
+        sc.particles.velocity["vector"][:] = [0.5, -2.0, 0.7]
+        return sc
+
+    def damaged_sand():
+        # phase = 0 particles: DruckerPrager with only_active_when_failed, corotated stress split (phase != 1 path)
+        from sparkl_amd.models import CorotatedLinearElasticity, DruckerPragerPlasticity, ParticleModel, ParticleModelSet
+        sc = scenes.sand_column(12, 8, 10)
+        dp = DruckerPragerPlasticity(1.0e7, 0.2)
+        dp.only_active_when_failed = True
+        ms = ParticleModelSet()
+        ms.insert(ParticleModel.with_plasticity(CorotatedLinearElasticity(1.0e7, 0.2), dp))
+        sc.models = ms
+        sc.particles.status["model_index"] = 0
+        sc.particles.phase["phase"][::2] = 0.0
+        sc.particles.velocity["vector"][:, 1] = -2.0
+        return sc
+    return {"kinematic": kinematic, "static_and_failed": static_and_failed, "stick_and_locked_dof": stick_and_locked_dof, "damaged_sand": damaged_sand}
+
+
+@pytest.mark.parametrize("name", ["kinematic", "static_and_failed", "stick_and_locked_dof", "damaged_sand"])
+def test_status_flags_and_solver_options_parity(Pipeline, name):
+    sc = _edge_scenes()[name]()
+    dt = 2.5e-4
+    o32, o64 = _oracle(sc), _oracle(sc, f64=True)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        for _ in range(60):
+            o32.substep_fixed(sc.params, sc.gravity, dt)
+            o64.substep_fixed(sc.params, sc.gravity, dt)
+        p.substeps(sc.params, sc.gravity, dt, 60)
+        got, r32, r64 = p.read_particles(), o32.get_particles(), o64.get_particles()
+    e = particle_errors(got, r32, sc.cell_width)
+    floor = particle_errors(r32, r64, sc.cell_width)
+    _report(f"edge_{name}", {"vs_f32": e, "oracle_f32_vs_f64": floor})
+    assert e["failed_mismatch"] == 0 and e["eps_x"] <= TOL, (e, floor)
+    assert e["eps_v"] <= TOL or e["eps_v"] <= 3 * floor["eps_v"], (e, floor)
+    if name == "kinematic":
+        k = sc.particles.status["kinematic_vel_enabled"] == 1
+        np.testing.assert_array_equal(got.velocity["vector"][k], np.broadcast_to(np.float32([10.0, 0.0, 0.0]), (k.sum(), 3)))
+    if name == "static_and_failed":
+        st = sc.particles.status["is_static"] == 1
+        assert (got.velocity["vector"][st] == 0).all() and (got.velocity_gradient["m"][st] == 0).all()
+        fl = sc.particles.status["failed"] == 1
+        np.testing.assert_array_equal(got.volume["deformation_gradient"][fl], np.broadcast_to(np.eye(3, dtype=np.float32).reshape(9), (fl.sum(), 9)))
+    if name == "stick_and_locked_dof":
+        assert np.abs(got.velocity["vector"][:, 2]).max() == 0.0
+
+
+def test_empty_and_single_particle_sets(Pipeline):
+    """mls_solver.rs:25-28: an empty set steps trivially; one particle in free fall follows v = g t exactly enough."""
+    from sparkl_amd.particles import ParticleComponents
+    sc = scenes.sand_column(4, 4, 4)
+    with Pipeline(sc.cell_width) as p:
+        p.set_models(sc.models)
+        p.set_colliders(sc.colliders)
+        p.upload_particles(ParticleComponents(0))
+        assert len(p) == 0
+        t = p.step(sc.params, sc.gravity)
+        assert t == pytest.approx(sc.params.dt)
+        p.substeps(sc.params, sc.gravity, 1e-4, 3)
+        assert len(p.read_positions()) == 0
+        one = sc.particles.copy()
+        for k in one.__slots__:
+            setattr(one, k, getattr(one, k)[:1].copy())
+        one.position["point"][0] = [3.0, 3.0, 3.0]
+        p.upload_particles(one)
+        p.substeps(sc.params, sc.gravity, 1e-3, 50)
+        v = p.read_velocities()["vector"][0]
+    assert v[1] == pytest.approx(-9.81 * 0.05, rel=1e-4) and abs(v[0]) < 1e-6 and abs(v[2]) < 1e-6
+
+
+def test_reorder_policy_does_not_change_results(Pipeline):
+    """The in-place block reorder only changes f32 summation order: forced on every check vs never."""
+    sc = scenes.elastic_cube(16)
+    sc.particles.velocity["vector"] *= 25.0       # fast enough to fragment the lane runs within tens of substeps
+    out = {}
+    for tag, limit in (("off", 0.0), ("eager", 1.0)):
+        with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+            p.load_scene(sc)
+            p.reorder_policy_set(limit, 0.0)
+            p.substeps(sc.params, sc.gravity, 2.0e-4, 96)
+            out[tag] = (p.read_particles(), p.reorder_policy_stats())
+    e = particle_errors(out["eager"][0], out["off"][0], sc.cell_width)
+    _report("reorder_invariance", {**e, "reorders": out["eager"][1]["reorders"]})
+    assert out["off"][1]["reorders"] == 0 and out["eager"][1]["reorders"] >= 2
+    assert e["eps_x"] <= 1e-5 and e["eps_v"] <= 1e-4 and e["failed_mismatch"] == 0
+
+
 def test_adaptive_step_matches_oracle(Pipeline):
     """`MpmPipeline::step` with dt = 1/60: same substep count and lengths as the CPU path (mls_solver.rs:33-59)."""
     sc = scenes.sand_column(16, 10, 12, with_block=True)
