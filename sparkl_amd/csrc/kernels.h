@@ -300,6 +300,77 @@ SPK_DEV int p2g_scatter(double (*tile)[TILE_N], const Scatter& sc, bool live, in
     return nheads;
 }
 
+// Two particles per lane (slots 2j, 2j + 1: neighbours in the cell-sorted order, so usually the same cell).  Their node
+// values are added in the lane first, which halves the DPP reduction, the f64 conversions and the LDS atomic
+// instructions per particle; a pair that straddles two cells deposits its second particle on its own.
+template <int REDUCE_STEPS>
+SPK_DEV int p2g_scatter_pair(double (*tile)[TILE_N], const Scatter& sa, const Scatter& sb, bool live_a, bool live_b, int tid) {
+    static_assert(REDUCE_STEPS >= 2 && REDUCE_STEPS <= 4, "");
+    if (!__any(live_a | live_b)) return 0;
+    constexpr int G = 1 << REDUCE_STEPS;
+    const int lane = tid & 63;
+    const int r = lane & (G - 1);
+    const int key = live_a ? sa.base : -1;
+    const bool same = live_a & live_b & (sb.base == sa.base);
+    const bool lone_b = live_b & !same;
+    const int key_prev = dpp_shr1_i(key, -2), key_next = dpp_shl_i<1>(key);
+    const bool head = (r == 0) | (key_prev != key);
+    const int nheads = (int)__popcll(__ballot(live_a & head)) + (int)__popcll(__ballot(lone_b));
+    const bool any_lone = __any(lone_b);
+    const int i1 = ((r + 1 < G) & (key_next == key)) ? 1 : 0;
+    const int i2 = i1 & dpp_shl_i<1>(i1) & (r + 2 < G ? 1 : 0);
+    const int i4 = (REDUCE_STEPS >= 3) ? (i2 & dpp_shl_i<2>(i2) & (r + 4 < G ? 1 : 0)) : 0;
+    const int i8 = (REDUCE_STEPS >= 4) ? (i4 & dpp_shl_i<4>(i4) & (r + 8 < G ? 1 : 0)) : 0;
+    const float f1 = (float)i1, f2 = (float)i2, f4 = (float)i4, f8 = (float)i8;
+    const float fs = same ? 1.f : 0.f;
+    const f2v XA01 = {0.f, sa.A.m[0]}, XA23 = {sa.A.m[1], sa.A.m[2]}, XB01 = {0.f, sb.A.m[0]}, XB23 = {sb.A.m[1], sb.A.m[2]};
+#pragma unroll
+    for (int sz = 0; sz < 3; ++sz)
+#pragma unroll
+        for (int sy = 0; sy < 3; ++sy) {
+            const float wa_yz = sa.wgt[1][sy] * sa.wgt[2][sz], wb_yz = sb.wgt[1][sy] * sb.wgt[2][sz];
+            f2v PA01 = {sa.val_m, sa.qv[0] + sy * sa.A.m[3] + sz * sa.A.m[6]};
+            f2v PA23 = {sa.qv[1] + sy * sa.A.m[4] + sz * sa.A.m[7], sa.qv[2] + sy * sa.A.m[5] + sz * sa.A.m[8]};
+            f2v PB01 = {sb.val_m, sb.qv[0] + sy * sb.A.m[3] + sz * sb.A.m[6]};
+            f2v PB23 = {sb.qv[1] + sy * sb.A.m[4] + sz * sb.A.m[7], sb.qv[2] + sy * sb.A.m[5] + sz * sb.A.m[8]};
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx) {
+                if (sx > 0) { PA01 += XA01; PA23 += XA23; PB01 += XB01; PB23 += XB23; }
+                const float wa = sa.wgt[0][sx] * wa_yz, wb = sb.wgt[0][sx] * wb_yz;
+                const f2v b01 = PB01 * wb, b23 = PB23 * wb;
+                const f2v c01 = PA01 * wa + b01 * fs, c23 = PA23 * wa + b23 * fs;
+                float c0 = c01.x, c1 = c01.y, c2 = c23.x, c3 = c23.y;
+                if (REDUCE_STEPS == 2) {
+                    asm volatile("s_nop 1\n" SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2));
+                } else if (REDUCE_STEPS == 3) {
+                    asm volatile("s_nop 1\n" SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") SPK_FMAC_DPP("4", "%6")
+                                 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4));
+                } else {
+                    asm volatile("s_nop 1\n" SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") SPK_FMAC_DPP("4", "%6") SPK_FMAC_DPP("8", "%7")
+                                 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4), "v"(f8));
+                }
+                const int off = sx + TILE_W * sy + TILE_W * TILE_W * sz;
+                if (live_a && head) {
+                    const int n = sa.base + off;
+                    atomicAdd(&tile[0][n], (double)c0);
+                    atomicAdd(&tile[1][n], (double)c1);
+                    atomicAdd(&tile[2][n], (double)c2);
+                    atomicAdd(&tile[3][n], (double)c3);
+                }
+                if (any_lone) {   // wave-uniform
+                    if (lone_b) {
+                        const int n = sb.base + off;
+                        atomicAdd(&tile[0][n], (double)b01.x);
+                        atomicAdd(&tile[1][n], (double)b01.y);
+                        atomicAdd(&tile[2][n], (double)b23.x);
+                        atomicAdd(&tile[3][n], (double)b23.y);
+                    }
+                }
+            }
+        }
+    return nheads;
+}
+
 // Tile write-out (ends with the workgroup barrier the caller needs anyway).  Most blocks have no particle in the drift
 // margin, so only the 6^3 core (216 of 512 nodes) goes to HBM: -58 % tile traffic here and in the grid update.
 SPK_DEV void tile_write(double (*tile)[TILE_N], const GridArrays& G, int pb, int tid, bool shell_used) {
@@ -392,6 +463,54 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
             shell_used |= sc.shell != 0;
         }
         wave_heads += p2g_scatter<REDUCE_STEPS>(tile, sc, live, tid);
+    }
+    if ((tid & 63) == 0) atomicAdd(&s_heads, wave_heads);
+    tile_write(tile, G, pb, tid, shell_used);
+    if (tid == 0) atomicAdd(&ctl->heads[S.parity], (uint32_t)s_heads);
+}
+
+// k_p2g with two particles per lane (see p2g_scatter_pair).
+template <int REDUCE_STEPS>
+__global__ __launch_bounds__(BLK_THREADS) void k_p2g_pair(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models,
+                                                          Ctl* __restrict__ ctl, StepParams S) {
+    if (ctl->abort_flag[S.parity]) return;
+    __shared__ double tile[4][TILE_N];
+    __shared__ int s_heads;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_heads = 0;
+    if (blockIdx.x == 0 && tid == 0) disorder_policy(ctl, (S.parity + 1) & 1, S.parity);
+    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
+    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int pfirst = rng.x, pcount = rng.y;
+    const float h = S.h, inv_h = 1.0f / S.h;
+    __syncthreads();
+    bool shell_used = false;
+    int wave_heads = 0;
+    for (int base = 0; base < pcount; base += 2 * BLK_THREADS) {
+        Scatter sc[2];
+        bool live[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int li = base + 2 * tid + k;
+            const bool active = li < pcount;
+            const int i = pfirst + (active ? li : 0);
+            const float4 q0 = P.q[0][i], q1 = P.q[1][i], q2 = P.q[2][i], q3 = P.q[3][i], q4 = P.q[4][i], q5 = P.q[5][i], kk = P.k[i];
+            const uint32_t flags = __float_as_uint(kk.w);
+            live[k] = active && !(flags & FLAG_INVALID);
+            scatter_clear(sc[k]);
+            if (live[k]) {
+                const float px[3] = {q0.x, q0.y, q0.z}, v[3] = {q3.x, q3.y, q3.z};
+                const M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
+                const M3 C = {{q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
+                const DevModel& mo = models[flags >> FLAG_MODEL_SHIFT];
+                const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
+                const float jp = mo.is_fluid ? P.d[i].z : 1.f;
+                sc[k] = p2g_prepare(mo, flags, px, v, C, F, kk.x, kk.y, kk.z, phase, jp, org, h, inv_h, S.inv_d, S.dt);
+                shell_used |= sc[k].shell != 0;
+            }
+        }
+        wave_heads += p2g_scatter_pair<REDUCE_STEPS>(tile, sc[0], sc[1], live[0], live[1], tid);
     }
     if ((tid & 63) == 0) atomicAdd(&s_heads, wave_heads);
     tile_write(tile, G, pb, tid, shell_used);
