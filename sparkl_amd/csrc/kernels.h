@@ -1000,8 +1000,11 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
 // `S` carries substep s (parity, dt); the scatter uses the same dt (fixed) and writes the tiles of substep s+1.
 // The G2P half is always valid.  The P2G half is only valid if no particle left its tile margin; otherwise the
 // re-bin flag is raised, every later kernel is a no-op and the host re-bins and restarts with a standalone k_p2g.
+#ifndef SPK_G2P2G_MIN_BLOCKS
+#define SPK_G2P2G_MIN_BLOCKS 4
+#endif
 template <int REDUCE_STEPS, bool RARE>
-__global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
+__global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
     const int tid = threadIdx.x;
     if (ctl->abort_flag[S.parity]) {
         if (blockIdx.x == 0 && tid == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
@@ -1010,6 +1013,11 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p2g(ParticleArrays P, Grid
     __shared__ float4 vt[TILE_N];
     __shared__ double tile[4][TILE_N];
     __shared__ int s_heads;
+#ifdef SPK_EXP_LDS_PAD   // occupancy experiment: fewer resident workgroups per CU
+    __shared__ float lds_pad[SPK_EXP_LDS_PAD / 4];
+    if (S.h < 0.f) lds_pad[tid] = 1.f;
+    if (S.h < -1.f) tile[0][0] = lds_pad[tid + 1];
+#endif
     if (tid == 0) s_heads = 0;
     // this launch scatters for substep s + 1: its heads go to [(parity + 1) & 1], the previous scatter's are at [parity]
     if (blockIdx.x == 0 && tid == 0) disorder_policy(ctl, S.parity, S.parity);
@@ -1017,11 +1025,13 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p2g(ParticleArrays P, Grid
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int b = org.w, pfirst = rng.x, pcount = rng.y;
     const int niter = (pcount + BLK_THREADS - 1) / BLK_THREADS;
+#ifndef SPK_EXP_NO_PREFETCH
     float4 n0, n1, n2, nd, nk;
     {
         const int i0 = pfirst + min(tid, pcount - 1);
         n0 = P.q[0][i0]; n1 = P.q[1][i0]; n2 = P.q[2][i0]; nd = P.d[i0]; nk = P.k[i0];
     }
+#endif
     for (int n = tid; n < TILE_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
     load_vel_tile(vt, G, b, tid);
     if (blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
@@ -1033,11 +1043,15 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p2g(ParticleArrays P, Grid
         const int li = it * BLK_THREADS + tid;
         const bool active = li < pcount;
         const int i = pfirst + (active ? li : 0);
+#ifdef SPK_EXP_NO_PREFETCH
+        const float4 q0 = P.q[0][i], q1 = P.q[1][i], q2 = P.q[2][i], dd = P.d[i], kk = P.k[i];
+#else
         const float4 q0 = n0, q1 = n1, q2 = n2, dd = nd, kk = nk;
         if (it + 1 < niter) {
             const int inx = pfirst + min(li + BLK_THREADS, pcount - 1);
             n0 = P.q[0][inx]; n1 = P.q[1][inx]; n2 = P.q[2][inx]; nd = P.d[inx]; nk = P.k[inx];
         }
+#endif
         const uint32_t flags = __float_as_uint(kk.w);
         bool live = active && !(flags & FLAG_INVALID);
         Scatter sc;
