@@ -1164,41 +1164,65 @@ __global__ void k_reorder_done(Ctl* ctl, int parity) {
 // fluids_volume.rs:9-115: mass-only P2G (here), merge (k_grid_update<true>), then this gather.
 __global__ __launch_bounds__(BLK_THREADS) void k_p2g_mass(ParticleArrays P, GridArrays G, const Ctl* __restrict__ ctl, StepParams S) {
     if (ctl->abort_flag[S.parity]) return;
-    __shared__ float tile[TILE_N];
+    // same scheme as the full scatter: f64 LDS tile, same-cell lanes pre-summed over 16-lane groups with DPP (64 particles
+    // per cell in the fluid configs: without it every one of the 27 atomics of a wave hits one address 64 times)
+    __shared__ double tile[TILE_N];
     const int tid = threadIdx.x;
     const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
-    for (int n = tid; n < TILE_N; n += BLK_THREADS) tile[n] = 0.f;
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) tile[n] = 0.0;
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int pfirst = rng.x, pcount = rng.y;
     __syncthreads();
     const float h = S.h;
-    for (int li = tid; li < pcount; li += BLK_THREADS) {
-        const int i = pfirst + li;
+    const int lane = tid & 63, r = lane & 15;
+    const int niter = (pcount + BLK_THREADS - 1) / BLK_THREADS;
+    for (int it = 0; it < niter; ++it) {
+        const int li = it * BLK_THREADS + tid;
+        const bool active = li < pcount;
+        const int i = pfirst + (active ? li : 0);
         const float4 q0 = P.q[0][i], kk = P.k[i];
-        if (__float_as_uint(kk.w) & FLAG_INVALID) continue;
+        const bool live = active && !(__float_as_uint(kk.w) & FLAG_INVALID);
+        if (!__any(live)) continue;
         const float px[3] = {q0.x, q0.y, q0.z};
         const int orgv[3] = {org.x, org.y, org.z};
         float wgt[3][3];
         int lc[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const float r = roundf(px[a] / h);
-            const float d0 = (r - 1.0f) * h - px[a];
+            const float rc = roundf(px[a] / h);
+            const float d0 = (rc - 1.0f) * h - px[a];
             eval_all(-d0 / h, wgt[a]);
-            lc[a] = (int)r - 1 - orgv[a] + 1;
+            lc[a] = (int)rc - 1 - orgv[a] + 1;
         }
-        const int base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
+        const int base = live ? lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2] : 0;
+        const float m = live ? kk.x : 0.f;
+        const int key = live ? base : -1;
+        const int key_prev = dpp_shr1_i(key, -2), key_next = dpp_shl_i<1>(key);
+        const bool head = (r == 0) | (key_prev != key);
+        const int i1 = ((r + 1 < 16) & (key_next == key)) ? 1 : 0;
+        const int i2 = i1 & dpp_shl_i<1>(i1) & (r + 2 < 16 ? 1 : 0);
+        const int i4 = i2 & dpp_shl_i<2>(i2) & (r + 4 < 16 ? 1 : 0);
+        const int i8 = i4 & dpp_shl_i<4>(i4) & (r + 8 < 16 ? 1 : 0);
+        const float f1 = (float)i1, f2 = (float)i2, f4 = (float)i4, f8 = (float)i8;
 #pragma unroll
         for (int sz = 0; sz < 3; ++sz)
 #pragma unroll
-            for (int sy = 0; sy < 3; ++sy)
-#pragma unroll
-                for (int sx = 0; sx < 3; ++sx)
-                    atomicAdd(&tile[base + sx + TILE_W * sy + TILE_W * TILE_W * sz], (wgt[0][sx] * wgt[1][sy] * wgt[2][sz]) * kk.x);
+            for (int sy = 0; sy < 3; ++sy) {
+                const float wyz = wgt[1][sy] * wgt[2][sz] * m;
+                float c0 = wgt[0][0] * wyz, c1 = wgt[0][1] * wyz, c2 = wgt[0][2] * wyz, c3 = 0.f;   // c3 pads the four interleaved DPP chains
+                asm volatile("s_nop 1\n" SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") SPK_FMAC_DPP("4", "%6") SPK_FMAC_DPP("8", "%7")
+                             : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4), "v"(f8));
+                if (live && head) {
+                    const int n = base + TILE_W * sy + TILE_W * TILE_W * sz;
+                    atomicAdd(&tile[n], (double)c0);
+                    atomicAdd(&tile[n + 1], (double)c1);
+                    atomicAdd(&tile[n + 2], (double)c2);
+                }
+            }
     }
     __syncthreads();
     float4* out = G.tiles + (size_t)pb * TILE_N;
-    for (int n = tid; n < TILE_N; n += BLK_THREADS) out[n] = make_float4(tile[n], 0.f, 0.f, 0.f);
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) out[n] = make_float4((float)tile[n], 0.f, 0.f, 0.f);
     if (tid == 0) G.tile_mode[pb] = 1;
 }
 
