@@ -19,6 +19,7 @@ for line in open(f"profiles/{tag}_pmc_summary.txt"):
         write[m.group(1)] = float(vals["WRITE_SIZE"])
 out = {"source": f"profiles/{tag}_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, 10M particles)",
        "particles_per_gpu": 10000000, "correction": "bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE)  [gfx950: FETCH_SIZE counts 64 B per 128 B request]",
-       "bytes_per_launch": {k: 1024.0 * (2.0 * fetch[k] + write.get(k, 0.0)) for k in fetch}}
+       # k_p2g_pair reads 32 B per lane at a 32 B stride: the x2 calibration (16 B per lane streaming reads) does not cover it
+       "bytes_per_launch": {k: 1024.0 * (2.0 * fetch[k] + write.get(k, 0.0)) for k in fetch if k != "k_p2g_pair"}}
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
