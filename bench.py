@@ -213,7 +213,7 @@ def main():
             out["resort"] = {"count": int(clock.resorts), "ms_total": clock.sort_ms}
             if mode == "slabs":
                 out["halo_ms_per_step"] = clock.halo_ms / max(int(clock.sampled_substeps), 1)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only: the other ranks would sit in the final barrier
             threads = len(os.sched_getaffinity(0))
             out["cpu_baseline"] = cpu_baseline(threads)
         print(json.dumps(out))

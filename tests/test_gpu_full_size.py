@@ -106,6 +106,41 @@ def test_config4_fluid_slice_mass_and_volume(Pipeline):
     assert abs(float(np.median(J[bulk])) - 1.0) < 0.02 and np.isfinite(J).all()
 
 
+def test_config4_20M_fluid_dam_break_hash_churn(Pipeline):
+    """BASELINE configs[3] at its full size: 20 M fluid particles, 64 per cell.  The dam front breaks away, so node blocks
+    appear and disappear and the re-bin (key sort, block list, hash, neighbour tables) runs repeatedly; every rebuild
+    must keep the particle set intact (ids a permutation, mass unchanged, nothing failed, J finite and near 1 in the bulk)."""
+    import time
+    sc = scenes.fluid_dam(344, 240, 244)
+    n = len(sc.particles)
+    assert n >= 20_000_000
+    mass0 = float(sc.particles.volume["mass"].astype(np.float64).sum())
+    sc.particles.velocity["vector"][:, 0] = 12.0        # the whole dam already runs: the front crosses cells within tens of substeps
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.clock_enable(True, stride=16)
+        p.substeps(sc.params, sc.gravity, sc.fixed_dt, 4)
+        blocks0 = p.num_active_blocks()
+        p.sync()
+        t0 = time.perf_counter()
+        p.substeps(sc.params, sc.gravity, 5.0e-4, 160)
+        p.sync()
+        ms = 1e3 * (time.perf_counter() - t0) / 160
+        k = p.clock_read()
+        blocks1 = p.num_active_blocks()
+        ids = p.read_sorted_particle_ids()
+        vol = p.read_volumes()
+        st = p.read_statuses()
+        pos = p.read_positions()["point"]
+    print(f"20M fluid: {ms:.3f} ms/substep, re-bins {int(k.resorts)} ({k.sort_ms:.1f} ms), node blocks {blocks0} -> {blocks1}")
+    assert k.resorts >= 2 and blocks1 != blocks0, "the scene must churn the sparse grid"
+    assert np.array_equal(np.sort(ids), np.arange(n, dtype=ids.dtype))
+    assert float(vol["mass"].astype(np.float64).sum()) == mass0
+    assert st["failed"].sum() == 0 and np.isfinite(pos).all()
+    J = vol["deformation_gradient"][:, 0]
+    assert np.isfinite(J).all() and abs(float(np.median(J)) - 1.0) < 0.05
+
+
 def test_long_collapse_stays_sane(Pipeline):
     """2000 substeps (0.5 s) of a 0.5 M-particle sand column collapsing: re-bins happen, nothing blows up, mass is where it should be."""
     sc = scenes.sand_column(64, 128, 64)
