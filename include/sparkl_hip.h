@@ -239,7 +239,8 @@ int sparkl_hip_particles_upload(SparklPipeline* p, uint64_t n,
                                 const SparklParticlePhase* phase,
                                 const SparklParticleData* data,
                                 const SparklVelocityGradient* velocity_gradients);
-/* CudaParticleSet::append (cuda_particle_set.rs:135-177) */
+/* CudaParticleSet::append (cuda_particle_set.rs:135-177, cuda_vec.rs:56-81): incremental -- the buffers grow in place and
+ * only the new records cross PCIe; caller indices of the new particles continue after the old ones. */
 int sparkl_hip_particles_append(SparklPipeline* p, uint64_t n,
                                 const SparklParticleStatus* status,
                                 const SparklParticlePosition* pos,
@@ -248,7 +249,8 @@ int sparkl_hip_particles_append(SparklPipeline* p, uint64_t n,
                                 const SparklParticlePhase* phase,
                                 const SparklParticleData* data,
                                 const SparklVelocityGradient* velocity_gradients);
-/* CudaParticleSet::remove_range / truncate / len (cuda_particle_set.rs:73-133) */
+/* CudaParticleSet::remove_range / truncate / len (cuda_particle_set.rs:73-133, cuda_vec.rs:83-110): device side; later
+ * caller indices move down like a Vec's.  Triggers a re-bin. */
 int sparkl_hip_particles_remove_range(SparklPipeline* p, uint64_t start, uint64_t end);
 int sparkl_hip_particles_truncate(SparklPipeline* p, uint64_t new_len);
 uint64_t sparkl_hip_particles_len(const SparklPipeline* p);

@@ -1499,6 +1499,16 @@ __global__ void k_read_render(ParticleArrays P, float* pos, float* vel, float* p
     if (vel) { const float4 q3 = P.q[3][i]; vel[3 * o] = q3.x; vel[3 * o + 1] = q3.y; vel[3 * o + 2] = q3.z; }
     if (phase) { phase[2 * o] = P.aux[i].x; phase[2 * o + 1] = P.d[i].w; }
 }
+// `CudaVec::remove_range` on every component at once (cuda_vec.rs:83-110): callers index particles by insertion order, so
+// the ids in [start, end) go away (dropped by the re-bin that follows) and every later id moves down by end - start.
+__global__ void k_remove_ids(ParticleArrays P, int n, uint32_t id_base, uint32_t start, uint32_t end) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t* aux_w = reinterpret_cast<uint32_t*>(&P.aux[i]) + 3;
+    const uint32_t id = *aux_w - id_base;
+    if (id >= start && id < end) reinterpret_cast<uint32_t*>(&P.k[i])[3] |= FLAG_REMOVED;
+    else if (id >= end) *aux_w = id_base + id - (end - start);
+}
 __global__ void k_read_ids(ParticleArrays P, uint32_t* out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = particle_id(P, i);

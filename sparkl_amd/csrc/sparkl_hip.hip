@@ -874,11 +874,6 @@ int sparkl_hip_particles_read_sorted_ids(SparklPipeline* p, uint32_t* out, uint6
     return SPARKL_OK;
 }
 
-// append / remove_range / truncate: cold paths, implemented as read-modify-upload
-struct HostAll {
-    std::vector<SparklParticleStatus> st; std::vector<SparklParticlePosition> pos; std::vector<SparklParticleVelocity> vel;
-    std::vector<SparklParticleVolume> vol; std::vector<SparklParticlePhase> ph; std::vector<SparklParticleData> da; std::vector<SparklVelocityGradient> vg;
-};
 // ---- asynchronous render readback (testbed_plugin.rs:533-588)
 int sparkl_hip_host_alloc(void** out, uint64_t bytes) {
     if (!out) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
@@ -925,38 +920,36 @@ int sparkl_hip_readback_wait(SparklPipeline* p) {
     return SPARKL_OK;
 }
 
-static int read_all(SparklPipeline* p, HostAll& h) {
-    const uint64_t n = p->n;
-    h.st.resize(n); h.pos.resize(n); h.vel.resize(n); h.vol.resize(n); h.ph.resize(n); h.da.resize(n); h.vg.resize(n);
-    if (!n) return SPARKL_OK;
-    CHK(sparkl_hip_particles_read_statuses(p, h.st.data(), n)); CHK(sparkl_hip_particles_read_positions(p, h.pos.data(), n));
-    CHK(sparkl_hip_particles_read_velocities(p, h.vel.data(), n)); CHK(sparkl_hip_particles_read_volumes(p, h.vol.data(), n));
-    CHK(sparkl_hip_particles_read_phases(p, h.ph.data(), n)); CHK(sparkl_hip_particles_read_data(p, h.da.data(), n));
-    CHK(sparkl_hip_particles_read_velocity_gradients(p, h.vg.data(), n));
-    return SPARKL_OK;
-}
+// ---- append / remove_range / truncate: device side, the resident particles never travel to the host
 int sparkl_hip_particles_append(SparklPipeline* p, uint64_t n, const SparklParticleStatus* status, const SparklParticlePosition* pos,
                                 const SparklParticleVelocity* vel, const SparklParticleVolume* volume, const SparklParticlePhase* phase,
                                 const SparklParticleData* data, const SparklVelocityGradient* vg) {
     if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
     if (n == 0) return SPARKL_OK;
     if (!status || !pos || !vel || !volume || !phase || !data) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null particle array");
-    HostAll h;
-    CHK(read_all(p, h));
-    h.st.insert(h.st.end(), status, status + n); h.pos.insert(h.pos.end(), pos, pos + n); h.vel.insert(h.vel.end(), vel, vel + n);
-    h.vol.insert(h.vol.end(), volume, volume + n); h.ph.insert(h.ph.end(), phase, phase + n); h.da.insert(h.da.end(), data, data + n);
-    if (vg) h.vg.insert(h.vg.end(), vg, vg + n); else h.vg.resize(h.vg.size() + n, SparklVelocityGradient{{0, 0, 0, 0, 0, 0, 0, 0, 0}});
-    return sparkl_hip_particles_upload(p, h.st.size(), h.st.data(), h.pos.data(), h.vel.data(), h.vol.data(), h.ph.data(), h.da.data(), h.vg.data());
+    if (p->slab_on) return set_error(SPARKL_ERR_UNSUPPORTED, "append on a slab pipeline: ids are global there, add particles before sparkl_hip_slab_set");
+    if (p->n + n >= (1ull << 31) || p->id_offset + p->n + n > 0xFFFFFFFFull) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "at most 2^31 - 1 particles per device");
+    for (uint64_t i = 0; i < n; ++i)
+        if (status[i].model_index >= (1ull << 24)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "model_index too large");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    // `CudaVec::append` (cuda_vec.rs:56-81): grow (x1.5, old contents kept), write the new records behind the old ones; the
+    // resident particles never leave the device.  The next step re-bins.
+    CHK(p->cur.reserve(p->n + n, true, p->stream));
+    CHK(upload_range(p, p->n, n, status, pos, vel, volume, phase, data, vg));
+    p->n += n;
+    p->sorted = false;
+    return SPARKL_OK;
 }
 int sparkl_hip_particles_remove_range(SparklPipeline* p, uint64_t start, uint64_t end) {
     if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
     if (start > end || end > p->n) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "bad range [%llu, %llu) of %llu", (unsigned long long)start, (unsigned long long)end, (unsigned long long)p->n);
     if (start == end) return SPARKL_OK;
-    HostAll h;
-    CHK(read_all(p, h));
-    auto cut = [&](auto& v) { v.erase(v.begin() + start, v.begin() + end); };
-    cut(h.st); cut(h.pos); cut(h.vel); cut(h.vol); cut(h.ph); cut(h.da); cut(h.vg);
-    return sparkl_hip_particles_upload(p, h.st.size(), h.st.data(), h.pos.data(), h.vel.data(), h.vol.data(), h.ph.data(), h.da.data(), h.vg.data());
+    if (p->slab_on) return set_error(SPARKL_ERR_UNSUPPORTED, "remove_range on a slab pipeline");
+    HIPCHK(hipSetDevice(p->device));
+    hipLaunchKernelGGL(k_remove_ids, dim3(grid_for(p->n, 256)), dim3(256), 0, p->stream, p->cur.arrays(), (int)p->n, (uint32_t)p->id_offset, (uint32_t)start, (uint32_t)end);
+    p->sorted = false;
+    return resort(p);   // compacts: the removed records sort behind every live one and p->n drops
 }
 int sparkl_hip_particles_truncate(SparklPipeline* p, uint64_t new_len) {
     if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");

@@ -422,6 +422,37 @@ def test_append_remove_roundtrip(Pipeline):
     np.testing.assert_array_equal(before.volume["deformation_gradient"], after.volume["deformation_gradient"])
 
 
+def test_incremental_append_and_remove_follow_vec_semantics(Pipeline):
+    """`CudaVec::{append, remove_range}` (cuda_vec.rs:56-110) on all components: caller indices behave like a Vec's."""
+    a, b = scenes.sand_column(8, 6, 8).particles, scenes.sand_column(5, 4, 3).particles
+    b.position["point"] += np.float32([3.0, 0.0, 0.0])
+    b.velocity["vector"][:] = [0.0, 1.0, 0.0]
+    sc = scenes.sand_column(8, 6, 8)
+    with Pipeline(sc.cell_width) as p:
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, 2.5e-4, 4)          # binned and physically re-ordered by now
+        state = p.read_particles()
+        p.append_particles(b)
+        assert len(p) == len(a) + len(b)
+        got = p.read_particles()
+        for k in ("position", "velocity", "volume", "status", "phase", "data", "velocity_gradient"):
+            want = np.concatenate([getattr(state, k), getattr(b, k)])
+            assert getattr(got, k).tobytes() == want.tobytes(), k
+        # drop a range that straddles the old and the new particles
+        lo, hi = len(a) - 37, len(a) + 11
+        p.remove_range(lo, hi)
+        assert len(p) == len(a) + len(b) - (hi - lo)
+        got2 = p.read_particles()
+        keep = np.r_[0:lo, hi:len(a) + len(b)]
+        for k in ("position", "velocity", "volume", "status", "phase", "data", "velocity_gradient"):
+            assert getattr(got2, k).tobytes() == getattr(got, k)[keep].tobytes(), k
+        p.substeps(sc.params, sc.gravity, 2.5e-4, 4)          # and the set still steps
+        assert np.isfinite(p.read_positions()["point"]).all()
+        p.truncate(10)
+        assert len(p) == 10
+        np.testing.assert_array_equal(p.read_statuses()["model_index"], got2.status["model_index"][:10])
+
+
 def test_out_of_domain_particles_fail_like_reference(Pipeline):
     """particle_set.rs:129-136: a particle whose neighbourhood leaves the SPGrid is flagged failed."""
     sc = scenes.sand_column(8, 6, 8)
