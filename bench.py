@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--particles", type=float, default=10.0e6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-clock", action="store_true", help="skip the per-kernel hipEvent spans")
+    ap.add_argument("--no-late-phase", dest="late_phase", action="store_false", help="skip the informational flowing-phase measurement")
     args = ap.parse_args()
 
     import torch
@@ -166,6 +167,16 @@ def main():
         elapsed = float(tt.item())
     clock = None if args.no_kernel_clock else pipe.clock_read(reset=False)
     n_blocks, n_pblocks = pipe.num_active_blocks(), pipe.num_particle_blocks()
+    # informational, outside the timed region and never part of `value`: the same column once it flows (cells hold uneven
+    # particle counts, re-bins and in-place reorders happen) -- see profiles/r01_reorder_policy.txt
+    late = None
+    if world == 1 and args.late_phase:
+        run(max(0, 640 - args.steps - args.warmup))
+        pipe.sync()
+        t1 = time.perf_counter()
+        run(128)
+        pipe.sync()
+        late = {"substeps_before": max(640, args.steps + args.warmup), "substeps_timed": 128, "ms_per_step": 1e3 * (time.perf_counter() - t1) / 128}
 
     if rank == 0:
         total_particles = n_particles * world
@@ -213,6 +224,8 @@ def main():
             out["resort"] = {"count": int(clock.resorts), "ms_total": clock.sort_ms}
             if mode == "slabs":
                 out["halo_ms_per_step"] = clock.halo_ms / max(int(clock.sampled_substeps), 1)
+        if late is not None:
+            out["late_collapse"] = late
         if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only: the other ranks would sit in the final barrier
             threads = len(os.sched_getaffinity(0))
             out["cpu_baseline"] = cpu_baseline(threads)

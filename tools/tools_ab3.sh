@@ -5,7 +5,7 @@ export SPARKL_HIP_LIB_AB=1
 for lib in "$@"; do
   export SPARKL_HIP_LIB=$PWD/sparkl_amd/lib/$lib
   echo "=== $lib"
-  python bench.py --steps 96 --warmup 16 --no-cpu-baseline 2>/dev/null | python -c "
+  python bench.py --steps 96 --warmup 16 --no-cpu-baseline --no-late-phase 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 print('ms/step %.3f  kernels %s' % (d['ms_per_step'], {k: round(v, 3) for k, v in d['kernels_avg_launch_ms'].items()}))"
