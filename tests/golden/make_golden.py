@@ -14,23 +14,43 @@ sys.path.insert(0, ROOT)
 
 from oracle import Oracle  # noqa: E402
 from sparkl_amd import scenes  # noqa: E402
+from sparkl_amd.models import (CorotatedLinearElasticity, MaximumStressFailure, NaccPlasticity, NeoHookeanElasticity, RankinePlasticity,  # noqa: E402
+                               SnowPlasticity)
 
 CASES = {
     "sand3_like": (lambda: scenes.sand_column(12, 8, 10, with_block=True), 2.5e-4),
     "neo_hookean": (lambda: scenes.elastic_cube(12), 1.0e-4),
     "fluid": (lambda: scenes.fluid_dam(16, 12, 12), 1.0e-4),
+    # heightfield ground and the material models no 3-D example uses (60 substeps so that they act)
+    "heightfield": (lambda: _moving(scenes.sand_on_heightfield(10, 6, 8)), 2.5e-4),
+    "snow": (lambda: scenes.block_on_floor(10, CorotatedLinearElasticity(1.4e5, 0.2), SnowPlasticity(), density=400.0, v0=(0.0, -8.0, 0.0), dt=2.0e-4, name="snow"), 2.0e-4),
+    "rankine": (lambda: scenes.block_on_floor(10, NeoHookeanElasticity(1.0e6, 0.3), RankinePlasticity(1.0e6, 0.3, 5.0e4, 5.0), expand=6.0, v0=(0.0, 0.0, 0.0),
+                                              gravity=(0.0, 0.0, 0.0), name="rankine"), 1.0e-4),
+    "nacc": (lambda: scenes.block_on_floor(10, NeoHookeanElasticity(2.0e5, 0.3), NaccPlasticity(2.0e5, 0.3, 0.05, True, 1.5, 0.6108652), density=1500.0,
+                                           v0=(0.0, -8.0, 0.0), dt=2.0e-4, name="nacc"), 2.0e-4),
+    "failure": (lambda: scenes.block_on_floor(10, CorotatedLinearElasticity(1.0e6, 0.3), None, MaximumStressFailure(5.0e4, 4.0e4), expand=6.0, v0=(0.0, 0.0, 0.0),
+                                              gravity=(0.0, 0.0, 0.0), name="failure"), 1.0e-4),
 }
+STEPS = {"heightfield": (1, 60), "snow": (1, 60), "rankine": (1, 60), "nacc": (1, 60), "failure": (1, 60)}   # default (1, 10)
+
+
+def _moving(sc):
+    sc.particles.velocity["vector"][:, 1] = -3.0
+    return sc
 
 
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
+    only = sys.argv[1:]
     for name, (build, dt) in CASES.items():
+        if only and name not in only:
+            continue
         sc = build()
         o = Oracle(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes)
         o.load_scene(sc)
         out = {"dt": dt, "n": len(sc.particles), "pos0": sc.particles.position["point"]}
         done = 0
-        for k in (1, 10):
+        for k in STEPS.get(name, (1, 10)):
             for _ in range(k - done):
                 o.substep_fixed(sc.params, sc.gravity, dt)
             done = k
@@ -39,7 +59,8 @@ def main():
             out[f"vel{k}"] = c.velocity["vector"]
             out[f"F{k}"] = c.volume["deformation_gradient"]
             out[f"C{k}"] = c.velocity_gradient["m"]
-            out[f"data{k}"] = np.stack([c.data["plastic_hardening"], c.data["log_vol_gain"], c.volume["plastic_deformation_gradient_det"]], 1)
+            out[f"data{k}"] = np.stack([c.data["plastic_hardening"], c.data["log_vol_gain"], c.volume["plastic_deformation_gradient_det"],
+                                        c.data["elastic_hardening"], c.data["nacc_alpha"], c.phase["phase"]], 1)
         np.savez_compressed(os.path.join(out_dir, f"trajectory_{name}.npz"), **out)
         print(name, len(sc.particles), "particles")
 

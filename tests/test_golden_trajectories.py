@@ -8,13 +8,30 @@ import numpy as np
 import pytest
 
 from sparkl_amd import scenes
+from sparkl_amd.models import (CorotatedLinearElasticity, MaximumStressFailure, NaccPlasticity, NeoHookeanElasticity, RankinePlasticity,
+                               SnowPlasticity)
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 CASES = {
     "sand3_like": (lambda: scenes.sand_column(12, 8, 10, with_block=True), 2.5e-4),
     "neo_hookean": (lambda: scenes.elastic_cube(12), 1.0e-4),
     "fluid": (lambda: scenes.fluid_dam(16, 12, 12), 1.0e-4),
+    # heightfield ground and the material models no 3-D example uses (60 substeps so that they act)
+    "heightfield": (lambda: _moving(scenes.sand_on_heightfield(10, 6, 8)), 2.5e-4),
+    "snow": (lambda: scenes.block_on_floor(10, CorotatedLinearElasticity(1.4e5, 0.2), SnowPlasticity(), density=400.0, v0=(0.0, -8.0, 0.0), dt=2.0e-4, name="snow"), 2.0e-4),
+    "rankine": (lambda: scenes.block_on_floor(10, NeoHookeanElasticity(1.0e6, 0.3), RankinePlasticity(1.0e6, 0.3, 5.0e4, 5.0), expand=6.0, v0=(0.0, 0.0, 0.0),
+                                              gravity=(0.0, 0.0, 0.0), name="rankine"), 1.0e-4),
+    "nacc": (lambda: scenes.block_on_floor(10, NeoHookeanElasticity(2.0e5, 0.3), NaccPlasticity(2.0e5, 0.3, 0.05, True, 1.5, 0.6108652), density=1500.0,
+                                           v0=(0.0, -8.0, 0.0), dt=2.0e-4, name="nacc"), 2.0e-4),
+    "failure": (lambda: scenes.block_on_floor(10, CorotatedLinearElasticity(1.0e6, 0.3), None, MaximumStressFailure(5.0e4, 4.0e4), expand=6.0, v0=(0.0, 0.0, 0.0),
+                                              gravity=(0.0, 0.0, 0.0), name="failure"), 1.0e-4),
 }
+STEPS = {"heightfield": (1, 60), "snow": (1, 60), "rankine": (1, 60), "nacc": (1, 60), "failure": (1, 60)}   # default (1, 10)
+
+
+def _moving(sc):
+    sc.particles.velocity["vector"][:, 1] = -3.0
+    return sc
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -27,7 +44,7 @@ def test_oracle_reproduces_golden(name):
     o = Oracle(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes)
     o.load_scene(sc)
     done = 0
-    for k in (1, 10):
+    for k in STEPS.get(name, (1, 10)):
         for _ in range(k - done):
             o.substep_fixed(sc.params, sc.gravity, dt)
         done = k
@@ -47,7 +64,7 @@ def test_hip_matches_golden(name):
     with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
         p.load_scene(sc)
         done = 0
-        for k in (1, 10):
+        for k in STEPS.get(name, (1, 10)):
             p.substeps(sc.params, sc.gravity, dt, k - done)
             done = k
             c = p.read_particles()
@@ -56,5 +73,7 @@ def test_hip_matches_golden(name):
             ev = np.linalg.norm(c.velocity["vector"] - g[f"vel{k}"], axis=1).max() / vmax
             eF = np.abs(c.volume["deformation_gradient"] - g[f"F{k}"]).max()
             # 1e-4 on positions; velocities of the stiff sand sit on its f32 noise floor
-            assert ex <= 1e-4 and eF <= 1e-4, (name, k, ex, ev, eF)
-            assert ev <= (1e-3 if name == "sand3_like" else 1e-4), (name, k, ev)
+            # NACC snaps particles onto the tips / the yield surface by thresholds: a particle sitting on one may take the other
+            # branch (the f32 and f64 oracles differ by 6e-3 in F there, test_rare_material_models_parity)
+            assert ex <= 1e-4 and eF <= (1e-2 if name == "nacc" else 1e-4), (name, k, ex, ev, eF)
+            assert ev <= (1e-3 if name in ("sand3_like", "heightfield") else 1e-4), (name, k, ev)
