@@ -79,6 +79,7 @@ struct GridArrays {
     float4* node_vel;          // [B][64]  (vx, vy, vz, mass)
     float4* node_mom;          // [B][64]  (px, py, pz, -) debug capture or NULL
     const float4* halo_in;     // [B][64]  (mass, px, py, pz) received from neighbour slabs, or NULL
+    uint32_t* dt_partial;      // [gridDim] per-workgroup minimum of the dt bound (float bits), reduced by k_dt_reduce
     int num_blocks;
     int num_pblocks;
 };
@@ -95,6 +96,7 @@ struct StepParams {
     int num_cuboids;
     int num_heightfields;
     int want_dt;      // G2P also reduces the next substep's dt bound into ctl->dt_bits (adaptive stepping)
+    float dt_next;    // k_g2p2g: the step length the fused scatter (P2G of the NEXT substep) is built for; = dt for fixed-dt batches
 };
 
 struct DevCuboid {
@@ -768,12 +770,37 @@ SPK_DEV bool failure_check(const DevModel& mo, float phase, float eh, const M3& 
     return maximum_stress_failed(mo, tau);
 }
 
-// Global minimum of the dt bound (float bits, dt >= 0 so the integer order is the float order).  156 k waves hammering one
-// address with atomicMin cost 1.6 ms at 10M particles; the running minimum is read first (a stale, larger value only
-// costs a redundant atomic) and the atomic is issued by the few waves that actually lower it.
-SPK_DEV void dt_min_publish(uint32_t* target, float dt) {
-    const uint32_t bits = __float_as_uint(dt);
-    if (bits < __atomic_load_n(target, __ATOMIC_RELAXED)) atomicMin(target, bits);
+// Minimum of the dt bound over the particles (float bits; dt >= 0, so the integer order is the float order).  No global
+// atomics: one atomicMin per wave on a single word cost 1.6 ms at 10M particles (the L2 serialises ~10 ns per operation on
+// one line, plain or atomic), and a read-before-atomic filter still cost 1.2 ms inside k_g2p2g, whose run-head counters
+// share the line.  Each workgroup stores its minimum; k_dt_reduce (one workgroup) folds them into ctl->dt_bits.
+SPK_DEV void dt_block_min_store(uint32_t* dt_partial, float dt_bound, bool dt_nan, Ctl* ctl, int tid) {
+    __shared__ uint32_t s_dt[BLK_THREADS / 64];
+    if (dt_nan) dt_bound = 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dt_bound = fminf(dt_bound, __shfl_xor(dt_bound, off));
+    if ((tid & 63) == 0) s_dt[tid >> 6] = __float_as_uint(dt_bound);
+    if (__any(dt_nan) && (tid & 63) == 0) ctl->dt_nan = 1u;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t m = s_dt[0];
+#pragma unroll
+        for (int w = 1; w < BLK_THREADS / 64; ++w) m = min(m, s_dt[w]);
+        dt_partial[blockIdx.x] = m;
+    }
+}
+__global__ __launch_bounds__(1024) void k_dt_reduce(const uint32_t* __restrict__ dt_partial, int n, Ctl* ctl) {
+    __shared__ uint32_t s[16];
+    uint32_t m = 0x7f7fffffu;   // f32::MAX
+    for (int i = threadIdx.x; i < n; i += 1024) m = min(m, dt_partial[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) m = min(m, s[w]);
+        ctl->dt_bits = m;
+    }
 }
 
 // State of one particle after grid_to_particle.rs:62-164 (gather .. psi_pos), before it is written back.
@@ -995,11 +1022,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
         if ((tid & 63) == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
     }
     if (S.want_dt) {
-        if (dt_nan) dt_bound = 0.f;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) dt_bound = fminf(dt_bound, __shfl_xor(dt_bound, off));
-        if ((tid & 63) == 0) dt_min_publish(&ctl->dt_bits, dt_bound);
-        if (__any(dt_nan) && (tid & 63) == 0) ctl->dt_nan = 1u;
+        dt_block_min_store(G.dt_partial, dt_bound, dt_nan, ctl, tid);
     }
 }
 
@@ -1047,6 +1070,8 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     const float h = S.h, inv_h = 1.0f / S.h;
     bool want_sort = false, shell_used = false;
     int wave_heads = 0;
+    float dt_bound = 3.402823466e+38f;
+    bool dt_nan = false;
     for (int it = 0; it < niter; ++it) {
         const int li = it * BLK_THREADS + tid;
         const bool active = li < pcount;
@@ -1071,7 +1096,12 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
             g2p_store(P, i, o);
             want_sort |= !o.in_tile;
             live = o.in_tile;
-            if (live) { sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.F, kk.x, kk.y, o.eh, o.phase, o.Jp, org, h, inv_h, S.inv_d, S.dt); shell_used |= sc.shell != 0; }
+            if (S.want_dt) {  // the bound the next substep's estimator would compute from this state
+                const float bnd = particle_dt_bound(mo, o.flags, o.vel, o.C, kk.x, kk.y, o.eh, o.F.m[0], S.h);
+                dt_nan |= bnd != bnd;
+                dt_bound = fminf(dt_bound, bnd);
+            }
+            if (live) { sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.F, kk.x, kk.y, o.eh, o.phase, o.Jp, org, h, inv_h, S.inv_d, S.dt_next); shell_used |= sc.shell != 0; }
         }
         wave_heads += p2g_scatter<REDUCE_STEPS>(tile, sc, live, tid);
     }
@@ -1080,6 +1110,9 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     if (tid == 0) atomicAdd(&ctl->heads[(S.parity + 1) & 1], (uint32_t)s_heads);
     if (__any(want_sort)) {
         if ((tid & 63) == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
+    }
+    if (S.want_dt) {
+        dt_block_min_store(G.dt_partial, dt_bound, dt_nan, ctl, tid);
     }
 }
 
@@ -1279,7 +1312,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p_volume(ParticleArrays P, Gr
 
 // ----------------------------------------------------------------------------------- dt estimate
 // timestep_estimator.rs:10-51: min over particles of the velocity bound and the model bound.
-__global__ __launch_bounds__(BLK_THREADS) void k_estimate_dt(ParticleArrays P, const DevModel* __restrict__ models, Ctl* ctl, int n, float h) {
+__global__ __launch_bounds__(BLK_THREADS) void k_estimate_dt(ParticleArrays P, const DevModel* __restrict__ models, Ctl* ctl, int n, float h, uint32_t* dt_partial) {
     const int i = blockIdx.x * BLK_THREADS + threadIdx.x;
     float dt = 3.402823466e+38f;
     bool nan = false;
@@ -1292,11 +1325,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_estimate_dt(ParticleArrays P, c
         dt = particle_dt_bound(mo, flags, v, C, kk.x, kk.y, kk.z, mo.is_fluid ? P.q[0][i].w : 1.f, h);
         nan = dt != dt;
     }
-    if (nan) dt = 0.f;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) dt = fminf(dt, __shfl_xor(dt, off));
-    if ((threadIdx.x & 63) == 0) dt_min_publish(&ctl->dt_bits, dt);
-    if (__any(nan) && (threadIdx.x & 63) == 0) ctl->dt_nan = 1u;
+    dt_block_min_store(dt_partial, dt, nan, ctl, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------- re-bin (resort)

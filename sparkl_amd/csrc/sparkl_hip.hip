@@ -139,6 +139,7 @@ struct SparklPipeline {
     DevBuf<uint32_t> idx_a, idx_b, pb_counts, pb_first, cand_a, cand_b;
     DevBuf<uint8_t> cub_temp;
     DevBuf<int> d_scalars;  // [0] num_runs, [1] num_unique
+    DevBuf<uint32_t> dt_partial;            // per-workgroup dt-bound minima (adaptive stepping)
     DevBuf<float> staging;
     float reorder_limit = -1.f, rebin_limit = 0.f;   // sparkl_hip_reorder_policy_set: < 0 = default, 0 = off
     DevBuf<float> rb_staging;               // asynchronous render readback: 8 floats per particle, own copy stream
@@ -149,6 +150,8 @@ struct SparklPipeline {
     DevBuf<unsigned long long> d_count;
 
     // clock: per-kernel hipEvent spans on every clock_stride-th substep (events cost ~2 % when on every launch)
+    uint32_t spec_prev_bound_bits = 0;   // adaptive step: speculative fusion bookkeeping (sparkl_hip_pipeline_step)
+    uint64_t spec_hits = 0, spec_misses = 0;
     bool rare_models = false;      // some model needs the kernels that carry snow / Rankine / NACC / failure code
     bool fuse_fixed_dt = true;     // SPARKL_HIP_NO_FUSE=1 in the environment turns the fused schedule off (A/B)
     bool clock_on = false;
@@ -212,7 +215,7 @@ static constexpr uint32_t REORDER_PERIOD = 16;   // substeps between (mostly no-
 
 static GridArrays grid_arrays(const SparklPipeline* p) {
     GridArrays g;
-    g.blk_origin = p->blk_origin.p; g.blk_pfirst = p->blk_pfirst.p; g.blk_pcount = p->blk_pcount.p; g.blk_nbr = p->blk_nbr.p; g.blk_tnbr = p->blk_tnbr.p;
+    g.blk_origin = p->blk_origin.p; g.blk_pfirst = p->blk_pfirst.p; g.blk_pcount = p->blk_pcount.p; g.blk_nbr = p->blk_nbr.p; g.blk_tnbr = p->blk_tnbr.p; g.dt_partial = p->dt_partial.p;
     g.pblk = p->pblk.p; g.pb_info = p->pb_info.p; g.tile_mode = p->tile_mode.p; g.tiles = p->tiles.p; g.node_vel = p->node_vel.p; g.node_mom = p->capture_mom ? p->node_mom.p : nullptr;
     g.halo_in = (p->slab_on && p->num_blocks) ? p->halo_in.p : nullptr;
     g.num_blocks = p->num_blocks; g.num_pblocks = p->num_pblocks;
@@ -374,6 +377,7 @@ static StepParams make_params(const SparklPipeline* p, const SparklSolverParams*
     S.gx = g[0]; S.gy = g[1]; S.gz = g[2];
     S.boundary_handling = sp->boundary_handling; S.dofs = sp->simulation_dofs;
     S.parity = (int)(p->substep_index & 1u); S.dom = p->dom; S.num_cuboids = p->num_cuboids; S.num_heightfields = p->num_heightfields; S.want_dt = 0;
+    S.dt_next = dt;
     return S;
 }
 
@@ -448,6 +452,45 @@ static int enqueue_substep(SparklPipeline* p, const SparklSolverParams* sp, cons
     return SPARKL_OK;
 }
 
+// One substep of the adaptive loop.  `reuse_tiles`: the previous substep's fused kernel already scattered for exactly this dt.
+// `dt_guess` > 0: run G2P fused with the scatter of the next substep built for that step length (speculation, see
+// sparkl_hip_pipeline_step); otherwise the plain G2P.  Both reduce the next dt bound.
+static int enqueue_adaptive_substep(SparklPipeline* p, const SparklSolverParams* sp, const float g[3], float dt, bool reuse_tiles, float dt_guess) {
+    if (p->num_pblocks == 0) { p->substep_index++; return SPARKL_OK; }
+    hipStream_t st = p->stream;
+    StepParams S = make_params(p, sp, g, dt);
+    S.want_dt = 1;
+    const GridArrays G = grid_arrays(p);
+    const ParticleArrays P = p->cur.arrays();
+    size_t t0 = 0, t1 = 0, t2 = 0;
+    const bool was_on = p->clock_on;
+    if (was_on && (p->substep_index % p->clock_stride) != 0) p->clock_on = false;
+    if (p->clock_on) p->clock_sampled++;
+    CHK(maybe_reorder(p, S.parity));
+    if (!reuse_tiles) {
+        CHK(clock_begin(p, SPAN_P2G, &t0));
+        launch_p2g(p, P, G, S, st);
+        CHK(clock_end(p, t0));
+    }
+    CHK(clock_begin(p, SPAN_GRID, &t1));
+    launch_grid_update(p, G, S, st);
+    CHK(clock_end(p, t1));
+    if (dt_guess > 0.f) {
+        S.dt_next = dt_guess;
+        CHK(clock_begin(p, SPAN_FUSED, &t2));
+        launch_g2p2g(p, P, G, S, st);
+        CHK(clock_end(p, t2));
+    } else {
+        CHK(clock_begin(p, SPAN_G2P, &t2));
+        launch_g2p(p, P, G, S, st);
+        CHK(clock_end(p, t2));
+    }
+    hipLaunchKernelGGL(k_dt_reduce, dim3(1), dim3(1024), 0, st, p->dt_partial.p, p->num_pblocks, p->d_ctl);
+    p->clock_on = was_on;
+    p->substep_index++;
+    return SPARKL_OK;
+}
+
 // Fixed-dt batch with the fused schedule:  P2G_s ; { GU ; G2P+P2G } x (n-1) ; GU ; G2P.  Same arithmetic as the
 // unfused order (the scatter of substep s+1 starts from the registers G2P of substep s just produced).
 static int enqueue_fused_batch(SparklPipeline* p, const SparklSolverParams* sp, const float g[3], float dt, uint32_t n) {
@@ -465,8 +508,10 @@ static int enqueue_fused_batch(SparklPipeline* p, const SparklSolverParams* sp, 
         CHK(clock_end(p, tk));
         p->clock_on = was_on;
     }
+    static const int force_want_dt = getenv("SPARKL_HIP_FORCE_WANT_DT") ? atoi(getenv("SPARKL_HIP_FORCE_WANT_DT")) : 0;   // experiment
     for (uint32_t j = 0; j < n; ++j) {
-        const StepParams S = make_params(p, sp, g, dt);
+        StepParams S = make_params(p, sp, g, dt);
+        S.want_dt = force_want_dt;
         if (was_on && (p->substep_index % p->clock_stride) != 0) p->clock_on = false;
         if (p->clock_on) p->clock_sampled++;
         if (j > 0) CHK(maybe_reorder(p, S.parity));   // between two fused kernels: the tiles of this substep are already scattered
@@ -549,7 +594,7 @@ void sparkl_hip_pipeline_destroy(SparklPipeline* p) {
     p->tiles.release(); p->node_vel.release(); p->node_mom.release(); p->hash_keys.release(); p->hash_vals.release();
     p->keys_a.release(); p->keys_b.release(); p->pb_keys.release(); p->bkeys.release(); p->idx_a.release(); p->idx_b.release();
     p->pb_counts.release(); p->pb_first.release(); p->cand_a.release(); p->cand_b.release(); p->cub_temp.release(); p->d_scalars.release();
-    p->staging.release(); p->node_staging.release(); p->d_count.release();
+    p->staging.release(); p->node_staging.release(); p->d_count.release(); p->dt_partial.release();
     if (p->rb_stream) { (void)hipStreamSynchronize(p->rb_stream); (void)hipStreamDestroy(p->rb_stream); (void)hipEventDestroy(p->rb_gathered); (void)hipEventDestroy(p->rb_done); }
     p->rb_staging.release();
     for (auto e : p->ev_pool) (void)hipEventDestroy(e);
@@ -1020,24 +1065,50 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
     const float fmax = std::numeric_limits<float>::max();
     uint32_t init_bits;
     memcpy(&init_bits, &fmax, 4);
+    // Speculative fusion.  The P2G of substep s+1 depends on dt_{s+1}, which is only known after G2P of substep s -- but in
+    // the usual regime (stiffness-bound: alpha h / c_sound, the same f32 number every substep) it can be predicted exactly:
+    // dt' = min(remaining, max_substep_dt, bound_s).  While two consecutive bounds agree bit for bit, G2P runs fused with the
+    // scatter for dt'; if the next substep then asks for another step length the tiles are simply scattered again.
+    // The substep sequence is the reference's in every case.
+    CHK(p->dt_partial.reserve(std::max<size_t>(grid_for(p->n, BLK_THREADS), (size_t)std::max(p->num_pblocks, 1))));
+    const bool may_fuse = p->fuse_fixed_dt && !(params->force_fluids_volume_recomputation && p->any_fluid) && !params->stop_after_one_substep;
+    bool spec_tiles = false;
+    uint32_t spec_dt_bits = 0;
     while (remaining > 0.0f) {
         // one host sync per substep, as in the reference (cuda_mpm_pipeline.rs:393-398)
         if (!have_bound) {
             size_t tok = 0;
             HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dt_bits, (int)init_bits, 1, p->stream));
             CHK(clock_begin(p, SPAN_DT, &tok));
-            hipLaunchKernelGGL(k_estimate_dt, dim3(grid_for(p->n, BLK_THREADS)), dim3(BLK_THREADS), 0, p->stream, p->cur.arrays(), p->d_models.p, p->d_ctl, (int)p->n, p->h);
+            hipLaunchKernelGGL(k_estimate_dt, dim3(grid_for(p->n, BLK_THREADS)), dim3(BLK_THREADS), 0, p->stream, p->cur.arrays(), p->d_models.p, p->d_ctl, (int)p->n, p->h,
+                               p->dt_partial.p);
+            hipLaunchKernelGGL(k_dt_reduce, dim3(1), dim3(1024), 0, p->stream, p->dt_partial.p, (int)grid_for(p->n, BLK_THREADS), p->d_ctl);
             CHK(clock_end(p, tok));
         }
         CHK(read_ctl(p));
-        if (p->h_ctl->abort_flag[0] || p->h_ctl->abort_flag[1]) CHK(resort(p));
+        if (p->h_ctl->abort_flag[0] || p->h_ctl->abort_flag[1]) { CHK(resort(p)); spec_tiles = false; }
         if (p->h_ctl->dt_nan) { rc = set_error(SPARKL_ERR_NAN_TIMESTEP, "NaN timestep bound (the reference panics: timestep_estimator.rs:46)"); break; }
         float bound;
         memcpy(&bound, &p->h_ctl->dt_bits, 4);
-        float dt = std::fmin(std::fmin(remaining, params->max_substep_dt), bound);  // timestep_estimator.rs:25,35,44
-        if (dt < min_dt && remaining > min_dt) dt = min_dt;                           // mls_solver.rs:57-59
+        auto pick = [&](float rem) {
+            float d = std::fmin(std::fmin(rem, params->max_substep_dt), bound);   // timestep_estimator.rs:25,35,44
+            if (d < min_dt && rem > min_dt) d = min_dt;                              // mls_solver.rs:57-59
+            return d;
+        };
+        const float dt = pick(remaining);
+        uint32_t dt_bits, bound_bits;
+        memcpy(&dt_bits, &dt, 4);
+        memcpy(&bound_bits, &bound, 4);
+        const bool reuse = spec_tiles && spec_dt_bits == dt_bits;
+        if (spec_tiles) { if (reuse) p->spec_hits++; else p->spec_misses++; }
+        const float rem_after = remaining - dt;
+        float dt_guess = -1.f;
+        if (may_fuse && rem_after > 0.0f && bound_bits == p->spec_prev_bound_bits) dt_guess = pick(rem_after);
+        p->spec_prev_bound_bits = bound_bits;
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dt_bits, (int)init_bits, 1, p->stream));
-        CHK(enqueue_substep(p, params, gravity, dt, /*want_dt=*/true));
+        CHK(enqueue_adaptive_substep(p, params, gravity, dt, reuse, dt_guess));
+        spec_tiles = dt_guess > 0.f && p->num_pblocks > 0;
+        memcpy(&spec_dt_bits, &dt_guess, 4);
         have_bound = p->num_pblocks > 0;
         ++nsub;
         remaining -= dt;
@@ -1053,7 +1124,7 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
         CHK(clock_collect(p));
         timings->dt = result; timings->num_substeps = nsub; timings->num_resorts = (uint32_t)p->clock.resorts;
         timings->grid_resize_and_sort_ms = (float)p->clock.sort_ms; timings->estimate_timestep_ms = (float)p->clock.dt_ms;
-        timings->p2g_ms = (float)p->clock.p2g_ms; timings->grid_update_ms = (float)p->clock.grid_update_ms; timings->g2p_ms = (float)p->clock.g2p_ms;
+        timings->p2g_ms = (float)p->clock.p2g_ms; timings->grid_update_ms = (float)p->clock.grid_update_ms; timings->g2p_ms = (float)(p->clock.g2p_ms + p->clock.g2p2g_ms);   // fused launches count as G2P
         timings->total_ms = ms;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         p->clock = saved; p->clock_on = was_clock;
