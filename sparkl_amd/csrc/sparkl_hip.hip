@@ -508,10 +508,8 @@ static int enqueue_fused_batch(SparklPipeline* p, const SparklSolverParams* sp, 
         CHK(clock_end(p, tk));
         p->clock_on = was_on;
     }
-    static const int force_want_dt = getenv("SPARKL_HIP_FORCE_WANT_DT") ? atoi(getenv("SPARKL_HIP_FORCE_WANT_DT")) : 0;   // experiment
     for (uint32_t j = 0; j < n; ++j) {
-        StepParams S = make_params(p, sp, g, dt);
-        S.want_dt = force_want_dt;
+        const StepParams S = make_params(p, sp, g, dt);
         if (was_on && (p->substep_index % p->clock_stride) != 0) p->clock_on = false;
         if (p->clock_on) p->clock_sampled++;
         if (j > 0) CHK(maybe_reorder(p, S.parity));   // between two fused kernels: the tiles of this substep are already scattered
