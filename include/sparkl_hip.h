@@ -191,6 +191,25 @@ typedef struct {
     uint8_t _pad[3];
 } SparklHeightFieldCollider;
 
+/* rapier `ColliderBuilder::trimesh(vertices, indices)` (parry3d TriMesh), the third shape of
+ * CudaColliderSet::from_collider_set (cuda_collider_set.rs:88-102).  Vertices in the collider's local frame.
+ * `oriented` = TriMeshFlags::ORIENTED: parry then decides inside / outside from the pseudo-normal of the closest feature
+ * (angle-weighted vertex normals, summed face normals on edges); without it the mesh is a two-sided surface and
+ * is_inside is never set, which is what the default rapier trimesh gives the CPU path (grid_update.rs:78-82).
+ * `flip_interior` as CudaColliderOptions::flip_interior (only meaningful with `oriented`). */
+typedef struct {
+    uint32_t num_vertices;
+    const float* vertices;        /* 3 * num_vertices */
+    uint32_t num_triangles;
+    const uint32_t* indices;      /* 3 * num_triangles */
+    float rotation[4];            /* (i, j, k, w) */
+    float translation[3];
+    float friction;
+    uint8_t oriented;
+    uint8_t flip_interior;
+    uint8_t _pad[2];
+} SparklTriMeshCollider;
+
 /* ------------------------------------------------------------------- timings
  * reference: CudaTimestepTimings / CudaSubstepTimings / CudaDeviceTimings
  * (src/cuda/cuda_mpm_pipeline.rs:28-85).  Milliseconds from hipEvents, summed over the
@@ -286,6 +305,9 @@ int sparkl_hip_models_set(SparklPipeline* p, uint32_t n, const SparklParticleMod
 int sparkl_hip_colliders_set_cuboids(SparklPipeline* p, uint32_t n, const SparklCuboidCollider* colliders);
 /* CudaColliderSet::from_collider_set (heightfields); applied after the cuboids.  Heights are copied. */
 int sparkl_hip_colliders_set_heightfields(SparklPipeline* p, uint32_t n, const SparklHeightFieldCollider* colliders);
+/* CudaColliderSet::from_collider_set (triangle meshes); applied after the heightfields.  The mesh is copied and indexed by
+ * a uniform grid of its bounding box built on the host. */
+int sparkl_hip_colliders_set_trimeshes(SparklPipeline* p, uint32_t n, const SparklTriMeshCollider* colliders);
 
 /* MpmPipeline::step / CudaMpmPipeline::step
  * (src/pipelines/mpm_pipeline.rs:15-42, src/cuda/cuda_mpm_pipeline.rs:262-271):

@@ -278,6 +278,8 @@ public:
     void set_colliders(const std::vector<SparklCuboidCollider>& cuboids) { check(sparkl_hip_colliders_set_cuboids(h_, (uint32_t)cuboids.size(), cuboids.data())); }
     // heightfield colliders (rapier `ColliderBuilder::heightfield`); heights are copied, the pointers need not outlive the call
     void set_heightfields(const std::vector<SparklHeightFieldCollider>& hfs) { check(sparkl_hip_colliders_set_heightfields(h_, (uint32_t)hfs.size(), hfs.data())); }
+    // triangle meshes (rapier `ColliderBuilder::trimesh`); the mesh is copied
+    void set_trimeshes(const std::vector<SparklTriMeshCollider>& meshes) { check(sparkl_hip_colliders_set_trimeshes(h_, (uint32_t)meshes.size(), meshes.data())); }
     void upload(const ParticleSet& particles) {  // CudaParticleSet::from_particles(extract_particles_components(..))
         ParticleComponents c = extract_particles_components(particles.particles());
         check(sparkl_hip_particles_upload(h_, c.status.size(), c.status.data(), c.position.data(), c.velocity.data(), c.volume.data(), c.phase.data(), c.data.data(),

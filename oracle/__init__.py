@@ -114,10 +114,16 @@ class Oracle:
         self._keep.append(heightfields)
         self.L.oracle_set_heightfields(self.h, C.c_uint32(len(heightfields)), arr)
 
+    def set_trimeshes(self, trimeshes):
+        arr = (abi.TriMeshColliderC * max(len(trimeshes), 1))(*trimeshes)
+        self._keep.append(trimeshes)
+        self.L.oracle_set_trimeshes(self.h, C.c_uint32(len(trimeshes)), arr)
+
     def load_scene(self, scene):
         self.set_models(scene.models)
         self.set_cuboids(scene.colliders)
         self.set_heightfields(getattr(scene, "heightfields", []))
+        self.set_trimeshes(getattr(scene, "trimeshes", []))
         self.set_particles(scene.particles)
 
     # ---- stepping
@@ -266,6 +272,14 @@ def heightfield_project(hf, pt):
     out = np.zeros(3)
     inside = C.c_int(0)
     lib().oracle_heightfield_project(C.byref(hf), pp, out.ctypes.data_as(C.c_void_p), C.byref(inside))
+    return out, bool(inside.value)
+
+
+def trimesh_project(tm, pt):
+    _, pp = _d(pt, 3)
+    out = np.zeros(3)
+    inside = C.c_int(0)
+    lib().oracle_trimesh_project(C.byref(tm), pp, out.ctypes.data_as(C.c_void_p), C.byref(inside))
     return out, bool(inside.value)
 
 

@@ -97,6 +97,23 @@ void set_heightfields(Oracle<R>& o, uint32_t n, const SparklHeightFieldCollider*
 }
 
 template <class R>
+void fill_trimesh(TriMesh<R>& m, const SparklTriMeshCollider& c) {
+    m.v.resize(c.num_vertices);
+    for (uint32_t k = 0; k < c.num_vertices; ++k) m.v[k] = Vec3<R>{{(R)c.vertices[3 * k], (R)c.vertices[3 * k + 1], (R)c.vertices[3 * k + 2]}};
+    m.idx.resize(c.num_triangles);
+    for (uint32_t k = 0; k < c.num_triangles; ++k) m.idx[k] = {{c.indices[3 * k], c.indices[3 * k + 1], c.indices[3 * k + 2]}};
+    for (int a = 0; a < 3; ++a) m.t[a] = c.translation[a];
+    for (int a = 0; a < 4; ++a) m.q[a] = c.rotation[a];
+    m.friction = c.friction; m.oriented = c.oriented != 0; m.flip_interior = c.flip_interior != 0;
+    if (m.oriented) m.compute_pseudo_normals();
+}
+template <class R>
+void set_trimeshes(Oracle<R>& o, uint32_t n, const SparklTriMeshCollider* c) {
+    o.trimeshes.resize(n);
+    for (uint32_t i = 0; i < n; ++i) fill_trimesh(o.trimeshes[i], c[i]);
+}
+
+template <class R>
 uint64_t get_nodes(Oracle<R>& o, SparklGridNode* out, uint64_t cap) {
     uint64_t n = 0;
     for (const auto& reg : o.regions)
@@ -188,6 +205,17 @@ void oracle_set_cuboids(void* hv, uint32_t n, const SparklCuboidCollider* c) {
 void oracle_set_heightfields(void* hv, uint32_t n, const SparklHeightFieldCollider* c) {
     Handle* h = (Handle*)hv;
     if (h->f64) set_heightfields(*h->od, n, c); else set_heightfields(*h->of, n, c);
+}
+void oracle_set_trimeshes(void* hv, uint32_t n, const SparklTriMeshCollider* c) {
+    Handle* h = (Handle*)hv;
+    if (h->f64) set_trimeshes(*h->od, n, c); else set_trimeshes(*h->of, n, c);
+}
+void oracle_trimesh_project(const SparklTriMeshCollider* c, const double pt[3], double out[3], int* is_inside) {
+    TriMesh<double> m;
+    fill_trimesh(m, *c);
+    Projection<double> p = trimesh_project_point(m, Vec3<double>{{pt[0], pt[1], pt[2]}});
+    for (int a = 0; a < 3; ++a) out[a] = p.point[a];
+    *is_inside = p.is_inside;
 }
 void oracle_heightfield_project(const SparklHeightFieldCollider* c, const double pt[3], double out[3], int* is_inside) {
     Oracle<double>* dummy = nullptr; (void)dummy;

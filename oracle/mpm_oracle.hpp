@@ -27,7 +27,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <array>
 #include <limits>
+#include <map>
 #include <unordered_set>
 #include <utility>
 #include <vector>
@@ -633,6 +635,90 @@ template <class R> Projection<R> heightfield_project_point(const HeightField<R>&
     return Projection<R>{inside, Vec3<R>{{w[0] + hf.t[0], w[1] + hf.t[1], w[2] + hf.t[2]}}};
 }
 
+// parry3d 0.13 TriMesh::project_local_point: closest point over all triangles (a BVH there, brute force here); is_inside only
+// with TriMeshFlags::ORIENTED, from the pseudo-normal of the closest feature (TriMesh::compute_pseudo_normals: angle-weighted
+// sum of the incident face normals on a vertex, sum of the two face normals on an edge).  Third party, unpinned.
+template <class R> struct TriMesh {
+    std::vector<Vec3<R>> v;
+    std::vector<std::array<uint32_t, 3>> idx;
+    std::vector<Vec3<double>> vn;                                 // per vertex
+    std::vector<std::array<Vec3<double>, 3>> en;                  // per triangle: edges ab, ac, bc
+    std::vector<Vec3<double>> fn;
+    R q[4]; Vec3<R> t; R friction; bool oriented, flip_interior;
+    void compute_pseudo_normals() {
+        vn.assign(v.size(), Vec3<double>{{0, 0, 0}});
+        fn.assign(idx.size(), Vec3<double>{{0, 0, 0}});
+        en.assign(idx.size(), std::array<Vec3<double>, 3>{{Vec3<double>{{0, 0, 0}}, Vec3<double>{{0, 0, 0}}, Vec3<double>{{0, 0, 0}}}});
+        std::map<std::pair<uint32_t, uint32_t>, Vec3<double>> acc;
+        auto d = [&](uint32_t a, uint32_t b) { return Vec3<double>{{(double)v[a][0] - (double)v[b][0], (double)v[a][1] - (double)v[b][1], (double)v[a][2] - (double)v[b][2]}}; };
+        auto ang = [](const Vec3<double>& x, const Vec3<double>& y) {
+            const double nx = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]), ny = std::sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+            if (nx == 0 || ny == 0) return 0.0;
+            return std::acos(std::max(-1.0, std::min(1.0, (x[0] * y[0] + x[1] * y[1] + x[2] * y[2]) / (nx * ny))));
+        };
+        for (size_t k = 0; k < idx.size(); ++k) {
+            const uint32_t a = idx[k][0], b = idx[k][1], c = idx[k][2];
+            const Vec3<double> ab = d(b, a), ac = d(c, a);
+            Vec3<double> n{{ab[1] * ac[2] - ab[2] * ac[1], ab[2] * ac[0] - ab[0] * ac[2], ab[0] * ac[1] - ab[1] * ac[0]}};
+            const double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            if (l == 0) continue;
+            for (int e = 0; e < 3; ++e) n[e] /= l;
+            fn[k] = n;
+            const double w[3] = {ang(ab, ac), ang(d(a, b), d(c, b)), ang(d(a, c), d(b, c))};
+            const uint32_t vid[3] = {a, b, c};
+            for (int j = 0; j < 3; ++j) for (int e = 0; e < 3; ++e) vn[vid[j]][e] += n[e] * w[j];
+            const uint32_t ed[3][2] = {{a, b}, {a, c}, {b, c}};
+            for (int j = 0; j < 3; ++j) {
+                auto& s = acc.emplace(std::make_pair(std::min(ed[j][0], ed[j][1]), std::max(ed[j][0], ed[j][1])), Vec3<double>{{0, 0, 0}}).first->second;
+                for (int e = 0; e < 3; ++e) s[e] += n[e];
+            }
+        }
+        for (size_t k = 0; k < idx.size(); ++k) {
+            const uint32_t a = idx[k][0], b = idx[k][1], c = idx[k][2];
+            const uint32_t ed[3][2] = {{a, b}, {a, c}, {b, c}};
+            for (int j = 0; j < 3; ++j) en[k][j] = acc[std::make_pair(std::min(ed[j][0], ed[j][1]), std::max(ed[j][0], ed[j][1]))];
+        }
+    }
+};
+// which feature of (a, b, c) the closest point sits on: 0 1 2 vertices, 3 4 5 edges ab ac bc, 6 face (same regions as closest_on_triangle)
+template <class R> int triangle_feature(const Vec3<R>& p, const Vec3<R>& a, const Vec3<R>& b, const Vec3<R>& c) {
+    auto sub = [](const Vec3<R>& x, const Vec3<R>& y) { return Vec3<R>{{x[0] - y[0], x[1] - y[1], x[2] - y[2]}}; };
+    Vec3<R> ab = sub(b, a), ac = sub(c, a), ap = sub(p, a);
+    R d1 = dot(ab, ap), d2 = dot(ac, ap);
+    if (d1 <= 0 && d2 <= 0) return 0;
+    Vec3<R> bp = sub(p, b);
+    R d3 = dot(ab, bp), d4 = dot(ac, bp);
+    if (d3 >= 0 && d4 <= d3) return 1;
+    if (d1 * d4 - d3 * d2 <= 0 && d1 >= 0 && d3 <= 0) return 3;
+    Vec3<R> cp = sub(p, c);
+    R d5 = dot(ab, cp), d6 = dot(ac, cp);
+    if (d6 >= 0 && d5 <= d6) return 2;
+    if (d5 * d2 - d1 * d6 <= 0 && d2 >= 0 && d6 <= 0) return 4;
+    if (d3 * d6 - d5 * d4 <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) return 5;
+    return 6;
+}
+template <class R> Projection<R> trimesh_project_point(const TriMesh<R>& m, const Vec3<R>& pt_world) {
+    Vec3<R> rel{{pt_world[0] - m.t[0], pt_world[1] - m.t[1], pt_world[2] - m.t[2]}};
+    Vec3<R> lp = quat_rotate(m.q, rel, true);
+    R best = std::numeric_limits<R>::max();
+    Vec3<R> bp = lp;
+    size_t bt = 0;
+    for (size_t k = 0; k < m.idx.size(); ++k) {
+        Vec3<R> c = closest_on_triangle(lp, m.v[m.idx[k][0]], m.v[m.idx[k][1]], m.v[m.idx[k][2]]);
+        R d = (c[0] - lp[0]) * (c[0] - lp[0]) + (c[1] - lp[1]) * (c[1] - lp[1]) + (c[2] - lp[2]) * (c[2] - lp[2]);
+        if (d < best) { best = d; bp = c; bt = k; }
+    }
+    bool inside = false;
+    if (m.oriented && !m.idx.empty()) {
+        const int f = triangle_feature(lp, m.v[m.idx[bt][0]], m.v[m.idx[bt][1]], m.v[m.idx[bt][2]]);
+        const Vec3<double>& n = f < 3 ? m.vn[m.idx[bt][f]] : (f < 6 ? m.en[bt][f - 3] : m.fn[bt]);
+        inside = ((double)(lp[0] - bp[0]) * n[0] + (double)(lp[1] - bp[1]) * n[1] + (double)(lp[2] - bp[2]) * n[2]) <= 0.0;
+        if (m.flip_interior) inside = !inside;
+    }
+    Vec3<R> w = quat_rotate(m.q, bp, false);
+    return Projection<R>{inside, Vec3<R>{{w[0] + m.t[0], w[1] + m.t[1], w[2] + m.t[2]}}};
+}
+
 // ---------------------------------------------------------------------------------------- solver
 struct Region { uint64_t id; size_t begin, end; };
 
@@ -651,6 +737,7 @@ struct Oracle {
     std::vector<SparklParticleModel> models;
     std::vector<Cuboid<R>> cuboids;
     std::vector<HeightField<R>> heightfields;
+    std::vector<TriMesh<R>> trimeshes;
     int last_num_substeps = 0;
     std::vector<double> last_dts;
     int num_threads = 1;
@@ -880,6 +967,7 @@ struct Oracle {
                 };
                 for (const auto& col : cuboids) apply(cuboid_project_point(col, cell_pos), col.friction);
                 for (const auto& hf : heightfields) apply(heightfield_project_point(hf, cell_pos), hf.friction);
+                for (const auto& tm : trimeshes) apply(trimesh_project_point(tm, cell_pos), tm.friction);
             }
         }
     }

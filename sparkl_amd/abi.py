@@ -156,6 +156,28 @@ def heightfield(heights, scale, translation=(0.0, 0.0, 0.0), rotation=(0.0, 0.0,
     return c
 
 
+class TriMeshColliderC(C.Structure):
+    _fields_ = [("num_vertices", C.c_uint32), ("vertices", C.POINTER(C.c_float)), ("num_triangles", C.c_uint32), ("indices", C.POINTER(C.c_uint32)),
+                ("rotation", C.c_float * 4), ("translation", C.c_float * 3), ("friction", C.c_float),
+                ("oriented", C.c_uint8), ("flip_interior", C.c_uint8), ("_pad", C.c_uint8 * 2)]
+
+
+def trimesh(vertices, indices, translation=(0.0, 0.0, 0.0), rotation=(0.0, 0.0, 0.0, 1.0), friction=0.5, oriented=False, flip_interior=False):
+    """`ColliderBuilder::trimesh(vertices, indices)` (+ TriMeshFlags::ORIENTED through `oriented`)."""
+    v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+    i = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+    c = TriMeshColliderC()
+    c._keep = (v, i)
+    c.num_vertices, c.num_triangles = len(v), len(i)
+    c.vertices = v.ctypes.data_as(C.POINTER(C.c_float))
+    c.indices = i.ctypes.data_as(C.POINTER(C.c_uint32))
+    c.rotation[:] = [float(x) for x in rotation]
+    c.translation[:] = [float(x) for x in translation]
+    c.friction = friction
+    c.oriented, c.flip_interior = int(oriented), int(flip_interior)
+    return c
+
+
 class TimingsC(C.Structure):
     _fields_ = [("dt", C.c_float), ("num_substeps", C.c_uint32), ("num_resorts", C.c_uint32),
                 ("grid_resize_and_sort_ms", C.c_float), ("reset_grid_ms", C.c_float),

@@ -95,6 +95,7 @@ struct StepParams {
     int dom;          // valid cell coords: 0 <= c, c + 5 < dom
     int num_cuboids;
     int num_heightfields;
+    int num_trimeshes;
     int want_dt;      // G2P also reduces the next substep's dt bound into ctl->dt_bits (adaptive stepping)
     float dt_next;    // k_g2p2g: the step length the fused scatter (P2G of the NEXT substep) is built for; = dt for fixed-dt batches
 };
@@ -113,6 +114,22 @@ struct DevHeightField {
     float t[3];
     float friction;
     int below_is_solid;
+};
+
+// Triangle mesh: 30 floats per triangle (a, b, c | pseudo-normals of a, b, c | of the edges ab, ac, bc | face normal; the
+// normals are zero for a mesh that is not oriented) and a uniform grid over the bounding box: cell -> triangles whose box,
+// grown by the search reach, touches the cell.
+struct DevTriMesh {
+    const float* tris;
+    const int* cell_start;   // [ncells + 1]
+    const int* cell_tris;
+    float lo[3], hi[3];      // bounding box grown by the reach
+    float inv_cell;
+    int dims[3];
+    float q[4];
+    float t[3];
+    float friction;
+    int oriented, flip_interior;
 };
 
 // Observed placement is workgroup b -> XCD b % 8: give each XCD a contiguous run of Morton-ordered
@@ -566,31 +583,69 @@ SPK_DEV bool cuboid_project(const DevCuboid& c, const float ptw[3], float projw[
 
 // closest point on triangle (a, b, c) to p (Ericson, Real-Time Collision Detection 5.1.5 -- the algorithm of parry's
 // Triangle::project_local_point)
-SPK_DEV void closest_on_triangle(const float p[3], const float a[3], const float b[3], const float c[3], float out[3]) {
+// Returns the feature the closest point lies on: 0 1 2 = vertex a b c, 3 4 5 = edge ab ac bc, 6 = face.
+SPK_DEV int closest_on_triangle(const float p[3], const float a[3], const float b[3], const float c[3], float out[3]) {
     float ab[3], ac[3], ap[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; }
     const float d1 = ab[0] * ap[0] + ab[1] * ap[1] + ab[2] * ap[2], d2 = ac[0] * ap[0] + ac[1] * ap[1] + ac[2] * ap[2];
-    if (d1 <= 0.f && d2 <= 0.f) { out[0] = a[0]; out[1] = a[1]; out[2] = a[2]; return; }
+    if (d1 <= 0.f && d2 <= 0.f) { out[0] = a[0]; out[1] = a[1]; out[2] = a[2]; return 0; }
     float bp[3] = {p[0] - b[0], p[1] - b[1], p[2] - b[2]};
     const float d3 = ab[0] * bp[0] + ab[1] * bp[1] + ab[2] * bp[2], d4 = ac[0] * bp[0] + ac[1] * bp[1] + ac[2] * bp[2];
-    if (d3 >= 0.f && d4 <= d3) { out[0] = b[0]; out[1] = b[1]; out[2] = b[2]; return; }
+    if (d3 >= 0.f && d4 <= d3) { out[0] = b[0]; out[1] = b[1]; out[2] = b[2]; return 1; }
     const float vc = d1 * d4 - d3 * d2;
-    if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { const float v = d1 / (d1 - d3); out[0] = a[0] + v * ab[0]; out[1] = a[1] + v * ab[1]; out[2] = a[2] + v * ab[2]; return; }
+    if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { const float v = d1 / (d1 - d3); out[0] = a[0] + v * ab[0]; out[1] = a[1] + v * ab[1]; out[2] = a[2] + v * ab[2]; return 3; }
     float cp[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
     const float d5 = ab[0] * cp[0] + ab[1] * cp[1] + ab[2] * cp[2], d6 = ac[0] * cp[0] + ac[1] * cp[1] + ac[2] * cp[2];
-    if (d6 >= 0.f && d5 <= d6) { out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; return; }
+    if (d6 >= 0.f && d5 <= d6) { out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; return 2; }
     const float vb = d5 * d2 - d1 * d6;
-    if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { const float w = d2 / (d2 - d6); out[0] = a[0] + w * ac[0]; out[1] = a[1] + w * ac[1]; out[2] = a[2] + w * ac[2]; return; }
+    if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { const float w = d2 / (d2 - d6); out[0] = a[0] + w * ac[0]; out[1] = a[1] + w * ac[1]; out[2] = a[2] + w * ac[2]; return 4; }
     const float va = d3 * d6 - d5 * d4;
     if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
         const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
         out[0] = b[0] + w * (c[0] - b[0]); out[1] = b[1] + w * (c[1] - b[1]); out[2] = b[2] + w * (c[2] - b[2]);
-        return;
+        return 5;
     }
     const float denom = 1.f / (va + vb + vc), v = vb * denom, w = vc * denom;
 #pragma unroll
     for (int i = 0; i < 3; ++i) out[i] = a[i] + ab[i] * v + ac[i] * w;
+    return 6;
+}
+
+// Closest point of a triangle mesh within `reach` of a world point (parry TriMesh::project_local_point walks a BVH over all
+// triangles; here the grid cell of the point lists every triangle that can be within reach of it).
+SPK_DEV bool trimesh_project(const DevTriMesh& tm, const float ptw[3], float reach, float projw[3], bool& inside) {
+    float rel[3] = {ptw[0] - tm.t[0], ptw[1] - tm.t[1], ptw[2] - tm.t[2]};
+    float lp[3];
+    quat_rot(tm.q, rel, -1.f, lp);
+    int cell[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (lp[a] < tm.lo[a] || lp[a] > tm.hi[a]) return false;
+        cell[a] = min((int)((lp[a] - tm.lo[a]) * tm.inv_cell), tm.dims[a] - 1);
+    }
+    const int ci = cell[0] + tm.dims[0] * (cell[1] + tm.dims[1] * cell[2]);
+    float best = 3.402823466e+38f, bp[3] = {0.f, 0.f, 0.f};
+    int best_tri = -1, best_feat = 6;
+    for (int k = tm.cell_start[ci]; k < tm.cell_start[ci + 1]; ++k) {
+        const int ti = tm.cell_tris[k];
+        const float* T = tm.tris + (size_t)ti * 30;
+        const float a[3] = {T[0], T[1], T[2]}, b[3] = {T[3], T[4], T[5]}, c[3] = {T[6], T[7], T[8]};
+        float cpt[3];
+        const int feat = closest_on_triangle(lp, a, b, c, cpt);
+        const float d = (cpt[0] - lp[0]) * (cpt[0] - lp[0]) + (cpt[1] - lp[1]) * (cpt[1] - lp[1]) + (cpt[2] - lp[2]) * (cpt[2] - lp[2]);
+        if (d < best) { best = d; bp[0] = cpt[0]; bp[1] = cpt[1]; bp[2] = cpt[2]; best_tri = ti; best_feat = feat; }
+    }
+    if (best_tri < 0 || best > reach * reach) return false;
+    inside = false;
+    if (tm.oriented) {
+        const float* N = tm.tris + (size_t)best_tri * 30 + 9 + 3 * best_feat;
+        inside = ((lp[0] - bp[0]) * N[0] + (lp[1] - bp[1]) * N[1] + (lp[2] - bp[2]) * N[2]) <= 0.f;
+        if (tm.flip_interior) inside = !inside;
+    }
+    quat_rot(tm.q, bp, 1.f, projw);
+    projw[0] += tm.t[0]; projw[1] += tm.t[1]; projw[2] += tm.t[2];
+    return true;
 }
 
 // Closest point of a heightfield to a world point, searching only the cells within `reach` (world units) of the point
@@ -666,7 +721,7 @@ SPK_DEV void boundary_rule(float v[3], const float cpos[3], const float proj[3],
 // One wave per node block, 4 blocks per workgroup.  MASS_ONLY: fluid volume recompute (fluids_volume.rs).
 // HEIGHTFIELDS keeps the triangle search out of the kernel every scene without a heightfield runs.
 template <bool MASS_ONLY, bool HEIGHTFIELDS = false>
-__global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const DevCuboid* __restrict__ cuboids, const DevHeightField* __restrict__ heightfields,
+__global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const DevCuboid* __restrict__ cuboids, const DevHeightField* __restrict__ heightfields, const DevTriMesh* __restrict__ trimeshes,
                                                              const Ctl* __restrict__ ctl, StepParams S) {
     // The abort flag is only consulted before the store: the topology arrays stay valid (stale) after an abort, and
     // this keeps the dependent-load chain at  blk_tnbr -> tile_mode -> tile  (3 hops; it used to be 5).
@@ -730,6 +785,12 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
             float proj[3];
             bool inside = false;
             if (heightfield_project(hf, cpos, 4.0f * S.h, proj, inside)) boundary_rule(v, cpos, proj, inside, hf.friction, S.boundary_handling, S.h, S.dt);
+        }
+        if (HEIGHTFIELDS) for (int ti = 0; ti < S.num_trimeshes; ++ti) {
+            const DevTriMesh tm = trimeshes[ti];
+            float proj[3];
+            bool inside = false;
+            if (trimesh_project(tm, cpos, 4.0f * S.h, proj, inside)) boundary_rule(v, cpos, proj, inside, tm.friction, S.boundary_handling, S.h, S.dt);
         }
     }
     G.node_vel[(size_t)b * 64 + lane] = make_float4(v[0], v[1], v[2], m);

@@ -9,7 +9,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <array>
 #include <limits>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -139,6 +141,9 @@ struct SparklPipeline {
     DevBuf<uint32_t> idx_a, idx_b, pb_counts, pb_first, cand_a, cand_b;
     DevBuf<uint8_t> cub_temp;
     DevBuf<int> d_scalars;  // [0] num_runs, [1] num_unique
+    DevBuf<DevTriMesh> d_trimeshes;
+    std::vector<void*> d_mesh_bufs;         // triangle / grid arrays of the uploaded meshes
+    int num_trimeshes = 0;
     DevBuf<uint32_t> dt_partial;            // per-workgroup dt-bound minima (adaptive stepping)
     DevBuf<float> staging;
     float reorder_limit = -1.f, rebin_limit = 0.f;   // sparkl_hip_reorder_policy_set: < 0 = default, 0 = off
@@ -376,7 +381,7 @@ static StepParams make_params(const SparklPipeline* p, const SparklSolverParams*
     S.h = p->h; S.inv_d = 4.0f / (p->h * p->h); S.dt = dt;
     S.gx = g[0]; S.gy = g[1]; S.gz = g[2];
     S.boundary_handling = sp->boundary_handling; S.dofs = sp->simulation_dofs;
-    S.parity = (int)(p->substep_index & 1u); S.dom = p->dom; S.num_cuboids = p->num_cuboids; S.num_heightfields = p->num_heightfields; S.want_dt = 0;
+    S.parity = (int)(p->substep_index & 1u); S.dom = p->dom; S.num_cuboids = p->num_cuboids; S.num_heightfields = p->num_heightfields; S.num_trimeshes = p->num_trimeshes; S.want_dt = 0;
     S.dt_next = dt;
     return S;
 }
@@ -387,10 +392,10 @@ static StepParams make_params(const SparklPipeline* p, const SparklSolverParams*
 
 static void launch_grid_update(SparklPipeline* p, const GridArrays& G, const StepParams& S, hipStream_t st) {
     const dim3 grid((p->num_blocks + 3) / 4), block(BLK_THREADS);
-    if (p->num_heightfields > 0)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, true>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_ctl, S);
+    if (p->num_heightfields > 0 || p->num_trimeshes > 0)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, true>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, false>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_ctl, S);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, false>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);
 }
 
 static void launch_p2g(SparklPipeline* p, const ParticleArrays& P, const GridArrays& G, const StepParams& S, hipStream_t st) {
@@ -419,7 +424,7 @@ static int enqueue_fluid_volumes(SparklPipeline* p, const StepParams& S) {
     GridArrays G = grid_arrays(p);
     G.node_mom = nullptr;
     hipLaunchKernelGGL(k_p2g_mass, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, p->cur.arrays(), G, p->d_ctl, S);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<true>), dim3((p->num_blocks + 3) / 4), dim3(BLK_THREADS), 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_ctl, S);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<true>), dim3((p->num_blocks + 3) / 4), dim3(BLK_THREADS), 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);
     hipLaunchKernelGGL(k_g2p_volume, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, p->cur.arrays(), G, p->d_models.p, p->d_ctl, S);
     return SPARKL_OK;
 }
@@ -588,6 +593,8 @@ void sparkl_hip_pipeline_destroy(SparklPipeline* p) {
     p->cur.release(); p->alt.release();
     p->d_models.release(); p->d_cuboids.release(); p->d_heightfields.release();
     for (float* d : p->d_heights) (void)hipFree(d);
+    for (void* d : p->d_mesh_bufs) (void)hipFree(d);
+    p->d_trimeshes.release();
     p->blk_origin.release(); p->blk_pfirst.release(); p->blk_pcount.release(); p->blk_nbr.release(); p->blk_tnbr.release(); p->pblk.release(); p->pb_info.release(); p->tile_mode.release(); p->blk_keys.release();
     p->tiles.release(); p->node_vel.release(); p->node_mom.release(); p->hash_keys.release(); p->hash_vals.release();
     p->keys_a.release(); p->keys_b.release(); p->pb_keys.release(); p->bkeys.release(); p->idx_a.release(); p->idx_b.release();
@@ -745,6 +752,128 @@ int sparkl_hip_colliders_set_heightfields(SparklPipeline* p, uint32_t n, const S
     CHK(p->d_heightfields.reserve(std::max<uint32_t>(n, 1)));
     if (n) HIPCHK(hipMemcpy(p->d_heightfields.p, dh.data(), n * sizeof(DevHeightField), hipMemcpyHostToDevice));
     p->num_heightfields = (int)n;
+    return SPARKL_OK;
+}
+
+// Triangle meshes: pseudo-normals (Baerentzen & Aanaes, as parry's TriMesh::compute_pseudo_normals: angle-weighted on
+// vertices, summed face normals on edges) and a uniform grid over the bounding box, both built here on the host.
+int sparkl_hip_colliders_set_trimeshes(SparklPipeline* p, uint32_t n, const SparklTriMeshCollider* c) {
+    if (!p || (n && !c)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!c[i].num_triangles || !c[i].num_vertices || !c[i].vertices || !c[i].indices)
+            return set_error(SPARKL_ERR_INVALID_ARGUMENT, "trimesh %u: empty mesh", i);
+        for (uint64_t k = 0; k < 3ull * c[i].num_triangles; ++k)
+            if (c[i].indices[k] >= c[i].num_vertices) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "trimesh %u: index %u out of range", i, c[i].indices[k]);
+    }
+    for (void* d : p->d_mesh_bufs) (void)hipFree(d);
+    p->d_mesh_bufs.clear();
+    const float reach = 4.0f * p->h;
+    std::vector<DevTriMesh> dm(n);
+    auto to_device = [&](const void* src, size_t bytes, const void** out) -> int {
+        void* d = nullptr;
+        HIPCHK(hipMalloc(&d, std::max<size_t>(bytes, 4)));
+        p->d_mesh_bufs.push_back(d);
+        if (bytes) HIPCHK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+        *out = d;
+        return SPARKL_OK;
+    };
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t nt = c[i].num_triangles, nv = c[i].num_vertices;
+        const float* V = c[i].vertices;
+        std::vector<float> tris((size_t)nt * 30, 0.f);
+        std::vector<double> vn((size_t)nv * 3, 0.0);
+        std::map<std::pair<uint32_t, uint32_t>, std::array<double, 3>> en;
+        std::vector<std::array<double, 3>> fn(nt, std::array<double, 3>{{0, 0, 0}});
+        float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+        auto sub = [](const float* a, const float* b, double* o) { for (int k = 0; k < 3; ++k) o[k] = (double)a[k] - (double)b[k]; };
+        auto angle = [](const double* u, const double* v) {
+            const double nu = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), nvv = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            if (nu == 0.0 || nvv == 0.0) return 0.0;
+            return std::acos(std::max(-1.0, std::min(1.0, (u[0] * v[0] + u[1] * v[1] + u[2] * v[2]) / (nu * nvv))));
+        };
+        for (uint32_t t = 0; t < nt; ++t) {
+            const uint32_t* id = c[i].indices + 3 * t;
+            const float *a = V + 3 * id[0], *b = V + 3 * id[1], *cc = V + 3 * id[2];
+            for (int k = 0; k < 3; ++k) {
+                tris[30 * t + k] = a[k]; tris[30 * t + 3 + k] = b[k]; tris[30 * t + 6 + k] = cc[k];
+                lo[k] = std::min(lo[k], std::min(a[k], std::min(b[k], cc[k]))); hi[k] = std::max(hi[k], std::max(a[k], std::max(b[k], cc[k])));
+            }
+            if (!c[i].oriented) continue;
+            double ab[3], ac[3], bc[3], ba[3], ca[3], cb[3];
+            sub(b, a, ab); sub(cc, a, ac); sub(cc, b, bc); sub(a, b, ba); sub(a, cc, ca); sub(b, cc, cb);
+            double nrm[3] = {ab[1] * ac[2] - ab[2] * ac[1], ab[2] * ac[0] - ab[0] * ac[2], ab[0] * ac[1] - ab[1] * ac[0]};
+            const double l = std::sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+            if (l == 0.0) continue;   // degenerate triangle: no normal (Triangle::normal() == None)
+            for (int k = 0; k < 3; ++k) nrm[k] /= l;
+            fn[t] = {{nrm[0], nrm[1], nrm[2]}};
+            const double ang[3] = {angle(ab, ac), angle(ba, bc), angle(ca, cb)};
+            for (int v = 0; v < 3; ++v) for (int k = 0; k < 3; ++k) vn[3 * id[v] + k] += nrm[k] * ang[v];
+            const uint32_t e[3][2] = {{id[0], id[1]}, {id[0], id[2]}, {id[1], id[2]}};
+            for (int q = 0; q < 3; ++q) {
+                auto key = std::make_pair(std::min(e[q][0], e[q][1]), std::max(e[q][0], e[q][1]));
+                auto& acc = en[key];
+                for (int k = 0; k < 3; ++k) acc[k] += nrm[k];
+            }
+        }
+        if (c[i].oriented)
+            for (uint32_t t = 0; t < nt; ++t) {
+                const uint32_t* id = c[i].indices + 3 * t;
+                for (int v = 0; v < 3; ++v) for (int k = 0; k < 3; ++k) tris[30 * t + 9 + 3 * v + k] = (float)vn[3 * id[v] + k];
+                const uint32_t e[3][2] = {{id[0], id[1]}, {id[0], id[2]}, {id[1], id[2]}};
+                for (int q = 0; q < 3; ++q) {
+                    const auto& acc = en[std::make_pair(std::min(e[q][0], e[q][1]), std::max(e[q][0], e[q][1]))];
+                    for (int k = 0; k < 3; ++k) tris[30 * t + 18 + 3 * q + k] = (float)acc[k];
+                }
+                for (int k = 0; k < 3; ++k) tris[30 * t + 27 + k] = (float)fn[t][k];
+            }
+        // uniform grid over the box grown by the reach
+        DevTriMesh& d = dm[i];
+        float ext = 0.f;
+        for (int k = 0; k < 3; ++k) { d.lo[k] = lo[k] - reach; d.hi[k] = hi[k] + reach; ext = std::max(ext, d.hi[k] - d.lo[k]); }
+        const float cell = std::max(2.0f * p->h, ext / 64.0f);
+        d.inv_cell = 1.0f / cell;
+        size_t ncell = 1;
+        for (int k = 0; k < 3; ++k) { d.dims[k] = std::max(1, (int)std::ceil((d.hi[k] - d.lo[k]) / cell)); ncell *= (size_t)d.dims[k]; }
+        std::vector<int> count(ncell + 1, 0);
+        auto cell_range = [&](uint32_t t, int r0[3], int r1[3]) {
+            for (int k = 0; k < 3; ++k) {
+                const float mn = std::min(tris[30 * t + k], std::min(tris[30 * t + 3 + k], tris[30 * t + 6 + k])) - reach;
+                const float mx = std::max(tris[30 * t + k], std::max(tris[30 * t + 3 + k], tris[30 * t + 6 + k])) + reach;
+                r0[k] = std::max(0, std::min(d.dims[k] - 1, (int)std::floor((mn - d.lo[k]) * d.inv_cell)));
+                r1[k] = std::max(0, std::min(d.dims[k] - 1, (int)std::floor((mx - d.lo[k]) * d.inv_cell)));
+            }
+        };
+        for (int pass = 0; pass < 2; ++pass) {
+            std::vector<int> fill;
+            std::vector<int> list;
+            if (pass == 1) {
+                for (size_t k = 0; k < ncell; ++k) count[k + 1] += count[k];   // count[k + 1] held the size of cell k
+                fill.assign(count.begin(), count.end() - 1);
+                list.resize((size_t)count[ncell]);
+            }
+            for (uint32_t t = 0; t < nt; ++t) {
+                int r0[3], r1[3];
+                cell_range(t, r0, r1);
+                for (int z = r0[2]; z <= r1[2]; ++z) for (int y = r0[1]; y <= r1[1]; ++y) for (int x = r0[0]; x <= r1[0]; ++x) {
+                    const size_t ci = (size_t)x + (size_t)d.dims[0] * ((size_t)y + (size_t)d.dims[1] * (size_t)z);
+                    if (pass == 0) count[ci + 1]++; else list[(size_t)fill[ci]++] = (int)t;
+                }
+            }
+            if (pass == 1) {
+                CHK(to_device(tris.data(), tris.size() * sizeof(float), (const void**)&d.tris));
+                CHK(to_device(count.data(), count.size() * sizeof(int), (const void**)&d.cell_start));
+                CHK(to_device(list.data(), list.size() * sizeof(int), (const void**)&d.cell_tris));
+            }
+        }
+        for (int a = 0; a < 3; ++a) d.t[a] = c[i].translation[a];
+        for (int a = 0; a < 4; ++a) d.q[a] = c[i].rotation[a];
+        d.friction = c[i].friction; d.oriented = c[i].oriented; d.flip_interior = c[i].flip_interior;
+    }
+    CHK(p->d_trimeshes.reserve(std::max<uint32_t>(n, 1)));
+    if (n) HIPCHK(hipMemcpy(p->d_trimeshes.p, dm.data(), n * sizeof(DevTriMesh), hipMemcpyHostToDevice));
+    p->num_trimeshes = (int)n;
     return SPARKL_OK;
 }
 

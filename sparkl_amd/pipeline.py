@@ -87,6 +87,11 @@ class MpmPipeline:
         arr = (abi.HeightFieldColliderC * max(len(heightfields), 1))(*heightfields)
         check(self.L.sparkl_hip_colliders_set_heightfields(self.h, C.c_uint32(len(heightfields)), arr))
 
+    def set_trimeshes(self, trimeshes):
+        """`CudaColliderSet::from_collider_set` for triangle meshes (abi.trimesh(..)); applied after the heightfields."""
+        arr = (abi.TriMeshColliderC * max(len(trimeshes), 1))(*trimeshes)
+        check(self.L.sparkl_hip_colliders_set_trimeshes(self.h, C.c_uint32(len(trimeshes)), arr))
+
     # ---- CudaParticleSet
     def _args(self, c):
         return (C.c_uint64(len(c)), abi.ptr(c.status, abi.STATUS_DTYPE), abi.ptr(c.position, abi.POSITION_DTYPE),
@@ -183,6 +188,7 @@ class MpmPipeline:
         self.set_models(scene.models)
         self.set_colliders(scene.colliders)
         self.set_heightfields(getattr(scene, "heightfields", []))
+        self.set_trimeshes(getattr(scene, "trimeshes", []))
         self.upload_particles(scene.particles)
 
     # ---- stepping

@@ -73,6 +73,7 @@ class Scene:
         self.colliders, self.params, self.gravity, self.fixed_dt = colliders, params, gravity, fixed_dt
         self.domain_log2_bytes = domain_log2_bytes
         self.heightfields = []
+        self.trimeshes = []
 
 
 def _domain_bits_for(max_cell):
@@ -197,6 +198,28 @@ def sand_on_heightfield(nx, ny, nz, h=0.2, jitter=True, below_is_solid=False):
     ty = float(lo[1]) - 2.0 * h + 1.5
     sc.colliders = []
     sc.heightfields = [abi.heightfield(heights, (side, 1.5, side), translation=(cx, ty, cz), friction=0.5, below_is_solid=below_is_solid)]
+    return sc
+
+
+def box_mesh(half_extents):
+    """A closed, outward-oriented triangle mesh of the box [-he, he]: 8 vertices, 12 triangles."""
+    hx, hy, hz = [float(x) for x in half_extents]
+    v = np.array([[-hx, -hy, -hz], [hx, -hy, -hz], [hx, hy, -hz], [-hx, hy, -hz], [-hx, -hy, hz], [hx, -hy, hz], [hx, hy, hz], [-hx, hy, hz]], dtype=f32)
+    i = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [3, 7, 6], [3, 6, 2], [0, 4, 7], [0, 7, 3], [1, 2, 6], [1, 6, 5]], dtype=np.uint32)
+    return v, i
+
+
+def sand_on_trimesh(nx, ny, nz, h=0.2, jitter=True, oriented=True):
+    """The sand column over a tilted wedge given as a triangle mesh (a rotated box): the third collider shape of
+    cuda_collider_set.rs:88-102."""
+    sc = sand_column(nx, ny, nz, h=h, jitter=jitter, name=f"sand_on_trimesh_{nx}x{ny}x{nz}")
+    lo, hi = sc.particles.position["point"].min(0), sc.particles.position["point"].max(0)
+    v, i = box_mesh([3.0, 0.5, 3.0])
+    ang = 0.35                                        # rotation about z: the sand slides down the slope
+    q = (0.0, 0.0, float(np.sin(ang / 2)), float(np.cos(ang / 2)))
+    centre = (float(0.5 * (lo[0] + hi[0])), float(lo[1]) - 1.5 * h - 0.5 / np.cos(ang), float(0.5 * (lo[2] + hi[2])))
+    sc.colliders = []
+    sc.trimeshes = [abi.trimesh(v, i, translation=centre, rotation=q, friction=0.5, oriented=oriented)]
     return sc
 
 

@@ -150,6 +150,40 @@ def test_heightfield_ground_parity(Pipeline, below_is_solid):
     assert e["eps_v"] <= TOL or e["eps_v"] <= 3 * floor["eps_v"], (e, floor)
 
 
+@pytest.mark.parametrize("oriented", [True, False])
+def test_trimesh_ground_parity(Pipeline, oriented):
+    """Triangle-mesh collider (cuda_collider_set.rs:88-102): node velocities after one substep and particle state after 100
+    against the oracle's brute-force closest triangle + pseudo-normal inside test."""
+    sc = scenes.sand_on_trimesh(16, 8, 12, oriented=oriented)
+    sc.particles.velocity["vector"][:, 1] = -3.0
+    dt = 2.5e-4
+    o = _oracle(sc)
+    o.sort(); o.p2g(dt, sc.gravity); o.grid_update(dt, sc.params.boundary_handling, 0)
+    ref = o.nodes()
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.grid_debug_capture(True)
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, dt, 1)
+        e = node_errors(p.read_grid_nodes(), ref)
+    _report(f"trimesh_nodes_oriented{int(oriented)}", e)
+    assert e["n_got"] == e["n_ref"] == e["n_common"] and e["velocity_rel"] < 2e-5
+    o32, o64 = _oracle(sc), _oracle(sc, f64=True)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        for _ in range(100):
+            o32.substep_fixed(sc.params, sc.gravity, dt)
+            o64.substep_fixed(sc.params, sc.gravity, dt)
+        p.substeps(sc.params, sc.gravity, dt, 100)
+        got, r32, r64 = p.read_particles(), o32.get_particles(), o64.get_particles()
+    e = particle_errors(got, r32, sc.cell_width)
+    floor = particle_errors(r32, r64, sc.cell_width)
+    _report(f"trimesh_k100_oriented{int(oriented)}", {"vs_f32": e, "oracle_f32_vs_f64": floor})
+    touched = (np.abs(r32.velocity["vector"][:, 1] - (-3.0 + sc.gravity[1] * dt * 100)) > 0.05).sum()
+    assert touched > 100, "the scene must actually exercise the collider"
+    assert e["failed_mismatch"] == 0 and e["eps_x"] <= TOL
+    assert e["eps_v"] <= TOL or e["eps_v"] <= 3 * floor["eps_v"], (e, floor)
+
+
 def _rare_model_scenes():
     from sparkl_amd.models import (CorotatedLinearElasticity, MaximumStressFailure, NaccPlasticity, NeoHookeanElasticity, RankinePlasticity,
                                    SnowPlasticity)

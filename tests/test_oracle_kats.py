@@ -341,6 +341,42 @@ def test_heightfield_projection():
     assert not oracle.heightfield_project(hs, [9.0, -3.0, 3.0])[1]
 
 
+def test_trimesh_projection_matches_the_box_it_triangulates():
+    """parry TriMesh::project_local_point on a closed oriented box mesh == Cuboid::project_point (clamp outside, closest face
+    inside); without ORIENTED the mesh is a two-sided surface (is_inside never set); flip_interior inverts."""
+    he = [1.0, 2.0, 1.5]
+    v, i = scenes.box_mesh(he)
+    q = [0.0, 0.0, math.sin(0.3), math.cos(0.3)]
+    t = [3.0, -1.0, 0.5]
+    box = abi.CuboidColliderC()
+    box.half_extents[:] = he
+    box.rotation[:] = q
+    box.translation[:] = t
+    solid = abi.trimesh(v, i, translation=t, rotation=q, oriented=True)
+    sheet = abi.trimesh(v, i, translation=t, rotation=q, oriented=False)
+    flipped = abi.trimesh(v, i, translation=t, rotation=q, oriented=True, flip_interior=True)
+    rng = np.random.default_rng(11)
+    n_in = 0
+    for _ in range(300):
+        pt = rng.uniform(-3.0, 3.0, 3) + t
+        want, want_inside = oracle.cuboid_project(box, pt)
+        got, inside = oracle.trimesh_project(solid, pt)
+        assert inside == want_inside
+        assert np.linalg.norm(got - pt) == pytest.approx(np.linalg.norm(want - pt), abs=1e-9)   # the closest point may be another face at equal distance
+        if np.linalg.norm(want - pt) > 1e-3 and not want_inside:
+            assert np.allclose(got, want, atol=1e-9)
+        got2, inside2 = oracle.trimesh_project(sheet, pt)
+        assert not inside2 and np.allclose(got2, got, atol=1e-12)
+        assert oracle.trimesh_project(flipped, pt)[1] == (not want_inside)
+        n_in += want_inside
+    assert 5 < n_in < 295
+    # closest feature is a vertex / an edge of a convex corner: the pseudo-normals still say "outside"
+    for local in ([1.5, 2.5, 2.0], [1.5, 2.5, 0.0], [-1.2, 0.3, -1.9]):
+        c, s_ = math.cos(0.6), math.sin(0.6)
+        world = np.array([c * local[0] - s_ * local[1], s_ * local[0] + c * local[1], local[2]]) + t
+        assert not oracle.trimesh_project(solid, world)[1]
+
+
 def test_heightfield_scene_sand_comes_to_rest_on_the_surface():
     sc = scenes.sand_on_heightfield(6, 4, 6)
     o = oracle.Oracle(sc.cell_width)
