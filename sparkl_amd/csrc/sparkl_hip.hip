@@ -1175,6 +1175,8 @@ int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* pa
 int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params, const float gravity[3], SparklTimings* timings, float* simulated_time) {
     if (!p || !params || !gravity) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
     if (timings) memset(timings, 0, sizeof(*timings));
+    if (p->slab_on && (p->slab_lo != INT32_MIN || p->slab_hi != INT32_MAX))
+        return set_error(SPARKL_ERR_UNSUPPORTED, "adaptive step on a slab with finite cuts: the dt bound is per rank; drive fixed-length substeps through substep_begin/finish");
     // mls_solver.rs:25-28
     if (p->n == 0 || params->dt == 0.0f) { if (simulated_time) *simulated_time = params->dt; return SPARKL_OK; }
     CHK(ensure_ready(p));
