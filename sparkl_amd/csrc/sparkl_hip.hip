@@ -216,7 +216,10 @@ static inline int grid_for(size_t n, int threads) { return (int)((n + threads - 
 // Default reorder budget (see Ctl): an in-place block reorder costs about as much as this many excess run heads per
 // particle (~0.1 ns per excess head, ~0.6 ms per reorder at 10M: tools/long_run_probe.py, profiles/r01_reorder_policy.txt).
 static constexpr float DEFAULT_REORDER_HEADS_PER_PARTICLE = 0.6f;
-static constexpr uint32_t REORDER_PERIOD = 16;   // substeps between (mostly no-op) k_block_reorder launches
+#ifndef SPK_REORDER_PERIOD
+#define SPK_REORDER_PERIOD 16
+#endif
+static constexpr uint32_t REORDER_PERIOD = SPK_REORDER_PERIOD;   // substeps between (mostly no-op) k_block_reorder launches
 
 static GridArrays grid_arrays(const SparklPipeline* p) {
     GridArrays g;
