@@ -399,6 +399,11 @@ int sparkl_hip_rebin(SparklPipeline* p);
 int sparkl_hip_slab_emigrant_count(SparklPipeline* p, int side, uint64_t* n);          /* side 0 = low cut, 1 = high */
 int sparkl_hip_slab_emigrants_pack(SparklPipeline* p, int side, void* dev_out);        /* removes them locally */
 int sparkl_hip_slab_immigrants_add(SparklPipeline* p, const void* dev_in, uint64_t n);  /* needs a re-bin afterwards */
+/* Adaptive stepping across slabs: the local dt bound (timestep_estimator.rs:10-51 over this rank's particles, f32 bits,
+ * f32::MAX when the rank owns none) written to 4 bytes of device memory; the host takes the MIN over ranks (the bits of a
+ * non-negative float order like the float) and applies the step-length rule of mls_solver.rs:33-59.  `sparkl_amd/slab.py`
+ * (`SlabStepper.step`) does exactly that. */
+int sparkl_hip_dt_bound_export(SparklPipeline* p, void* dev_u32);
 /* re-bin request flag of the UPCOMING substep <-> a device u32 the host all-reduces (max) */
 int sparkl_hip_flags_export(SparklPipeline* p, void* dev_u32);
 int sparkl_hip_flags_import(SparklPipeline* p, const void* dev_u32);

@@ -22,7 +22,7 @@ SYMBOLS = [
     "sparkl_hip_grid_num_particle_blocks", "sparkl_hip_grid_debug_capture", "sparkl_hip_grid_read_nodes",
     "sparkl_hip_last_error_string", "sparkl_hip_version",
     "sparkl_hip_slab_set", "sparkl_hip_halo_record_bytes", "sparkl_hip_migration_record_bytes", "sparkl_hip_rebin",
-    "sparkl_hip_slab_emigrant_count", "sparkl_hip_slab_emigrants_pack", "sparkl_hip_slab_immigrants_add", "sparkl_hip_flags_export",
+    "sparkl_hip_slab_emigrant_count", "sparkl_hip_slab_emigrants_pack", "sparkl_hip_slab_immigrants_add", "sparkl_hip_dt_bound_export", "sparkl_hip_flags_export",
     "sparkl_hip_flags_import", "sparkl_hip_substep_begin", "sparkl_hip_halo_count", "sparkl_hip_halo_pack", "sparkl_hip_halo_merge",
     "sparkl_hip_substep_finish", "sparkl_hip_substep_finish_fused", "sparkl_hip_substep_status",
 ]

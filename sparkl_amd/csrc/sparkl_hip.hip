@@ -1306,6 +1306,23 @@ int sparkl_hip_rebin(SparklPipeline* p) {
     CHK(validate_models(p));
     return resort(p);
 }
+int sparkl_hip_dt_bound_export(SparklPipeline* p, void* dev_u32) {
+    if (!p || !dev_u32) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    HIPCHK(hipSetDevice(p->device));
+    CHK(validate_models(p));
+    const float fmax = std::numeric_limits<float>::max();
+    uint32_t bits;
+    memcpy(&bits, &fmax, 4);
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dt_bits, (int)bits, 1, p->stream));
+    if (p->n > 0) {
+        const int nblk = (int)grid_for(p->n, BLK_THREADS);
+        CHK(p->dt_partial.reserve(std::max<size_t>(nblk, (size_t)std::max(p->num_pblocks, 1))));
+        hipLaunchKernelGGL(k_estimate_dt, dim3(nblk), dim3(BLK_THREADS), 0, p->stream, p->cur.arrays(), p->d_models.p, p->d_ctl, (int)p->n, p->h, p->dt_partial.p);
+        hipLaunchKernelGGL(k_dt_reduce, dim3(1), dim3(1024), 0, p->stream, p->dt_partial.p, nblk, p->d_ctl);
+    }
+    HIPCHK(hipMemcpyAsync(dev_u32, &p->d_ctl->dt_bits, 4, hipMemcpyDeviceToDevice, p->stream));
+    return SPARKL_OK;
+}
 int sparkl_hip_flags_export(SparklPipeline* p, void* dev_u32) {
     if (!p || !dev_u32) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
     HIPCHK(hipMemcpyAsync(dev_u32, &p->d_ctl->abort_flag[p->substep_index & 1u], 4, hipMemcpyDeviceToDevice, p->stream));

@@ -91,6 +91,9 @@ class HipSlabBackend:
     def halo_merge(self, side, buf, n):
         check(self.L.sparkl_hip_halo_merge(self.h, side, self._ptr(buf), C.c_uint64(n)))
 
+    def dt_bound_export(self, buf):
+        check(self.L.sparkl_hip_dt_bound_export(self.h, self._ptr(buf)))
+
     def flags_export(self, buf):
         check(self.L.sparkl_hip_flags_export(self.h, self._ptr(buf)))
 
@@ -163,6 +166,18 @@ class SlabStepper:
             v.copy_(c)
         else:
             dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.group)
+
+    def _allreduce_min_f32_bits(self, t_u8):
+        """t_u8[:4] holds the bits of a non-negative f32: integer MIN == float MIN.  Returns the float (host sync)."""
+        v = t_u8[:4].view(torch.int32)
+        if self.world > 1:
+            if self.staged and v.is_cuda:
+                c = v.cpu()
+                dist.all_reduce(c, op=dist.ReduceOp.MIN, group=self.group)
+                v.copy_(c)
+            else:
+                dist.all_reduce(v, op=dist.ReduceOp.MIN, group=self.group)
+        return float(np.array([int(v.cpu().item())], dtype=np.int32).view(np.float32)[0])
 
     def _allreduce_max_host(self, value):
         """max over ranks of a host integer."""
@@ -237,6 +252,31 @@ class SlabStepper:
             if self.n_recv[side]:
                 b.halo_merge(side, self.recv[side], self.n_recv[side])
         b.substep_finish(fuse_next)
+
+    def step(self, params, gravity):
+        """`MpmPipeline::step` across the slabs: advances by params.dt in adaptive substeps whose length follows the rule of
+        mls_solver.rs:33-59 with the dt bound taken over ALL ranks' particles (timestep_estimator.rs:10-51).  Returns
+        (simulated time, list of substep lengths); every rank gets the same values."""
+        f32 = np.float32
+        if not self.binned:
+            self.rebin()
+        total = f32(params.dt)
+        if total == 0:
+            return float(total), []
+        min_dt = total / f32(params.max_num_substeps)
+        remaining, dts = total, []
+        while remaining > 0:
+            self.b.dt_bound_export(self.flag)
+            bound = f32(self._allreduce_min_f32_bits(self.flag))
+            dt = min(min(remaining, f32(params.max_substep_dt)), bound)
+            if dt < min_dt and remaining > min_dt:
+                dt = min_dt
+            self.substeps(params, gravity, float(dt), 1)
+            dts.append(float(dt))
+            remaining = f32(remaining - dt)
+            if params.stop_after_one_substep:
+                return float(dt), dts
+        return float(total), dts
 
     def substeps(self, params, gravity, dt, n):
         """n fixed-length substeps; re-bins (collectively) whenever any rank's particles leave their tile margin."""

@@ -55,12 +55,17 @@ def _worker(rank, world, port, kind, nsteps, out_dir):
         pipe.set_colliders(sc.colliders)
         pipe.upload_particles(comps)
         st = SlabStepper(HipSlabBackend(pipe, torch.device("cuda", 0)), rank, world, chunk=8)
-        st.substeps(sc.params, sc.gravity, dt, nsteps)
+        dts = []
+        if nsteps > 0:
+            st.substeps(sc.params, sc.gravity, dt, nsteps)
+        else:   # adaptive: -nsteps frames of params.dt through SlabStepper.step
+            for _ in range(-nsteps):
+                dts += st.step(sc.params, sc.gravity)[1]
         got = pipe.read_particles()
         local_ids = pipe.read_sorted_particle_ids()
     # local ids index this rank's upload order only for particles that never migrated; carry global ids through `user`:
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pos=got.position["point"], vel=got.velocity["vector"], F=got.volume["deformation_gradient"],
-             mass=got.volume["mass"], rebins=st.num_rebins, n0=len(gids), n1=len(got))
+             mass=got.volume["mass"], rebins=st.num_rebins, n0=len(gids), n1=len(got), dts=np.array(dts))
     pipe.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -106,3 +111,30 @@ def test_two_slabs_one_gpu_match_single_pipeline(tmp_path, kind, nsteps):
     assert ex < 2e-5 and ev < 2e-4 and eF < 2e-5
     if kind == "spin":
         assert any(int(q["n0"]) != int(q["n1"]) for q in parts), "the spinning cube must migrate particles across the cut"
+
+
+def test_two_slabs_adaptive_step_matches_single_pipeline(tmp_path):
+    """`SlabStepper.step` (dt bound = MIN over the ranks) against `sparkl_hip_pipeline_step` on the un-decomposed set."""
+    from sparkl_amd.pipeline import MpmPipeline
+    world, frames = 2, 2
+    mp.spawn(_worker, args=(world, _free_port(), "sand", -frames, str(tmp_path)), nprocs=world, join=True)
+    sc, _ = _scene("sand")
+    nsub = 0
+    with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        for _ in range(frames):
+            _, tim = p.step(sc.params, sc.gravity, timings=True)
+            nsub += tim.num_substeps
+        ref = p.read_particles()
+    parts = [np.load(os.path.join(tmp_path, f"rank{k}.npz")) for k in range(world)]
+    for q in parts:
+        assert len(q["dts"]) == nsub and abs(float(q["dts"].sum()) - frames * sc.params.dt) < 1e-6
+    assert np.array_equal(parts[0]["dts"], parts[1]["dts"])
+    pos = np.concatenate([q["pos"] for q in parts])
+    vel = np.concatenate([q["vel"] for q in parts])
+    assert len(pos) == len(sc.particles)
+    ka, kb = _match(pos, ref.position["point"])
+    ex = np.abs(pos[ka] - ref.position["point"][kb]).max() / sc.cell_width
+    ev = np.abs(vel[ka] - ref.velocity["vector"][kb]).max() / np.abs(ref.velocity["vector"]).max()
+    print("adaptive slab vs single:", ex, ev, nsub)
+    assert ex < 2e-5 and ev < 2e-4

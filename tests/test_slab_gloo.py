@@ -109,6 +109,10 @@ class OracleSlabBackend:
     def halo_count(self, side):
         return len(self.halo_ids[side])
 
+    def dt_bound_export(self, buf):
+        bound = np.float32(self.o.estimate_dt(float(np.finfo(np.float32).max))) if len(self.local_idx) else np.finfo(np.float32).max
+        buf[:4] = torch.from_numpy(np.array([bound], np.float32).view(np.uint8).copy())
+
     def flags_export(self, buf):
         buf[:4] = torch.from_numpy(np.array([self.next_flag], np.int32).view(np.uint8).copy())
 
@@ -176,9 +180,14 @@ def _worker(rank, world, port, nsteps, dt, out_dir):
         setattr(comps, k, np.ascontiguousarray(getattr(sc.particles, k)[mine]))
     backend = OracleSlabBackend(sc, comps, np.nonzero(mine)[0], 0, cuts[rank], cuts[rank + 1])
     st = SlabStepper(backend, rank, world, chunk=4)
-    st.substeps(sc.params, sc.gravity, dt, nsteps)
+    dts = []
+    if nsteps > 0:
+        st.substeps(sc.params, sc.gravity, dt, nsteps)
+    else:   # adaptive: -nsteps frames of params.dt
+        for _ in range(-nsteps):
+            dts += st.step(sc.params, sc.gravity)[1]
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), gid=backend.gids, pos=backend.comps.position["point"], vel=backend.comps.velocity["vector"],
-             F=backend.comps.volume["deformation_gradient"], rebins=st.num_rebins, n0=int(mine.sum()))
+             F=backend.comps.volume["deformation_gradient"], rebins=st.num_rebins, n0=int(mine.sum()), dts=np.array(dts))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -214,6 +223,31 @@ def test_two_slabs_match_single_domain(tmp_path):
     # the cloud rotates through the cut: particles must have migrated, i.e. collective re-bins happened
     assert max(int(p["rebins"]) for p in parts) >= 2
     assert any(len(p["gid"]) != int(p["n0"]) for p in parts)
+
+
+def test_two_slabs_adaptive_step_matches_single_domain(tmp_path):
+    """`SlabStepper.step`: the dt bound is the MIN over both ranks, so the substep lengths are the single-domain ones."""
+    from oracle import Oracle
+    frames, world = 2, 2
+    mp.spawn(_worker, args=(world, _free_port(), -frames, 0.0, str(tmp_path)), nprocs=world, join=True)
+    sc = _scene()
+    ref = Oracle(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes)
+    ref.load_scene(sc)
+    want_dts = []
+    for _ in range(frames):
+        ref.step(sc.params, sc.gravity)
+        want_dts += ref.last_dts().tolist()
+    r = ref.get_particles()
+    parts = [np.load(os.path.join(tmp_path, f"rank{k}.npz")) for k in range(world)]
+    for p in parts:
+        assert len(p["dts"]) == len(want_dts) and np.allclose(p["dts"], want_dts, rtol=1e-6), (p["dts"], want_dts)
+    gid = np.concatenate([p["gid"] for p in parts]).astype(np.int64)
+    assert sorted(gid.tolist()) == list(range(len(sc.particles)))
+    pos = np.concatenate([p["pos"] for p in parts])[np.argsort(gid)]
+    vel = np.concatenate([p["vel"] for p in parts])[np.argsort(gid)]
+    vmax = np.abs(r.velocity["vector"]).max()
+    assert np.abs(pos - r.position["point"]).max() / sc.cell_width < 5e-5
+    assert np.abs(vel - r.velocity["vector"]).max() / vmax < 5e-5
 
 
 def test_cut_helpers():
