@@ -973,6 +973,7 @@ struct Oracle {
     }
 
     // ---- grid_to_particle.rs:10-166 (DamageModel::None, no failure model, no projection)
+    bool project_particles = false;   // SolverParameters::enable_boundary_particle_projection (set by substep / oracle_g2p_project)
     void g2p(R dt) {
         R invd = inv_d(h);
         uint64_t pshift[27];
@@ -1036,6 +1037,16 @@ struct Oracle {
                 if (model.has_failure_model && model.failure_model.tag == SPARKL_FAILURE_MAXIMUM_STRESS &&
                     maximum_stress_failed(model.failure_model.u.maximum_stress, stress_of(p)))
                     p.phase = R(0);
+                // grid_to_particle.rs:146-163: particles found inside a collider are put back on its surface
+                if (project_particles) {
+                    auto fix = [&](const Projection<R>& proj) {
+                        if (!proj.is_inside) return;
+                        for (int a = 0; a < 3; ++a) { p.velocity[a] += (proj.point[a] - p.position[a]) / dt; p.position[a] = proj.point[a]; }
+                    };
+                    for (const auto& col : cuboids) fix(cuboid_project_point(col, p.position));
+                    for (const auto& hf : heightfields) fix(heightfield_project_point(hf, p.position));
+                    for (const auto& tm : trimeshes) fix(trimesh_project_point(tm, p.position));
+                }
             }
         }
     }
@@ -1100,6 +1111,7 @@ struct Oracle {
         }
         p2g(dt, gravity);
         grid_update(dt, params.boundary_handling, params.simulation_dofs);
+        project_particles = params.enable_boundary_particle_projection != 0;
         g2p(dt);
         return dt;
     }

@@ -66,6 +66,9 @@ struct ParticleArrays {
 };
 SPK_DEV uint32_t particle_id(const ParticleArrays& P, int i) { return reinterpret_cast<const uint32_t*>(&P.aux[i])[3]; }
 
+struct DevCuboid;
+struct DevHeightField;
+struct DevTriMesh;
 struct GridArrays {
     const int4* blk_origin;    // cell coordinate of node (0,0,0) of the block, w = tile index or -1
     const int* blk_pfirst;
@@ -80,6 +83,9 @@ struct GridArrays {
     float4* node_mom;          // [B][64]  (px, py, pz, -) debug capture or NULL
     const float4* halo_in;     // [B][64]  (mass, px, py, pz) received from neighbour slabs, or NULL
     uint32_t* dt_partial;      // [gridDim] per-workgroup minimum of the dt bound (float bits), reduced by k_dt_reduce
+    const DevCuboid* cuboids;  // the collider arrays, for enable_boundary_particle_projection (G2P tail)
+    const DevHeightField* heightfields;
+    const DevTriMesh* trimeshes;
     int num_blocks;
     int num_pblocks;
 };
@@ -96,6 +102,7 @@ struct StepParams {
     int num_cuboids;
     int num_heightfields;
     int num_trimeshes;
+    int project_particles;   // SolverParameters::enable_boundary_particle_projection
     int want_dt;      // G2P also reduces the next substep's dt bound into ctl->dt_bits (adaptive stepping)
     float dt_next;    // k_g2p2g: the step length the fused scatter (P2G of the NEXT substep) is built for; = dt for fixed-dt batches
 };
@@ -864,6 +871,35 @@ __global__ __launch_bounds__(1024) void k_dt_reduce(const uint32_t* __restrict__
     }
 }
 
+// grid_to_particle.rs:146-163 (enable_boundary_particle_projection): a particle found inside a collider is put back on its
+// surface and its velocity corrected by the displacement / dt.  Colliders in the order of the grid update.
+SPK_DEV void project_particle_on_colliders(const GridArrays& G, const StepParams& S, float px[3], float vel[3]) {
+    const float inv_dt = 1.0f / S.dt;
+    for (int ci = 0; ci < S.num_cuboids; ++ci) {
+        float proj[3];
+        if (cuboid_project(G.cuboids[ci], px, proj)) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { vel[a] += (proj[a] - px[a]) * inv_dt; px[a] = proj[a]; }
+        }
+    }
+    for (int hi = 0; hi < S.num_heightfields; ++hi) {
+        float proj[3];
+        bool inside = false;
+        if (heightfield_project(G.heightfields[hi], px, 4.0f * S.h, proj, inside) && inside) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { vel[a] += (proj[a] - px[a]) * inv_dt; px[a] = proj[a]; }
+        }
+    }
+    for (int ti = 0; ti < S.num_trimeshes; ++ti) {
+        float proj[3];
+        bool inside = false;
+        if (trimesh_project(G.trimeshes[ti], px, 4.0f * S.h, proj, inside) && inside) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { vel[a] += (proj[a] - px[a]) * inv_dt; px[a] = proj[a]; }
+        }
+    }
+}
+
 // State of one particle after grid_to_particle.rs:62-164 (gather .. psi_pos), before it is written back.
 struct Advected {
     float px[3], vel[3];
@@ -882,7 +918,7 @@ struct Advected {
 // model of the set needs it, so the elastic / Drucker-Prager kernels keep their register budget (inlining that code,
 // or calling it out of line, cost the hot kernel 35 %).
 template <bool RARE>
-SPK_DEV Advected g2p_update(const float4* vt, const DevModel& mo, uint32_t flags, const float4& q0, const float4& q1, const float4& q2, const float4& dd,
+SPK_DEV Advected g2p_update(const GridArrays& G, const float4* vt, const DevModel& mo, uint32_t flags, const float4& q0, const float4& q1, const float4& q2, const float4& dd,
                             const float4& kk, const float4* kinvel_i, const float4* aux_i, float phase, const int4& org, const StepParams& S, float inv_h,
                             unsigned* num_invalid) {
     Advected o;
@@ -996,6 +1032,7 @@ mo, phase, F, Jp, q, lvg, sv, sv_valid);
         o.store_aux = true;
         if (!(flags & FLAG_PHASE_NOT_ONE)) { flags |= FLAG_PHASE_NOT_ONE; newly_failed = true; }   // the flags word must be stored
     }
+    if (RARE && S.project_particles) project_particle_on_colliders(G, S, px, vel);
     // does the particle still sit inside its home block's tile, and inside the domain?
     bool invalid = false, in_tile = true;
 #pragma unroll
@@ -1070,7 +1107,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
         if (flags & FLAG_INVALID) continue;
         const DevModel& mo = models[flags >> FLAG_MODEL_SHIFT];
         const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
-        const Advected o = g2p_update<RARE>(vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
+        const Advected o = g2p_update<RARE>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
         g2p_store(P, i, o);
         want_sort |= !o.in_tile;
         if (S.want_dt) {  // the bound the next substep's estimator would compute from this state
@@ -1153,7 +1190,7 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
         if (live) {
             const DevModel& mo = models[flags >> FLAG_MODEL_SHIFT];
             const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
-            const Advected o = g2p_update<RARE>(vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
+            const Advected o = g2p_update<RARE>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
             g2p_store(P, i, o);
             want_sort |= !o.in_tile;
             live = o.in_tile;

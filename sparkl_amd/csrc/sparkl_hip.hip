@@ -224,6 +224,7 @@ static constexpr uint32_t REORDER_PERIOD = SPK_REORDER_PERIOD;   // substeps bet
 static GridArrays grid_arrays(const SparklPipeline* p) {
     GridArrays g;
     g.blk_origin = p->blk_origin.p; g.blk_pfirst = p->blk_pfirst.p; g.blk_pcount = p->blk_pcount.p; g.blk_nbr = p->blk_nbr.p; g.blk_tnbr = p->blk_tnbr.p; g.dt_partial = p->dt_partial.p;
+    g.cuboids = p->d_cuboids.p; g.heightfields = p->d_heightfields.p; g.trimeshes = p->d_trimeshes.p;
     g.pblk = p->pblk.p; g.pb_info = p->pb_info.p; g.tile_mode = p->tile_mode.p; g.tiles = p->tiles.p; g.node_vel = p->node_vel.p; g.node_mom = p->capture_mom ? p->node_mom.p : nullptr;
     g.halo_in = (p->slab_on && p->num_blocks) ? p->halo_in.p : nullptr;
     g.num_blocks = p->num_blocks; g.num_pblocks = p->num_pblocks;
@@ -385,6 +386,7 @@ static StepParams make_params(const SparklPipeline* p, const SparklSolverParams*
     S.gx = g[0]; S.gy = g[1]; S.gz = g[2];
     S.boundary_handling = sp->boundary_handling; S.dofs = sp->simulation_dofs;
     S.parity = (int)(p->substep_index & 1u); S.dom = p->dom; S.num_cuboids = p->num_cuboids; S.num_heightfields = p->num_heightfields; S.num_trimeshes = p->num_trimeshes; S.want_dt = 0;
+    S.project_particles = sp->enable_boundary_particle_projection ? 1 : 0;
     S.dt_next = dt;
     return S;
 }
@@ -413,12 +415,12 @@ static void launch_p2g(SparklPipeline* p, const ParticleArrays& P, const GridArr
 }
 static void launch_g2p(SparklPipeline* p, const ParticleArrays& P, const GridArrays& G, const StepParams& S, hipStream_t st) {
     const dim3 grid(p->num_pblocks), block(BLK_THREADS);
-    if (p->rare_models) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p<true>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
+    if (p->rare_models || S.project_particles) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p<true>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p<false>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
 }
 static void launch_g2p2g(SparklPipeline* p, const ParticleArrays& P, const GridArrays& G, const StepParams& S, hipStream_t st) {
     const dim3 grid(p->num_pblocks), block(BLK_THREADS);
-    if (p->rare_models) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<SPK_P2G_REDUCE_STEPS, true>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
+    if (p->rare_models || S.project_particles) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<SPK_P2G_REDUCE_STEPS, true>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<SPK_P2G_REDUCE_STEPS, false>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
 }
 

@@ -310,6 +310,44 @@ def test_status_flags_and_solver_options_parity(Pipeline, name):
         assert np.abs(got.velocity["vector"][:, 2]).max() == 0.0
 
 
+def test_boundary_particle_projection(Pipeline):
+    """`enable_boundary_particle_projection` (grid_to_particle.rs:146-163): particles found inside a collider are put back on
+    its surface, velocity corrected by displacement / dt."""
+    import oracle as orc
+    sc = scenes.sand_column(14, 10, 10)
+    c = sc.particles.position["point"].astype(np.float64)
+    centre = 0.5 * (c.min(0) + c.max(0))
+    obstacle = abi.CuboidColliderC()
+    obstacle.half_extents[:] = [0.22, 0.17, 0.19]
+    obstacle.rotation[:] = [0.0, 0.0, np.sin(0.2), np.cos(0.2)]
+    obstacle.translation[:] = [float(x) for x in centre]
+    obstacle.friction = 0.3
+    sc.colliders = list(sc.colliders) + [obstacle]
+    sc.params.enable_boundary_particle_projection = 1
+    inside0 = sum(orc.cuboid_project(obstacle, x)[1] for x in c)
+    assert inside0 > 50
+    dt = 2.5e-4
+    o32, o64 = _oracle(sc), _oracle(sc, f64=True)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        for _ in range(30):
+            o32.substep_fixed(sc.params, sc.gravity, dt)
+            o64.substep_fixed(sc.params, sc.gravity, dt)
+        p.substeps(sc.params, sc.gravity, dt, 30)
+        got, r32, r64 = p.read_particles(), o32.get_particles(), o64.get_particles()
+    e = particle_errors(got, r32, sc.cell_width)
+    floor = particle_errors(r32, r64, sc.cell_width)
+    _report("particle_projection", {"vs_f32": e, "oracle_f32_vs_f64": floor, "inside_at_start": int(inside0)})
+    # nobody is left strictly inside (a particle on the surface may round to either side: allow a 1e-5 skin)
+    shrunk = abi.CuboidColliderC()
+    shrunk.half_extents[:] = [h - 1e-5 for h in obstacle.half_extents]
+    shrunk.rotation[:] = list(obstacle.rotation)
+    shrunk.translation[:] = list(obstacle.translation)
+    assert sum(orc.cuboid_project(shrunk, x)[1] for x in got.position["point"].astype(np.float64)) == 0
+    assert e["failed_mismatch"] == 0 and e["eps_x"] <= TOL, (e, floor)
+    assert e["eps_v"] <= TOL or e["eps_v"] <= 3 * floor["eps_v"], (e, floor)
+
+
 def test_empty_and_single_particle_sets(Pipeline):
     """mls_solver.rs:25-28: an empty set steps trivially; one particle in free fall follows v = g t exactly enough."""
     from sparkl_amd.particles import ParticleComponents
