@@ -1597,25 +1597,69 @@ __global__ void k_read_velocities(ParticleArrays P, float* out, int n, long long
     float* o = out + 3 * out_slot(P, i, id_base);
     o[0] = q3.x; o[1] = q3.y; o[2] = q3.z;
 }
-// 24 floats per particle: F[9], Jp, q, lvg | psi, flags(bits), mass, volume0 | eh, phase, radius0, nacc_alpha | kin[3], id(bits)
-__global__ void k_read_state(ParticleArrays P, float* out, int n, long long id_base) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 q0 = P.q[0][i], q1 = P.q[1][i], q2 = P.q[2][i], dd = P.d[i], kk = P.k[i], ax = P.aux[i], kv = P.kinvel[i];
-    float4* o = reinterpret_cast<float4*>(out + 24 * out_slot(P, i, id_base));
-    o[0] = make_float4(q0.w, q1.x, q1.y, q1.z);
-    o[1] = make_float4(q1.w, q2.x, q2.y, q2.z);
-    o[2] = make_float4(q2.w, dd.z, dd.x, dd.y);
-    o[3] = make_float4(dd.w, kk.w, kk.x, kk.y);
-    o[4] = make_float4(kk.z, ax.x, ax.y, ax.z);
-    o[5] = make_float4(kv.x, kv.y, kv.z, ax.w);
-}
 __global__ void k_read_velgrad(ParticleArrays P, float* out, int n, long long id_base) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 q3 = P.q[3][i], q4 = P.q[4][i], q5 = P.q[5][i];
     float* o = out + 9 * out_slot(P, i, id_base);
     o[0] = q3.w; o[1] = q4.x; o[2] = q4.y; o[3] = q4.z; o[4] = q4.w; o[5] = q5.x; o[6] = q5.y; o[7] = q5.z; o[8] = q5.w;
+}
+// `CudaParticleSet::from_particles`: the caller's seven repr(C) component arrays (raw bytes, copied to the device as they are)
+// packed into the float4 streams.  status 24 B | position 12 | velocity 12 | volume 52 | phase 8 | data 16 | velocity gradient 36.
+__global__ void k_pack_upload(ParticleArrays P, int first, int n, uint32_t id_base, const uint32_t* __restrict__ status, const float* __restrict__ pos,
+                              const float* __restrict__ vel, const float* __restrict__ vol, const float* __restrict__ phase, const float* __restrict__ data,
+                              const float* __restrict__ vg) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int i = first + j;
+    const float* V = vol + 13 * (size_t)j;       // mass, volume0, radius0, F[9], Jp
+    const float* X = pos + 3 * (size_t)j;
+    const float* U = vel + 3 * (size_t)j;
+    const uint32_t* S = status + 6 * (size_t)j;
+    const float* D = data + 4 * (size_t)j;       // nacc_alpha, plastic_hardening, elastic_hardening, log_vol_gain
+    float C[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (vg) for (int e = 0; e < 9; ++e) C[e] = vg[9 * (size_t)j + e];
+    P.q[0][i] = make_float4(X[0], X[1], X[2], V[3]);
+    P.q[1][i] = make_float4(V[4], V[5], V[6], V[7]);
+    P.q[2][i] = make_float4(V[8], V[9], V[10], V[11]);
+    P.q[3][i] = make_float4(U[0], U[1], U[2], C[0]);
+    P.q[4][i] = make_float4(C[1], C[2], C[3], C[4]);
+    P.q[5][i] = make_float4(C[5], C[6], C[7], C[8]);
+    const float ph = phase[2 * (size_t)j], psi = phase[2 * (size_t)j + 1];
+    P.d[i] = make_float4(D[1], D[3], V[12], psi);
+    uint32_t flags = S[4] << FLAG_MODEL_SHIFT;
+    if (S[0] & 0xFFu) flags |= FLAG_FAILED;
+    if (S[0] & 0xFF00u) flags |= FLAG_STATIC;
+    if (S[0] & 0xFF0000u) flags |= FLAG_KINEMATIC;
+    if (ph != 1.0f) flags |= FLAG_PHASE_NOT_ONE;
+    P.k[i] = make_float4(V[0], V[1], D[2], __uint_as_float(flags));
+    P.kinvel[i] = make_float4(__uint_as_float(S[1]), __uint_as_float(S[2]), __uint_as_float(S[3]), 0.f);
+    P.aux[i] = make_float4(ph, V[2], D[0], __uint_as_float(id_base + (uint32_t)i));
+}
+// the repr(C) component structs written on the device, one kernel per component (what = 0 volume 13 floats, 1 status 6 words,
+// 2 data 4 floats), so that the host side is one memcpy into the caller's array
+__global__ void k_read_struct(ParticleArrays P, uint32_t* out, int n, long long id_base, int what) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t o = out_slot(P, i, id_base);
+    if (what == 0) {          // SparklParticleVolume: mass, volume0, radius0, F[9], plastic_deformation_gradient_det
+        const float4 q0 = P.q[0][i], q1 = P.q[1][i], q2 = P.q[2][i], dd = P.d[i], kk = P.k[i], ax = P.aux[i];
+        float* w = reinterpret_cast<float*>(out) + 13 * o;
+        w[0] = kk.x; w[1] = kk.y; w[2] = ax.y;
+        w[3] = q0.w; w[4] = q1.x; w[5] = q1.y; w[6] = q1.z; w[7] = q1.w; w[8] = q2.x; w[9] = q2.y; w[10] = q2.z; w[11] = q2.w;
+        w[12] = dd.z;
+    } else if (what == 1) {   // SparklParticleStatus: failed, is_static, kinematic_vel_enabled, pad | kinematic_vel[3] | model_index u64
+        const float4 kk = P.k[i], kv = P.kinvel[i];
+        const uint32_t flags = __float_as_uint(kk.w);
+        uint32_t* w = out + 6 * o;
+        w[0] = ((flags & FLAG_FAILED) ? 1u : 0u) | ((flags & FLAG_STATIC) ? 0x100u : 0u) | ((flags & FLAG_KINEMATIC) ? 0x10000u : 0u);
+        w[1] = __float_as_uint(kv.x); w[2] = __float_as_uint(kv.y); w[3] = __float_as_uint(kv.z);
+        w[4] = flags >> FLAG_MODEL_SHIFT; w[5] = 0u;
+    } else {                  // SparklParticleData: nacc_alpha, plastic_hardening, elastic_hardening, log_vol_gain
+        const float4 dd = P.d[i], kk = P.k[i], ax = P.aux[i];
+        float* w = reinterpret_cast<float*>(out) + 4 * o;
+        w[0] = ax.z; w[1] = dd.x; w[2] = kk.z; w[3] = dd.y;
+    }
 }
 // the three per-frame render components in one pass (any output may be null)
 __global__ void k_read_render(ParticleArrays P, float* pos, float* vel, float* phase, int n, long long id_base) {

@@ -886,42 +886,35 @@ int sparkl_hip_colliders_set_trimeshes(SparklPipeline* p, uint32_t n, const Spar
 static int upload_range(SparklPipeline* p, uint64_t first, uint64_t n, const SparklParticleStatus* status, const SparklParticlePosition* pos,
                         const SparklParticleVelocity* vel, const SparklParticleVolume* volume, const SparklParticlePhase* phase,
                         const SparklParticleData* data, const SparklVelocityGradient* vg) {
-    // pack the caller's SoA into the eight float4 streams (host), then one H2D per stream
-    std::vector<float4> hq[6], hd(n), hk(n), hkin(n), haux(n);
-    for (auto& v : hq) v.resize(n);
-    for (uint64_t i = 0; i < n; ++i) {
-        const float* F = volume[i].deformation_gradient;
-        const float zero9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        const float* C = vg ? vg[i].m : zero9;
-        hq[0][i] = make_float4(pos[i].point[0], pos[i].point[1], pos[i].point[2], F[0]);
-        hq[1][i] = make_float4(F[1], F[2], F[3], F[4]);
-        hq[2][i] = make_float4(F[5], F[6], F[7], F[8]);
-        hq[3][i] = make_float4(vel[i].vector[0], vel[i].vector[1], vel[i].vector[2], C[0]);
-        hq[4][i] = make_float4(C[1], C[2], C[3], C[4]);
-        hq[5][i] = make_float4(C[5], C[6], C[7], C[8]);
-        hd[i] = make_float4(data[i].plastic_hardening, data[i].log_vol_gain, volume[i].plastic_deformation_gradient_det, phase[i].psi_pos);
-        uint32_t flags = ((uint32_t)status[i].model_index << FLAG_MODEL_SHIFT);
-        if (status[i].failed) flags |= FLAG_FAILED;
-        if (status[i].is_static) flags |= FLAG_STATIC;
-        if (status[i].kinematic_vel_enabled) flags |= FLAG_KINEMATIC;
-        if (phase[i].phase != 1.0f) flags |= FLAG_PHASE_NOT_ONE;
-        float fl;
-        memcpy(&fl, &flags, 4);
-        hk[i] = make_float4(volume[i].mass, volume[i].volume0, data[i].elastic_hardening, fl);
-        hkin[i] = make_float4(status[i].kinematic_vel[0], status[i].kinematic_vel[1], status[i].kinematic_vel[2], 0.f);
-        const uint32_t gid = (uint32_t)(p->id_offset + first + i);
-        float gidf;
-        memcpy(&gidf, &gid, 4);
-        haux[i] = make_float4(phase[i].phase, volume[i].radius0, data[i].nacc_alpha, gidf);
-        p->max_model_index = std::max(p->max_model_index, (uint32_t)status[i].model_index);
-    }
+    // the caller's arrays go to the device as they are (160 B per particle) and are packed into the float4 streams there
+    static_assert(sizeof(SparklParticleStatus) == 24 && sizeof(SparklParticlePosition) == 12 && sizeof(SparklParticleVelocity) == 12 &&
+                  sizeof(SparklParticleVolume) == 52 && sizeof(SparklParticlePhase) == 8 && sizeof(SparklParticleData) == 16 && sizeof(SparklVelocityGradient) == 36, "");
+    for (uint64_t i = 0; i < n; ++i) p->max_model_index = std::max(p->max_model_index, (uint32_t)status[i].model_index);
     hipStream_t st = p->stream;
-    for (int a = 0; a < 6; ++a) HIPCHK(hipMemcpyAsync(p->cur.q[a].p + first, hq[a].data(), n * sizeof(float4), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(p->cur.d.p + first, hd.data(), n * sizeof(float4), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(p->cur.k.p + first, hk.data(), n * sizeof(float4), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(p->cur.kinvel.p + first, hkin.data(), n * sizeof(float4), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(p->cur.aux.p + first, haux.data(), n * sizeof(float4), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));
+    // chunks bound the staging area (40 floats per particle) for very large sets
+    const uint64_t CHUNK = 1ull << 24;
+    CHK(p->staging.reserve((size_t)std::min(n, CHUNK) * 40));
+    for (uint64_t c0 = 0; c0 < n; c0 += CHUNK) {
+        const uint64_t m = std::min(CHUNK, n - c0);
+        float* base = p->staging.p;
+        uint32_t* d_status = (uint32_t*)base;            // 6 words
+        float* d_pos = base + 6 * m;                     // 3
+        float* d_vel = d_pos + 3 * m;                    // 3
+        float* d_vol = d_vel + 3 * m;                    // 13
+        float* d_phase = d_vol + 13 * m;                 // 2
+        float* d_data = d_phase + 2 * m;                 // 4
+        float* d_vg = d_data + 4 * m;                    // 9
+        HIPCHK(hipMemcpyAsync(d_status, status + c0, m * 24, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_pos, pos + c0, m * 12, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_vel, vel + c0, m * 12, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_vol, volume + c0, m * 52, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_phase, phase + c0, m * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_data, data + c0, m * 16, hipMemcpyHostToDevice, st));
+        if (vg) HIPCHK(hipMemcpyAsync(d_vg, vg + c0, m * 36, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_pack_upload, dim3(grid_for(m, 256)), dim3(256), 0, st, p->cur.arrays(), (int)(first + c0), (int)m, (uint32_t)p->id_offset, d_status, d_pos, d_vel,
+                           d_vol, d_phase, d_data, vg ? d_vg : (const float*)nullptr);
+        HIPCHK(hipStreamSynchronize(st));   // the staging area is reused by the next chunk (and by the read paths)
+    }
     return SPARKL_OK;
 }
 
@@ -955,7 +948,6 @@ static int launch_read(SparklPipeline* p, int what, size_t floats_per, long long
     switch (what) {
         case 0: hipLaunchKernelGGL(k_read_positions, g, b, 0, st, P, p->staging.p, n, id_base); break;
         case 1: hipLaunchKernelGGL(k_read_velocities, g, b, 0, st, P, p->staging.p, n, id_base); break;
-        case 2: hipLaunchKernelGGL(k_read_state, g, b, 0, st, P, p->staging.p, n, id_base); break;
         default: hipLaunchKernelGGL(k_read_velgrad, g, b, 0, st, P, p->staging.p, n, id_base); break;
     }
     return SPARKL_OK;
@@ -981,41 +973,22 @@ int sparkl_hip_particles_read_velocities(SparklPipeline* p, SparklParticleVeloci
     HIPCHK(hipStreamSynchronize(p->stream));
     return SPARKL_OK;
 }
-static int read_state(SparklPipeline* p, std::vector<float>& st) {
-    CHK(launch_read(p, 2, 24, read_base(p)));
-    st.resize((size_t)p->n * 24);
-    HIPCHK(hipMemcpyAsync(st.data(), p->staging.p, st.size() * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+static int read_struct(SparklPipeline* p, void* out, uint64_t n, int what, size_t words) {
+    CHK(p->staging.reserve(n * words));
+    hipLaunchKernelGGL(k_read_struct, dim3(grid_for(n, 256)), dim3(256), 0, p->stream, p->cur.arrays(), (uint32_t*)p->staging.p, (int)n, read_base(p), what);
+    HIPCHK(hipMemcpyAsync(out, p->staging.p, n * words * 4, hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     return SPARKL_OK;
 }
 int sparkl_hip_particles_read_volumes(SparklPipeline* p, SparklParticleVolume* out, uint64_t n) {
     READ_PROLOGUE
-    std::vector<float> st;
-    CHK(read_state(p, st));
-    for (uint64_t i = 0; i < n; ++i) {
-        const float* s = &st[24 * i];
-        out[i].mass = s[14]; out[i].volume0 = s[15]; out[i].radius0 = s[18];
-        for (int k = 0; k < 9; ++k) out[i].deformation_gradient[k] = s[k];
-        out[i].plastic_deformation_gradient_det = s[9];
-    }
-    return SPARKL_OK;
+    static_assert(sizeof(SparklParticleVolume) == 52, "");
+    return read_struct(p, out, n, 0, 13);
 }
 int sparkl_hip_particles_read_statuses(SparklPipeline* p, SparklParticleStatus* out, uint64_t n) {
     READ_PROLOGUE
-    std::vector<float> st;
-    CHK(read_state(p, st));
-    for (uint64_t i = 0; i < n; ++i) {
-        const float* s = &st[24 * i];
-        uint32_t flags;
-        memcpy(&flags, &s[13], 4);
-        memset(&out[i], 0, sizeof(out[i]));
-        out[i].failed = (flags & FLAG_FAILED) ? 1 : 0;
-        out[i].is_static = (flags & FLAG_STATIC) ? 1 : 0;
-        out[i].kinematic_vel_enabled = (flags & FLAG_KINEMATIC) ? 1 : 0;
-        out[i].kinematic_vel[0] = s[20]; out[i].kinematic_vel[1] = s[21]; out[i].kinematic_vel[2] = s[22];
-        out[i].model_index = flags >> FLAG_MODEL_SHIFT;
-    }
-    return SPARKL_OK;
+    static_assert(sizeof(SparklParticleStatus) == 24, "");
+    return read_struct(p, out, n, 1, 6);
 }
 int sparkl_hip_particles_read_phases(SparklPipeline* p, SparklParticlePhase* out, uint64_t n) {
     READ_PROLOGUE
@@ -1027,13 +1000,8 @@ int sparkl_hip_particles_read_phases(SparklPipeline* p, SparklParticlePhase* out
 }
 int sparkl_hip_particles_read_data(SparklPipeline* p, SparklParticleData* out, uint64_t n) {
     READ_PROLOGUE
-    std::vector<float> st;
-    CHK(read_state(p, st));
-    for (uint64_t i = 0; i < n; ++i) {
-        const float* s = &st[24 * i];
-        out[i].nacc_alpha = s[19]; out[i].plastic_hardening = s[10]; out[i].elastic_hardening = s[16]; out[i].log_vol_gain = s[11];
-    }
-    return SPARKL_OK;
+    static_assert(sizeof(SparklParticleData) == 16, "");
+    return read_struct(p, out, n, 2, 4);
 }
 int sparkl_hip_particles_read_velocity_gradients(SparklPipeline* p, SparklVelocityGradient* out, uint64_t n) {
     READ_PROLOGUE
