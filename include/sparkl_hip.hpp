@@ -280,6 +280,11 @@ public:
     void set_heightfields(const std::vector<SparklHeightFieldCollider>& hfs) { check(sparkl_hip_colliders_set_heightfields(h_, (uint32_t)hfs.size(), hfs.data())); }
     // triangle meshes (rapier `ColliderBuilder::trimesh`); the mesh is copied
     void set_trimeshes(const std::vector<SparklTriMeshCollider>& meshes) { check(sparkl_hip_colliders_set_trimeshes(h_, (uint32_t)meshes.size(), meshes.data())); }
+    // per-frame render readback (testbed_plugin.rs:533-588): pinned buffers, copies overlapped with the next step
+    template <class T> static T* host_alloc(size_t count) { void* ptr = nullptr; check(sparkl_hip_host_alloc(&ptr, count * sizeof(T))); return (T*)ptr; }
+    static void host_free(void* ptr) { check(sparkl_hip_host_free(ptr)); }
+    void readback_begin(SparklParticlePosition* pos, SparklParticleVelocity* vel, SparklParticlePhase* phase) { check(sparkl_hip_readback_begin(h_, pos, vel, phase, len())); }
+    void readback_wait() { check(sparkl_hip_readback_wait(h_)); }
     void upload(const ParticleSet& particles) {  // CudaParticleSet::from_particles(extract_particles_components(..))
         ParticleComponents c = extract_particles_components(particles.particles());
         check(sparkl_hip_particles_upload(h_, c.status.size(), c.status.data(), c.position.data(), c.velocity.data(), c.volume.data(), c.phase.data(), c.data.data(),
