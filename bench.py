@@ -1,23 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- particle-steps/s of the MI355X MPM hot path on BASELINE.json's 10M-particle Drucker-Prager column.
+"""bench.py -- particle-steps/s of the MI355X MPM hot path on BASELINE.json's configurations.
 
-One "step" = one substep (P2G -> grid update -> G2P, re-bin when a particle leaves its tile margin) of fixed
-length dt = 2.5e-4 on synthetic, HBM-resident particles.  Prints ONE JSON line.
+One "step" = one substep (P2G -> grid update -> G2P, re-bin when a particle leaves its tile margin) of fixed length on
+synthetic, HBM-resident particles.  Prints ONE JSON line.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--particles P] [--no-cpu-baseline]
-N > 1 is launched by torch.distributed.run (one rank per GPU); see DESIGN.md "Multi-GPU".
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config sand10m|neo1m|fluid20m] [--particles P] [--no-cpu-baseline]
+
+--config sand10m (default) is BASELINE.json's metric: the 10 M-particle Drucker-Prager column (configs[2]);
+neo1m = configs[1] (1 M neo-Hookean cube), fluid20m = configs[3] (20 M fluid particles, volume recompute sweep).
+--gpus N > 1 with no WORLD_SIZE in the environment starts N ranks by itself (one process per GPU, RCCL); under
+torch.distributed.run the ranks come from the environment.  See DESIGN.md "Multi-GPU".
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # algorithmic bytes: per particle and per active node, by kernel
@@ -27,16 +31,93 @@ BYTES = {
     "fluid": {"p2g": 76, "g2p_r": 20, "g2p_w": 64},
 }
 NODE_BYTES = {"p2g": 16, "grid_update": 28, "g2p": 12}
+# config 4's volume-recompute sweep (+48 B/particle, +12 B/node): mass-only P2G 20 B, its gather 24 + 4 B
+VOLUME_BYTES = {"p2g_mass": 20, "g2p_volume": 28}
+VOLUME_NODE_BYTES = {"p2g_mass": 4, "grid_update_mass": 8}
+KERNEL_NAMES = {"p2g": "k_p2g_pair", "g2p": "k_g2p", "grid_update": "k_grid_update", "g2p2g": "k_g2p2g", "p2g_mass": "k_p2g_mass",
+                "grid_update_mass": "k_grid_update<mass>", "g2p_volume": "k_g2p_volume"}
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=("sand10m", "neo1m", "fluid20m"), default="sand10m")
+    ap.add_argument("--particles", type=float, default=None, help="particles per GPU (default: the configuration's own size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-clock", action="store_true", help="skip the per-kernel hipEvent spans")
+    ap.add_argument("--no-late-phase", dest="late_phase", action="store_false", help="skip the flowing-phase measurement (sand10m, N = 1)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------ N > 1: launcher
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) and relay rank 0's JSON line.
+
+    The parent never touches the GPU (no torch import, no HIP call): it only spawns `python bench.py <same flags>` N times
+    with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, as torch.distributed.run would."""
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=None, text=True, start_new_session=True))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if any(codes) or line is None:
+        print(f"bench.py: rank exit codes {codes}" + ("" if line else "; rank 0 printed no result line"), file=sys.stderr)
+        return 1
+    print(line)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------ workloads
 def column_dims(n_particles):
     """200 x 250 x 200 at 10M (SURVEY config 3), scaled isotropically otherwise."""
     f = (n_particles / 10.0e6) ** (1.0 / 3.0)
     return max(8, int(round(200 * f))), max(8, int(round(250 * f))), max(8, int(round(200 * f)))
 
 
+def build_scene(args, rank, world, mode):
+    """Returns (scene, material key of BYTES, description, x-lattice size)."""
+    from sparkl_amd import scenes
+    if args.config == "sand10m":
+        nx, ny, nz = column_dims(args.particles or 10.0e6)
+        if mode == "slabs":
+            nx = max(8, int(round(nx / 8.0)) * 8)          # whole 4-cell blocks per slab (200 at the 10M default)
+        sc = scenes.sand_column(nx, ny, nz, name="config3_drucker_prager_column", x_slab=(rank, world) if mode == "slabs" else (0, 1))
+        desc = (f"3D Drucker-Prager sand column collapse, {len(sc.particles)} particles/GPU ({nx}x{ny}x{nz} lattice, 8 ppc, h=0.2, "
+                f"E=1e7 nu=0.2 rho=2700, cuboid friction floor), fixed dt={sc.fixed_dt}")
+        return sc, "sand", desc, nx
+    if mode == "slabs":
+        raise SystemExit("--gpus > 1 runs the slab decomposition of the sand column only (BASELINE configs[2] / configs[4])")
+    if args.config == "neo1m":
+        n = max(8, int(round((args.particles or 1.0e6) ** (1.0 / 3.0))))
+        sc = scenes.elastic_cube(n, name="config2_neo_hookean_cube")
+        desc = (f"3D neo-Hookean elastic cube, {len(sc.particles)} particles ({n}^3 lattice, 8 ppc, h=0.2, E=1e6 nu=0.3 rho=1000, no gravity / collider, "
+                f"spinning + expanding), fixed dt={sc.fixed_dt}")
+        return sc, "elastic", desc, n
+    f = ((args.particles or 20.1e6) / 20.1e6) ** (1.0 / 3.0)
+    nx, ny, nz = max(8, int(round(344 * f))), max(8, int(round(240 * f))), max(8, int(round(244 * f)))
+    sc = scenes.fluid_dam(nx, ny, nz, name="config4_fluid_dam")
+    desc = (f"3D weakly-compressible fluid dam break (Monaghan EOS p0=1e6 gamma=7, rho=1000), {len(sc.particles)} particles ({nx}x{ny}x{nz} lattice, r=0.1, h=0.8: "
+            f"64 ppc), force_fluids_volume_recomputation, frictionless cuboid floor, fixed dt={sc.fixed_dt}")
+    return sc, "fluid", desc, nx
+
+
 def cpu_baseline(max_threads, seconds_budget=20.0):
-    """The oracle (restated sparkl CPU path, f32, OpenMP) on a bounded sample of the same workload.
+    """The oracle (restated sparkl CPU path, f32, OpenMP) on a bounded sample of the sand workload.
 
     Like the reference (serial region loop, particle_set.rs:171-253) it stops scaling early: the thread count is probed
     on one substep each and the best one is used and reported."""
@@ -67,30 +148,63 @@ def cpu_baseline(max_threads, seconds_budget=20.0):
                       f"best of 8/16/32/64/128 threads on a {max_threads}-thread host"}
 
 
-def recorded_traffic(kernel, n_particles):
+def recorded_traffic(kernel, n_particles, config):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (they cannot run inside the timed bench);
-    only reported for the particle count they were recorded at."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    only reported for the configuration and particle count they were recorded at."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         rec = json.load(open(path))
     except (OSError, ValueError):
         return None, None
+    rec = rec.get(config, rec if config == "sand10m" else {})
     if abs(rec.get("particles_per_gpu", 0) - n_particles) > 0.001 * n_particles or kernel not in rec.get("bytes_per_launch", {}):
         return None, None
     return rec["bytes_per_launch"][kernel], rec["source"] + "; " + rec["correction"]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--particles", type=float, default=10.0e6)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-clock", action="store_true", help="skip the per-kernel hipEvent spans")
-    ap.add_argument("--no-late-phase", dest="late_phase", action="store_false", help="skip the informational flowing-phase measurement")
-    args = ap.parse_args()
+def kernel_bytes(material, n_particles, nodes, fluid_volumes):
+    b = BYTES[material]
+    kb = {
+        "p2g": n_particles * b["p2g"] + nodes * NODE_BYTES["p2g"],
+        "grid_update": nodes * NODE_BYTES["grid_update"],
+        "g2p": n_particles * (b["g2p_r"] + b["g2p_w"]) + nodes * NODE_BYTES["g2p"],
+    }
+    # fixed dt: G2P of substep s and P2G of substep s+1 run as ONE kernel (k_g2p2g); its algorithmic bytes are the sum
+    kb["g2p2g"] = kb["p2g"] + kb["g2p"]
+    step = kb["p2g"] + kb["grid_update"] + kb["g2p"]
+    if fluid_volumes:
+        kb["p2g_mass"] = n_particles * VOLUME_BYTES["p2g_mass"] + nodes * VOLUME_NODE_BYTES["p2g_mass"]
+        kb["grid_update_mass"] = nodes * VOLUME_NODE_BYTES["grid_update_mass"]
+        kb["g2p_volume"] = n_particles * VOLUME_BYTES["g2p_volume"]
+        step += kb["p2g_mass"] + kb["grid_update_mass"] + kb["g2p_volume"]
+    return kb, step
 
+
+def clock_spans(clock):
+    spans = {"p2g": (clock.p2g_ms, clock.p2g_launches), "grid_update": (clock.grid_update_ms, clock.grid_update_launches),
+             "g2p": (clock.g2p_ms, clock.g2p_launches), "g2p2g": (clock.g2p2g_ms, clock.g2p2g_launches)}
+    for name in ("p2g_mass", "grid_update_mass", "g2p_volume"):
+        if hasattr(clock, name + "_ms"):
+            spans[name] = (getattr(clock, name + "_ms"), getattr(clock, name + "_launches"))
+    return {k: v for k, v in spans.items() if v[1] > 0}
+
+
+def roofline_of(clock, kb, n_particles, config, kernel=None):
+    """`roofline` object for the kernel the span set spends most of its time in (or the named one)."""
+    spans = clock_spans(clock)
+    if not spans:
+        return None, {}
+    avg_ms = {name: ms / n for name, (ms, n) in spans.items()}
+    dom = kernel if kernel in spans else max(spans, key=lambda k: spans[k][0])
+    achieved = kb[dom] / (avg_ms[dom] * 1e-3) / 1e9
+    traffic, traffic_src = recorded_traffic(KERNEL_NAMES[dom].split("<")[0] if dom != "grid_update_mass" else "k_grid_update_mass", n_particles, config)
+    return {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": kb[dom], "avg_launch_ms": avg_ms[dom],
+            "launches_sampled": int(spans[dom][1])}, avg_ms
+
+
+# ------------------------------------------------------------------------------------------ one rank
+def main(args):
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,28 +215,31 @@ def main():
     backend = os.environ.get("SPARKL_BENCH_BACKEND", "nccl")
     device_id = 0 if os.environ.get("SPARKL_BENCH_ONE_DEVICE") else local_rank
     torch.cuda.set_device(device_id)
+    ranks = 1
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_id))
         else:
             dist.init_process_group(backend)
+        # the rank count the job really runs with: an all-reduce of ones over the transport that carries the halo
+        ones = torch.ones(1, device="cuda" if backend == "nccl" else "cpu", dtype=torch.int64)
+        dist.all_reduce(ones)
+        ranks = int(ones.item())
+        assert ranks == dist.get_world_size() == world, (ranks, dist.get_world_size(), world)
 
-    from sparkl_amd import scenes
     from sparkl_amd.pipeline import MpmPipeline
     from sparkl_amd.slab import INT32_MAX, INT32_MIN, HipSlabBackend, SlabStepper
 
     # weak scaling: rank k owns the k-th x-slab of a column `world` times longer (config 5's decomposition);
     # each slab holds `particles` particles, cut on block planes, ghost node-block planes swapped every substep
-    nx, ny, nz = column_dims(args.particles)
     mode = os.environ.get("SPARKL_BENCH_MODE", "slabs" if world > 1 else "single")
-    if mode == "slabs":
-        nx = max(8, int(round(nx / 8.0)) * 8)          # whole 4-cell blocks per slab (200 at the 10M default)
     t0 = time.time()
-    sc = scenes.sand_column(nx, ny, nz, name="config3_drucker_prager_column", x_slab=(rank, world) if mode == "slabs" else (0, 1))
+    sc, material, desc, nx = build_scene(args, rank, world, mode)
     n_particles = len(sc.particles)
     gen_s = time.time() - t0
     dt = sc.fixed_dt
+    fluid_volumes = bool(sc.params.force_fluids_volume_recomputation) and material == "fluid"
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     pipe = MpmPipeline(sc.cell_width, device_id=device_id, domain_log2_bytes=sc.domain_log2_bytes, stream=stream.cuda_stream)
@@ -153,8 +270,11 @@ def main():
         pipe.sync()
 
     run(args.warmup)
+    # event spans on every launch of a short timed region (the driver's --steps 20), on every 4th substep of a long one
+    # (<1 % perturbation)
+    stride = 1 if args.steps <= 32 else 4
     if not args.no_kernel_clock:
-        pipe.clock_enable(True, stride=4)   # event spans on every 4th substep: <1 % perturbation of the timed region
+        pipe.clock_enable(True, stride=stride)
         pipe.clock_read(reset=True)
     barrier()
     t0 = time.perf_counter()
@@ -165,71 +285,73 @@ def main():
         tt = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    clock = None if args.no_kernel_clock else pipe.clock_read(reset=False)
+    clock = None if args.no_kernel_clock else pipe.clock_read(reset=True)
     n_blocks, n_pblocks = pipe.num_active_blocks(), pipe.num_particle_blocks()
-    # informational, outside the timed region and never part of `value`: the same column once it flows (cells hold uneven
-    # particle counts, re-bins and in-place reorders happen) -- see profiles/r01_reorder_policy.txt
+    kb, step_bytes = kernel_bytes(material, n_particles, n_blocks * 64, fluid_volumes)
+
+    # The same column once it flows (cells hold uneven particle counts, re-bins and in-place reorders happen): outside the
+    # timed region and never part of `value`, but measured the same way -- wall clock over 128 substeps and the dominant
+    # kernel's hipEvent spans -> `roofline_late` (see profiles/r01_reorder_policy.txt)
     late = None
-    if world == 1 and args.late_phase:
-        run(max(0, 640 - args.steps - args.warmup))
+    if world == 1 and args.late_phase and args.config == "sand10m":
+        before = max(0, 640 - args.steps - args.warmup)
+        pipe.clock_enable(False)
+        run(before)
+        if not args.no_kernel_clock:
+            pipe.clock_enable(True, stride=4)
+            pipe.clock_read(reset=True)
         pipe.sync()
         t1 = time.perf_counter()
         run(128)
         pipe.sync()
-        late = {"substeps_before": max(640, args.steps + args.warmup), "substeps_timed": 128, "ms_per_step": 1e3 * (time.perf_counter() - t1) / 128}
+        late_ms = 1e3 * (time.perf_counter() - t1) / 128
+        late = {"substeps_before": args.steps + args.warmup + before, "substeps_timed": 128, "ms_per_step": late_ms}
+        if not args.no_kernel_clock:
+            lclock = pipe.clock_read(reset=True)
+            nb_late = pipe.num_active_blocks()
+            kb_late, step_bytes_late = kernel_bytes(material, n_particles, nb_late * 64, fluid_volumes)
+            late["roofline"], late_avg = roofline_of(lclock, kb_late, n_particles, args.config, kernel="g2p2g")
+            late["kernels_avg_launch_ms"] = late_avg
+            late["step_frac_of_hbm_peak"] = step_bytes_late / (late_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            late["resorts"] = int(lclock.resorts)
+            late["reorder_ms_total"] = lclock.reorder_ms
+            late["active_node_blocks"] = nb_late
 
     if rank == 0:
         total_particles = n_particles * world
         value = total_particles * args.steps / elapsed
-        nodes = n_blocks * 64
-        b = BYTES["sand"]
-        per_kernel_bytes = {
-            "p2g": n_particles * b["p2g"] + nodes * NODE_BYTES["p2g"],
-            "grid_update": nodes * NODE_BYTES["grid_update"],
-            "g2p": n_particles * (b["g2p_r"] + b["g2p_w"]) + nodes * NODE_BYTES["g2p"],
-        }
-        step_bytes = sum(per_kernel_bytes.values())
+        metric = "particle-steps/sec (whole node) + achieved HBM GB/s, 3D sand 10M particles" if args.config == "sand10m" else \
+            f"particle-steps/sec (whole node) + achieved HBM GB/s, {args.config} (not BASELINE.json's headline metric)"
         out = {
-            "metric": "particle-steps/sec (whole node) + achieved HBM GB/s, 3D sand 10M particles",
+            "metric": metric,
             "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"3D Drucker-Prager sand column collapse, {n_particles} particles/GPU ({nx}x{ny}x{nz} lattice, 8 ppc, h=0.2, "
-                                   f"E=1e7 nu=0.2 rho=2700, cuboid friction floor), fixed dt={dt}", "particles_per_gpu": n_particles,
+            "dtype": "f32", "data": "synthetic", "ranks": ranks,
+            "config": {"workload": desc, "name": args.config, "particles_per_gpu": n_particles,
                        "active_node_blocks": n_blocks, "particle_blocks": n_pblocks,
                        "parallelism": "single GPU" if world == 1 else (
-                           f"{world} x-slabs of one {world * nx}x{ny}x{nz} column, ghost node-block planes swapped with both neighbours every substep "
+                           f"{world} x-slabs of one {world * nx}-long column, ghost node-block planes swapped with both neighbours every substep "
                            f"({backend} send/recv), re-bin flag all-reduce" if mode == "slabs" else f"{world} independent replicas")},
             "step_gbs": step_bytes * world / (elapsed / args.steps) / 1e9,
             "step_frac_of_hbm_peak": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
             "setup_s": {"generate": gen_s, "upload_and_pack": upload_s},
         }
         if clock is not None and clock.sampled_substeps > 0:
-            # fixed dt: G2P of substep s and P2G of substep s+1 run as ONE kernel (k_g2p2g); its algorithmic bytes are the sum
-            per_kernel_bytes["g2p2g"] = per_kernel_bytes["p2g"] + per_kernel_bytes["g2p"]
-            spans = {"p2g": (clock.p2g_ms, clock.p2g_launches), "grid_update": (clock.grid_update_ms, clock.grid_update_launches),
-                     "g2p": (clock.g2p_ms, clock.g2p_launches), "g2p2g": (clock.g2p2g_ms, clock.g2p2g_launches)}
-            avg_ms = {name: ms / n for name, (ms, n) in spans.items() if n > 0}
-            total_ms = {name: ms for name, (ms, n) in spans.items() if n > 0}
-            dom = max(total_ms, key=total_ms.get)          # the kernel the timed region spends most of its time in
-            achieved = per_kernel_bytes[dom] / (avg_ms[dom] * 1e-3) / 1e9
-            kname = {"p2g": "k_p2g", "g2p": "k_g2p", "grid_update": "k_grid_update", "g2p2g": "k_g2p2g"}[dom]
-            traffic, traffic_src = recorded_traffic(kname, n_particles)
-            out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                               "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": per_kernel_bytes[dom],
-                               "avg_launch_ms": avg_ms[dom], "launches_sampled": int(spans[dom][1])}
+            out["roofline"], avg_ms = roofline_of(clock, kb, n_particles, args.config)
             out["kernels_avg_launch_ms"] = avg_ms
-            out["kernels_gbs"] = {name: per_kernel_bytes[name] / (avg_ms[name] * 1e-3) / 1e9 for name in avg_ms}
+            out["kernels_gbs"] = {name: kb[name] / (avg_ms[name] * 1e-3) / 1e9 for name in avg_ms}
             out["kernel_clock_sampled_substeps"] = int(clock.sampled_substeps)
             out["resort"] = {"count": int(clock.resorts), "ms_total": clock.sort_ms}
             if mode == "slabs":
                 out["halo_ms_per_step"] = clock.halo_ms / max(int(clock.sampled_substeps), 1)
         if late is not None:
             out["late_collapse"] = late
+            if late.get("roofline"):
+                out["roofline_late"] = late["roofline"]
         if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only: the other ranks would sit in the final barrier
             threads = len(os.sched_getaffinity(0))
             out["cpu_baseline"] = cpu_baseline(threads)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     pipe.close()
     if world > 1:
         dist.barrier()
@@ -237,4 +359,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    _args = parse_args()
+    if _args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(_args))
+    main(_args)

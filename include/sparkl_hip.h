@@ -321,8 +321,11 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
 /* Run `nsubsteps` substeps of fixed length `dt` with NO host synchronisation inside
  * (the dt estimator is skipped; equivalent to the reference when max_substep_dt == dt
  * is the binding bound).  Only params->{boundary_handling, simulation_dofs,
- * force_fluids_volume_recomputation, damage_model} are read.  Asynchronous: returns after
- * enqueueing unless a re-bin was needed; call sparkl_hip_pipeline_sync to wait. */
+ * force_fluids_volume_recomputation, enable_boundary_particle_projection, damage_model} are read;
+ * damage_model other than SPARKL_DAMAGE_NONE returns SPARKL_ERR_UNSUPPORTED (here, in
+ * sparkl_hip_pipeline_step and in sparkl_hip_substep_begin).  Substeps are enqueued in batches; the
+ * host reads the 64-byte control block back once per batch (a stream sync) to learn whether a re-bin
+ * is needed, so the call returns when the last batch has been read. */
 int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* params,
                                  const float gravity[3], float dt, uint32_t nsubsteps);
 int sparkl_hip_pipeline_sync(SparklPipeline* p);
@@ -353,6 +356,9 @@ typedef struct {
     uint64_t p2g_launches, grid_update_launches, g2p_launches, g2p2g_launches;
     double reorder_ms;           /* k_block_reorder launches (most return at once: see sparkl_hip_reorder_policy_set) */
     uint64_t reorder_launches;
+    /* force_fluids_volume_recomputation sweep (fluids_volume.rs:9-115): mass-only scatter, mass-only node merge, volume gather */
+    double p2g_mass_ms, grid_update_mass_ms, g2p_volume_ms;
+    uint64_t p2g_mass_launches, grid_update_mass_launches, g2p_volume_launches;
 } SparklKernelClock;
 /* enable: 0 = off, 1 = spans on every substep, N > 1 = spans on every N-th substep */
 int sparkl_hip_pipeline_clock_enable(SparklPipeline* p, int enable);

@@ -315,6 +315,7 @@ public:
             ps[i].plastic_deformation_gradient_det = vol[i].plastic_deformation_gradient_det;
             ps[i].failed = st[i].failed; ps[i].psi_pos = ph[i].psi_pos; ps[i].phase = ph[i].phase;
             ps[i].plastic_hardening = da[i].plastic_hardening; ps[i].log_vol_gain = da[i].log_vol_gain;
+            ps[i].elastic_hardening = da[i].elastic_hardening; ps[i].nacc_alpha = da[i].nacc_alpha;   // snow / NACC rewrite them
         }
     }
 };

@@ -170,7 +170,7 @@ struct SparklPipeline {
     uint64_t total_resorts = 0;
 };
 
-enum { SPAN_P2G = 0, SPAN_GRID = 1, SPAN_G2P = 2, SPAN_SORT = 3, SPAN_DT = 4, SPAN_HALO = 5, SPAN_FUSED = 6, SPAN_REORDER = 7 };
+enum { SPAN_P2G = 0, SPAN_GRID = 1, SPAN_G2P = 2, SPAN_SORT = 3, SPAN_DT = 4, SPAN_HALO = 5, SPAN_FUSED = 6, SPAN_REORDER = 7, SPAN_P2G_MASS = 8, SPAN_GRID_MASS = 9, SPAN_G2P_VOLUME = 10 };
 
 static int clock_begin(SparklPipeline* p, int kind, size_t* tok) {
     if (!p->clock_on) return SPARKL_OK;
@@ -203,6 +203,9 @@ static int clock_collect(SparklPipeline* p) {
             case SPAN_SORT: p->clock.sort_ms += ms; break;
             case SPAN_REORDER: p->clock.reorder_ms += ms; p->clock.reorder_launches++; break;
             case SPAN_DT: p->clock.dt_ms += ms; break;
+            case SPAN_P2G_MASS: p->clock.p2g_mass_ms += ms; p->clock.p2g_mass_launches++; break;
+            case SPAN_GRID_MASS: p->clock.grid_update_mass_ms += ms; p->clock.grid_update_mass_launches++; break;
+            case SPAN_G2P_VOLUME: p->clock.g2p_volume_ms += ms; p->clock.g2p_volume_launches++; break;
             default: p->clock.halo_ms += ms; break;
         }
     }
@@ -349,6 +352,9 @@ static int resort(SparklPipeline* p) {
             HIPCHK(hipMemsetAsync(p->node_vel.p, 0, (size_t)nb * 64 * sizeof(float4), st));
             p->num_blocks = nb;
             p->num_pblocks = npb;
+            // the G2P kernels store one dt-bound minimum per workgroup (= particle block): keep the buffer large enough for
+            // whatever block count this re-bin produced (a re-bin inside step() used to leave it at the old size)
+            CHK(p->dt_partial.reserve(std::max<size_t>(grid_for(n, BLK_THREADS), (size_t)npb)));
             p->halo_count[0] = p->halo_count[1] = 0;
             if (p->slab_on) {
                 CHK(p->halo_in.reserve((size_t)nb * 64));
@@ -428,9 +434,20 @@ static int enqueue_fluid_volumes(SparklPipeline* p, const StepParams& S) {
     hipStream_t st = p->stream;
     GridArrays G = grid_arrays(p);
     G.node_mom = nullptr;
+    // sampled like the substep the sweep belongs to
+    const bool was_on = p->clock_on;
+    if (was_on && (p->substep_index % p->clock_stride) != 0) p->clock_on = false;
+    size_t t0 = 0, t1 = 0, t2 = 0;
+    CHK(clock_begin(p, SPAN_P2G_MASS, &t0));
     hipLaunchKernelGGL(k_p2g_mass, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, p->cur.arrays(), G, p->d_ctl, S);
+    CHK(clock_end(p, t0));
+    CHK(clock_begin(p, SPAN_GRID_MASS, &t1));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<true>), dim3((p->num_blocks + 3) / 4), dim3(BLK_THREADS), 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);
+    CHK(clock_end(p, t1));
+    CHK(clock_begin(p, SPAN_G2P_VOLUME, &t2));
     hipLaunchKernelGGL(k_g2p_volume, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, p->cur.arrays(), G, p->d_models.p, p->d_ctl, S);
+    CHK(clock_end(p, t2));
+    p->clock_on = was_on;
     return SPARKL_OK;
 }
 
@@ -605,6 +622,7 @@ void sparkl_hip_pipeline_destroy(SparklPipeline* p) {
     p->keys_a.release(); p->keys_b.release(); p->pb_keys.release(); p->bkeys.release(); p->idx_a.release(); p->idx_b.release();
     p->pb_counts.release(); p->pb_first.release(); p->cand_a.release(); p->cand_b.release(); p->cub_temp.release(); p->d_scalars.release();
     p->staging.release(); p->node_staging.release(); p->d_count.release(); p->dt_partial.release();
+    p->halo_list[0].release(); p->halo_list[1].release(); p->halo_in.release(); p->d_tail.release();
     if (p->rb_stream) { (void)hipStreamSynchronize(p->rb_stream); (void)hipStreamDestroy(p->rb_stream); (void)hipEventDestroy(p->rb_gathered); (void)hipEventDestroy(p->rb_done); }
     p->rb_staging.release();
     for (auto e : p->ev_pool) (void)hipEventDestroy(e);
@@ -1103,6 +1121,11 @@ int sparkl_hip_particles_truncate(SparklPipeline* p, uint64_t new_len) {
 }
 
 // ------------------------------------------------------------------------------------------ stepping
+// DamageModel::{CdMpm, Eigenerosion, ModifiedEigenerosion} (mls_solver.rs:68-83) are not built: refuse instead of silently
+// stepping with DamageModel::None.
+static int unsupported_damage_model(const SparklSolverParams* params) {
+    return set_error(SPARKL_ERR_UNSUPPORTED, "damage_model %d is not implemented (only SPARKL_DAMAGE_NONE)", (int)params->damage_model);
+}
 static int ensure_ready(SparklPipeline* p) {
     HIPCHK(hipSetDevice(p->device));
     CHK(validate_models(p));
@@ -1114,6 +1137,7 @@ int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* pa
     if (!p || !params || !gravity) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
     if (p->slab_on && (p->slab_lo != INT32_MIN || p->slab_hi != INT32_MAX))
         return set_error(SPARKL_ERR_INVALID_ARGUMENT, "a slab with finite cuts must be stepped through substep_begin/halo_*/substep_finish");
+    if (params->damage_model != SPARKL_DAMAGE_NONE) return unsupported_damage_model(params);
     if (p->n == 0 || nsubsteps == 0) return SPARKL_OK;
     CHK(ensure_ready(p));
     CHK(read_ctl(p));
@@ -1150,6 +1174,7 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
     if (timings) memset(timings, 0, sizeof(*timings));
     if (p->slab_on && (p->slab_lo != INT32_MIN || p->slab_hi != INT32_MAX))
         return set_error(SPARKL_ERR_UNSUPPORTED, "adaptive step on a slab with finite cuts: the dt bound is per rank; drive fixed-length substeps through substep_begin/finish");
+    if (params->damage_model != SPARKL_DAMAGE_NONE) return unsupported_damage_model(params);
     // mls_solver.rs:25-28
     if (p->n == 0 || params->dt == 0.0f) { if (simulated_time) *simulated_time = params->dt; return SPARKL_OK; }
     CHK(ensure_ready(p));
@@ -1176,19 +1201,35 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
     const bool may_fuse = p->fuse_fixed_dt && !(params->force_fluids_volume_recomputation && p->any_fluid) && !params->stop_after_one_substep;
     bool spec_tiles = false;
     uint32_t spec_dt_bits = 0;
+    // mls_solver.rs:46-48: with force_fluids_volume_recomputation the fluid volumes are recomputed after the sort and BEFORE
+    // the dt estimate of every substep, so the bound G2P left behind (computed from the volumes before the recompute) is not
+    // the reference's: the estimator pass runs every substep in that mode.
+    const bool fluid_volumes = params->force_fluids_volume_recomputation && p->any_fluid;
     while (remaining > 0.0f) {
         // one host sync per substep, as in the reference (cuda_mpm_pipeline.rs:393-398)
-        if (!have_bound) {
-            size_t tok = 0;
-            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dt_bits, (int)init_bits, 1, p->stream));
-            CHK(clock_begin(p, SPAN_DT, &tok));
-            hipLaunchKernelGGL(k_estimate_dt, dim3(grid_for(p->n, BLK_THREADS)), dim3(BLK_THREADS), 0, p->stream, p->cur.arrays(), p->d_models.p, p->d_ctl, (int)p->n, p->h,
-                               p->dt_partial.p);
-            hipLaunchKernelGGL(k_dt_reduce, dim3(1), dim3(1024), 0, p->stream, p->dt_partial.p, (int)grid_for(p->n, BLK_THREADS), p->d_ctl);
-            CHK(clock_end(p, tok));
+        if (fluid_volumes) have_bound = false;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if (fluid_volumes && p->num_pblocks > 0) {
+                const float g0[3] = {gravity[0], gravity[1], gravity[2]};
+                CHK(enqueue_fluid_volumes(p, make_params(p, params, g0, 0.f)));
+            }
+            if (!have_bound) {
+                size_t tok = 0;
+                HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dt_bits, (int)init_bits, 1, p->stream));
+                CHK(clock_begin(p, SPAN_DT, &tok));
+                hipLaunchKernelGGL(k_estimate_dt, dim3(grid_for(p->n, BLK_THREADS)), dim3(BLK_THREADS), 0, p->stream, p->cur.arrays(), p->d_models.p, p->d_ctl, (int)p->n, p->h,
+                                   p->dt_partial.p);
+                hipLaunchKernelGGL(k_dt_reduce, dim3(1), dim3(1024), 0, p->stream, p->dt_partial.p, (int)grid_for(p->n, BLK_THREADS), p->d_ctl);
+                CHK(clock_end(p, tok));
+            }
+            CHK(read_ctl(p));
+            if (!(p->h_ctl->abort_flag[0] || p->h_ctl->abort_flag[1])) break;
+            CHK(resort(p));
+            spec_tiles = false;
+            // the volumes (and with them the bound) must be recomputed on the new binning; without fluids the bound read
+            // above is a function of the particle state alone and stays valid
+            if (!fluid_volumes) break;
         }
-        CHK(read_ctl(p));
-        if (p->h_ctl->abort_flag[0] || p->h_ctl->abort_flag[1]) { CHK(resort(p)); spec_tiles = false; }
         if (p->h_ctl->dt_nan) { rc = set_error(SPARKL_ERR_NAN_TIMESTEP, "NaN timestep bound (the reference panics: timestep_estimator.rs:46)"); break; }
         float bound;
         memcpy(&bound, &p->h_ctl->dt_bits, 4);
@@ -1316,6 +1357,7 @@ int sparkl_hip_substep_status(SparklPipeline* p, uint32_t* steps_done, uint32_t*
 int sparkl_hip_substep_begin(SparklPipeline* p, const SparklSolverParams* params, const float gravity[3], float dt) {
     if (!p || !params || !gravity) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
     if (p->in_substep) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "substep_begin called twice");
+    if (params->damage_model != SPARKL_DAMAGE_NONE) return unsupported_damage_model(params);
     if (params->force_fluids_volume_recomputation && p->any_fluid && p->slab_on && (p->slab_lo != INT32_MIN || p->slab_hi != INT32_MAX))
         return set_error(SPARKL_ERR_UNSUPPORTED, "fluid volume recomputation across slab cuts is not implemented");
     HIPCHK(hipSetDevice(p->device));

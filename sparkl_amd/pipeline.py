@@ -37,6 +37,7 @@ class MpmPipeline:
         check(self.L.sparkl_hip_pipeline_create(C.byref(desc), C.byref(h)))
         self.h = h
         self.cell_width = cell_width
+        self.stream = stream   # hipStream_t handle the kernels run on (None: a library-owned non-blocking stream)
 
     def close(self):
         if getattr(self, "h", None):

@@ -52,6 +52,12 @@ class HipSlabBackend:
 
     def __init__(self, pipe, device):
         self.pipe, self.L, self.h, self.device = pipe, pipe.L, pipe.h, device
+        # pack / merge kernels and the torch-side send / recv / .cpu() must be ordered on ONE stream: the pipeline has to be
+        # created on torch's current stream (a library-owned stream would race with the exchange)
+        cur = torch.cuda.current_stream(device).cuda_stream
+        if pipe.stream is None or int(pipe.stream) != cur:
+            raise ValueError("HipSlabBackend: create the MpmPipeline with stream=torch.cuda.current_stream(device).cuda_stream "
+                             f"(pipeline stream {pipe.stream!r}, torch current stream {cur:#x})")
         self.halo_record_bytes = int(self.L.sparkl_hip_halo_record_bytes())
         self.migration_record_bytes = int(self.L.sparkl_hip_migration_record_bytes())
 

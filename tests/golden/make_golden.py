@@ -2,7 +2,8 @@
 
 The reference holds no dynamics fixture and cannot be run here (Rust, F2/F4), so these vectors are produced by
 the restated CPU path itself: inputs are rebuilt from the seeded scene generators, outputs are the particle state after
-1 and 10 fixed substeps.  Run from the repo root:  python tests/golden/make_golden.py
+1, 10 (60, 100) fixed substeps -- of the f32 oracle (the reference's arithmetic) and, as `*_f64`, of the same algorithm
+evaluated in f64 (the arbiter of the parity gate, tests/parity.py).  Run from the repo root:  python tests/golden/make_golden.py
 """
 import os
 import sys
@@ -31,7 +32,7 @@ CASES = {
     "failure": (lambda: scenes.block_on_floor(10, CorotatedLinearElasticity(1.0e6, 0.3), None, MaximumStressFailure(5.0e4, 4.0e4), expand=6.0, v0=(0.0, 0.0, 0.0),
                                               gravity=(0.0, 0.0, 0.0), name="failure"), 1.0e-4),
 }
-STEPS = {"heightfield": (1, 60), "snow": (1, 60), "rankine": (1, 60), "nacc": (1, 60), "failure": (1, 60)}   # default (1, 10)
+STEPS = {"sand3_like": (1, 10, 100), "heightfield": (1, 60, 100), "snow": (1, 60), "rankine": (1, 60), "nacc": (1, 60), "failure": (1, 60)}   # default (1, 10)
 
 
 def _moving(sc):
@@ -48,13 +49,19 @@ def main():
         sc = build()
         o = Oracle(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes)
         o.load_scene(sc)
+        o64 = Oracle(sc.cell_width, f64=True, domain_log2_bytes=sc.domain_log2_bytes)
+        o64.load_scene(sc)
         out = {"dt": dt, "n": len(sc.particles), "pos0": sc.particles.position["point"]}
         done = 0
         for k in STEPS.get(name, (1, 10)):
             for _ in range(k - done):
                 o.substep_fixed(sc.params, sc.gravity, dt)
+                o64.substep_fixed(sc.params, sc.gravity, dt)
             done = k
             c = o.get_particles()
+            c64 = o64.get_particles()
+            out[f"pos{k}_f64"] = c64.position["point"]
+            out[f"vel{k}_f64"] = c64.velocity["vector"]
             out[f"pos{k}"] = c.position["point"]
             out[f"vel{k}"] = c.velocity["vector"]
             out[f"F{k}"] = c.volume["deformation_gradient"]

@@ -1,7 +1,9 @@
-"""Committed golden trajectories (tests/golden/trajectory_*.npz, made by tests/golden/make_golden.py with the f32 oracle).
+"""Committed golden trajectories (tests/golden/trajectory_*.npz, made by tests/golden/make_golden.py with the f32 oracle and,
+as `*_f64`, with the same algorithm evaluated in f64).
 
 CPU: the oracle still reproduces them bit-for-bit (guards the checker against accidental edits) and the scene generators
-still produce the same seeded inputs.  GPU: the HIP path matches them within the parity tolerance."""
+still produce the same seeded inputs.  GPU: the HIP path matches them under the parity gate of tests/parity.py:
+eps(HIP vs f64 golden) <= max(1e-4, eps(f32 golden vs f64 golden)), positions in h, velocities relative to max |v|."""
 import os
 
 import numpy as np
@@ -26,7 +28,7 @@ CASES = {
     "failure": (lambda: scenes.block_on_floor(10, CorotatedLinearElasticity(1.0e6, 0.3), None, MaximumStressFailure(5.0e4, 4.0e4), expand=6.0, v0=(0.0, 0.0, 0.0),
                                               gravity=(0.0, 0.0, 0.0), name="failure"), 1.0e-4),
 }
-STEPS = {"heightfield": (1, 60), "snow": (1, 60), "rankine": (1, 60), "nacc": (1, 60), "failure": (1, 60)}   # default (1, 10)
+STEPS = {"sand3_like": (1, 10, 100), "heightfield": (1, 60, 100), "snow": (1, 60), "rankine": (1, 60), "nacc": (1, 60), "failure": (1, 60)}   # default (1, 10)
 
 
 def _moving(sc):
@@ -68,12 +70,17 @@ def test_hip_matches_golden(name):
             p.substeps(sc.params, sc.gravity, dt, k - done)
             done = k
             c = p.read_particles()
-            vmax = np.linalg.norm(g[f"vel{k}"], axis=1).max()
-            ex = np.linalg.norm(c.position["point"] - g[f"pos{k}"], axis=1).max() / sc.cell_width
-            ev = np.linalg.norm(c.velocity["vector"] - g[f"vel{k}"], axis=1).max() / vmax
+            p64, v64 = g[f"pos{k}_f64"].astype(np.float64), g[f"vel{k}_f64"].astype(np.float64)
+            vmax = np.linalg.norm(v64, axis=1).max()
+
+            def eps(pos, vel):
+                return (np.linalg.norm(pos.astype(np.float64) - p64, axis=1).max() / sc.cell_width,
+                        np.linalg.norm(vel.astype(np.float64) - v64, axis=1).max() / vmax)
+            ex, ev = eps(c.position["point"], c.velocity["vector"])
+            fx, fv = eps(g[f"pos{k}"], g[f"vel{k}"])          # the reference's own f32 arithmetic against the same arbiter
             eF = np.abs(c.volume["deformation_gradient"] - g[f"F{k}"]).max()
-            # 1e-4 on positions; velocities of the stiff sand sit on its f32 noise floor
+            print(f"golden {name} k={k}: eps_x {ex:.3e} (f32 oracle {fx:.3e})  eps_v {ev:.3e} (f32 oracle {fv:.3e})  eps_F {eF:.3e}")
+            assert ex <= max(1e-4, fx) and ev <= max(1e-4, fv), (name, k, ex, fx, ev, fv)
             # NACC snaps particles onto the tips / the yield surface by thresholds: a particle sitting on one may take the other
             # branch (the f32 and f64 oracles differ by 6e-3 in F there, test_rare_material_models_parity)
-            assert ex <= 1e-4 and eF <= (1e-2 if name == "nacc" else 1e-4), (name, k, ex, ev, eF)
-            assert ev <= (1e-3 if name in ("sand3_like", "heightfield") else 1e-4), (name, k, ev)
+            assert eF <= (1e-2 if name == "nacc" else 1e-3 if k >= 100 else 1e-4), (name, k, eF)

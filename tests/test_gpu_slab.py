@@ -26,8 +26,29 @@ def _scene(kind):
         sc = scenes.elastic_cube(20)
         sc.particles.velocity["vector"] *= 25.0
         return sc, 2.0e-4
+    if kind == "cube":
+        # BASELINE configs[4] in small (examples3d/cube_through_sand3.rs:40-81): a kinematic cube ploughs through a sand bed at
+        # 10 m/s.  The cube is placed one cell short of the slab cut, so that it crosses the cut (and its particles migrate)
+        # within the 100 substeps of the test.
+        sc = scenes.cube_through_sand(24, 6, 14, cube_n=6)
+        h = sc.cell_width
+        kin = sc.particles.status["kinematic_vel_enabled"] == 1
+        cell = np.round(sc.particles.position["point"][:, 0] / np.float32(h)).astype(np.int64) - 1
+        cut = block_cuts_balanced(cell >> 2, 2)[1]
+        x = sc.particles.position["point"][:, 0]
+        x[kin] += np.float32((4 * cut + 0.5) * h - 1.0 * h) - x[kin].min()
+        return sc, 2.5e-4
     sc = scenes.sand_column(24, 12, 16, with_block=True)
     return sc, 2.5e-4
+
+
+def _ownership(sc, world):
+    """Per rank: the caller indices it uploads (ascending).  Rank r's particles get the ids [offset_r, offset_r + n_r)."""
+    h = sc.cell_width
+    cell = np.round(sc.particles.position["point"][:, 0] / np.float32(h)).astype(np.int64) - 1
+    cuts = block_cuts_balanced(cell >> 2, world)
+    gids = [np.nonzero(((cell >> 2) >= cuts[r]) & ((cell >> 2) < cuts[r + 1]))[0] for r in range(world)]
+    return cuts, gids
 
 
 def _worker(rank, world, port, kind, nsteps, out_dir):
@@ -37,20 +58,18 @@ def _worker(rank, world, port, kind, nsteps, out_dir):
     from sparkl_amd.pipeline import MpmPipeline
     sc, dt = _scene(kind)
     h = sc.cell_width
-    cell = np.round(sc.particles.position["point"][:, 0] / np.float32(h)).astype(np.int64) - 1
-    cuts = block_cuts_balanced(cell >> 2, world)
-    mine = ((cell >> 2) >= cuts[rank]) & ((cell >> 2) < cuts[rank + 1])
-    # contiguous id ranges per rank: remap ids so that rank r uploads ids [offset, offset + n)
-    order = np.argsort(~mine, kind="stable") if rank == 0 else np.argsort(mine, kind="stable")
+    cuts, all_gids = _ownership(sc, world)
+    gids = all_gids[rank]
+    id_offset = int(sum(len(g) for g in all_gids[:rank]))
+    id_to_caller = np.concatenate(all_gids)          # global id (as the slabs number them) -> caller index
     comps = ParticleComponents(0)
     for k in ParticleComponents.__slots__:
-        setattr(comps, k, np.ascontiguousarray(getattr(sc.particles, k)[mine]))
-    gids = np.nonzero(mine)[0]
+        setattr(comps, k, np.ascontiguousarray(getattr(sc.particles, k)[gids]))
     torch.cuda.set_device(0)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         pipe = MpmPipeline(h, device_id=0, domain_log2_bytes=sc.domain_log2_bytes, stream=stream.cuda_stream)
-        pipe.set_slab(0, cuts[rank], cuts[rank + 1], id_offset=0)
+        pipe.set_slab(0, cuts[rank], cuts[rank + 1], id_offset=id_offset)
         pipe.set_models(sc.models)
         pipe.set_colliders(sc.colliders)
         pipe.upload_particles(comps)
@@ -63,8 +82,9 @@ def _worker(rank, world, port, kind, nsteps, out_dir):
                 dts += st.step(sc.params, sc.gravity)[1]
         got = pipe.read_particles()
         local_ids = pipe.read_sorted_particle_ids()
-    # local ids index this rank's upload order only for particles that never migrated; carry global ids through `user`:
+    # slab pipelines read back in device order; the ids travel with the particles through migrations
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pos=got.position["point"], vel=got.velocity["vector"], F=got.volume["deformation_gradient"],
+             C=got.velocity_gradient["m"], failed=got.status["failed"], caller=id_to_caller[local_ids],
              mass=got.volume["mass"], rebins=st.num_rebins, n0=len(gids), n1=len(got), dts=np.array(dts))
     pipe.close()
     dist.barrier()
@@ -138,3 +158,41 @@ def test_two_slabs_adaptive_step_matches_single_pipeline(tmp_path):
     ev = np.abs(vel[ka] - ref.velocity["vector"][kb]).max() / np.abs(ref.velocity["vector"]).max()
     print("adaptive slab vs single:", ex, ev, nsub)
     assert ex < 2e-5 and ev < 2e-4
+
+
+def test_cube_through_sand_two_slabs_match_oracle(tmp_path):
+    """BASELINE configs[4]'s scene on the slab path: the kinematic cube crosses the cut (migration, halo planes under load),
+    and the union of the two slabs is held to the same parity gate as the single-GPU path -- against the CPU oracle."""
+    from oracle import Oracle
+    from tests.parity import parity_verdict
+    world, nsteps = 2, 100
+    mp.spawn(_worker, args=(world, _free_port(), "cube", nsteps, str(tmp_path)), nprocs=world, join=True)
+    sc, dt = _scene("cube")
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    refs = []
+    for f64 in (False, True):
+        o = Oracle(sc.cell_width, f64=f64, domain_log2_bytes=sc.domain_log2_bytes, threads=threads)
+        o.load_scene(sc)
+        for _ in range(nsteps):
+            o.substep_fixed(sc.params, sc.gravity, dt)
+        refs.append(o.get_particles())
+        o.close()
+    parts = [np.load(os.path.join(tmp_path, f"rank{k}.npz")) for k in range(world)]
+    caller = np.concatenate([q["caller"] for q in parts])
+    assert np.array_equal(np.sort(caller), np.arange(len(sc.particles))), "particles lost or duplicated across slabs"
+    got = ParticleComponents(len(sc.particles))
+    inv = np.argsort(caller)
+    got.position["point"] = np.concatenate([q["pos"] for q in parts])[inv]
+    got.velocity["vector"] = np.concatenate([q["vel"] for q in parts])[inv]
+    got.volume["deformation_gradient"] = np.concatenate([q["F"] for q in parts])[inv]
+    got.velocity_gradient["m"] = np.concatenate([q["C"] for q in parts])[inv]
+    got.status["failed"] = np.concatenate([q["failed"] for q in parts])[inv]
+    rep, bad = parity_verdict(got, refs[0], refs[1], sc.cell_width)
+    kin = sc.particles.status["kinematic_vel_enabled"] == 1
+    _, gids = _ownership(sc, world)
+    crossed = int(kin[gids[0]].sum()) - int(kin[caller[: len(parts[0]["caller"])]].sum())
+    print("cube_through_sand slabs vs oracle:", rep["vs_f64"], rep["oracle_f32_vs_f64"], "kinematic particles that crossed the cut:", crossed,
+          "re-bins:", [int(q["rebins"]) for q in parts])
+    assert crossed > 20, "the kinematic cube must cross the cut"
+    assert all(int(q["rebins"]) >= 2 for q in parts)
+    assert not bad, (bad, rep)

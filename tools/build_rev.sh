@@ -1,7 +1,7 @@
 #!/bin/bash
 # build_rev.sh <git-rev> <name> [EXTRA flags]: build sparkl_amd/lib/<name>.so from the kernel sources of a git revision (A/B baselines)
 set -e
-cd /root/repo
+cd "$(dirname "$0")/.."
 rev=$1; name=$2; shift 2
 d=/tmp/spk_rev_$name; rm -rf $d; mkdir -p $d/sparkl_amd/csrc $d/include
 for f in sparkl_amd/csrc/sparkl_hip.hip sparkl_amd/csrc/kernels.h sparkl_amd/csrc/device_math.h include/sparkl_hip.h; do git show $rev:$f > $d/$f; done
