@@ -22,6 +22,12 @@ namespace spk {
 constexpr int TILE_W = 8;
 constexpr int TILE_N = TILE_W * TILE_W * TILE_W;  // 512 nodes
 constexpr int BLK_THREADS = 256;
+// The f64 accumulation tile of the scatter kernels lives in LDS with padded z-planes: logical node n = x + 8 y + 64 z sits at
+// acc_slot(n) = n + 8 z - 4 (z & 1), i.e. the planes start at 0, 68, 144, 212, 288, ... doubles.  A wave's scatter tasks hit,
+// in ONE ds_add_f64, the same (sx, sy) node of 8 neighbouring cells (4 in x, 2 in y) in 3 consecutive z-planes: with a 64-double
+// plane stride the three planes fall on the same LDS banks (512 B = 2 x the bank period), with this layout the 24 addresses
+// occupy 24 different bank pairs whichever plane the run starts in (residues 0, 4, 16, 20 mod 32 doubles, cyclically).
+constexpr int ACC_N = 576;
 
 enum : uint32_t {
     FLAG_FAILED = 1u << 0,
@@ -32,6 +38,8 @@ enum : uint32_t {
     FLAG_REMOVED = 1u << 5,       // migrated to a neighbour slab; dropped at the next re-bin
     FLAG_MODEL_SHIFT = 8
 };
+
+__device__ __forceinline__ int acc_slot(int n) { const int p = n >> 6; return n + 8 * p - 4 * (p & 1); }
 
 struct Ctl {
     uint32_t abort_flag[2];  // parity double-buffer: kernels of substep s read [s&1], G2P of s writes [(s+1)&1]
@@ -179,7 +187,7 @@ SPK_DEV int dpp_shr1_i(int v, int fill) { return __builtin_amdgcn_update_dpp(fil
 
 // What one particle scatters: node s of its 3x3x3 support receives  w_s * (mass ; qv + sx A0 + sy A1 + sz A2).
 struct Scatter {
-    float wgt[3][3];
+    float fx[3];   // position in units of h relative to the first support node, in [0.5, 1.5]: the B-spline weights are eval_all(fx[a])
     float val_m;
     float qv[3];   // affine * d0 + m v
     M3 A;          // affine * h
@@ -188,8 +196,10 @@ struct Scatter {
 };
 
 // particle_to_grid.rs:42-59: stress, affine, weights.  `org` = cell origin of the home block.
+// `T` (fused kernel only): the corotated stress the Drucker-Prager return map of this very thread formed from the decomposition
+// of F it held (corotated_kirchhoff_from_svd) -- a rank-3 update instead of a polar iteration.
 SPK_DEV Scatter p2g_prepare(const DevModel& mo, uint32_t flags, const float px[3], const float v[3], const M3& C, const M3& F, float mass, float vol0, float eh,
-                            float phase, float fluid_jp, const int4& org, float h, float inv_h, float inv_d, float dt) {
+                            float phase, float fluid_jp, const int4& org, float h, float inv_h, float inv_d, float dt, const SymStress* T = nullptr) {
     Scatter sc;
     float d0[3];
     int lc[3];
@@ -198,7 +208,7 @@ SPK_DEV Scatter p2g_prepare(const DevModel& mo, uint32_t flags, const float px[3
     for (int a = 0; a < 3; ++a) {
         const float r = round_cell(px[a], h, inv_h);
         d0[a] = (r - 1.0f) * h - px[a];
-        eval_all(-d0[a] * inv_h, sc.wgt[a]);
+        sc.fx[a] = -d0[a] * inv_h;
         lc[a] = (int)r - 1 - orgv[a] + 1;  // tile coordinate of the associated cell, in [0, 5]
     }
     sc.base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
@@ -209,8 +219,13 @@ SPK_DEV Scatter p2g_prepare(const DevModel& mo, uint32_t flags, const float px[3
 #else
     if (!(flags & FLAG_FAILED)) {
 #endif
-        if (mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR) tau = corotated_kirchhoff(mo, phase, eh, F);
-        else if (mo.ctag == SPARKL_CONSTITUTIVE_NEO_HOOKEAN) tau = neo_hookean_kirchhoff(mo, phase, eh, F);
+        if (mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR) {
+#ifndef SPK_EXP_NO_SVD_STRESS
+            if (T != nullptr && T->valid && phase == 1.f) tau = sym_to_m3(*T);
+            else
+#endif
+                tau = corotated_kirchhoff(mo, phase, eh, F);
+        } else if (mo.ctag == SPARKL_CONSTITUTIVE_NEO_HOOKEAN) tau = neo_hookean_kirchhoff(mo, phase, eh, F);
         else if (mo.ctag == SPARKL_CONSTITUTIVE_EOS_MONAGHAN_SPH) tau = monaghan_kirchhoff(mo, mass, vol0, F.m[0], fluid_jp, C);
     }
     // affine = m C - (V0 inv_d dt) tau   (particle_to_grid.rs:58-59)
@@ -227,8 +242,15 @@ SPK_DEV Scatter p2g_prepare(const DevModel& mo, uint32_t flags, const float px[3
 }
 SPK_DEV void scatter_clear(Scatter& sc) {
     sc.val_m = 0.f; sc.qv[0] = sc.qv[1] = sc.qv[2] = 0.f; sc.A = m3_zero(); sc.base = 0; sc.shell = 0;
+    sc.fx[0] = sc.fx[1] = sc.fx[2] = 1.f;
+}
+// the 3 x 3 B-spline weights of a scatter descriptor (QuadraticKernel::eval_all per axis)
+struct ScatterWeights { float w[3][3]; };
+SPK_DEV ScatterWeights scatter_weights(const Scatter& sc) {
+    ScatterWeights W;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) sc.wgt[a][0] = sc.wgt[a][1] = sc.wgt[a][2] = 0.f;
+    for (int a = 0; a < 3; ++a) eval_all(sc.fx[a], W.w[a]);
+    return W;
 }
 
 // Accumulate one batch of scatters (one per lane; every lane of the wave must call this) into the f64 LDS tile.
@@ -241,9 +263,10 @@ SPK_DEV void scatter_clear(Scatter& sc) {
 // run head.  Cross-lane ops are hoisted out of every `&&` / `||`: they must execute with all lanes enabled.
 // Returns the number of run heads of the wave (wave-uniform): the disorder measure of the re-bin policy.
 template <int REDUCE_STEPS>
-SPK_DEV int p2g_scatter(double (*tile)[TILE_N], const Scatter& sc, bool live, int tid) {
+SPK_DEV int p2g_scatter(double (*tile)[ACC_N], const Scatter& sc, bool live, int tid) {
     int nheads = 0;
     if (!__any(live)) return 0;   // wave-uniform: the tail waves of a partly filled batch skip the ~650 instructions below
+    const ScatterWeights SW = scatter_weights(sc);
     if (REDUCE_STEPS > 0) {
         constexpr int G = 1 << REDUCE_STEPS;
         const int lane = tid & 63;
@@ -265,13 +288,13 @@ SPK_DEV int p2g_scatter(double (*tile)[TILE_N], const Scatter& sc, bool live, in
         for (int sz = 0; sz < 3; ++sz)
 #pragma unroll
             for (int sy = 0; sy < 3; ++sy) {
-                const float wyz = sc.wgt[1][sy] * sc.wgt[2][sz];
+                const float wyz = SW.w[1][sy] * SW.w[2][sz];
                 f2v P01 = {sc.val_m, sc.qv[0] + sy * sc.A.m[3] + sz * sc.A.m[6]};
                 f2v P23 = {sc.qv[1] + sy * sc.A.m[4] + sz * sc.A.m[7], sc.qv[2] + sy * sc.A.m[5] + sz * sc.A.m[8]};
 #pragma unroll
                 for (int sx = 0; sx < 3; ++sx) {
                     if (sx > 0) { P01 += X01; P23 += X23; }
-                    const float w = sc.wgt[0][sx] * wyz;
+                    const float w = SW.w[0][sx] * wyz;
                     const f2v c01 = P01 * w, c23 = P23 * w;
                     float c0 = c01.x, c1 = c01.y, c2 = c23.x, c3 = c23.y;
                     // c += f_o * row_shl:o(c), o = 1, 2, 4[, 8]: one v_fmac_f32_dpp each.  hipcc emits v_mov_b32_dpp +
@@ -300,7 +323,7 @@ SPK_DEV int p2g_scatter(double (*tile)[TILE_N], const Scatter& sc, bool live, in
 #else
                     if (live && head) {
 #endif
-                        const int n = sc.base + sx + TILE_W * sy + TILE_W * TILE_W * sz;
+                        const int n = acc_slot(sc.base + sx + TILE_W * sy + TILE_W * TILE_W * sz);
                         atomicAdd(&tile[0][n], (double)c0);
                         atomicAdd(&tile[1][n], (double)c1);
                         atomicAdd(&tile[2][n], (double)c2);
@@ -315,8 +338,8 @@ SPK_DEV int p2g_scatter(double (*tile)[TILE_N], const Scatter& sc, bool live, in
             for (int sy = 0; sy < 3; ++sy)
 #pragma unroll
                 for (int sx = 0; sx < 3; ++sx) {
-                    const float w = sc.wgt[0][sx] * sc.wgt[1][sy] * sc.wgt[2][sz];
-                    const int n = sc.base + sx + TILE_W * sy + TILE_W * TILE_W * sz;
+                    const float w = SW.w[0][sx] * SW.w[1][sy] * SW.w[2][sz];
+                    const int n = acc_slot(sc.base + sx + TILE_W * sy + TILE_W * TILE_W * sz);
                     atomicAdd(&tile[0][n], (double)(w * sc.val_m));
                     atomicAdd(&tile[1][n], (double)(w * (sc.qv[0] + sx * sc.A.m[0] + sy * sc.A.m[3] + sz * sc.A.m[6])));
                     atomicAdd(&tile[2][n], (double)(w * (sc.qv[1] + sx * sc.A.m[1] + sy * sc.A.m[4] + sz * sc.A.m[7])));
@@ -330,7 +353,7 @@ SPK_DEV int p2g_scatter(double (*tile)[TILE_N], const Scatter& sc, bool live, in
 // values are added in the lane first, which halves the DPP reduction, the f64 conversions and the LDS atomic
 // instructions per particle; a pair that straddles two cells deposits its second particle on its own.
 template <int REDUCE_STEPS>
-SPK_DEV int p2g_scatter_pair(double (*tile)[TILE_N], const Scatter& sa, const Scatter& sb, bool live_a, bool live_b, int tid) {
+SPK_DEV int p2g_scatter_pair(double (*tile)[ACC_N], const Scatter& sa, const Scatter& sb, bool live_a, bool live_b, int tid) {
     static_assert(REDUCE_STEPS >= 2 && REDUCE_STEPS <= 4, "");
     if (!__any(live_a | live_b)) return 0;
     constexpr int G = 1 << REDUCE_STEPS;
@@ -349,12 +372,13 @@ SPK_DEV int p2g_scatter_pair(double (*tile)[TILE_N], const Scatter& sa, const Sc
     const int i8 = (REDUCE_STEPS >= 4) ? (i4 & dpp_shl_i<4>(i4) & (r + 8 < G ? 1 : 0)) : 0;
     const float f1 = (float)i1, f2 = (float)i2, f4 = (float)i4, f8 = (float)i8;
     const float fs = same ? 1.f : 0.f;
+    const ScatterWeights WA = scatter_weights(sa), WB = scatter_weights(sb);
     const f2v XA01 = {0.f, sa.A.m[0]}, XA23 = {sa.A.m[1], sa.A.m[2]}, XB01 = {0.f, sb.A.m[0]}, XB23 = {sb.A.m[1], sb.A.m[2]};
 #pragma unroll
     for (int sz = 0; sz < 3; ++sz)
 #pragma unroll
         for (int sy = 0; sy < 3; ++sy) {
-            const float wa_yz = sa.wgt[1][sy] * sa.wgt[2][sz], wb_yz = sb.wgt[1][sy] * sb.wgt[2][sz];
+            const float wa_yz = WA.w[1][sy] * WA.w[2][sz], wb_yz = WB.w[1][sy] * WB.w[2][sz];
             f2v PA01 = {sa.val_m, sa.qv[0] + sy * sa.A.m[3] + sz * sa.A.m[6]};
             f2v PA23 = {sa.qv[1] + sy * sa.A.m[4] + sz * sa.A.m[7], sa.qv[2] + sy * sa.A.m[5] + sz * sa.A.m[8]};
             f2v PB01 = {sb.val_m, sb.qv[0] + sy * sb.A.m[3] + sz * sb.A.m[6]};
@@ -362,7 +386,7 @@ SPK_DEV int p2g_scatter_pair(double (*tile)[TILE_N], const Scatter& sa, const Sc
 #pragma unroll
             for (int sx = 0; sx < 3; ++sx) {
                 if (sx > 0) { PA01 += XA01; PA23 += XA23; PB01 += XB01; PB23 += XB23; }
-                const float wa = sa.wgt[0][sx] * wa_yz, wb = sb.wgt[0][sx] * wb_yz;
+                const float wa = WA.w[0][sx] * wa_yz, wb = WB.w[0][sx] * wb_yz;
                 const f2v b01 = PB01 * wb, b23 = PB23 * wb;
                 const f2v c01 = PA01 * wa + b01 * fs, c23 = PA23 * wa + b23 * fs;
                 float c0 = c01.x, c1 = c01.y, c2 = c23.x, c3 = c23.y;
@@ -377,7 +401,7 @@ SPK_DEV int p2g_scatter_pair(double (*tile)[TILE_N], const Scatter& sa, const Sc
                 }
                 const int off = sx + TILE_W * sy + TILE_W * TILE_W * sz;
                 if (live_a && head) {
-                    const int n = sa.base + off;
+                    const int n = acc_slot(sa.base + off);
                     atomicAdd(&tile[0][n], (double)c0);
                     atomicAdd(&tile[1][n], (double)c1);
                     atomicAdd(&tile[2][n], (double)c2);
@@ -385,7 +409,7 @@ SPK_DEV int p2g_scatter_pair(double (*tile)[TILE_N], const Scatter& sa, const Sc
                 }
                 if (any_lone) {   // wave-uniform
                     if (lone_b) {
-                        const int n = sb.base + off;
+                        const int n = acc_slot(sb.base + off);
                         atomicAdd(&tile[0][n], (double)b01.x);
                         atomicAdd(&tile[1][n], (double)b01.y);
                         atomicAdd(&tile[2][n], (double)b23.x);
@@ -397,16 +421,158 @@ SPK_DEV int p2g_scatter_pair(double (*tile)[TILE_N], const Scatter& sa, const Sc
     return nheads;
 }
 
+// ---- run-task scatter -----------------------------------------------------------------------------------------------
+// The DPP scheme above makes every lane carry all 27 x 4 node values of its particle through 4 reduction steps (432
+// v_fmac_f32_dpp per particle, each ~1.7 plain VALU ops) although only the run heads' results are used.  Here the wave
+// turns the work around after the per-particle phase: the scatter descriptors stay in the registers of the lanes that
+// computed them, the wave enumerates its runs of same-cell lanes (ballot + a 64-entry run list in LDS), and lane t becomes
+// TASK t = (run, z-plane of the 3x3x3 support[, half of the run's particles]).  A task walks its particles, fetching their
+// descriptors from the owning lanes with ds_bpermute (16 per particle), accumulates its 9 nodes x (m, px, py, pz) in
+// registers with plain (packed) FMAs and deposits them with 36 f64 LDS atomics.  Per 64 particles of the lattice phase
+// (8 runs of 8): 60 busy lanes x 4 particles x 9 nodes instead of 64 lanes x 27 nodes x 4 DPP steps; 36 instead of 108
+// ds_add_f64 wave-instructions; no f32 -> f64 conversion per particle.  Ragged runs (the flowing phase) only change the
+// task list: more runs -> more tasks -> more rounds of 64 tasks.
+SPK_DEV float bperm_f(int byte_addr, float x) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(x))); }
+// maximum over the wave as a scalar: 4 DPP steps inside the 16-lane rows, then the four row results through readlane
+// (a __shfl_xor butterfly costs six dependent LDS round trips)
+SPK_DEV int wave_max_i32(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141 /* row_half_mirror */, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140 /* row_mirror */, 0xF, 0xF, false));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+SPK_DEV int wave_shr1_i(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false); }
+
+// `s_run`: this wave's 64-entry run list in LDS.  Every lane of the wave must call this (cross-lane operations inside).
+// Returns the number of live runs of the wave (wave-uniform): the disorder measure of the re-order policy.
+SPK_DEV int p2g_scatter_runs(double (*tile)[ACC_N], const Scatter& sc, bool live, int tid, int* s_run, float (*s_A)[64]) {
+    if (!__any(live)) return 0;   // wave-uniform
+    const int lane = tid & 63;
+    // the affine part of the descriptor goes through LDS (9 KB per workgroup) instead of staying in 9 registers for ds_bpermute:
+    // the task phase is where the kernel's register pressure peaks, and those 9 pay for carrying the whole next batch in flight
+#pragma unroll
+    for (int e = 0; e < 9; ++e) s_A[e][lane] = sc.A.m[e];
+    const int key = live ? sc.base : -1;                       // dead lanes form runs of their own, skipped below
+    const int prev = wave_shr1_i(key, -2);
+    const bool head = (lane == 0) | (prev != key);
+    const unsigned long long hb = __ballot(head);
+    const int nruns = (int)__popcll(hb);
+    const int nheads = (int)__popcll(__ballot(head & live));
+    {
+        const int rank = (int)__popcll(hb & ((1ull << lane) - 1ull));          // heads strictly below this lane
+        const unsigned long long above = (lane == 63) ? 0ull : (hb >> (lane + 1));
+        const int len = above ? (int)__ffsll((long long)above) : (64 - lane);  // distance to the next head
+        if (head) s_run[rank] = lane | (len << 8) | (key < 0 ? 0x10000 : 0);
+    }
+    __builtin_amdgcn_wave_barrier();   // LDS operations of one wave execute in order: the list is visible to its lanes
+    // tasks per run: 3 z-planes x S particle halves; the halves keep the 64 lanes busy while the runs are long
+#ifdef SPK_EXP_RUNS_S1
+    const int S = 1;
+#else
+    const int S = (6 * nruns <= 64) ? 2 : 1;
+#endif
+    const int TPR = 3 * S;
+    const int ntasks = nruns * TPR;
+    for (int t0 = 0; t0 < ntasks; t0 += 64) {
+        const int t = t0 + lane;
+        const bool valid = t < ntasks;
+        const int r = valid ? ((t * (S == 2 ? 10923 : 21846)) >> 16) : 0;     // t / TPR for t < 4096
+        const int sub = t - r * TPR;
+        const int z = (S == 2) ? (sub >> 1) : sub;
+        const int half = (S == 2) ? (sub & 1) : 0;
+        const int info = s_run[r];
+        const int start = info & 63, len = (info >> 8) & 127;
+        int first = start, cnt = len;
+        if (S == 2) { const int n0 = (len + 1) >> 1; first = half ? start + n0 : start; cnt = half ? len - n0 : n0; }
+        if (!valid || (info & 0x10000)) cnt = 0;
+        const int run_base = __builtin_amdgcn_ds_bpermute(start << 2, sc.base);
+        // trip count of the wave (scalar): the longest task
+        const int maxcnt = wave_max_i32(cnt);
+        const float fz = (float)z;
+        // this task's z-weight is  za + zb (x - zg)^2  (eval_all: 0.5 (1.5 - x)^2 | 0.75 - (x - 1)^2 | 0.5 (x - 0.5)^2)
+        const float za = z == 1 ? 0.75f : 0.f, zb = z == 1 ? -1.f : 0.5f, zg = 1.5f - 0.5f * fz;
+        f2v acc01[9], acc23[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { acc01[k] = f2v{0.f, 0.f}; acc23[k] = f2v{0.f, 0.f}; }
+#ifdef SPK_EXP_RUNS_NO_LOOP
+        for (int j = 0; j < 0; ++j) {
+#else
+        for (int j = 0; j < maxcnt; ++j) {
+#endif
+            const bool on = j < cnt;
+            const int src = on ? first + j : start;                             // an idle iteration re-reads a lane of its own run
+            const int addr = src << 2;
+            // stage 1: the plane's base value (m ; qv + z A2) and z-weight
+            const float xz = bperm_f(addr, sc.fx[2]) - zg;
+            const float wz = on ? za + zb * (xz * xz) : 0.f;
+            const float m = bperm_f(addr, sc.val_m);
+            const float q0 = bperm_f(addr, sc.qv[0]), q1 = bperm_f(addr, sc.qv[1]), q2 = bperm_f(addr, sc.qv[2]);
+            const float a6 = s_A[6][src], a7 = s_A[7][src], a8 = s_A[8][src];
+            f2v P01 = {m, q0 + fz * a6}, P23 = {q1 + fz * a7, q2 + fz * a8};
+            // stage 2: the in-plane weights and increments; node (sx, sy) receives  wx wy wz * (m ; qv + sx A0 + sy A1 + z A2)
+            float wy[3], wx[3];
+            eval_all(bperm_f(addr, sc.fx[1]), wy);
+            eval_all(bperm_f(addr, sc.fx[0]), wx);
+            const f2v Y01 = {0.f, s_A[3][src]}, Y23 = {s_A[4][src], s_A[5][src]};
+            const f2v X01 = {0.f, s_A[0][src]}, X23 = {s_A[1][src], s_A[2][src]};
+#pragma unroll
+            for (int sy = 0; sy < 3; ++sy) {
+                if (sy > 0) { P01 += Y01; P23 += Y23; }
+                const float wyz = wy[sy] * wz;
+                f2v Q01 = P01, Q23 = P23;
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) {
+                    if (sx > 0) { Q01 += X01; Q23 += X23; }
+                    const float w = wx[sx] * wyz;
+                    acc01[3 * sy + sx] += Q01 * w;
+                    acc23[3 * sy + sx] += Q23 * w;
+                }
+            }
+        }
+        // the two halves of a run sit in neighbouring lanes (sub = 2 z + half): add the odd lane's sums into the even one, so
+        // that one lane deposits per (run, plane) -- two lanes adding to the SAME address serialise in the LDS
+        bool deposit = cnt > 0;
+        if (S == 2) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                acc01[k].x += dpp_shl<1>(acc01[k].x); acc01[k].y += dpp_shl<1>(acc01[k].y);
+                acc23[k].x += dpp_shl<1>(acc23[k].x); acc23[k].y += dpp_shl<1>(acc23[k].y);
+            }
+            deposit = deposit && half == 0;
+        }
+#ifdef SPK_EXP_RUNS_NO_ATOMICS
+        if (deposit && fz == 123.f) {
+#else
+        if (deposit) {
+#endif
+            const int p = (run_base >> 6) + z;
+            const int n0 = run_base + TILE_W * TILE_W * z + 8 * p - 4 * (p & 1);      // acc_slot of the plane's (0, 0) node
+#pragma unroll
+            for (int sy = 0; sy < 3; ++sy)
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) {
+                    const int n = n0 + sx + TILE_W * sy;
+                    atomicAdd(&tile[0][n], (double)acc01[3 * sy + sx].x);
+                    atomicAdd(&tile[1][n], (double)acc01[3 * sy + sx].y);
+                    atomicAdd(&tile[2][n], (double)acc23[3 * sy + sx].x);
+                    atomicAdd(&tile[3][n], (double)acc23[3 * sy + sx].y);
+                }
+        }
+    }
+    return nheads;
+}
+
 // Tile write-out (ends with the workgroup barrier the caller needs anyway).  Most blocks have no particle in the drift
 // margin, so only the 6^3 core (216 of 512 nodes) goes to HBM: -58 % tile traffic here and in the grid update.
-SPK_DEV void tile_write(double (*tile)[TILE_N], const GridArrays& G, int pb, int tid, bool shell_used) {
+SPK_DEV void tile_write(double (*tile)[ACC_N], const GridArrays& G, int pb, int tid, bool shell_used) {
     const int full = __syncthreads_or(shell_used ? 1 : 0);
     float4* out = G.tiles + (size_t)pb * TILE_N;
     if (full) {
-        for (int n = tid; n < TILE_N; n += BLK_THREADS) out[n] = make_float4((float)tile[0][n], (float)tile[1][n], (float)tile[2][n], (float)tile[3][n]);
+        for (int l = tid; l < TILE_N; l += BLK_THREADS) { const int n = acc_slot(l); out[l] = make_float4((float)tile[0][n], (float)tile[1][n], (float)tile[2][n], (float)tile[3][n]); }
     } else if (tid < 216) {
         const int x = tid % 6, y = (tid / 6) % 6, z = tid / 36;
-        const int n = (x + 1) + TILE_W * (y + 1) + TILE_W * TILE_W * (z + 1);
+        const int n = acc_slot((x + 1) + TILE_W * (y + 1) + TILE_W * TILE_W * (z + 1));
         out[tid] = make_float4((float)tile[0][n], (float)tile[1][n], (float)tile[2][n], (float)tile[3][n]);
     }
     if (tid == 0) G.tile_mode[pb] = full;
@@ -444,13 +610,13 @@ template <int REDUCE_STEPS>
 __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models,
                                                      Ctl* __restrict__ ctl, StepParams S) {
     if (ctl->abort_flag[S.parity]) return;
-    __shared__ double tile[4][TILE_N];
+    __shared__ double tile[4][ACC_N];
     __shared__ int s_heads;
     const int tid = threadIdx.x;
     if (tid == 0) s_heads = 0;
     if (blockIdx.x == 0 && tid == 0) disorder_policy(ctl, (S.parity + 1) & 1, S.parity);
     const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
-    for (int n = tid; n < TILE_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
+    for (int n = tid; n < ACC_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int pfirst = rng.x, pcount = rng.y;
     const float h = S.h, inv_h = 1.0f / S.h;
@@ -500,13 +666,13 @@ template <int REDUCE_STEPS>
 __global__ __launch_bounds__(BLK_THREADS) void k_p2g_pair(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models,
                                                           Ctl* __restrict__ ctl, StepParams S) {
     if (ctl->abort_flag[S.parity]) return;
-    __shared__ double tile[4][TILE_N];
+    __shared__ double tile[4][ACC_N];
     __shared__ int s_heads;
     const int tid = threadIdx.x;
     if (tid == 0) s_heads = 0;
     if (blockIdx.x == 0 && tid == 0) disorder_policy(ctl, (S.parity + 1) & 1, S.parity);
     const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
-    for (int n = tid; n < TILE_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
+    for (int n = tid; n < ACC_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int pfirst = rng.x, pcount = rng.y;
     const float h = S.h, inv_h = 1.0f / S.h;
@@ -912,12 +1078,13 @@ struct Advected {
     float alpha;
     bool newly_failed;   // flags word must be stored
     bool in_tile;        // the NEW position still scatters inside the home block's tile (and inside the domain)
+    SymStress T;         // corotated stress of the final F, formed by the Drucker-Prager return map (fused kernel: scattered next substep)
 };
 
 // RARE: the instantiation that also carries snow / Rankine / NACC plasticity and the failure model; launched only when a
 // model of the set needs it, so the elastic / Drucker-Prager kernels keep their register budget (inlining that code,
 // or calling it out of line, cost the hot kernel 35 %).
-template <bool RARE>
+template <bool RARE, bool WANT_STRESS = false>
 SPK_DEV Advected g2p_update(const GridArrays& G, const float4* vt, const DevModel& mo, uint32_t flags, const float4& q0, const float4& q1, const float4& q2, const float4& dd,
                             const float4& kk, const float4* kinvel_i, const float4* aux_i, float phase, const int4& org, const StepParams& S, float inv_h,
                             unsigned* num_invalid) {
@@ -998,6 +1165,7 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const float4* vt, const DevMode
     float sv[3] = {1.f, 1.f, 1.f};
     bool sv_valid = false;
     o.store_k = false; o.store_aux = false; o.alpha = 0.f;
+    o.T.valid = false;
     if (RARE && mo.ptag > SPARKL_PLASTIC_DRUCKER_PRAGER) {   // snow / Rankine / NACC (plastic_model.update_particle, :102-104)
         float alpha = mo.ptag == SPARKL_PLASTIC_NACC ? aux_i->z : 0.f;
         const float eh0 = eh, alpha0 = alpha;
@@ -1007,11 +1175,11 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const float4* vt, const DevMode
         o.alpha = alpha;
     }
 #ifdef SPK_EXP_NO_PLASTICITY
-    if (mo.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER && Jp == 123.456f) dp_update(
+    if (mo.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER && Jp == 123.456f) dp_update<WANT_STRESS>(
 #else
-    if (mo.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER) dp_update(
+    if (mo.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER) dp_update<WANT_STRESS>(
 #endif
-mo, phase, F, Jp, q, lvg, sv, sv_valid);
+mo, phase, eh, F, Jp, q, lvg, sv, sv_valid, o.T);
     if (flags & FLAG_STATIC) { vel[0] = vel[1] = vel[2] = 0.f; C = m3_zero(); }
     // fail guards (:111-121); density_def_grad() == 0  <=>  mass/volume0 == 0 or det(F) overflowed
     const bool zero_density = (kk.x == 0.f) || !(fabsf(m3_det(F)) < 1.0e30f);
@@ -1022,6 +1190,7 @@ mo, phase, F, Jp, q, lvg, sv, sv_valid);
         F = m3_identity();
         C = m3_zero();
         sv_valid = false;
+        o.T.valid = false;
     }
     // positive energy bookkeeping (:127-132)
     psi = fmaxf(psi, model_pos_energy(mo, phase, eh, F, sv, sv_valid));
@@ -1132,6 +1301,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
 #ifndef SPK_G2P2G_MIN_BLOCKS
 #define SPK_G2P2G_MIN_BLOCKS 4
 #endif
+// REDUCE_STEPS >= 0: DPP pre-reduction over groups of 2^REDUCE_STEPS lanes (p2g_scatter); -1: run tasks (p2g_scatter_runs).
 template <int REDUCE_STEPS, bool RARE>
 __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
     const int tid = threadIdx.x;
@@ -1140,8 +1310,10 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
         return;
     }
     __shared__ float4 vt[TILE_N];
-    __shared__ double tile[4][TILE_N];
+    __shared__ double tile[4][ACC_N];
     __shared__ int s_heads;
+    __shared__ int s_runs[BLK_THREADS / 64][64];   // run list of each wave (run-task scatter)
+    __shared__ float s_A[BLK_THREADS / 64][9][64]; // affine part of the scatter descriptors, per wave
 #ifdef SPK_EXP_LDS_PAD   // occupancy experiment: fewer resident workgroups per CU
     __shared__ float lds_pad[SPK_EXP_LDS_PAD / 4];
     if (S.h < 0.f) lds_pad[tid] = 1.f;
@@ -1154,14 +1326,26 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int b = org.w, pfirst = rng.x, pcount = rng.y;
     const int niter = (pcount + BLK_THREADS - 1) / BLK_THREADS;
-#ifndef SPK_EXP_NO_PREFETCH
+    // Software pipeline: the position stream (needed first: weights -> gather) and the constants (the flags decide whether the
+    // lane works at all) are carried in registers one batch ahead; F and the plastic scalars are requested at the top of their
+    // own batch and first used after the gather (~700 cycles later).  Carrying all five float4 ahead costs 12 more VGPRs than
+    // the 128 of 4 waves per SIMD leave.
+#if !defined(SPK_EXP_PF2) && !defined(SPK_EXP_PF3) && !defined(SPK_EXP_NO_PREFETCH)
     float4 n0, n1, n2, nd, nk;
     {
         const int i0 = pfirst + min(tid, pcount - 1);
         n0 = P.q[0][i0]; n1 = P.q[1][i0]; n2 = P.q[2][i0]; nd = P.d[i0]; nk = P.k[i0];
     }
+#elif defined(SPK_EXP_PF3)
+    float4 n0, n1, n2;
+    {
+        const int i0 = pfirst + min(tid, pcount - 1);
+        n0 = P.q[0][i0]; n1 = P.q[1][i0]; n2 = P.q[2][i0];
+    }
+#elif defined(SPK_EXP_PF2)
+    float4 n0 = P.q[0][pfirst + min(tid, pcount - 1)], nk = P.k[pfirst + min(tid, pcount - 1)];
 #endif
-    for (int n = tid; n < TILE_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
+    for (int n = tid; n < ACC_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
     load_vel_tile(vt, G, b, tid);
     if (blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
     __syncthreads();
@@ -1174,14 +1358,23 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
         const int li = it * BLK_THREADS + tid;
         const bool active = li < pcount;
         const int i = pfirst + (active ? li : 0);
-#ifdef SPK_EXP_NO_PREFETCH
+#if defined(SPK_EXP_NO_PREFETCH)
         const float4 q0 = P.q[0][i], q1 = P.q[1][i], q2 = P.q[2][i], dd = P.d[i], kk = P.k[i];
-#else
+#elif !defined(SPK_EXP_PF2) && !defined(SPK_EXP_PF3)
         const float4 q0 = n0, q1 = n1, q2 = n2, dd = nd, kk = nk;
         if (it + 1 < niter) {
             const int inx = pfirst + min(li + BLK_THREADS, pcount - 1);
             n0 = P.q[0][inx]; n1 = P.q[1][inx]; n2 = P.q[2][inx]; nd = P.d[inx]; nk = P.k[inx];
         }
+#elif defined(SPK_EXP_PF3)
+        const float4 q0 = n0, q1 = n1, q2 = n2, kk = P.k[i], dd = P.d[i];
+        if (it + 1 < niter) {
+            const int inx = pfirst + min(li + BLK_THREADS, pcount - 1);
+            n0 = P.q[0][inx]; n1 = P.q[1][inx]; n2 = P.q[2][inx];
+        }
+#elif defined(SPK_EXP_PF2)
+        const float4 q0 = n0, kk = nk, q1 = P.q[1][i], q2 = P.q[2][i], dd = P.d[i];
+        if (it + 1 < niter) { const int inx = pfirst + min(li + BLK_THREADS, pcount - 1); n0 = P.q[0][inx]; nk = P.k[inx]; }
 #endif
         const uint32_t flags = __float_as_uint(kk.w);
         bool live = active && !(flags & FLAG_INVALID);
@@ -1190,7 +1383,7 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
         if (live) {
             const DevModel& mo = models[flags >> FLAG_MODEL_SHIFT];
             const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
-            const Advected o = g2p_update<RARE>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
+            const Advected o = g2p_update<RARE, true>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
             g2p_store(P, i, o);
             want_sort |= !o.in_tile;
             live = o.in_tile;
@@ -1199,9 +1392,10 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
                 dt_nan |= bnd != bnd;
                 dt_bound = fminf(dt_bound, bnd);
             }
-            if (live) { sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.F, kk.x, kk.y, o.eh, o.phase, o.Jp, org, h, inv_h, S.inv_d, S.dt_next); shell_used |= sc.shell != 0; }
+            if (live) { sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.F, kk.x, kk.y, o.eh, o.phase, o.Jp, org, h, inv_h, S.inv_d, S.dt_next, &o.T); shell_used |= sc.shell != 0; }
         }
-        wave_heads += p2g_scatter<REDUCE_STEPS>(tile, sc, live, tid);
+        if (REDUCE_STEPS < 0) wave_heads += p2g_scatter_runs(tile, sc, live, tid, s_runs[tid >> 6], s_A[tid >> 6]);
+        else wave_heads += p2g_scatter<(REDUCE_STEPS < 0 ? 0 : REDUCE_STEPS)>(tile, sc, live, tid);
     }
     if ((tid & 63) == 0) atomicAdd(&s_heads, wave_heads);
     tile_write(tile, G, pb, tid, shell_used);

@@ -426,8 +426,11 @@ static void launch_g2p(SparklPipeline* p, const ParticleArrays& P, const GridArr
 }
 static void launch_g2p2g(SparklPipeline* p, const ParticleArrays& P, const GridArrays& G, const StepParams& S, hipStream_t st) {
     const dim3 grid(p->num_pblocks), block(BLK_THREADS);
-    if (p->rare_models || S.project_particles) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<SPK_P2G_REDUCE_STEPS, true>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<SPK_P2G_REDUCE_STEPS, false>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
+    // SPARKL_HIP_SCATTER=dpp selects the DPP pre-reduction scatter (A/B); the default is the run-task scatter
+    static const bool dpp = getenv("SPARKL_HIP_SCATTER") && !strcmp(getenv("SPARKL_HIP_SCATTER"), "dpp");
+    if (p->rare_models || S.project_particles) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<-1, true>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
+    else if (dpp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<SPK_P2G_REDUCE_STEPS, false>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<-1, false>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
 }
 
 static int enqueue_fluid_volumes(SparklPipeline* p, const StepParams& S) {

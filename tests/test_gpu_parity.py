@@ -161,19 +161,20 @@ def test_step_in_a_spreading_sparse_scene_regrows_its_buffers(Pipeline):
     """A re-bin inside step() that raises the particle-block count (sparse scene: fewer than 256 particles per block, so the
     per-workgroup dt-bound buffer was sized exactly to the old block count)."""
     sc = scenes.elastic_cube(10)
-    sc.particles.velocity["vector"] *= 60.0          # the cloud spreads over new blocks within a frame
+    x = sc.particles.position["point"]
+    sc.particles.velocity["vector"] = (np.float32(30.0) * (x - x.mean(0))).astype(np.float32)   # radial burst: 2.6x wider after 8 frames
     sc.params.dt = 4.0e-3
     o32, o64 = _oracle(sc), _oracle(sc, f64=True)
+    blocks = []
     with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
         p.load_scene(sc)
-        p.substeps(sc.params, sc.gravity, 0.0, 1)
-        blocks0 = p.num_particle_blocks()
-        for frame in range(4):
+        for frame in range(8):
             t_ref = o32.step(sc.params, sc.gravity)
             o64.step(sc.params, sc.gravity)
-            t_got = p.step(sc.params, sc.gravity)
-            assert t_got == pytest.approx(t_ref, rel=1e-7)
-        blocks1 = p.num_particle_blocks()
+            t_got, tim = p.step(sc.params, sc.gravity, timings=True)
+            assert t_got == pytest.approx(t_ref, rel=1e-7) and tim.num_substeps == len(o32.last_dts())
+            blocks.append(p.num_particle_blocks())
+        blocks0, blocks1 = blocks[0], max(blocks)
         rep, bad = parity_verdict(p.read_particles(), o32.get_particles(), o64.get_particles(), sc.cell_width)
     _report("step_spreading", {**rep, "particle_blocks": [blocks0, blocks1]})
     assert blocks1 > blocks0, "the scene must grow the block list inside step()"
