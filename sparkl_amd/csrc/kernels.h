@@ -112,6 +112,7 @@ struct StepParams {
     int num_trimeshes;
     int project_particles;   // SolverParameters::enable_boundary_particle_projection
     int want_dt;      // G2P also reduces the next substep's dt bound into ctl->dt_bits (adaptive stepping)
+    int num_models;   // entries of the model table (<= MAX_LDS_MODELS: the particle kernels stage it in LDS)
     float dt_next;    // k_g2p2g: the step length the fused scatter (P2G of the NEXT substep) is built for; = dt for fixed-dt batches
 };
 
@@ -175,6 +176,34 @@ template <int N>
 SPK_DEV int dpp_shl_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xF, 0xF, true); }
 typedef float f2v __attribute__((ext_vector_type(2)));
 SPK_DEV int dpp_shr1_i(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xF, 0xF, false); }
+
+// The model table is read-only for the lifetime of a launch.  Reading it through per-lane global pointers costs a vector load per
+// parameter, each followed by s_waitcnt vmcnt(0) -- which, loads returning in order, also waits for every particle load issued
+// before it: the software prefetch of the next batch was being waited for at the first model parameter the compiler touched.
+// The particle kernels therefore copy the table into LDS in their prologue (the barrier that follows the tile staging covers
+// it) and read parameters with ds_read (lgkmcnt): no interplay with the vector memory counter.  Tables longer than
+// MAX_LDS_MODELS are read from global memory as before (template parameter LDS_MODELS = false).
+// Cold per-particle words (phase of a damaged particle, kinematic velocity) sit behind a flag.  `flag ? *p : default` makes the
+// compiler wait for the load -- with s_waitcnt vmcnt(0), i.e. for the whole prefetch in flight -- at the first USE of the value
+// in the common path too.  rare_load keeps load and wait inside a wave-uniform branch that the common case skips.
+SPK_DEV float rare_load(bool cond, const float* p, float dflt) {
+    float r = dflt;
+    if (__any(cond)) {
+        float t = dflt;
+        if (cond) t = *p;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(t));   // consumed here: the wait stays in this block
+    }
+    return r;
+}
+constexpr int MAX_LDS_MODELS = 16;
+constexpr int MODEL_WORDS = (int)(sizeof(DevModel) / 4);
+static_assert(sizeof(DevModel) % 4 == 0, "");
+SPK_DEV void stage_models(DevModel* s_models, const DevModel* __restrict__ models, int num_models, int tid) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(models);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(s_models);
+    const int n = min(num_models, MAX_LDS_MODELS) * MODEL_WORDS;
+    for (int w = tid; w < n; w += BLK_THREADS) dst[w] = src[w];
+}
 
 // ------------------------------------------------------------------------------------------- P2G
 // One workgroup per particle block.  LDS tile: 4 SoA planes of 512 floats.
@@ -606,13 +635,15 @@ SPK_DEV void disorder_policy(Ctl* ctl, int prev, int parity) {
 }
 
 // One workgroup per particle block: scatter its particles into the LDS tile, write the tile once.
-template <int REDUCE_STEPS>
+template <int REDUCE_STEPS, bool LDS_MODELS = true>
 __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models,
                                                      Ctl* __restrict__ ctl, StepParams S) {
     if (ctl->abort_flag[S.parity]) return;
     __shared__ double tile[4][ACC_N];
     __shared__ int s_heads;
     const int tid = threadIdx.x;
+    __shared__ DevModel s_models[LDS_MODELS ? MAX_LDS_MODELS : 1];
+    if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
     if (tid == 0) s_heads = 0;
     if (blockIdx.x == 0 && tid == 0) disorder_policy(ctl, (S.parity + 1) & 1, S.parity);
     const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
@@ -648,8 +679,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
             const float px[3] = {q0.x, q0.y, q0.z}, v[3] = {q3.x, q3.y, q3.z};
             const M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
             const M3 C = {{q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
-            const DevModel& mo = models[flags >> FLAG_MODEL_SHIFT];
-            const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
+            const DevModel& mo = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
+            const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
             const float jp = mo.is_fluid ? P.d[i].z : 1.f;
             sc = p2g_prepare(mo, flags, px, v, C, F, kk.x, kk.y, kk.z, phase, jp, org, h, inv_h, S.inv_d, S.dt);
             shell_used |= sc.shell != 0;
@@ -662,13 +693,15 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
 }
 
 // k_p2g with two particles per lane (see p2g_scatter_pair).
-template <int REDUCE_STEPS>
+template <int REDUCE_STEPS, bool LDS_MODELS = true>
 __global__ __launch_bounds__(BLK_THREADS) void k_p2g_pair(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models,
                                                           Ctl* __restrict__ ctl, StepParams S) {
     if (ctl->abort_flag[S.parity]) return;
     __shared__ double tile[4][ACC_N];
     __shared__ int s_heads;
     const int tid = threadIdx.x;
+    __shared__ DevModel s_models[LDS_MODELS ? MAX_LDS_MODELS : 1];
+    if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
     if (tid == 0) s_heads = 0;
     if (blockIdx.x == 0 && tid == 0) disorder_policy(ctl, (S.parity + 1) & 1, S.parity);
     const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
@@ -695,8 +728,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_pair(ParticleArrays P, Grid
                 const float px[3] = {q0.x, q0.y, q0.z}, v[3] = {q3.x, q3.y, q3.z};
                 const M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
                 const M3 C = {{q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
-                const DevModel& mo = models[flags >> FLAG_MODEL_SHIFT];
-                const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
+                const DevModel& mo = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
+                const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
                 const float jp = mo.is_fluid ? P.d[i].z : 1.f;
                 sc[k] = p2g_prepare(mo, flags, px, v, C, F, kk.x, kk.y, kk.z, phase, jp, org, h, inv_h, S.inv_d, S.dt);
                 shell_used |= sc[k].shell != 0;
@@ -1146,7 +1179,11 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const float4* vt, const DevMode
     }
     const float div = C.m[0] + C.m[4] + C.m[8];
     // kinematic override, advection (grid_to_particle.rs:82-86)
-    if (flags & FLAG_KINEMATIC) { const float4 kv = *kinvel_i; vel[0] = kv.x; vel[1] = kv.y; vel[2] = kv.z; }
+    {
+        const bool kin = (flags & FLAG_KINEMATIC) != 0;
+        const float* kp = reinterpret_cast<const float*>(kinvel_i);
+        vel[0] = rare_load(kin, kp, vel[0]); vel[1] = rare_load(kin, kp + 1, vel[1]); vel[2] = rare_load(kin, kp + 2, vel[2]);
+    }
     px[0] += vel[0] * dt; px[1] += vel[1] * dt; px[2] += vel[2] * dt;
     // deformation gradient update (:91-100)
     M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
@@ -1239,9 +1276,10 @@ SPK_DEV void g2p_store(const ParticleArrays& P, int i, const Advected& o) {
     if (o.store_aux) { float* a = reinterpret_cast<float*>(&P.aux[i]); a[0] = o.phase; a[2] = o.alpha; }
 }
 
-template <bool RARE>
+template <bool RARE, bool LDS_MODELS = true>
 __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
     const int tid = threadIdx.x;
+    __shared__ DevModel s_models[LDS_MODELS ? MAX_LDS_MODELS : 1];
     if (ctl->abort_flag[S.parity]) {
         // sticky abort: keep every later substep a no-op until the host re-bins
         if (blockIdx.x == 0 && tid == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
@@ -1260,6 +1298,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
         n0 = P.q[0][i0]; n1 = P.q[1][i0]; n2 = P.q[2][i0]; nd = P.d[i0]; nk = P.k[i0];
     }
     load_vel_tile(vt, G, b, tid);
+    if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
     if (blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
     __syncthreads();
     const float inv_h = 1.0f / S.h;
@@ -1274,8 +1313,8 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
         if (have) { const int inx = pfirst + li; n0 = P.q[0][inx]; n1 = P.q[1][inx]; n2 = P.q[2][inx]; nd = P.d[inx]; nk = P.k[inx]; }
         const uint32_t flags = __float_as_uint(kk.w);
         if (flags & FLAG_INVALID) continue;
-        const DevModel& mo = models[flags >> FLAG_MODEL_SHIFT];
-        const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
+        const DevModel& mo = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
+        const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
         const Advected o = g2p_update<RARE>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
         g2p_store(P, i, o);
         want_sort |= !o.in_tile;
@@ -1301,8 +1340,9 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
 #ifndef SPK_G2P2G_MIN_BLOCKS
 #define SPK_G2P2G_MIN_BLOCKS 4
 #endif
+
 // REDUCE_STEPS >= 0: DPP pre-reduction over groups of 2^REDUCE_STEPS lanes (p2g_scatter); -1: run tasks (p2g_scatter_runs).
-template <int REDUCE_STEPS, bool RARE>
+template <int REDUCE_STEPS, bool RARE, bool LDS_MODELS = true>
 __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
     const int tid = threadIdx.x;
     if (ctl->abort_flag[S.parity]) {
@@ -1314,6 +1354,8 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     __shared__ int s_heads;
     __shared__ int s_runs[BLK_THREADS / 64][64];   // run list of each wave (run-task scatter)
     __shared__ float s_A[BLK_THREADS / 64][9][64]; // affine part of the scatter descriptors, per wave
+    __shared__ DevModel s_models[LDS_MODELS ? MAX_LDS_MODELS : 1];
+    if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
 #ifdef SPK_EXP_LDS_PAD   // occupancy experiment: fewer resident workgroups per CU
     __shared__ float lds_pad[SPK_EXP_LDS_PAD / 4];
     if (S.h < 0.f) lds_pad[tid] = 1.f;
@@ -1381,8 +1423,8 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
         Scatter sc;
         scatter_clear(sc);
         if (live) {
-            const DevModel& mo = models[flags >> FLAG_MODEL_SHIFT];
-            const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
+            const DevModel& mo = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
+            const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
             const Advected o = g2p_update<RARE, true>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
             g2p_store(P, i, o);
             want_sort |= !o.in_tile;
@@ -1394,6 +1436,7 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
             }
             if (live) { sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.F, kk.x, kk.y, o.eh, o.phase, o.Jp, org, h, inv_h, S.inv_d, S.dt_next, &o.T); shell_used |= sc.shell != 0; }
         }
+        // (a hybrid -- run tasks for regular waves, DPP for ragged ones -- was measured: the two paths in one kernel spill, +15 %)
         if (REDUCE_STEPS < 0) wave_heads += p2g_scatter_runs(tile, sc, live, tid, s_runs[tid >> 6], s_A[tid >> 6]);
         else wave_heads += p2g_scatter<(REDUCE_STEPS < 0 ? 0 : REDUCE_STEPS)>(tile, sc, live, tid);
     }

@@ -394,6 +394,7 @@ static StepParams make_params(const SparklPipeline* p, const SparklSolverParams*
     S.parity = (int)(p->substep_index & 1u); S.dom = p->dom; S.num_cuboids = p->num_cuboids; S.num_heightfields = p->num_heightfields; S.num_trimeshes = p->num_trimeshes; S.want_dt = 0;
     S.project_particles = sp->enable_boundary_particle_projection ? 1 : 0;
     S.dt_next = dt;
+    S.num_models = (int)p->h_models.size();
     return S;
 }
 
@@ -409,28 +410,34 @@ static void launch_grid_update(SparklPipeline* p, const GridArrays& G, const Ste
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, false>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);
 }
 
+// Particle kernels stage the model table in LDS when it fits (see stage_models); longer tables are read from global memory.
+#define SPK_LAUNCH_MODELS(KERNEL, ...)                                                                                              \
+    do {                                                                                                                            \
+        if (S.num_models <= MAX_LDS_MODELS) hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<__VA_ARGS__, true>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);   \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<__VA_ARGS__, false>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);                                \
+    } while (0)
+
 static void launch_p2g(SparklPipeline* p, const ParticleArrays& P, const GridArrays& G, const StepParams& S, hipStream_t st) {
     const dim3 grid(p->num_pblocks), block(BLK_THREADS);
     // standalone P2G (adaptive-dt substeps, first substep of a fused batch): two particles per lane, 0.38 -> 0.357 ms at 10M.
     // SPARKL_HIP_P2G_PAIR=0 selects the one-particle-per-lane kernel (A/B).
     static const int pair_steps = getenv("SPARKL_HIP_P2G_PAIR") ? atoi(getenv("SPARKL_HIP_P2G_PAIR")) : 3;
-    if (pair_steps == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g_pair<2>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
-    else if (pair_steps == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g_pair<3>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
-    else if (pair_steps == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g_pair<4>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g<SPK_P2G_REDUCE_STEPS>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
+    if (pair_steps == 4) SPK_LAUNCH_MODELS(k_p2g_pair, 4);
+    else if (pair_steps == 0) SPK_LAUNCH_MODELS(k_p2g, SPK_P2G_REDUCE_STEPS);
+    else SPK_LAUNCH_MODELS(k_p2g_pair, 3);
 }
 static void launch_g2p(SparklPipeline* p, const ParticleArrays& P, const GridArrays& G, const StepParams& S, hipStream_t st) {
     const dim3 grid(p->num_pblocks), block(BLK_THREADS);
-    if (p->rare_models || S.project_particles) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p<true>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p<false>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
+    if (p->rare_models || S.project_particles) SPK_LAUNCH_MODELS(k_g2p, true);
+    else SPK_LAUNCH_MODELS(k_g2p, false);
 }
 static void launch_g2p2g(SparklPipeline* p, const ParticleArrays& P, const GridArrays& G, const StepParams& S, hipStream_t st) {
     const dim3 grid(p->num_pblocks), block(BLK_THREADS);
     // SPARKL_HIP_SCATTER=dpp selects the DPP pre-reduction scatter (A/B); the default is the run-task scatter
     static const bool dpp = getenv("SPARKL_HIP_SCATTER") && !strcmp(getenv("SPARKL_HIP_SCATTER"), "dpp");
-    if (p->rare_models || S.project_particles) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<-1, true>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
-    else if (dpp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<SPK_P2G_REDUCE_STEPS, false>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<-1, false>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
+    if (p->rare_models || S.project_particles) SPK_LAUNCH_MODELS(k_g2p2g, -1, true);
+    else if (dpp) SPK_LAUNCH_MODELS(k_g2p2g, SPK_P2G_REDUCE_STEPS, false);
+    else SPK_LAUNCH_MODELS(k_g2p2g, -1, false);
 }
 
 static int enqueue_fluid_volumes(SparklPipeline* p, const StepParams& S) {

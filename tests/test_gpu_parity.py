@@ -160,7 +160,7 @@ def test_adaptive_step_on_fluid_recomputes_volumes(Pipeline):
 def test_step_in_a_spreading_sparse_scene_regrows_its_buffers(Pipeline):
     """A re-bin inside step() that raises the particle-block count (sparse scene: fewer than 256 particles per block, so the
     per-workgroup dt-bound buffer was sized exactly to the old block count)."""
-    sc = scenes.elastic_cube(10)
+    sc = scenes.elastic_cube(6)       # 216 particles inside ONE particle block: the dt-bound buffer starts with a single entry
     x = sc.particles.position["point"]
     sc.particles.velocity["vector"] = (np.float32(30.0) * (x - x.mean(0))).astype(np.float32)   # radial burst: 2.6x wider after 8 frames
     sc.params.dt = 4.0e-3
