@@ -1645,6 +1645,225 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p_volume(ParticleArrays P, Gr
     }
 }
 
+// ---- the same sweep fused into the substep kernels (fixed dt and adaptive) ------------------------------------------------
+// Unfused, a substep with force_fluids_volume_recomputation is four passes over the particles (mass scatter, volume gather,
+// P2G, G2P).  But the mass scatter of substep s+1 only needs the positions G2P of substep s has just written, and the volume
+// gather only feeds the P2G that follows it: k_g2p_mass = G2P + mass scatter, k_vol_p2g = volume gather + P2G -- two passes.
+// FLUID_ONLY: every model of the table is a plain fluid (no plastic / failure model).  Fluids never touch F beyond F00
+// (grid_to_particle.rs:96-100), the plastic scalars or psi_pos (pos_energy == 0), so the F1..F8 and D streams are neither
+// read nor written: 96 + 112 B per particle-substep instead of ~400.
+
+// Mass-only scatter of one batch (one particle per lane) into a 512-entry f64 tile: same-cell lanes pre-summed over 16-lane rows
+// with DPP (64 particles per cell in the fluid configs), run heads deposit 3 x 9 atomics.
+SPK_DEV void mass_scatter(double* mtile, const float px[3], float mass, bool live, const int4& org, float h, int tid) {
+    if (!__any(live)) return;
+    const int r = tid & 15;
+    const int orgv[3] = {org.x, org.y, org.z};
+    float wgt[3][3];
+    int lc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float rc = roundf(px[a] / h);
+        const float d0 = (rc - 1.0f) * h - px[a];
+        eval_all(-d0 / h, wgt[a]);
+        lc[a] = (int)rc - 1 - orgv[a] + 1;
+    }
+    const int base = live ? lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2] : 0;
+    const float m = live ? mass : 0.f;
+    const int key = live ? base : -1;
+    const int key_prev = dpp_shr1_i(key, -2), key_next = dpp_shl_i<1>(key);
+    const bool head = (r == 0) | (key_prev != key);
+    const int i1 = ((r + 1 < 16) & (key_next == key)) ? 1 : 0;
+    const int i2 = i1 & dpp_shl_i<1>(i1) & (r + 2 < 16 ? 1 : 0);
+    const int i4 = i2 & dpp_shl_i<2>(i2) & (r + 4 < 16 ? 1 : 0);
+    const int i8 = i4 & dpp_shl_i<4>(i4) & (r + 8 < 16 ? 1 : 0);
+    const float f1 = (float)i1, f2 = (float)i2, f4 = (float)i4, f8 = (float)i8;
+#pragma unroll
+    for (int sz = 0; sz < 3; ++sz)
+#pragma unroll
+        for (int sy = 0; sy < 3; ++sy) {
+            const float wyz = wgt[1][sy] * wgt[2][sz] * m;
+            float c0 = wgt[0][0] * wyz, c1 = wgt[0][1] * wyz, c2 = wgt[0][2] * wyz, c3 = 0.f;   // c3 pads the four interleaved DPP chains
+            asm volatile("s_nop 1\n" SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") SPK_FMAC_DPP("4", "%6") SPK_FMAC_DPP("8", "%7")
+                         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4), "v"(f8));
+            if (live && head) {
+                const int n = base + TILE_W * sy + TILE_W * TILE_W * sz;
+                atomicAdd(&mtile[n], (double)c0);
+                atomicAdd(&mtile[n + 1], (double)c1);
+                atomicAdd(&mtile[n + 2], (double)c2);
+            }
+        }
+}
+
+// G2P of substep s + mass-only scatter of the advected particles (= the first half of substep s+1's volume sweep).
+template <bool FLUID_ONLY, bool LDS_MODELS>
+__global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
+    const int tid = threadIdx.x;
+    if (ctl->abort_flag[S.parity]) {
+        if (blockIdx.x == 0 && tid == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
+        return;
+    }
+    __shared__ float4 vt[TILE_N];
+    __shared__ double mtile[TILE_N];
+    __shared__ DevModel s_models[LDS_MODELS ? MAX_LDS_MODELS : 1];
+    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int b = org.w, pfirst = rng.x, pcount = rng.y;
+    const int niter = (pcount + BLK_THREADS - 1) / BLK_THREADS;
+    float4 n0, n1, n2, nd, nk;
+    {
+        const int i0 = pfirst + min(tid, pcount - 1);
+        n0 = P.q[0][i0]; nk = P.k[i0];
+        if (!FLUID_ONLY) { n1 = P.q[1][i0]; n2 = P.q[2][i0]; nd = P.d[i0]; }
+    }
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) mtile[n] = 0.0;
+    load_vel_tile(vt, G, b, tid);
+    if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
+    __syncthreads();
+    const float inv_h = 1.0f / S.h;
+    bool want_sort = false;
+    float dt_bound = 3.402823466e+38f;
+    bool dt_nan = false;
+    for (int it = 0; it < niter; ++it) {
+        const int li = it * BLK_THREADS + tid;
+        const bool active = li < pcount;
+        const int i = pfirst + (active ? li : 0);
+        const float4 q0 = n0, kk = nk;
+        // a plain fluid keeps F1..F8 = identity and never reads its plastic scalars
+        const float4 q1 = FLUID_ONLY ? make_float4(0.f, 0.f, 0.f, 1.f) : n1, q2 = FLUID_ONLY ? make_float4(0.f, 0.f, 0.f, 1.f) : n2;
+        const float4 dd = FLUID_ONLY ? make_float4(1.f, 0.f, 1.f, 0.f) : nd;
+        if (it + 1 < niter) {
+            const int inx = pfirst + min(li + BLK_THREADS, pcount - 1);
+            n0 = P.q[0][inx]; nk = P.k[inx];
+            if (!FLUID_ONLY) { n1 = P.q[1][inx]; n2 = P.q[2][inx]; nd = P.d[inx]; }
+        }
+        const uint32_t flags = __float_as_uint(kk.w);
+        bool live = active && !(flags & FLAG_INVALID);
+        float npx[3] = {0.f, 0.f, 0.f};
+        if (live) {
+            const DevModel& mo = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
+            const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
+            const Advected o = g2p_update<false>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
+            if (FLUID_ONLY) {
+                P.q[0][i] = make_float4(o.px[0], o.px[1], o.px[2], o.F.m[0]);
+                P.q[3][i] = make_float4(o.vel[0], o.vel[1], o.vel[2], o.C.m[0]);
+                P.q[4][i] = make_float4(o.C.m[1], o.C.m[2], o.C.m[3], o.C.m[4]);
+                P.q[5][i] = make_float4(o.C.m[5], o.C.m[6], o.C.m[7], o.C.m[8]);
+                if (o.newly_failed) reinterpret_cast<uint32_t*>(&P.k[i])[3] = o.flags;
+            } else {
+                g2p_store(P, i, o);
+            }
+            want_sort |= !o.in_tile;
+            live = o.in_tile;
+            npx[0] = o.px[0]; npx[1] = o.px[1]; npx[2] = o.px[2];
+            if (S.want_dt) {
+                const float bnd = particle_dt_bound(mo, o.flags, o.vel, o.C, kk.x, kk.y, o.eh, o.F.m[0], S.h);
+                dt_nan |= bnd != bnd;
+                dt_bound = fminf(dt_bound, bnd);
+            }
+        }
+        mass_scatter(mtile, npx, kk.x, live, org, S.h, tid);
+    }
+    __syncthreads();
+    float4* out = G.tiles + (size_t)pb * TILE_N;
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) out[n] = make_float4((float)mtile[n], 0.f, 0.f, 0.f);
+    if (tid == 0) G.tile_mode[pb] = 1;
+    if (__any(want_sort)) {
+        if ((tid & 63) == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
+    }
+    if (S.want_dt) dt_block_min_store(G.dt_partial, dt_bound, dt_nan, ctl, tid);
+}
+
+// Volume gather (second half of the sweep: F00 = (m / rho_grid) / V0 for fluid particles, fluids_volume.rs:83-110) + P2G.
+// Two particles per lane like k_p2g_pair.
+#ifndef SPK_VOLP2G_STEPS
+#define SPK_VOLP2G_STEPS 4   // 16-lane groups: 64 particles per cell in the fluid configs (0.88 -> 0.73 ms at 20M against 8-lane groups)
+#endif
+template <bool FLUID_ONLY, bool LDS_MODELS>
+__global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* __restrict__ ctl, StepParams S) {
+    if (ctl->abort_flag[S.parity]) return;
+    __shared__ double tile[4][ACC_N];
+    __shared__ float vm[TILE_N];          // node masses of the 8^3 tile (the merged mass-only grid)
+    __shared__ int s_heads;
+    __shared__ DevModel s_models[LDS_MODELS ? MAX_LDS_MODELS : 1];
+    const int tid = threadIdx.x;
+    if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
+    if (tid == 0) s_heads = 0;
+    if (blockIdx.x == 0 && tid == 0) disorder_policy(ctl, (S.parity + 1) & 1, S.parity);
+    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    for (int n = tid; n < ACC_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
+    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int b = org.w, pfirst = rng.x, pcount = rng.y;
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) {
+        const int tx = n & 7, ty = (n >> 3) & 7, tz = n >> 6;
+        const int dx = tx == 0 ? -1 : (tx <= 4 ? 0 : 1), dy = ty == 0 ? -1 : (ty <= 4 ? 0 : 1), dz = tz == 0 ? -1 : (tz <= 4 ? 0 : 1);
+        const int cx = tx - 1 - 4 * dx, cy = ty - 1 - 4 * dy, cz = tz - 1 - 4 * dz;
+        const int nb = G.blk_nbr[b * 27 + (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1)];
+        vm[n] = nb >= 0 ? G.node_vel[(size_t)nb * 64 + cx + 4 * cy + 16 * cz].w : 0.f;
+    }
+    const float h = S.h, inv_h = 1.0f / S.h;
+    __syncthreads();
+    bool shell_used = false;
+    int wave_heads = 0;
+    for (int base = 0; base < pcount; base += 2 * BLK_THREADS) {
+        Scatter sc[2];
+        bool live[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int li = base + 2 * tid + k;
+            const bool active = li < pcount;
+            const int i = pfirst + (active ? li : 0);
+            float4 q0 = P.q[0][i];
+            const float4 q3 = P.q[3][i], q4 = P.q[4][i], q5 = P.q[5][i], kk = P.k[i];
+            const float4 q1 = FLUID_ONLY ? make_float4(0.f, 0.f, 0.f, 1.f) : P.q[1][i], q2 = FLUID_ONLY ? make_float4(0.f, 0.f, 0.f, 1.f) : P.q[2][i];
+            const float jp_stored = P.d[i].z;
+            const uint32_t flags = __float_as_uint(kk.w);
+            live[k] = active && !(flags & FLAG_INVALID);
+            scatter_clear(sc[k]);
+            if (live[k]) {
+                const DevModel& mo = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
+                const float px[3] = {q0.x, q0.y, q0.z}, v[3] = {q3.x, q3.y, q3.z};
+                if (mo.is_fluid) {   // fluids_volume.rs:83-110 with the weights of k_g2p_volume
+                    const int orgv[3] = {org.x, org.y, org.z};
+                    float wgt[3][3];
+                    int lc[3];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const float r = roundf(px[a] / h);
+                        const float d0 = (r - 1.0f) * h - px[a];
+                        eval_all(-d0 / h, wgt[a]);
+                        lc[a] = (int)r - 1 - orgv[a] + 1;
+                    }
+                    const int vb = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
+                    float new_mass = 0.f;
+#pragma unroll
+                    for (int sz = 0; sz < 3; ++sz)
+#pragma unroll
+                        for (int sy = 0; sy < 3; ++sy)
+#pragma unroll
+                            for (int sx = 0; sx < 3; ++sx)
+                                new_mass += (wgt[0][sx] * wgt[1][sy] * wgt[2][sz]) * vm[vb + sx + TILE_W * sy + TILE_W * TILE_W * sz];
+                    const float new_density = new_mass / (h * h * h);
+                    const float new_volume = kk.x / new_density;
+                    q0.w = new_volume / kk.y;
+                    P.q[0][i] = q0;
+                }
+                const M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
+                const M3 C = {{q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
+                const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
+                const float jp = mo.is_fluid ? jp_stored : 1.f;
+                sc[k] = p2g_prepare(mo, flags, px, v, C, F, kk.x, kk.y, kk.z, phase, jp, org, h, inv_h, S.inv_d, S.dt);
+                shell_used |= sc[k].shell != 0;
+            }
+        }
+        wave_heads += p2g_scatter_pair<SPK_VOLP2G_STEPS>(tile, sc[0], sc[1], live[0], live[1], tid);
+    }
+    if ((tid & 63) == 0) atomicAdd(&s_heads, wave_heads);
+    tile_write(tile, G, pb, tid, shell_used);
+    if (tid == 0) atomicAdd(&ctl->heads[S.parity], (uint32_t)s_heads);
+}
+
 // ----------------------------------------------------------------------------------- dt estimate
 // timestep_estimator.rs:10-51: min over particles of the velocity bound and the model bound.
 __global__ __launch_bounds__(BLK_THREADS) void k_estimate_dt(ParticleArrays P, const DevModel* __restrict__ models, Ctl* ctl, int n, float h, uint32_t* dt_partial) {

@@ -112,6 +112,8 @@ struct SparklPipeline {
     DevBuf<DevModel> d_models;
     std::vector<DevModel> h_models;
     bool any_fluid = false;
+    bool all_plain_fluid = false;   // every model is a fluid without plastic / failure model: the FLUID_ONLY kernels apply
+    bool mass_tiles_ready = false;  // k_g2p_mass of the previous substep already scattered the next volume sweep's masses
     DevBuf<DevCuboid> d_cuboids;
     int num_cuboids = 0;
     DevBuf<DevHeightField> d_heightfields;
@@ -380,6 +382,7 @@ static int resort(SparklPipeline* p) {
     CHK(clock_end(p, tok));
     p->sorted = true;
     p->tiles_ready = false;
+    p->mass_tiles_ready = false;
     p->clock.resorts++;
     p->total_resorts++;
     return SPARKL_OK;
@@ -568,6 +571,52 @@ static int enqueue_fused_batch(SparklPipeline* p, const SparklSolverParams* sp, 
     return SPARKL_OK;
 }
 
+// Fixed-dt batch with force_fluids_volume_recomputation:  M ; { GUm ; V+P ; GU ; G+M } x n  (see k_g2p_mass / k_vol_p2g).
+// Same arithmetic as the unfused sweep (mass scatter, mass merge, volume gather, P2G, grid update, G2P), two passes over the
+// particles per substep instead of four.
+static int enqueue_fluid_batch(SparklPipeline* p, const SparklSolverParams* sp, const float g[3], float dt, uint32_t n) {
+    if (p->num_pblocks == 0) { p->substep_index += n; return SPARKL_OK; }
+    hipStream_t st = p->stream;
+    GridArrays G = grid_arrays(p);
+    const ParticleArrays P = p->cur.arrays();
+    const bool was_on = p->clock_on;
+    const dim3 grid(p->num_pblocks), block(BLK_THREADS), ggrid((p->num_blocks + 3) / 4);
+    size_t tk = 0;
+    const bool fluid_only = p->all_plain_fluid && !sp->enable_boundary_particle_projection;
+    if (!p->mass_tiles_ready) {
+        const StepParams S = make_params(p, sp, g, dt);
+        if (was_on && (p->substep_index % p->clock_stride) != 0) p->clock_on = false;
+        CHK(clock_begin(p, SPAN_P2G_MASS, &tk));
+        hipLaunchKernelGGL(k_p2g_mass, grid, block, 0, st, P, G, p->d_ctl, S);
+        CHK(clock_end(p, tk));
+        p->clock_on = was_on;
+    }
+    for (uint32_t j = 0; j < n; ++j) {
+        const StepParams S = make_params(p, sp, g, dt);
+        if (was_on && (p->substep_index % p->clock_stride) != 0) p->clock_on = false;
+        if (p->clock_on) p->clock_sampled++;
+        GridArrays Gm = G;
+        Gm.node_mom = nullptr;
+        CHK(clock_begin(p, SPAN_GRID_MASS, &tk));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<true>), ggrid, block, 0, st, Gm, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);
+        CHK(clock_end(p, tk));
+        CHK(clock_begin(p, SPAN_P2G, &tk));
+        if (fluid_only) SPK_LAUNCH_MODELS(k_vol_p2g, true); else SPK_LAUNCH_MODELS(k_vol_p2g, false);
+        CHK(clock_end(p, tk));
+        CHK(maybe_reorder(p, S.parity));
+        CHK(clock_begin(p, SPAN_GRID, &tk));
+        launch_grid_update(p, G, S, st);
+        CHK(clock_end(p, tk));
+        CHK(clock_begin(p, SPAN_G2P, &tk));
+        if (fluid_only) SPK_LAUNCH_MODELS(k_g2p_mass, true); else SPK_LAUNCH_MODELS(k_g2p_mass, false);
+        CHK(clock_end(p, tk));
+        p->clock_on = was_on;
+        p->substep_index++;
+    }
+    p->mass_tiles_ready = true;
+    return SPARKL_OK;
+}
+
 static int read_ctl(SparklPipeline* p) {
     HIPCHK(hipMemcpyAsync(p->h_ctl, p->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
@@ -741,7 +790,11 @@ int sparkl_hip_models_set(SparklPipeline* p, uint32_t n, const SparklParticleMod
     p->h_models = dm;
     p->any_fluid = any_fluid;
     p->rare_models = false;
-    for (const DevModel& d : dm) p->rare_models |= d.ptag > SPARKL_PLASTIC_DRUCKER_PRAGER || d.has_failure;
+    p->all_plain_fluid = n > 0;
+    for (const DevModel& d : dm) {
+        p->rare_models |= d.ptag > SPARKL_PLASTIC_DRUCKER_PRAGER || d.has_failure;
+        p->all_plain_fluid &= d.is_fluid && d.ptag < 0 && !d.has_failure;
+    }
     return SPARKL_OK;
 }
 
@@ -1155,12 +1208,16 @@ int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* pa
     uint32_t done = 0;
     // fixed dt: G2P of substep s and P2G of substep s+1 run as one kernel (see k_g2p2g); a batch pays one standalone
     // P2G + G2P, so fused batches are longer.  After a re-bin request the rest of a batch is no-op launches (~3 us each).
-    const bool fuse = p->fuse_fixed_dt && !(params->force_fluids_volume_recomputation && p->any_fluid);
+    const bool fluid_sweep = params->force_fluids_volume_recomputation && p->any_fluid;
+    const bool fuse = p->fuse_fixed_dt && !fluid_sweep;
+    const bool fuse_fluid = p->fuse_fixed_dt && fluid_sweep && !p->rare_models;
     const uint32_t CHUNK = fuse ? 128 : 32;
+    p->mass_tiles_ready = false;   // only trusted from one batch of this call to the next
     int guard = 0;
     while (done < nsubsteps) {
         const uint32_t batch = std::min(CHUNK, nsubsteps - done);
         if (fuse) CHK(enqueue_fused_batch(p, params, gravity, dt, batch));
+        else if (fuse_fluid) CHK(enqueue_fluid_batch(p, params, gravity, dt, batch));
         else for (uint32_t i = 0; i < batch; ++i) CHK(enqueue_substep(p, params, gravity, dt));
         CHK(read_ctl(p));
         if (p->clock_on) CHK(clock_collect(p));
