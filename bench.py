@@ -222,17 +222,25 @@ def main(args):
     device_id = 0 if os.environ.get("SPARKL_BENCH_ONE_DEVICE") else local_rank
     torch.cuda.set_device(device_id)
     ranks = 1
+    # N > 1 transports: "rccl" (default) = the exchange inside libsparkl_hip.so (sparkl_hip_group_substeps: RCCL send / recv of the
+    # ghost planes, flag all-reduce, migration); torch.distributed (gloo, CPU) only bootstraps the 128-byte communicator id and
+    # takes the MAX of the elapsed times.  "torch" = the Python SlabStepper over torch.distributed (nccl, or gloo for the
+    # one-GPU test hook, where two ranks cannot open one device twice in RCCL).
+    comm_mode = os.environ.get("SPARKL_BENCH_COMM", "rccl" if backend == "nccl" else "torch")
     if world > 1:
         import torch.distributed as dist
-        if backend == "nccl":
+        if comm_mode == "rccl":
+            dist.init_process_group("gloo")
+        elif backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_id))
         else:
             dist.init_process_group(backend)
-        # the rank count the job really runs with: an all-reduce of ones over the transport that carries the halo
-        ones = torch.ones(1, device="cuda" if backend == "nccl" else "cpu", dtype=torch.int64)
-        dist.all_reduce(ones)
-        ranks = int(ones.item())
-        assert ranks == dist.get_world_size() == world, (ranks, dist.get_world_size(), world)
+        if comm_mode != "rccl":
+            # the rank count the job really runs with: an all-reduce of ones over the transport that carries the halo
+            ones = torch.ones(1, device="cuda" if backend == "nccl" else "cpu", dtype=torch.int64)
+            dist.all_reduce(ones)
+            ranks = int(ones.item())
+            assert ranks == dist.get_world_size() == world, (ranks, dist.get_world_size(), world)
 
     from sparkl_amd.pipeline import MpmPipeline
     from sparkl_amd.slab import INT32_MAX, INT32_MIN, HipSlabBackend, SlabStepper
@@ -260,11 +268,29 @@ def main(args):
     t0 = time.time()
     pipe.load_scene(sc)
     upload_s = time.time() - t0
-    if mode == "slabs":
+    in_library = mode == "slabs" and comm_mode == "rccl"
+    if in_library:
+        ids = [MpmPipeline.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            pipe.comm_init(ids[0], rank, world)
+            ranks = pipe.comm_allreduce_sum(1)      # counted over the RCCL communicator that carries the halo
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
+        assert ranks == dist.get_world_size() == world, (ranks, dist.get_world_size(), world)
+    elif mode == "slabs":
         stepper = SlabStepper(HipSlabBackend(pipe, torch.device("cuda", device_id)), rank, world, chunk=16)
 
     def run(n):
-        if stepper is not None:
+        if in_library:
+            MpmPipeline.group_substeps([pipe], sc.params, sc.gravity, dt, n)
+        elif stepper is not None:
             stepper.substeps(sc.params, sc.gravity, dt, n)
         else:
             pipe.substeps(sc.params, sc.gravity, dt, n)
@@ -288,7 +314,7 @@ def main(args):
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+        tt = torch.tensor([elapsed], device="cuda" if (backend == "nccl" and comm_mode != "rccl") else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     clock = None if args.no_kernel_clock else pipe.clock_read(reset=True)
@@ -337,7 +363,8 @@ def main(args):
                        "active_node_blocks": n_blocks, "particle_blocks": n_pblocks,
                        "parallelism": "single GPU" if world == 1 else (
                            f"{world} x-slabs of one {world * nx}-long column, ghost node-block planes swapped with both neighbours every substep "
-                           f"({backend} send/recv), re-bin flag all-reduce" if mode == "slabs" else f"{world} independent replicas")},
+                           f"({'RCCL send/recv inside libsparkl_hip.so (sparkl_hip_group_substeps)' if in_library else backend + ' send/recv from the Python SlabStepper'}), "
+                           f"re-bin flag all-reduce" if mode == "slabs" else f"{world} independent replicas")},
             "step_gbs": step_bytes * world / (elapsed / args.steps) / 1e9,
             "step_frac_of_hbm_peak": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
             "setup_s": {"generate": gen_s, "upload_and_pack": upload_s},

@@ -425,6 +425,28 @@ int sparkl_hip_substep_finish_fused(SparklPipeline* p);
 /* synchronises; steps_done counts substeps whose G2P really ran, need_rebin != 0 when a re-bin is due */
 int sparkl_hip_substep_status(SparklPipeline* p, uint32_t* steps_done, uint32_t* need_rebin);
 
+/* ---- the exchange inside the library: slab groups over RCCL ----
+ * `CudaMpmPipeline::step(.., &mut [SingleGpuMpmContext])` (cuda_mpm_pipeline.rs:262-271) drives every device from one host
+ * thread and moves the halo itself (cuda_mpm_pipeline.rs:407-533).  sparkl_hip_group_substeps is that entry point for the slab
+ * decomposition: `members` are the slab pipelines THIS process owns, ascending along the slab axis; each has been given its
+ * slab (sparkl_hip_slab_set), particles, models and colliders.  Their outer neighbours are reached through RCCL: every member
+ * joins the job-wide communicator with sparkl_hip_comm_init(p, id, rank, world) -- rank r owns slab r, its neighbours are
+ * ranks r - 1 and r + 1 (one process per GPU: one member per process; one process for all GPUs: one member and one
+ * communicator per device).  The 128-byte id comes from sparkl_hip_comm_unique_id on one rank and travels to the others by
+ * whatever bootstrap the host has (MPI, a file, torch.distributed).  Per substep the library runs, stream-ordered and without
+ * host synchronisation: MAX all-reduce of the 4-byte re-bin request, P2G, halo pack, grouped ncclSend / ncclRecv of the
+ * shared planes with both neighbours, halo merge, grid update, G2P (+ the next P2G); the host reads the control block once
+ * per batch of 16 substeps; re-bins (with particle migration across the cuts) are collective.
+ * Members WITHOUT a communicator must share one device and one stream and exchange by device copies: a single-GPU test mode
+ * of the same loop.  Fixed-length substeps only (adaptive steps across ranks: sparkl_hip_dt_bound_export + a MIN all-reduce,
+ * see sparkl_amd/slab.py).  librccl is loaded on first use (dlopen); SPARKL_ERR_UNSUPPORTED if it is absent. */
+int sparkl_hip_comm_unique_id(void* out_128_bytes);
+int sparkl_hip_comm_init(SparklPipeline* p, const void* unique_id_128_bytes, int rank, int world);
+int sparkl_hip_comm_allreduce_sum(SparklPipeline* p, long long* value);     /* host-synchronous; no-op without a communicator */
+int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params,
+                              const float gravity[3], float dt, uint32_t nsubsteps);
+uint64_t sparkl_hip_group_rebins(const SparklPipeline* p);                  /* collective re-bins this member has taken part in */
+
 const char* sparkl_hip_last_error_string(void);
 /* "sparkl_hip <version> gfx950" */
 const char* sparkl_hip_version(void);

@@ -3,6 +3,8 @@
 // The product path is HIP only: there is no CPU fallback anywhere in this file.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -112,6 +114,14 @@ struct SparklPipeline {
     DevBuf<DevModel> d_models;
     std::vector<DevModel> h_models;
     bool any_fluid = false;
+    // slab group stepping (sparkl_hip_group_substeps): RCCL communicator and exchange buffers live in the handle
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    DevBuf<uint8_t> x_send[2], x_recv[2], x_mig_send[2], x_mig_recv[2];
+    uint64_t x_nsend[2] = {0, 0}, x_nrecv[2] = {0, 0};
+    DevBuf<long long> x_dev;          // small device staging area for counts / flags
+    long long* x_host = nullptr;     // pinned
+    uint64_t group_rebins = 0;
     bool all_plain_fluid = false;   // every model is a fluid without plastic / failure model: the FLUID_ONLY kernels apply
     bool mass_tiles_ready = false;  // k_g2p_mass of the previous substep already scattered the next volume sweep's masses
     DevBuf<DevCuboid> d_cuboids;
@@ -172,6 +182,7 @@ struct SparklPipeline {
     uint64_t total_resorts = 0;
 };
 
+static void comm_destroy(SparklPipeline* p);
 enum { SPAN_P2G = 0, SPAN_GRID = 1, SPAN_G2P = 2, SPAN_SORT = 3, SPAN_DT = 4, SPAN_HALO = 5, SPAN_FUSED = 6, SPAN_REORDER = 7, SPAN_P2G_MASS = 8, SPAN_GRID_MASS = 9, SPAN_G2P_VOLUME = 10 };
 
 static int clock_begin(SparklPipeline* p, int kind, size_t* tok) {
@@ -682,6 +693,10 @@ void sparkl_hip_pipeline_destroy(SparklPipeline* p) {
     p->pb_counts.release(); p->pb_first.release(); p->cand_a.release(); p->cand_b.release(); p->cub_temp.release(); p->d_scalars.release();
     p->staging.release(); p->node_staging.release(); p->d_count.release(); p->dt_partial.release();
     p->halo_list[0].release(); p->halo_list[1].release(); p->halo_in.release(); p->d_tail.release();
+    for (int k = 0; k < 2; ++k) { p->x_send[k].release(); p->x_recv[k].release(); p->x_mig_send[k].release(); p->x_mig_recv[k].release(); }
+    p->x_dev.release();
+    if (p->x_host) (void)hipHostFree(p->x_host);
+    comm_destroy(p);
     if (p->rb_stream) { (void)hipStreamSynchronize(p->rb_stream); (void)hipStreamDestroy(p->rb_stream); (void)hipEventDestroy(p->rb_gathered); (void)hipEventDestroy(p->rb_done); }
     p->rb_staging.release();
     for (auto e : p->ev_pool) (void)hipEventDestroy(e);
@@ -1335,6 +1350,7 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
         timings->dt = result; timings->num_substeps = nsub; timings->num_resorts = (uint32_t)p->clock.resorts;
         timings->grid_resize_and_sort_ms = (float)p->clock.sort_ms; timings->estimate_timestep_ms = (float)p->clock.dt_ms;
         timings->p2g_ms = (float)p->clock.p2g_ms; timings->grid_update_ms = (float)p->clock.grid_update_ms; timings->g2p_ms = (float)(p->clock.g2p_ms + p->clock.g2p2g_ms);   // fused launches count as G2P
+        timings->halo_ms = (float)p->clock.halo_ms;
         timings->total_ms = ms;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         p->clock = saved; p->clock_on = was_clock;
@@ -1542,6 +1558,332 @@ int sparkl_hip_slab_immigrants_add(SparklPipeline* p, const void* dev_in, uint64
     p->sorted = false;
     return SPARKL_OK;
 }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ slab groups: the exchange inside the library
+// cuda_mpm_pipeline.rs:262-271 steps `&mut [SingleGpuMpmContext]` from one host thread and moves the halo itself
+// (cuda_mpm_pipeline.rs:407-533).  sparkl_hip_group_substeps is that entry point for the slab decomposition: the members are the
+// slabs this process owns (ascending along the slab axis); their outer neighbours are other ranks of an RCCL communicator
+// (sparkl_hip_comm_init: one process per GPU, or several members per process with one communicator each).  Without a
+// communicator the members must share one device and one stream and exchange by device copies (tests, single GPU).
+// Per substep: abort-flag MAX all-reduce (4 bytes), P2G, halo pack, grouped ncclSend / ncclRecv with both neighbours, halo
+// merge, grid update, G2P (+ next P2G).  Nothing synchronises with the host inside a batch of substeps.
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static Rccl g_rccl;
+static int rccl_load() {
+    if (g_rccl.lib) return SPARKL_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return set_error(SPARKL_ERR_UNSUPPORTED, "cannot load librccl.so.1: %s", dlerror());
+#define SPK_SYM(field, name) do { *(void**)(&g_rccl.field) = dlsym(h, name); if (!g_rccl.field) return set_error(SPARKL_ERR_UNSUPPORTED, "librccl: missing %s", name); } while (0)
+    SPK_SYM(GetUniqueId, "ncclGetUniqueId"); SPK_SYM(CommInitRank, "ncclCommInitRank"); SPK_SYM(CommDestroy, "ncclCommDestroy");
+    SPK_SYM(GroupStart, "ncclGroupStart"); SPK_SYM(GroupEnd, "ncclGroupEnd"); SPK_SYM(Send, "ncclSend"); SPK_SYM(Recv, "ncclRecv");
+    SPK_SYM(AllReduce, "ncclAllReduce"); SPK_SYM(GetErrorString, "ncclGetErrorString");
+#undef SPK_SYM
+    g_rccl.lib = h;
+    return SPARKL_OK;
+}
+#define NCCLCHK(expr)                                                                                              \
+    do {                                                                                                           \
+        ncclResult_t r__ = (expr);                                                                                 \
+        if (r__ != ncclSuccess) return set_error(SPARKL_ERR_HIP, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r__), __FILE__, __LINE__); \
+    } while (0)
+static void comm_destroy(SparklPipeline* p) {
+    if (p->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(p->comm);
+    p->comm = nullptr;
+}
+
+__global__ void k_max_i32(int* dst, const int* src) { *dst = max(*dst, *src); }
+
+namespace {
+struct Group {
+    SparklPipeline** m;
+    int n;
+    bool rccl;    // every member has a communicator
+    // neighbour of member i on `side` (0 = low, 1 = high): -2 none, -1 remote rank (RCCL), >= 0 local member index
+    int nbr(int i, int side) const {
+        SparklPipeline* p = m[i];
+        if ((side == 0 ? p->slab_lo == INT32_MIN : p->slab_hi == INT32_MAX)) return -2;
+        if (rccl) return (side == 0 ? p->comm_rank > 0 : p->comm_rank < p->comm_world - 1) ? -1 : -2;
+        const int j = side == 0 ? i - 1 : i + 1;
+        return (j >= 0 && j < n) ? j : -2;
+    }
+    int peer_rank(int i, int side) const { return m[i]->comm_rank + (side == 0 ? -1 : 1); }
+};
+
+static int x_staging(SparklPipeline* p) {
+    CHK(p->x_dev.reserve(64));
+    if (!p->x_host) HIPCHK(hipHostMalloc((void**)&p->x_host, 64 * sizeof(long long)));
+    return SPARKL_OK;
+}
+
+// MAX over all members and ranks of one host value per member (host-synchronous: only used around re-bins)
+static int group_max(const Group& G, const long long* per_member, long long* out) {
+    long long mx = 0;
+    for (int i = 0; i < G.n; ++i) mx = std::max(mx, per_member[i]);
+    if (G.rccl) {
+        for (int i = 0; i < G.n; ++i) {
+            SparklPipeline* p = G.m[i];
+            HIPCHK(hipSetDevice(p->device));
+            p->x_host[0] = mx;
+            HIPCHK(hipMemcpyAsync(p->x_dev.p, p->x_host, sizeof(long long), hipMemcpyHostToDevice, p->stream));
+        }
+        NCCLCHK(g_rccl.GroupStart());
+        for (int i = 0; i < G.n; ++i) NCCLCHK(g_rccl.AllReduce(G.m[i]->x_dev.p, G.m[i]->x_dev.p, 1, ncclInt64, ncclMax, G.m[i]->comm, G.m[i]->stream));
+        NCCLCHK(g_rccl.GroupEnd());
+        for (int i = 0; i < G.n; ++i) {
+            SparklPipeline* p = G.m[i];
+            HIPCHK(hipSetDevice(p->device));
+            HIPCHK(hipMemcpyAsync(p->x_host, p->x_dev.p, sizeof(long long), hipMemcpyDeviceToHost, p->stream));
+            HIPCHK(hipStreamSynchronize(p->stream));
+            mx = std::max(mx, p->x_host[0]);
+        }
+    }
+    *out = mx;
+    return SPARKL_OK;
+}
+
+// counts[i][side] announced to the neighbour on that side -> what the neighbours announced (host-synchronous)
+static int group_swap_counts(const Group& G, const uint64_t (*out_counts)[2], uint64_t (*in_counts)[2]) {
+    for (int i = 0; i < G.n; ++i) in_counts[i][0] = in_counts[i][1] = 0;
+    if (!G.rccl) {
+        for (int i = 0; i < G.n; ++i)
+            for (int side = 0; side < 2; ++side) { const int j = G.nbr(i, side); if (j >= 0) in_counts[i][side] = out_counts[j][1 - side]; }
+        return SPARKL_OK;
+    }
+    for (int i = 0; i < G.n; ++i) {
+        SparklPipeline* p = G.m[i];
+        HIPCHK(hipSetDevice(p->device));
+        p->x_host[0] = (long long)out_counts[i][0]; p->x_host[1] = (long long)out_counts[i][1]; p->x_host[2] = 0; p->x_host[3] = 0;
+        HIPCHK(hipMemcpyAsync(p->x_dev.p, p->x_host, 4 * sizeof(long long), hipMemcpyHostToDevice, p->stream));
+    }
+    NCCLCHK(g_rccl.GroupStart());
+    for (int i = 0; i < G.n; ++i)
+        for (int side = 0; side < 2; ++side)
+            if (G.nbr(i, side) == -1) {
+                NCCLCHK(g_rccl.Send(G.m[i]->x_dev.p + side, 1, ncclInt64, G.peer_rank(i, side), G.m[i]->comm, G.m[i]->stream));
+                NCCLCHK(g_rccl.Recv(G.m[i]->x_dev.p + 2 + side, 1, ncclInt64, G.peer_rank(i, side), G.m[i]->comm, G.m[i]->stream));
+            }
+    NCCLCHK(g_rccl.GroupEnd());
+    for (int i = 0; i < G.n; ++i) {
+        SparklPipeline* p = G.m[i];
+        HIPCHK(hipSetDevice(p->device));
+        HIPCHK(hipMemcpyAsync(p->x_host, p->x_dev.p, 4 * sizeof(long long), hipMemcpyDeviceToHost, p->stream));
+        HIPCHK(hipStreamSynchronize(p->stream));
+        for (int side = 0; side < 2; ++side) if (G.nbr(i, side) == -1) in_counts[i][side] = (uint64_t)p->x_host[2 + side];
+    }
+    return SPARKL_OK;
+}
+
+// send[side] (nsend bytes) of every member to its neighbour, into that neighbour's recv[1 - side]; stream ordered
+typedef DevBuf<uint8_t> (SparklPipeline::*BufPair)[2];
+static int group_exchange(const Group& G, BufPair send, BufPair recv, const uint64_t (*nsend)[2], const uint64_t (*nrecv)[2]) {
+    if (G.rccl) {
+        bool any = false;
+        for (int i = 0; i < G.n && !any; ++i) for (int side = 0; side < 2; ++side) any |= G.nbr(i, side) == -1 && (nsend[i][side] || nrecv[i][side]);
+        if (!any) return SPARKL_OK;
+        NCCLCHK(g_rccl.GroupStart());
+        for (int i = 0; i < G.n; ++i)
+            for (int side = 0; side < 2; ++side) {
+                if (G.nbr(i, side) != -1) continue;
+                SparklPipeline* p = G.m[i];
+                if (nsend[i][side]) NCCLCHK(g_rccl.Send((p->*send)[side].p, nsend[i][side], ncclUint8, G.peer_rank(i, side), p->comm, p->stream));
+                if (nrecv[i][side]) NCCLCHK(g_rccl.Recv((p->*recv)[side].p, nrecv[i][side], ncclUint8, G.peer_rank(i, side), p->comm, p->stream));
+            }
+        NCCLCHK(g_rccl.GroupEnd());
+        return SPARKL_OK;
+    }
+    for (int i = 0; i < G.n; ++i)
+        for (int side = 0; side < 2; ++side) {
+            const int j = G.nbr(i, side);
+            if (j < 0 || !nsend[i][side]) continue;
+            HIPCHK(hipMemcpyAsync((G.m[j]->*recv)[1 - side].p, (G.m[i]->*send)[side].p, nsend[i][side], hipMemcpyDeviceToDevice, G.m[i]->stream));
+        }
+    return SPARKL_OK;
+}
+
+static int group_rebin(const Group& G) {
+    const uint64_t mig_bytes = MIG_F4 * sizeof(float4), halo_bytes = sizeof(HaloRecord);
+    std::vector<std::array<uint64_t, 2>> n_out(G.n), n_in(G.n), b_out(G.n), b_in(G.n);
+    std::vector<long long> total(G.n);
+    for (int round = 0; round < 64; ++round) {
+        for (int i = 0; i < G.n; ++i) { HIPCHK(hipSetDevice(G.m[i]->device)); CHK(validate_models(G.m[i])); CHK(resort(G.m[i])); }
+        for (int i = 0; i < G.n; ++i) {
+            for (int side = 0; side < 2; ++side) n_out[i][side] = G.nbr(i, side) != -2 ? (uint64_t)G.m[i]->n_emig[side] : 0;
+            total[i] = (long long)(n_out[i][0] + n_out[i][1]);
+        }
+        long long any = 0;
+        CHK(group_max(G, total.data(), &any));
+        if (any == 0) break;
+        CHK(group_swap_counts(G, (const uint64_t(*)[2])n_out.data(), (uint64_t(*)[2])n_in.data()));
+        for (int i = 0; i < G.n; ++i) {
+            SparklPipeline* p = G.m[i];
+            HIPCHK(hipSetDevice(p->device));
+            for (int side = 0; side < 2; ++side) {
+                b_out[i][side] = n_out[i][side] * mig_bytes; b_in[i][side] = n_in[i][side] * mig_bytes;
+                CHK(p->x_mig_send[side].reserve(std::max<uint64_t>(b_out[i][side], 16)));
+                CHK(p->x_mig_recv[side].reserve(std::max<uint64_t>(b_in[i][side], 16)));
+                if (n_out[i][side]) CHK(sparkl_hip_slab_emigrants_pack(p, side, p->x_mig_send[side].p));
+            }
+        }
+        CHK(group_exchange(G, &SparklPipeline::x_mig_send, &SparklPipeline::x_mig_recv, (const uint64_t(*)[2])b_out.data(), (const uint64_t(*)[2])b_in.data()));
+        for (int i = 0; i < G.n; ++i)
+            for (int side = 0; side < 2; ++side)
+                if (n_in[i][side]) CHK(sparkl_hip_slab_immigrants_add(G.m[i], G.m[i]->x_mig_recv[side].p, n_in[i][side]));
+        if (round == 63) return set_error(SPARKL_ERR_INTERNAL, "slab migration did not settle");
+    }
+    // halo buffers for the new block lists
+    for (int i = 0; i < G.n; ++i) for (int side = 0; side < 2; ++side) n_out[i][side] = G.nbr(i, side) != -2 ? (uint64_t)G.m[i]->halo_count[side] : 0;
+    CHK(group_swap_counts(G, (const uint64_t(*)[2])n_out.data(), (uint64_t(*)[2])n_in.data()));
+    for (int i = 0; i < G.n; ++i) {
+        SparklPipeline* p = G.m[i];
+        HIPCHK(hipSetDevice(p->device));
+        for (int side = 0; side < 2; ++side) {
+            p->x_nsend[side] = n_out[i][side]; p->x_nrecv[side] = n_in[i][side];
+            CHK(p->x_send[side].reserve(std::max<uint64_t>(n_out[i][side] * halo_bytes, 16)));
+            CHK(p->x_recv[side].reserve(std::max<uint64_t>(n_in[i][side] * halo_bytes, 16)));
+        }
+        p->group_rebins++;
+    }
+    return SPARKL_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int sparkl_hip_comm_unique_id(void* out_128_bytes) {
+    if (!out_128_bytes) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    CHK(rccl_load());
+    static_assert(sizeof(ncclUniqueId) == 128, "");
+    NCCLCHK(g_rccl.GetUniqueId((ncclUniqueId*)out_128_bytes));
+    return SPARKL_OK;
+}
+int sparkl_hip_comm_init(SparklPipeline* p, const void* unique_id_128_bytes, int rank, int world) {
+    if (!p || !unique_id_128_bytes || world < 1 || rank < 0 || rank >= world) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "bad argument");
+    CHK(rccl_load());
+    HIPCHK(hipSetDevice(p->device));
+    comm_destroy(p);
+    ncclUniqueId id;
+    memcpy(&id, unique_id_128_bytes, sizeof(id));
+    NCCLCHK(g_rccl.CommInitRank(&p->comm, world, id, rank));
+    p->comm_rank = rank; p->comm_world = world;
+    return SPARKL_OK;
+}
+/* SUM over the ranks of the communicator of one 64-bit value (host-synchronous; the bench uses it to count its ranks) */
+int sparkl_hip_comm_allreduce_sum(SparklPipeline* p, long long* value) {
+    if (!p || !value) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    if (!p->comm) return SPARKL_OK;
+    HIPCHK(hipSetDevice(p->device));
+    CHK(x_staging(p));
+    p->x_host[0] = *value;
+    HIPCHK(hipMemcpyAsync(p->x_dev.p, p->x_host, sizeof(long long), hipMemcpyHostToDevice, p->stream));
+    NCCLCHK(g_rccl.AllReduce(p->x_dev.p, p->x_dev.p, 1, ncclInt64, ncclSum, p->comm, p->stream));
+    HIPCHK(hipMemcpyAsync(p->x_host, p->x_dev.p, sizeof(long long), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    *value = p->x_host[0];
+    return SPARKL_OK;
+}
+
+int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params, const float gravity[3], float dt, uint32_t nsubsteps) {
+    if (!members || n_members == 0 || !params || !gravity) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    Group G{members, (int)n_members, true};
+    for (int i = 0; i < G.n; ++i) {
+        if (!members[i] || !members[i]->slab_on) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "member %d is not a slab pipeline (sparkl_hip_slab_set)", i);
+        G.rccl = G.rccl && members[i]->comm != nullptr;
+    }
+    if (!G.rccl)
+        for (int i = 0; i < G.n; ++i) {
+            if (members[i]->comm) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "either every member has a communicator or none");
+            if (members[i]->device != members[0]->device || members[i]->stream != members[0]->stream)
+                return set_error(SPARKL_ERR_INVALID_ARGUMENT, "members without a communicator must share one device and one stream");
+        }
+    if (params->damage_model != SPARKL_DAMAGE_NONE) return unsupported_damage_model(params);
+    if (params->force_fluids_volume_recomputation) for (int i = 0; i < G.n; ++i) if (members[i]->any_fluid)
+        return set_error(SPARKL_ERR_UNSUPPORTED, "fluid volume recomputation across slab cuts is not implemented");
+    for (int i = 0; i < G.n; ++i) { HIPCHK(hipSetDevice(members[i]->device)); CHK(x_staging(members[i])); }
+    bool need_rebin = false;
+    for (int i = 0; i < G.n; ++i) need_rebin |= !members[i]->sorted || members[i]->group_rebins == 0;
+    {   // a member that still has to (re-)bin makes the whole job do it: the re-bin is collective
+        std::vector<long long> v(G.n, need_rebin ? 1 : 0);
+        long long any = 0;
+        CHK(group_max(G, v.data(), &any));
+        if (any) CHK(group_rebin(G));
+    }
+    std::vector<uint32_t> base(G.n);
+    for (int i = 0; i < G.n; ++i) { HIPCHK(hipSetDevice(members[i]->device)); CHK(read_ctl(members[i])); base[i] = members[i]->h_ctl->steps_done; }
+    uint32_t done = 0;
+    int guard = 0;
+    std::vector<std::array<uint64_t, 2>> bs(G.n), br(G.n);
+    while (done < nsubsteps) {
+        const uint32_t batch = std::min<uint32_t>(16, nsubsteps - done);
+        for (uint32_t j = 0; j < batch; ++j) {
+            // 1. the re-bin request of the upcoming substep, MAX over every slab: all ranks skip the same substeps
+            for (int i = 0; i < G.n; ++i) { HIPCHK(hipSetDevice(members[i]->device)); CHK(sparkl_hip_flags_export(members[i], members[i]->x_dev.p + 8)); }
+            if (G.rccl) {
+                NCCLCHK(g_rccl.GroupStart());
+                for (int i = 0; i < G.n; ++i) NCCLCHK(g_rccl.AllReduce(members[i]->x_dev.p + 8, members[i]->x_dev.p + 8, 1, ncclInt32, ncclMax, members[i]->comm, members[i]->stream));
+                NCCLCHK(g_rccl.GroupEnd());
+            } else if (G.n > 1) {
+                for (int i = 1; i < G.n; ++i) hipLaunchKernelGGL(k_max_i32, dim3(1), dim3(1), 0, members[0]->stream, (int*)(members[0]->x_dev.p + 8), (const int*)(members[i]->x_dev.p + 8));
+                for (int i = 1; i < G.n; ++i) HIPCHK(hipMemcpyAsync(members[i]->x_dev.p + 8, members[0]->x_dev.p + 8, 4, hipMemcpyDeviceToDevice, members[0]->stream));
+            }
+            for (int i = 0; i < G.n; ++i) { HIPCHK(hipSetDevice(members[i]->device)); CHK(sparkl_hip_flags_import(members[i], members[i]->x_dev.p + 8)); }
+            // 2. scatter, pack the shared planes, swap, merge, finish
+            for (int i = 0; i < G.n; ++i) CHK(sparkl_hip_substep_begin(members[i], params, gravity, dt));
+            for (int i = 0; i < G.n; ++i)
+                for (int side = 0; side < 2; ++side) {
+                    bs[i][side] = members[i]->x_nsend[side] * sizeof(HaloRecord); br[i][side] = members[i]->x_nrecv[side] * sizeof(HaloRecord);
+                    if (members[i]->x_nsend[side]) CHK(sparkl_hip_halo_pack(members[i], side, members[i]->x_send[side].p));
+                }
+            {
+                size_t tok = 0;
+                CHK(clock_begin(members[0], SPAN_HALO, &tok));
+                CHK(group_exchange(G, &SparklPipeline::x_send, &SparklPipeline::x_recv, (const uint64_t(*)[2])bs.data(), (const uint64_t(*)[2])br.data()));
+                CHK(clock_end(members[0], tok));
+            }
+            for (int i = 0; i < G.n; ++i)
+                for (int side = 0; side < 2; ++side)
+                    if (members[i]->x_nrecv[side]) CHK(sparkl_hip_halo_merge(members[i], side, members[i]->x_recv[side].p, members[i]->x_nrecv[side]));
+            for (int i = 0; i < G.n; ++i) CHK(substep_finish_impl(members[i], j + 1 < batch));
+        }
+        // one host read per batch; the flag is global, so every member ran the same substeps
+        long long need = 0;
+        uint32_t ran = 0;
+        std::vector<long long> needs(G.n, 0);
+        for (int i = 0; i < G.n; ++i) {
+            HIPCHK(hipSetDevice(members[i]->device));
+            CHK(read_ctl(members[i]));
+            if (members[i]->clock_on) CHK(clock_collect(members[i]));
+            const uint32_t r = members[i]->h_ctl->steps_done - base[i];
+            ran = i == 0 ? r : std::min(ran, r);
+            needs[i] = (r < done + batch || members[i]->h_ctl->abort_flag[0] || members[i]->h_ctl->abort_flag[1]) ? 1 : 0;
+        }
+        CHK(group_max(G, needs.data(), &need));
+        done = ran;
+        if (need) {
+            CHK(group_rebin(G));
+            if (++guard > (int)nsubsteps * 2 + 16) return set_error(SPARKL_ERR_INTERNAL, "re-bin loop did not make progress");
+        }
+    }
+    return SPARKL_OK;
+}
+uint64_t sparkl_hip_group_rebins(const SparklPipeline* p) { return p ? p->group_rebins : 0; }
+
+}  // extern "C"
+
+extern "C" {
 
 // --------------------------------------------------------------------------------- grid inspection
 uint64_t sparkl_hip_grid_num_active_blocks(SparklPipeline* p) { return p ? (uint64_t)p->num_blocks : 0; }

@@ -64,6 +64,34 @@ class MpmPipeline:
         s = SlabC(axis, block_lo, block_hi, 0, id_offset)
         check(self.L.sparkl_hip_slab_set(self.h, C.byref(s)))
 
+    # ---- the exchange inside the library (RCCL): see sparkl_hip_group_substeps in the header
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL id (ncclGetUniqueId): create on one rank, hand to every rank's comm_init."""
+        buf = (C.c_uint8 * 128)()
+        check(lib().sparkl_hip_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check(self.L.sparkl_hip_comm_init(self.h, buf, C.c_int(rank), C.c_int(world)))
+
+    def comm_allreduce_sum(self, value):
+        v = C.c_longlong(int(value))
+        check(self.L.sparkl_hip_comm_allreduce_sum(self.h, C.byref(v)))
+        return int(v.value)
+
+    @staticmethod
+    def group_substeps(members, params, gravity, dt, n):
+        """n fixed-length substeps of the slab pipelines `members` (ascending along the slab axis) in lockstep, halo exchange,
+        re-bin agreement and particle migration inside the library (RCCL between ranks, device copies inside a process)."""
+        arr = (C.c_void_p * len(members))(*[m.h for m in members])
+        g = (C.c_float * 3)(*[float(x) for x in gravity])
+        check(members[0].L.sparkl_hip_group_substeps(arr, C.c_uint32(len(members)), C.byref(params), g, C.c_float(dt), C.c_uint32(n)))
+
+    def group_rebins(self):
+        return int(self.L.sparkl_hip_group_rebins(self.h))
+
     # ---- CudaParticleModelSet / CudaColliderSet
     def set_models(self, model_set):
         arr = model_set.to_c_array()

@@ -196,3 +196,90 @@ def test_cube_through_sand_two_slabs_match_oracle(tmp_path):
     assert crossed > 20, "the kinematic cube must cross the cut"
     assert all(int(q["rebins"]) >= 2 for q in parts)
     assert not bad, (bad, rep)
+
+
+@pytest.mark.parametrize("kind,nsteps", [("spin", 40), ("cube", 100)])
+def test_group_substeps_two_slabs_in_the_library(kind, nsteps):
+    """sparkl_hip_group_substeps: the whole slab loop (re-bin agreement, halo swap, migration) inside the C ABI, no Python in
+    the exchange.  Two slabs share one GPU and one stream (device-copy transport of the same loop that uses RCCL between ranks);
+    the union must match the un-decomposed pipeline, and -- for the cube ploughing through sand -- the oracle."""
+    from sparkl_amd.pipeline import MpmPipeline
+    from tests.parity import parity_verdict
+    world = 2
+    sc, dt = _scene(kind)
+    cuts, all_gids = _ownership(sc, world)
+    id_to_caller = np.concatenate(all_gids)
+    stream = torch.cuda.Stream()
+    pipes = []
+    for r in range(world):
+        comps = ParticleComponents(0)
+        for k in ParticleComponents.__slots__:
+            setattr(comps, k, np.ascontiguousarray(getattr(sc.particles, k)[all_gids[r]]))
+        pipe = MpmPipeline(sc.cell_width, device_id=0, domain_log2_bytes=sc.domain_log2_bytes, stream=stream.cuda_stream)
+        pipe.set_slab(0, cuts[r], cuts[r + 1], id_offset=int(sum(len(g) for g in all_gids[:r])))
+        pipe.set_models(sc.models)
+        pipe.set_colliders(sc.colliders)
+        pipe.upload_particles(comps)
+        pipes.append(pipe)
+    MpmPipeline.group_substeps(pipes, sc.params, sc.gravity, dt, nsteps)
+    parts = [(p.read_particles(), id_to_caller[p.read_sorted_particle_ids()]) for p in pipes]
+    rebins = [p.group_rebins() for p in pipes]
+    n_after = [len(p) for p in pipes]
+    for p in pipes:
+        p.close()
+    caller = np.concatenate([c for _, c in parts])
+    assert np.array_equal(np.sort(caller), np.arange(len(sc.particles))), "particles lost or duplicated across slabs"
+    inv = np.argsort(caller)
+    got = ParticleComponents(len(sc.particles))
+    for k in ("position", "velocity", "volume", "status", "velocity_gradient", "phase", "data"):
+        setattr(got, k, np.concatenate([getattr(c, k) for c, _ in parts])[inv])
+    with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, dt, nsteps)
+        ref = p.read_particles()
+    h = sc.cell_width
+    vmax = np.abs(ref.velocity["vector"]).max()
+    ex = np.abs(got.position["point"] - ref.position["point"]).max() / h
+    ev = np.abs(got.velocity["vector"] - ref.velocity["vector"]).max() / vmax
+    print(kind, "group slabs vs single pipeline:", ex, ev, "re-bins", rebins, "particles per slab", [len(g) for g in all_gids], "->", n_after)
+    assert ex < 2e-5 and ev < 2e-4
+    assert all(r >= 2 for r in rebins) and n_after != [len(g) for g in all_gids], "the scene must migrate particles across the cut"
+    if kind == "cube":
+        from oracle import Oracle
+        threads = max(1, min(16, len(os.sched_getaffinity(0))))
+        refs = []
+        for f64 in (False, True):
+            o = Oracle(sc.cell_width, f64=f64, domain_log2_bytes=sc.domain_log2_bytes, threads=threads)
+            o.load_scene(sc)
+            for _ in range(nsteps):
+                o.substep_fixed(sc.params, sc.gravity, dt)
+            refs.append(o.get_particles())
+            o.close()
+        rep, bad = parity_verdict(got, refs[0], refs[1], h)
+        print("cube_through_sand group slabs vs oracle:", rep["vs_f64"], rep["oracle_f32_vs_f64"])
+        assert not bad, (bad, rep)
+
+
+def test_group_substeps_over_rccl_world_of_one():
+    """The RCCL code path of sparkl_hip_group_substeps with a one-rank communicator (this box has one GPU): librccl loads,
+    the communicator initialises, the per-substep flag all-reduce and the count exchanges run on the pipeline's stream, and the
+    result equals the plain pipeline's."""
+    from sparkl_amd.pipeline import MpmPipeline
+    from sparkl_amd.slab import INT32_MAX, INT32_MIN
+    sc, dt = _scene("spin")
+    with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.set_slab(0, INT32_MIN, INT32_MAX, id_offset=0)
+        p.comm_init(MpmPipeline.comm_unique_id(), 0, 1)
+        assert p.comm_allreduce_sum(1) == 1
+        p.load_scene(sc)
+        MpmPipeline.group_substeps([p], sc.params, sc.gravity, dt, 40)
+        got, ids, rebins = p.read_particles(), p.read_sorted_particle_ids(), p.group_rebins()
+    with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, dt, 40)
+        ref = p.read_particles()
+    inv = np.argsort(ids)
+    ex = np.abs(got.position["point"][inv] - ref.position["point"]).max() / sc.cell_width
+    ev = np.abs(got.velocity["vector"][inv] - ref.velocity["vector"]).max() / np.abs(ref.velocity["vector"]).max()
+    print("rccl world-1 group vs plain pipeline:", ex, ev, "re-bins", rebins)
+    assert rebins >= 2 and ex < 2e-5 and ev < 2e-4
