@@ -446,6 +446,8 @@ int sparkl_hip_comm_allreduce_sum(SparklPipeline* p, long long* value);     /* h
 int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params,
                               const float gravity[3], float dt, uint32_t nsubsteps);
 uint64_t sparkl_hip_group_rebins(const SparklPipeline* p);                  /* collective re-bins this member has taken part in */
+/* the hipStream_t the pipeline runs on (to create a second member on the same stream, or to order foreign work against it) */
+void* sparkl_hip_pipeline_stream(const SparklPipeline* p);
 
 const char* sparkl_hip_last_error_string(void);
 /* "sparkl_hip <version> gfx950" */

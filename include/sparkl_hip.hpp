@@ -298,6 +298,27 @@ public:
         return t;
     }
     void substeps(const SolverParameters& params, const Vector& gravity, Real dt, uint32_t n) { check(sparkl_hip_pipeline_substeps(h_, &params, gravity.data(), dt, n)); }
+    // ---- slabs (multi-GPU): `CudaMpmPipeline::step(.., &mut [SingleGpuMpmContext])` for a spatial decomposition.  Give every slab
+    // its block range before uploading its particles, join the RCCL communicator (one rank per slab) or keep all slabs on one
+    // device and stream, then step them together with group_substeps.
+    void* stream() const { return sparkl_hip_pipeline_stream(h_); }
+    void set_slab(int axis, int32_t block_lo, int32_t block_hi, uint64_t id_offset) {
+        SparklSlab s{axis, block_lo, block_hi, 0u, id_offset};
+        check(sparkl_hip_slab_set(h_, &s));
+    }
+    void comm_init(const void* unique_id_128_bytes, int rank, int world) { check(sparkl_hip_comm_init(h_, unique_id_128_bytes, rank, world)); }
+    static void group_substeps(const std::vector<MpmPipeline*>& members, const SolverParameters& params, const Vector& gravity, Real dt, uint32_t n) {
+        std::vector<SparklPipeline*> raw;
+        for (auto* m : members) raw.push_back(m->h_);
+        check(sparkl_hip_group_substeps(raw.data(), (uint32_t)raw.size(), &params, gravity.data(), dt, n));
+    }
+    // device order of a slab pipeline: positions / velocities as stored, plus the global id of every record
+    void read_device_order(std::vector<SparklParticlePosition>& pos, std::vector<SparklParticleVelocity>& vel, std::vector<uint32_t>& ids) {
+        const size_t n = len();
+        pos.resize(n); vel.resize(n); ids.resize(n);
+        check(sparkl_hip_particles_read_positions(h_, pos.data(), n)); check(sparkl_hip_particles_read_velocities(h_, vel.data(), n));
+        check(sparkl_hip_particles_read_sorted_ids(h_, ids.data(), n));
+    }
     // testbed_plugin.rs:533-588: read positions / velocities / F back into the CPU ParticleSet
     void download(ParticleSet& particles) {
         const size_t n = len();

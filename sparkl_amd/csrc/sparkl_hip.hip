@@ -1880,6 +1880,7 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
     return SPARKL_OK;
 }
 uint64_t sparkl_hip_group_rebins(const SparklPipeline* p) { return p ? p->group_rebins : 0; }
+void* sparkl_hip_pipeline_stream(const SparklPipeline* p) { return p ? (void*)p->stream : nullptr; }
 
 }  // extern "C"
 

@@ -1,6 +1,9 @@
 // C++ host program against include/sparkl_hip.hpp: a sand3-like scene (examples3d/sand3.rs:39-78, without jitter) stepped
 // through MpmPipeline::step and through fixed substeps.  Prints a small state digest that tests/test_cpp_host.py compares
 // with the Python host mirror driving the same library.
+#include <climits>
+#include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <tuple>
 
@@ -69,6 +72,40 @@ int main(int argc, char** argv) {
             for (auto& p : particles.particles()) sy3 += p.position[1];
             std::printf("readback: snapshot mean_y %.9g, five substeps later %.9g, %s\n", sy2 / (double)np, sy3 / (double)np, sy3 < sy2 ? "ok" : "NOT FALLING");
             MpmPipeline::host_free(pos); MpmPipeline::host_free(vel);
+        }
+        // two x-slabs of the same scene stepped together inside the library (sparkl_hip_group_substeps; between ranks the same loop
+        // moves the ghost planes with RCCL): the union must equal the un-decomposed pipeline
+        {
+            ParticleSet all;
+            all.insert_batch(cube_particles({x0, x0 + 10 * particle_rad * 2.0f, x0}, 16, 10, 12, sand_model, particle_rad, 2700.0f));
+            all.insert_batch(cube_particles({x0, x0, x0}, 16, 10, 12, block_model, particle_rad, 2700.0f));
+            const int32_t cut = 2;   // block index along x: cells 0..7 | 8..
+            ParticleSet lo, hi;
+            for (auto& p : all.particles()) {
+                const int cell = (int)std::lround(p.position[0] / cell_width) - 1;
+                ((cell >> 2) < cut ? lo : hi).insert(p);
+            }
+            MpmPipeline a(cell_width);
+            MpmPipeline b(cell_width, 0, 30, a.stream());
+            a.set_slab(0, INT32_MIN, cut, 0); b.set_slab(0, cut, INT32_MAX, lo.len());
+            for (auto* m : {&a, &b}) { m->set_models(models); m->set_colliders({floor}); }
+            a.upload(lo); b.upload(hi);
+            MpmPipeline::group_substeps({&a, &b}, params, gravity, 2.5e-4f, 40);
+            MpmPipeline whole(cell_width);
+            whole.set_models(models); whole.set_colliders({floor}); whole.upload(all);
+            whole.substeps(params, gravity, 2.5e-4f, 40);
+            whole.download(all);
+            double ref[2] = {0, 0}, got[2] = {0, 0};
+            for (auto& p : all.particles()) { ref[0] += p.position[1]; ref[1] += p.velocity[1]; }
+            size_t total = 0;
+            for (auto* m : {&a, &b}) {
+                std::vector<SparklParticlePosition> pos; std::vector<SparklParticleVelocity> vel; std::vector<uint32_t> ids;
+                m->read_device_order(pos, vel, ids);
+                total += pos.size();
+                for (size_t i = 0; i < pos.size(); ++i) { got[0] += pos[i].point[1]; got[1] += vel[i].vector[1]; }
+            }
+            const bool ok = total == all.len() && std::fabs(got[0] - ref[0]) <= 1e-6 * std::fabs(ref[0]) && std::fabs(got[1] - ref[1]) <= 2e-3 * std::fabs(ref[1]);
+            std::printf("slabs: %zu + %zu particles, sum_y %.9g vs %.9g, sum_vy %.9g vs %.9g, %s\n", lo.len(), hi.len(), got[0], ref[0], got[1], ref[1], ok ? "ok" : "MISMATCH");
         }
         // error behaviour: Custom models cannot cross the C ABI
         ParticleModelSet bad;

@@ -37,6 +37,7 @@ def test_cpp_host_matches_python_host():
     mean_pos = np.array([float(x) for x in line[7:10]])
     mean_vy, mean_fyy = float(line[11]), float(line[13])
     assert "custom: rejected code 2" in out
+    assert "slabs:" in out and out.split("slabs:")[1].splitlines()[0].rstrip().endswith("ok")   # two slabs stepped inside the library, no Python
     assert "readback: snapshot" in out and out.split("readback:")[1].splitlines()[0].rstrip().endswith("ok")
     # same scene through the Python mirror
     h, r = 0.2, 0.05
