@@ -15,8 +15,11 @@ Two formats:
          `(CoreConstitutiveModel, Option<CorePlasticModel>, Option<CoreFailureModel>)`
   with nalgebra 0.32's serde for fixed-size storage (`ArrayStorage` = `serialize_seq(Some(R * C))`, i.e. a u64 length
   followed by the column-major elements) and rapier's arena `Index { index: u32, generation: u32 }` as the model handle.
-  UNPINNED: there is no rustc in this image and the reference holds no serialized fixture, so this layout is restated
-  from the crates' published serde implementations and only round-trip tested here.
+  **UNVERIFIED AGAINST SPARKL.**  No byte of this format has ever been produced or read by a real sparkl build: there is no
+  rustc in this image, the crates are absent, and the reference holds no serialized fixture.  The layout is restated from
+  the crates' published serde implementations and only round-trip tested against itself here; treat a file written by
+  `dump_bincode` as a proposal to be checked against `bincode::serialize(&particles)` on a machine with the reference
+  toolchain before relying on it.  The native format above is the one the resume tests exercise (against the oracle).
 """
 import io
 import json

@@ -120,3 +120,50 @@ def test_resume_from_checkpoint_matches_uninterrupted_run(tmp_path):
     e = particle_errors(got, ref, sc.cell_width)
     # the re-bin after the upload orders particles differently from the uninterrupted run: f32 summation order only
     assert e["eps_x"] < 1e-5 and e["eps_v"] < 1e-4 and e["failed_mismatch"] == 0, e
+
+
+@pytest.mark.gpu
+def test_resume_from_checkpoint_matches_the_oracle(tmp_path):
+    """Checkpoint taken from the HIP path after 40 substeps, resumed on the HIP path for 60 more: the end state is held to the
+    parity gate against the ORACLE's uninterrupted 100 substeps (not against the HIP path itself), and the oracle resumed
+    from the same checkpoint file must agree with it as well -- the file carries everything the dynamics need."""
+    import os
+    from oracle import Oracle
+    from sparkl_amd.pipeline import MpmPipeline
+    from tests.parity import parity_verdict
+    sc = scenes.sand_column(16, 10, 12, with_block=True)
+    dt = 2.5e-4
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    refs = []
+    for f64 in (False, True):
+        o = Oracle(sc.cell_width, f64=f64, domain_log2_bytes=sc.domain_log2_bytes, threads=threads)
+        o.load_scene(sc)
+        for _ in range(100):
+            o.substep_fixed(sc.params, sc.gravity, dt)
+        refs.append(o.get_particles())
+        o.close()
+    with MpmPipeline(sc.cell_width) as p:
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, dt, 40)
+        checkpoint.save(tmp_path / "mid.npz", p.read_particles(), sc.models, sc.cell_width, params=sc.params, simulated_time=40 * dt)
+    c, models, header, params = checkpoint.load(tmp_path / "mid.npz")
+    assert header["simulated_time"] == pytest.approx(40 * dt)
+    with MpmPipeline(header["cell_width"]) as p:
+        p.set_models(models)
+        p.set_colliders(sc.colliders)
+        p.upload_particles(c)
+        p.substeps(params, sc.gravity, dt, 60)
+        got = p.read_particles()
+    rep, bad = parity_verdict(got, refs[0], refs[1], sc.cell_width)
+    print("resume (HIP) vs uninterrupted oracle:", rep["vs_f64"], rep["oracle_f32_vs_f64"])
+    assert not bad, (bad, rep)
+    # the oracle resumed from the HIP checkpoint lands in the same place
+    o = Oracle(header["cell_width"], domain_log2_bytes=sc.domain_log2_bytes, threads=threads)
+    o.set_models(models)
+    o.set_cuboids(sc.colliders)
+    o.set_particles(c)
+    for _ in range(60):
+        o.substep_fixed(params, sc.gravity, dt)
+    rep2, bad2 = parity_verdict(o.get_particles(), refs[0], refs[1], sc.cell_width)
+    o.close()
+    assert not bad2, (bad2, rep2)
