@@ -65,6 +65,9 @@ typedef struct {                                                     /* :201-208
     float elastic_hardening;
     float log_vol_gain;
 } SparklParticleData;
+/* Optional component (particle.rs:180-195; `Particle::{crack_propagation_factor, crack_threshold}` on the CPU path,
+ * src/dynamics/particle.rs:29-30): only read under SPARKL_DAMAGE_MODIFIED_EIGENEROSION.  Default (0, f32::MAX). */
+typedef struct { float crack_propagation_factor; float crack_threshold; } SparklParticleFracture;   /* 8 B */
 /* CPU-path-only state: `Particle::velocity_gradient` (src/dynamics/particle.rs:16).
  * The reference CUDA path never stores it (fused g2p2g); the CPU ordering needs it
  * between G2P and the next P2G.  Column-major. */
@@ -273,6 +276,11 @@ int sparkl_hip_particles_append(SparklPipeline* p, uint64_t n,
 int sparkl_hip_particles_remove_range(SparklPipeline* p, uint64_t start, uint64_t end);
 int sparkl_hip_particles_truncate(SparklPipeline* p, uint64_t new_len);
 uint64_t sparkl_hip_particles_len(const SparklPipeline* p);
+/* ParticleFracture of the resident particles, caller order, n == particles_len.  Travels with the particles through re-bins;
+ * appended particles get the default.  Read by DamageModel::ModifiedEigenerosion only (grid_to_particle.rs:65-77):
+ * the psi_mass / psi_momentum node transfer of particle_to_grid.rs:62-86 runs as three extra kernels per substep then. */
+int sparkl_hip_particles_set_fracture(SparklPipeline* p, const SparklParticleFracture* fracture, uint64_t n);
+int sparkl_hip_particles_read_fracture(SparklPipeline* p, SparklParticleFracture* out, uint64_t n);
 
 /* CudaParticleSet::read_* (cuda_particle_set.rs:91-121).  Arrays come back in CALLER order
  * (the library keeps particles physically block-sorted on the device).  `n` must equal len. */

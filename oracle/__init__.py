@@ -83,6 +83,12 @@ class Oracle:
                                     abi.ptr(comps.volume, abi.VOLUME_DTYPE), abi.ptr(comps.phase, abi.PHASE_DTYPE),
                                     abi.ptr(comps.data, abi.DATA_DTYPE), abi.ptr(comps.velocity_gradient, abi.VELGRAD_DTYPE))
 
+    def set_fracture(self, fracture):
+        """`ParticleFracture` per particle (caller order): numpy (n, 2) float32 = crack_propagation_factor, crack_threshold."""
+        f = np.ascontiguousarray(fracture, dtype=np.float32)
+        assert f.shape == (int(self.L.oracle_num_particles(self.h)), 2)
+        self.L.oracle_set_fracture(self.h, C.c_uint64(len(f)), f.ctypes.data_as(C.c_void_p))
+
     def get_particles(self):
         from sparkl_amd.particles import ParticleComponents
         n = int(self.L.oracle_num_particles(self.h))

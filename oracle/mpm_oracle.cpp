@@ -230,6 +230,14 @@ void oracle_heightfield_project(const SparklHeightFieldCollider* c, const double
     *is_inside = p.is_inside;
 }
 
+// ParticleFracture (src_core/dynamics/particle.rs:180-195): crack_propagation_factor, crack_threshold per particle, caller order
+void oracle_set_fracture(void* hv, uint64_t n, const float* cpf_and_threshold) {
+    Handle* h = (Handle*)hv;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (h->f64) { auto& p = h->od->particles[i]; p.crack_propagation_factor = cpf_and_threshold[2 * i]; p.crack_threshold = cpf_and_threshold[2 * i + 1]; }
+        else { auto& p = h->of->particles[i]; p.crack_propagation_factor = cpf_and_threshold[2 * i]; p.crack_threshold = cpf_and_threshold[2 * i + 1]; }
+    }
+}
 double oracle_step(void* hv, const SparklSolverParams* params, const float g[3]) {
     Handle* h = (Handle*)hv;
     if (h->f64) return h->od->step(*params, Vec3<double>{{g[0], g[1], g[2]}});

@@ -972,7 +972,9 @@ struct Oracle {
         }
     }
 
-    // ---- grid_to_particle.rs:10-166 (DamageModel::None, no failure model, no projection)
+    // ---- grid_to_particle.rs:10-166.  damage_model: DamageModel::ModifiedEigenerosion (grid_to_particle.rs:65-77) or None; the
+    // other two (CdMpm, Eigenerosion) are separate passes of mls_solver.rs:68-83 that this restatement does not hold.
+    int damage_model = SPARKL_DAMAGE_NONE;
     bool project_particles = false;   // SolverParameters::enable_boundary_particle_projection (set by substep / oracle_g2p_project)
     void g2p(R dt) {
         R invd = inv_d(h);
@@ -990,6 +992,7 @@ struct Oracle {
                 Vec3<R> vel{{0, 0, 0}};
                 Mat3<R> vg = Mat3<R>::zeros();
                 R vg_det = 0;
+                R psi_pos_momentum = 0;
                 R w[3][3];
                 for (int a = 0; a < 3; ++a) eval_all(-d0[a] / h, w[a]);
                 for (int k = 0; k < 27; ++k) {
@@ -1002,9 +1005,15 @@ struct Oracle {
                     R wi = weight * invd;
                     for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) vg(i, j) += (wi * cv[i]) * dpt[j];
                     vg_det += weight * dot(cv, dpt) * invd;
+                    psi_pos_momentum += weight * cell.psi_momentum * inv_exact(cell.psi_mass);   // grid_to_particle.rs:57-58
                 }
                 p.velocity = vel;
                 p.velocity_gradient = vg;
+                // Modified Eigenerosion (grid_to_particle.rs:65-77)
+                if (damage_model == SPARKL_DAMAGE_MODIFIED_EIGENEROSION && p.crack_propagation_factor != R(0) && p.phase > R(0)) {
+                    R crack_energy = p.crack_propagation_factor * h * psi_pos_momentum;
+                    if (crack_energy > p.crack_threshold) p.phase = R(0);
+                }
                 if (p.kinematic_vel_enabled) p.velocity = p.kinematic_vel;
                 for (int a = 0; a < 3; ++a) p.position[a] += p.velocity[a] * dt;
                 if (!fluid) {
@@ -1112,6 +1121,7 @@ struct Oracle {
         p2g(dt, gravity);
         grid_update(dt, params.boundary_handling, params.simulation_dofs);
         project_particles = params.enable_boundary_particle_projection != 0;
+        damage_model = params.damage_model;
         g2p(dt);
         return dt;
     }

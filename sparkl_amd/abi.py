@@ -17,6 +17,7 @@ VOLUME_DTYPE = np.dtype([("mass", "<f4"), ("volume0", "<f4"), ("radius0", "<f4")
 STATUS_DTYPE = np.dtype([("failed", "u1"), ("is_static", "u1"), ("kinematic_vel_enabled", "u1"),
                          ("_pad0", "u1"), ("kinematic_vel", "<f4", (3,)), ("model_index", "<u8")])  # 24 B
 PHASE_DTYPE = np.dtype([("phase", "<f4"), ("psi_pos", "<f4")])           # 8 B
+FRACTURE_DTYPE = np.dtype([("crack_propagation_factor", "<f4"), ("crack_threshold", "<f4")])   # 8 B, optional component
 DATA_DTYPE = np.dtype([("nacc_alpha", "<f4"), ("plastic_hardening", "<f4"),
                        ("elastic_hardening", "<f4"), ("log_vol_gain", "<f4")])  # 16 B
 VELGRAD_DTYPE = np.dtype([("m", "<f4", (9,))])                           # 36 B

@@ -71,6 +71,7 @@ struct ParticleArrays {
     float4* k;
     float4* kinvel;   // (kx, ky, kz, -)
     float4* aux;      // (phase, radius0, nacc_alpha, bits of the particle's caller/global id): cold, only moved by re-bins
+    float4* frac;     // (crack_propagation_factor, crack_threshold, -, -): ParticleFracture, NULL unless the caller uploaded it
 };
 SPK_DEV uint32_t particle_id(const ParticleArrays& P, int i) { return reinterpret_cast<const uint32_t*>(&P.aux[i])[3]; }
 
@@ -1471,7 +1472,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_block_reorder(ParticleArrays P,
         const int cnt = min(2 * BLK_THREADS, pcount - c0);
         for (int n = tid; n < 8 * TILE_N; n += BLK_THREADS) (&hist[0][0])[n] = 0;
         __syncthreads();
-        float4 r[2][10];
+        float4 r[2][10], fr[2];
         int key[2], rank[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -1481,6 +1482,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_block_reorder(ParticleArrays P,
 #pragma unroll
             for (int a = 0; a < 6; ++a) r[k][a] = P.q[a][i];
             r[k][6] = P.d[i]; r[k][7] = P.k[i]; r[k][8] = P.kinvel[i]; r[k][9] = P.aux[i];
+            if (P.frac) fr[k] = P.frac[i];
             const float px[3] = {r[k][0].x, r[k][0].y, r[k][0].z};
             int kk = 0;
 #pragma unroll
@@ -1524,6 +1526,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_block_reorder(ParticleArrays P,
 #pragma unroll
                 for (int a = 0; a < 6; ++a) P.q[a][dst] = r[k][a];
                 P.d[dst] = r[k][6]; P.k[dst] = r[k][7]; P.kinvel[dst] = r[k][8]; P.aux[dst] = r[k][9];
+                if (P.frac) P.frac[dst] = fr[k];
             }
         }
         __syncthreads();
@@ -1864,6 +1867,109 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
     if (tid == 0) atomicAdd(&ctl->heads[S.parity], (uint32_t)s_heads);
 }
 
+// ---- DamageModel::ModifiedEigenerosion: the psi_mass / psi_momentum node transfer -----------------------------------------
+// particle_to_grid.rs:62-86 scatters, beside mass and momentum, psi_mass = m (0 for failed / cracked particles and those whose
+// crack_propagation_factor is 0) and psi_momentum = psi_mass * psi_pos; grid_to_particle.rs:57-77 gathers
+// sum w psi_momentum / psi_mass, and a particle whose crack_propagation_factor * h * that exceeds its crack_threshold gets
+// phase = 0 before it is advected.  Three small kernels between the grid update and G2P, launched only under that damage model
+// with ParticleFracture uploaded, so the hot kernels do not carry two more node planes.
+__global__ __launch_bounds__(BLK_THREADS) void k_p2g_psi(ParticleArrays P, GridArrays G, const Ctl* __restrict__ ctl, StepParams S, float2* __restrict__ psi_tiles) {
+    if (ctl->abort_flag[S.parity]) return;
+    __shared__ double ta[TILE_N], tb[TILE_N];
+    const int tid = threadIdx.x;
+    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) { ta[n] = 0.0; tb[n] = 0.0; }
+    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int pfirst = rng.x, pcount = rng.y;
+    __syncthreads();
+    const int niter = (pcount + BLK_THREADS - 1) / BLK_THREADS;
+    for (int it = 0; it < niter; ++it) {
+        const int li = it * BLK_THREADS + tid;
+        const bool active = li < pcount;
+        const int i = pfirst + (active ? li : 0);
+        const float4 q0 = P.q[0][i], kk = P.k[i], dd = P.d[i], fr = P.frac[i];
+        const uint32_t flags = __float_as_uint(kk.w);
+        const bool live = active && !(flags & FLAG_INVALID);
+        const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
+        const float psi_mass = (live && phase > 0.f && fr.x != 0.f && !(flags & FLAG_FAILED)) ? kk.x : 0.f;
+        const float px[3] = {q0.x, q0.y, q0.z};
+        mass_scatter(ta, px, psi_mass, live, org, S.h, tid);
+        mass_scatter(tb, px, psi_mass * dd.w, live, org, S.h, tid);
+    }
+    __syncthreads();
+    float2* out = psi_tiles + (size_t)pb * TILE_N;
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) out[n] = make_float2((float)ta[n], (float)tb[n]);
+}
+// one wave per node block: psi_momentum * inv_exact(psi_mass) of its 64 nodes, summed over the <= 8 overlapping tiles
+__global__ __launch_bounds__(BLK_THREADS) void k_grid_psi(GridArrays G, const float2* __restrict__ psi_tiles, float* __restrict__ node_psi, const Ctl* __restrict__ ctl, int parity) {
+    if (ctl->abort_flag[parity]) return;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= G.num_blocks) return;
+    const int lane = threadIdx.x & 63;
+    const int cx = lane & 3, cy = (lane >> 2) & 3, cz = lane >> 4;
+    const int dx0 = cx <= 2 ? -1 : 0, dy0 = cy <= 2 ? -1 : 0, dz0 = cz <= 2 ? -1 : 0;
+    float m = 0.f, pm = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int dx = dx0 + (k & 1), dy = dy0 + ((k >> 1) & 1), dz = dz0 + (k >> 2);
+        const int t = G.blk_tnbr[b * 27 + (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1)];
+        if (t < 0) continue;
+        const int tx = cx - 4 * dx + 1, ty = cy - 4 * dy + 1, tz = cz - 4 * dz + 1;
+        const float2 v = psi_tiles[(size_t)t * TILE_N + tx + TILE_W * ty + TILE_W * TILE_W * tz];
+        m += v.x; pm += v.y;
+    }
+    node_psi[(size_t)b * 64 + lane] = pm * inv_exact(m);
+}
+__global__ __launch_bounds__(BLK_THREADS) void k_g2p_psi(ParticleArrays P, GridArrays G, const float* __restrict__ node_psi, const Ctl* __restrict__ ctl, StepParams S) {
+    if (ctl->abort_flag[S.parity]) return;
+    __shared__ float vp[TILE_N];
+    const int tid = threadIdx.x;
+    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int b = org.w, pfirst = rng.x, pcount = rng.y;
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) {
+        const int tx = n & 7, ty = (n >> 3) & 7, tz = n >> 6;
+        const int dx = tx == 0 ? -1 : (tx <= 4 ? 0 : 1), dy = ty == 0 ? -1 : (ty <= 4 ? 0 : 1), dz = tz == 0 ? -1 : (tz <= 4 ? 0 : 1);
+        const int cx = tx - 1 - 4 * dx, cy = ty - 1 - 4 * dy, cz = tz - 1 - 4 * dz;
+        const int nb = G.blk_nbr[b * 27 + (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1)];
+        vp[n] = nb >= 0 ? node_psi[(size_t)nb * 64 + cx + 4 * cy + 16 * cz] : 0.f;
+    }
+    __syncthreads();
+    const float h = S.h;
+    for (int li = tid; li < pcount; li += BLK_THREADS) {
+        const int i = pfirst + li;
+        const float4 fr = P.frac[i];
+        if (fr.x == 0.f) continue;
+        const float4 q0 = P.q[0][i];
+        const uint32_t flags = reinterpret_cast<const uint32_t*>(&P.k[i])[3];
+        if (flags & FLAG_INVALID) continue;
+        const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
+        if (!(phase > 0.f)) continue;
+        const float px[3] = {q0.x, q0.y, q0.z};
+        const int orgv[3] = {org.x, org.y, org.z};
+        float wgt[3][3];
+        int lc[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float r = roundf(px[a] / h);
+            const float d0 = (r - 1.0f) * h - px[a];
+            eval_all(-d0 / h, wgt[a]);
+            lc[a] = (int)r - 1 - orgv[a] + 1;
+        }
+        const int base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
+        float g = 0.f;
+#pragma unroll
+        for (int sz = 0; sz < 3; ++sz)
+#pragma unroll
+            for (int sy = 0; sy < 3; ++sy)
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) g += (wgt[0][sx] * wgt[1][sy] * wgt[2][sz]) * vp[base + sx + TILE_W * sy + TILE_W * TILE_W * sz];
+        if (fr.x * h * g > fr.y) {   // crack_energy > crack_threshold: phase = 0 from now on
+            reinterpret_cast<float*>(&P.aux[i])[0] = 0.f;
+            reinterpret_cast<uint32_t*>(&P.k[i])[3] = flags | FLAG_PHASE_NOT_ONE;
+        }
+    }
+}
 // ----------------------------------------------------------------------------------- dt estimate
 // timestep_estimator.rs:10-51: min over particles of the velocity bound and the model bound.
 __global__ __launch_bounds__(BLK_THREADS) void k_estimate_dt(ParticleArrays P, const DevModel* __restrict__ models, Ctl* ctl, int n, float h, uint32_t* dt_partial) {
@@ -1955,6 +2061,7 @@ __global__ void k_permute(ParticleArrays src, ParticleArrays dst, const uint32_t
     dst.k[i] = src.k[s];
     dst.kinvel[i] = src.kinvel[s];
     dst.aux[i] = src.aux[s];
+    if (src.frac) dst.frac[i] = src.frac[s];
 }
 
 // 27 candidate node blocks around every particle block
@@ -2140,6 +2247,17 @@ __global__ void k_read_ids(ParticleArrays P, uint32_t* out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = particle_id(P, i);
 }
+// ParticleFracture in caller order <-> the device stream (what = 0: upload, 1: read back, 2: defaults for [first, first + n))
+__global__ void k_fracture(ParticleArrays P, float2* host_order, int first, int n, long long id_base, int what) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int i = first + j;
+    if (what == 2) { P.frac[i] = make_float4(0.f, 3.402823466e+38f, 0.f, 0.f); return; }
+    const size_t o = out_slot(P, i, id_base);
+    if (what == 0) { const float2 v = host_order[o]; P.frac[i] = make_float4(v.x, v.y, 0.f, 0.f); }
+    else { const float4 v = P.frac[i]; host_order[o] = make_float2(v.x, v.y); }
+}
+
 
 // ------------------------------------------------------------------------------ slabs (multi-GPU)
 // a rank that owns no particle block still has to take part in the step counting / abort chain
@@ -2147,8 +2265,8 @@ __global__ void k_bump_steps(Ctl* ctl, int parity) {
     if (ctl->abort_flag[parity]) ctl->abort_flag[(parity + 1) & 1] = 1u;
     else atomicAdd(&ctl->steps_done, 1u);
 }
-// Migration record: the ten float4 of one particle (160 B).
-constexpr int MIG_F4 = 10;
+// Migration record: the eleven float4 of one particle (176 B; the last is ParticleFracture or its default).
+constexpr int MIG_F4 = 11;
 __global__ void k_pack_particles(ParticleArrays P, int first, int count, float4* out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
@@ -2157,6 +2275,7 @@ __global__ void k_pack_particles(ParticleArrays P, int first, int count, float4*
 #pragma unroll
     for (int a = 0; a < 6; ++a) o[a] = P.q[a][i];
     o[6] = P.d[i]; o[7] = P.k[i]; o[8] = P.kinvel[i]; o[9] = P.aux[i];
+    o[10] = P.frac ? P.frac[i] : make_float4(0.f, 3.402823466e+38f, 0.f, 0.f);
     reinterpret_cast<uint32_t*>(&P.k[i])[3] |= FLAG_REMOVED;
 }
 __global__ void k_unpack_particles(ParticleArrays P, int first, int count, const float4* in) {
@@ -2167,6 +2286,7 @@ __global__ void k_unpack_particles(ParticleArrays P, int first, int count, const
 #pragma unroll
     for (int a = 0; a < 6; ++a) P.q[a][i] = o[a];
     P.d[i] = o[6]; P.k[i] = o[7]; P.kinvel[i] = o[8]; P.aux[i] = o[9];
+    if (P.frac) P.frac[i] = o[10];
 }
 // first index of every tail class in the sorted key array: out[k] = first i with class(i) >= k,
 // classes 0..3 = EMIG_LO, EMIG_HI, INVALID, REMOVED (out[] preset to n)

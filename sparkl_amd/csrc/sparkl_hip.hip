@@ -67,19 +67,22 @@ struct DevBuf {
 };
 
 struct ParticleStore {
-    DevBuf<float4> q[6], d, k, kinvel, aux;
+    DevBuf<float4> q[6], d, k, kinvel, aux, frac;
+    bool has_frac = false;   // ParticleFracture uploaded (sparkl_hip_particles_set_fracture): an eleventh stream travels with the particles
     int reserve(size_t n, bool keep = false, hipStream_t st = nullptr) {
         for (auto& b : q) CHK(b.reserve(n, keep, st));
         CHK(d.reserve(n, keep, st)); CHK(k.reserve(n, keep, st)); CHK(kinvel.reserve(n, keep, st)); CHK(aux.reserve(n, keep, st));
+        if (has_frac) CHK(frac.reserve(n, keep, st));
         return SPARKL_OK;
     }
     ParticleArrays arrays() const {
         ParticleArrays a;
         for (int i = 0; i < 6; ++i) a.q[i] = q[i].p;
         a.d = d.p; a.k = k.p; a.kinvel = kinvel.p; a.aux = aux.p;
+        a.frac = has_frac ? frac.p : nullptr;
         return a;
     }
-    void release() { for (auto& b : q) b.release(); d.release(); k.release(); kinvel.release(); aux.release(); }
+    void release() { for (auto& b : q) b.release(); d.release(); k.release(); kinvel.release(); aux.release(); frac.release(); }
 };
 
 struct EventPair { hipEvent_t a, b; int kind; };
@@ -157,6 +160,8 @@ struct SparklPipeline {
     std::vector<void*> d_mesh_bufs;         // triangle / grid arrays of the uploaded meshes
     int num_trimeshes = 0;
     DevBuf<uint32_t> dt_partial;            // per-workgroup dt-bound minima (adaptive stepping)
+    DevBuf<float2> psi_tiles;               // DamageModel::ModifiedEigenerosion: per-tile (psi_mass, psi_momentum) partials
+    DevBuf<float> node_psi;                 // ... and psi_momentum / psi_mass per node
     DevBuf<float> staging;
     float reorder_limit = -1.f, rebin_limit = 0.f;   // sparkl_hip_reorder_policy_set: < 0 = default, 0 = off
     DevBuf<float> rb_staging;               // asynchronous render readback: 8 floats per particle, own copy stream
@@ -282,6 +287,7 @@ static int resort(SparklPipeline* p) {
         CHK(p->keys_a.reserve(n)); CHK(p->keys_b.reserve(n)); CHK(p->idx_a.reserve(n)); CHK(p->idx_b.reserve(n));
         CHK(p->bkeys.reserve(n)); CHK(p->pb_keys.reserve(n)); CHK(p->pb_counts.reserve(n)); CHK(p->pb_first.reserve(n));
         CHK(p->d_scalars.reserve(4));
+        p->alt.has_frac = p->cur.has_frac;
         CHK(p->alt.reserve(p->cur.q[0].cap));
         hipLaunchKernelGGL(k_compute_keys, dim3(grid_for(n, 256)), dim3(256), 0, st, p->cur.arrays(), p->keys_a.p, p->idx_a.p, n, p->h, p->dom, p->slab_axis,
                            p->slab_on ? p->slab_lo : INT32_MIN, p->slab_on ? p->slab_hi : INT32_MAX);
@@ -475,6 +481,20 @@ static int enqueue_fluid_volumes(SparklPipeline* p, const StepParams& S) {
     return SPARKL_OK;
 }
 
+static bool damage_supported(const SparklSolverParams* params) { return params->damage_model == SPARKL_DAMAGE_NONE || params->damage_model == SPARKL_DAMAGE_MODIFIED_EIGENEROSION; }
+// the psi sweep only has something to do when some particle carries a crack_propagation_factor
+static bool psi_sweep_on(const SparklPipeline* p, const SparklSolverParams* params) { return params->damage_model == SPARKL_DAMAGE_MODIFIED_EIGENEROSION && p->cur.has_frac; }
+// DamageModel::ModifiedEigenerosion: psi scatter, node merge, crack test -- between the grid update and G2P (see k_p2g_psi)
+static int enqueue_psi_sweep(SparklPipeline* p, const StepParams& S) {
+    CHK(p->psi_tiles.reserve((size_t)p->num_pblocks * TILE_N));
+    CHK(p->node_psi.reserve((size_t)p->num_blocks * 64));
+    const GridArrays G = grid_arrays(p);
+    hipLaunchKernelGGL(k_p2g_psi, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, p->stream, p->cur.arrays(), G, p->d_ctl, S, p->psi_tiles.p);
+    hipLaunchKernelGGL(k_grid_psi, dim3((p->num_blocks + 3) / 4), dim3(BLK_THREADS), 0, p->stream, G, p->psi_tiles.p, p->node_psi.p, p->d_ctl, S.parity);
+    hipLaunchKernelGGL(k_g2p_psi, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, p->stream, p->cur.arrays(), G, p->node_psi.p, p->d_ctl, S);
+    return SPARKL_OK;
+}
+
 // enqueue P2G -> grid update -> G2P for the current substep index (no host sync)
 static int enqueue_substep(SparklPipeline* p, const SparklSolverParams* sp, const float g[3], float dt, bool want_dt = false) {
     if (p->num_pblocks == 0) { p->substep_index++; return SPARKL_OK; }
@@ -495,6 +515,7 @@ static int enqueue_substep(SparklPipeline* p, const SparklSolverParams* sp, cons
     CHK(clock_begin(p, SPAN_GRID, &t1));
     launch_grid_update(p, G, S, st);
     CHK(clock_end(p, t1));
+    if (psi_sweep_on(p, sp)) CHK(enqueue_psi_sweep(p, S));
     CHK(clock_begin(p, SPAN_G2P, &t2));
     launch_g2p(p, P, G, S, st);
     CHK(clock_end(p, t2));
@@ -526,6 +547,7 @@ static int enqueue_adaptive_substep(SparklPipeline* p, const SparklSolverParams*
     CHK(clock_begin(p, SPAN_GRID, &t1));
     launch_grid_update(p, G, S, st);
     CHK(clock_end(p, t1));
+    if (psi_sweep_on(p, sp)) CHK(enqueue_psi_sweep(p, S));
     if (dt_guess > 0.f) {
         S.dt_next = dt_guess;
         CHK(clock_begin(p, SPAN_FUSED, &t2));
@@ -691,7 +713,7 @@ void sparkl_hip_pipeline_destroy(SparklPipeline* p) {
     p->tiles.release(); p->node_vel.release(); p->node_mom.release(); p->hash_keys.release(); p->hash_vals.release();
     p->keys_a.release(); p->keys_b.release(); p->pb_keys.release(); p->bkeys.release(); p->idx_a.release(); p->idx_b.release();
     p->pb_counts.release(); p->pb_first.release(); p->cand_a.release(); p->cand_b.release(); p->cub_temp.release(); p->d_scalars.release();
-    p->staging.release(); p->node_staging.release(); p->d_count.release(); p->dt_partial.release();
+    p->staging.release(); p->node_staging.release(); p->d_count.release(); p->dt_partial.release(); p->psi_tiles.release(); p->node_psi.release();
     p->halo_list[0].release(); p->halo_list[1].release(); p->halo_in.release(); p->d_tail.release();
     for (int k = 0; k < 2; ++k) { p->x_send[k].release(); p->x_recv[k].release(); p->x_mig_send[k].release(); p->x_mig_recv[k].release(); }
     p->x_dev.release();
@@ -1011,6 +1033,8 @@ static int upload_range(SparklPipeline* p, uint64_t first, uint64_t n, const Spa
                            d_vol, d_phase, d_data, vg ? d_vg : (const float*)nullptr);
         HIPCHK(hipStreamSynchronize(st));   // the staging area is reused by the next chunk (and by the read paths)
     }
+    if (p->cur.has_frac)   // appended particles get ParticleFracture::default() (particle.rs:187-194)
+        hipLaunchKernelGGL(k_fracture, dim3(grid_for(n, 256)), dim3(256), 0, st, p->cur.arrays(), (float2*)nullptr, (int)first, (int)n, -1ll, 2);
     return SPARKL_OK;
 }
 
@@ -1024,6 +1048,7 @@ int sparkl_hip_particles_upload(SparklPipeline* p, uint64_t n, const SparklParti
         if (status[i].model_index >= (1ull << 24)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "model_index too large");
     HIPCHK(hipSetDevice(p->device));
     HIPCHK(hipStreamSynchronize(p->stream));
+    p->cur.has_frac = false;
     CHK(p->cur.reserve(std::max<uint64_t>(n, 1)));
     p->n = n;
     p->max_model_index = 0;
@@ -1115,6 +1140,36 @@ int sparkl_hip_particles_read_sorted_ids(SparklPipeline* p, uint32_t* out, uint6
     return SPARKL_OK;
 }
 
+// ---- ParticleFracture (src_core/dynamics/particle.rs:180-195): optional component, caller order
+int sparkl_hip_particles_set_fracture(SparklPipeline* p, const SparklParticleFracture* fracture, uint64_t n) {
+    if (!p || (n && !fracture)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    if (n != p->n) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "n (%llu) != particle count (%llu)", (unsigned long long)n, (unsigned long long)p->n);
+    if (p->slab_on) return set_error(SPARKL_ERR_UNSUPPORTED, "ParticleFracture on a slab pipeline");
+    HIPCHK(hipSetDevice(p->device));
+    if (n == 0) return SPARKL_OK;
+    static_assert(sizeof(SparklParticleFracture) == 8, "");
+    HIPCHK(hipStreamSynchronize(p->stream));
+    p->cur.has_frac = true;
+    CHK(p->cur.frac.reserve(p->cur.q[0].cap));
+    CHK(p->staging.reserve(n * 2));
+    HIPCHK(hipMemcpyAsync(p->staging.p, fracture, n * sizeof(SparklParticleFracture), hipMemcpyHostToDevice, p->stream));
+    hipLaunchKernelGGL(k_fracture, dim3(grid_for(n, 256)), dim3(256), 0, p->stream, p->cur.arrays(), (float2*)p->staging.p, 0, (int)n, (long long)p->id_offset, 0);
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return SPARKL_OK;
+}
+int sparkl_hip_particles_read_fracture(SparklPipeline* p, SparklParticleFracture* out, uint64_t n) {
+    READ_PROLOGUE
+    if (!p->cur.has_frac) {   // never uploaded: every particle holds the default
+        for (uint64_t i = 0; i < n; ++i) { out[i].crack_propagation_factor = 0.f; out[i].crack_threshold = std::numeric_limits<float>::max(); }
+        return SPARKL_OK;
+    }
+    CHK(p->staging.reserve(n * 2));
+    hipLaunchKernelGGL(k_fracture, dim3(grid_for(n, 256)), dim3(256), 0, p->stream, p->cur.arrays(), (float2*)p->staging.p, 0, (int)n, read_base(p), 1);
+    HIPCHK(hipMemcpyAsync(out, p->staging.p, n * sizeof(SparklParticleFracture), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return SPARKL_OK;
+}
+
 // ---- asynchronous render readback (testbed_plugin.rs:533-588)
 int sparkl_hip_host_alloc(void** out, uint64_t bytes) {
     if (!out) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
@@ -1202,8 +1257,9 @@ int sparkl_hip_particles_truncate(SparklPipeline* p, uint64_t new_len) {
 // DamageModel::{CdMpm, Eigenerosion, ModifiedEigenerosion} (mls_solver.rs:68-83) are not built: refuse instead of silently
 // stepping with DamageModel::None.
 static int unsupported_damage_model(const SparklSolverParams* params) {
-    return set_error(SPARKL_ERR_UNSUPPORTED, "damage_model %d is not implemented (only SPARKL_DAMAGE_NONE)", (int)params->damage_model);
+    return set_error(SPARKL_ERR_UNSUPPORTED, "damage_model %d is not implemented (SPARKL_DAMAGE_NONE and SPARKL_DAMAGE_MODIFIED_EIGENEROSION are)", (int)params->damage_model);
 }
+
 static int ensure_ready(SparklPipeline* p) {
     HIPCHK(hipSetDevice(p->device));
     CHK(validate_models(p));
@@ -1215,7 +1271,7 @@ int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* pa
     if (!p || !params || !gravity) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
     if (p->slab_on && (p->slab_lo != INT32_MIN || p->slab_hi != INT32_MAX))
         return set_error(SPARKL_ERR_INVALID_ARGUMENT, "a slab with finite cuts must be stepped through substep_begin/halo_*/substep_finish");
-    if (params->damage_model != SPARKL_DAMAGE_NONE) return unsupported_damage_model(params);
+    if (!damage_supported(params)) return unsupported_damage_model(params);
     if (p->n == 0 || nsubsteps == 0) return SPARKL_OK;
     CHK(ensure_ready(p));
     CHK(read_ctl(p));
@@ -1224,8 +1280,8 @@ int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* pa
     // fixed dt: G2P of substep s and P2G of substep s+1 run as one kernel (see k_g2p2g); a batch pays one standalone
     // P2G + G2P, so fused batches are longer.  After a re-bin request the rest of a batch is no-op launches (~3 us each).
     const bool fluid_sweep = params->force_fluids_volume_recomputation && p->any_fluid;
-    const bool fuse = p->fuse_fixed_dt && !fluid_sweep;
-    const bool fuse_fluid = p->fuse_fixed_dt && fluid_sweep && !p->rare_models;
+    const bool fuse = p->fuse_fixed_dt && !fluid_sweep && !psi_sweep_on(p, params);
+    const bool fuse_fluid = p->fuse_fixed_dt && fluid_sweep && !p->rare_models && !psi_sweep_on(p, params);
     const uint32_t CHUNK = fuse ? 128 : 32;
     p->mass_tiles_ready = false;   // only trusted from one batch of this call to the next
     int guard = 0;
@@ -1256,7 +1312,7 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
     if (timings) memset(timings, 0, sizeof(*timings));
     if (p->slab_on && (p->slab_lo != INT32_MIN || p->slab_hi != INT32_MAX))
         return set_error(SPARKL_ERR_UNSUPPORTED, "adaptive step on a slab with finite cuts: the dt bound is per rank; drive fixed-length substeps through substep_begin/finish");
-    if (params->damage_model != SPARKL_DAMAGE_NONE) return unsupported_damage_model(params);
+    if (!damage_supported(params)) return unsupported_damage_model(params);
     // mls_solver.rs:25-28
     if (p->n == 0 || params->dt == 0.0f) { if (simulated_time) *simulated_time = params->dt; return SPARKL_OK; }
     CHK(ensure_ready(p));
@@ -1280,7 +1336,7 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
     // scatter for dt'; if the next substep then asks for another step length the tiles are simply scattered again.
     // The substep sequence is the reference's in every case.
     CHK(p->dt_partial.reserve(std::max<size_t>(grid_for(p->n, BLK_THREADS), (size_t)std::max(p->num_pblocks, 1))));
-    const bool may_fuse = p->fuse_fixed_dt && !(params->force_fluids_volume_recomputation && p->any_fluid) && !params->stop_after_one_substep;
+    const bool may_fuse = p->fuse_fixed_dt && !(params->force_fluids_volume_recomputation && p->any_fluid) && !params->stop_after_one_substep && !psi_sweep_on(p, params);
     bool spec_tiles = false;
     uint32_t spec_dt_bits = 0;
     // mls_solver.rs:46-48: with force_fluids_volume_recomputation the fluid volumes are recomputed after the sort and BEFORE
@@ -1440,7 +1496,7 @@ int sparkl_hip_substep_status(SparklPipeline* p, uint32_t* steps_done, uint32_t*
 int sparkl_hip_substep_begin(SparklPipeline* p, const SparklSolverParams* params, const float gravity[3], float dt) {
     if (!p || !params || !gravity) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
     if (p->in_substep) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "substep_begin called twice");
-    if (params->damage_model != SPARKL_DAMAGE_NONE) return unsupported_damage_model(params);
+    if (params->damage_model != SPARKL_DAMAGE_NONE) return unsupported_damage_model(params);   // slabs: the psi planes do not cross cuts
     if (params->force_fluids_volume_recomputation && p->any_fluid && p->slab_on && (p->slab_lo != INT32_MIN || p->slab_hi != INT32_MAX))
         return set_error(SPARKL_ERR_UNSUPPORTED, "fluid volume recomputation across slab cuts is not implemented");
     HIPCHK(hipSetDevice(p->device));

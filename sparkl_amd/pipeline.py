@@ -167,6 +167,15 @@ class MpmPipeline:
     def read_data(self):
         return self._read(self.L.sparkl_hip_particles_read_data, abi.DATA_DTYPE)
 
+    def set_fracture(self, fracture):
+        """`ParticleFracture` of the resident particles (caller order): crack_propagation_factor, crack_threshold.  Only read under
+        DamageModel::ModifiedEigenerosion (grid_to_particle.rs:65-77)."""
+        fracture = np.ascontiguousarray(fracture, dtype=abi.FRACTURE_DTYPE)
+        check(self.L.sparkl_hip_particles_set_fracture(self.h, abi.ptr(fracture, abi.FRACTURE_DTYPE), C.c_uint64(len(fracture))))
+
+    def read_fracture(self):
+        return self._read(self.L.sparkl_hip_particles_read_fracture, abi.FRACTURE_DTYPE)
+
     def read_velocity_gradients(self):
         return self._read(self.L.sparkl_hip_particles_read_velocity_gradients, abi.VELGRAD_DTYPE)
 

@@ -184,12 +184,13 @@ def test_step_in_a_spreading_sparse_scene_regrows_its_buffers(Pipeline):
 
 
 def test_damage_models_are_refused(Pipeline):
-    """DamageModel::{CdMpm, Eigenerosion, ModifiedEigenerosion} are not built: stepping must say so, not run DamageModel::None."""
+    """DamageModel::{CdMpm, Eigenerosion} are not built: stepping must say so, not run DamageModel::None.  ModifiedEigenerosion is
+    (test_modified_eigenerosion_parity)."""
     from sparkl_amd._lib import SparklHipError
     sc = scenes.elastic_cube(6)
     with Pipeline(sc.cell_width) as p:
         p.load_scene(sc)
-        for dm in (abi.DAMAGE_CDMPM, abi.DAMAGE_EIGENEROSION, abi.DAMAGE_MODIFIED_EIGENEROSION):
+        for dm in (abi.DAMAGE_CDMPM, abi.DAMAGE_EIGENEROSION):
             sc.params.damage_model = dm
             with pytest.raises(SparklHipError) as e:
                 p.substeps(sc.params, sc.gravity, 1e-4, 1)
@@ -197,8 +198,50 @@ def test_damage_models_are_refused(Pipeline):
             with pytest.raises(SparklHipError) as e:
                 p.step(sc.params, sc.gravity)
             assert e.value.code == 2
-        sc.params.damage_model = abi.DAMAGE_NONE
-        p.substeps(sc.params, sc.gravity, 1e-4, 1)
+        for dm in (abi.DAMAGE_MODIFIED_EIGENEROSION, abi.DAMAGE_NONE):
+            sc.params.damage_model = dm
+            p.substeps(sc.params, sc.gravity, 1e-4, 1)
+
+
+def test_modified_eigenerosion_parity(Pipeline):
+    """DamageModel::ModifiedEigenerosion (particle_to_grid.rs:62-86, grid_to_particle.rs:57-77): psi_mass / psi_momentum node
+    transfer and the crack test, with ParticleFracture uploaded.  A block torn by an expanding velocity field; the thresholds are
+    set from an undamaged oracle run so that the crack front passes through the block during the 100 substeps."""
+    from sparkl_amd.models import CorotatedLinearElasticity
+    sc = scenes.block_on_floor(16, CorotatedLinearElasticity(1.0e6, 0.3), expand=6.0, v0=(0.0, 0.0, 0.0), gravity=(0.0, 0.0, 0.0), name="eigenerosion")
+    dt, n = sc.fixed_dt, len(sc.particles)
+    probe = _oracle(sc)
+    for _ in range(60):
+        probe.substep_fixed(sc.params, sc.gravity, dt)
+    psi60 = probe.get_particles().phase["psi_pos"]
+    probe.close()
+    frac = np.zeros(n, dtype=abi.FRACTURE_DTYPE)
+    frac["crack_propagation_factor"] = 1.0
+    frac["crack_propagation_factor"][::7] = 0.0                       # some particles do not take part (psi_mass = 0)
+    frac["crack_threshold"] = np.float32(sc.cell_width * np.percentile(psi60, 70))
+    sc.params.damage_model = abi.DAMAGE_MODIFIED_EIGENEROSION
+    o32, o64 = _oracle(sc), _oracle(sc, f64=True)
+    fr2 = np.stack([frac["crack_propagation_factor"], frac["crack_threshold"]], 1)
+    o32.set_fracture(fr2)
+    o64.set_fracture(fr2)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.set_fracture(frac)
+        for _ in range(100):
+            o32.substep_fixed(sc.params, sc.gravity, dt)
+            o64.substep_fixed(sc.params, sc.gravity, dt)
+        p.substeps(sc.params, sc.gravity, dt, 100)
+        got, r32, r64 = p.read_particles(), o32.get_particles(), o64.get_particles()
+        back = p.read_fracture()
+    np.testing.assert_array_equal(back, frac)                         # the component travels with the particles through re-bins
+    cracked = int((r32.phase["phase"] == 0.0).sum())
+    mismatch = int((got.phase["phase"] != r32.phase["phase"]).sum())
+    rep, bad = parity_verdict(got, r32, r64, sc.cell_width)
+    _report("modified_eigenerosion", {**rep, "cracked_in_oracle": cracked, "phase_mismatch": mismatch, "n": n})
+    assert n // 20 < cracked < n - n // 20, "the crack front must pass through part of the block"
+    assert (r32.phase["phase"][::7] == 1.0).all(), "particles without a crack_propagation_factor never crack"
+    assert mismatch <= max(2, cracked // 100), (mismatch, cracked)   # a threshold decision: particles sitting on it may flip
+    assert not bad, (bad, rep)
 
 
 @pytest.mark.parametrize("below_is_solid", [False, True])

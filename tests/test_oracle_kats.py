@@ -456,3 +456,25 @@ def test_step_driver_substep_rule():
     assert dts[:5] == pytest.approx([2.806e-3] * 5, rel=1e-3) and dts.sum() == pytest.approx(1 / 60, rel=1e-5)
     p = abi.SolverParameters(stop_after_one_substep=1)
     assert o.step(p, sc.gravity) == pytest.approx(dts[0], rel=1e-3)
+
+
+def test_modified_eigenerosion_threshold_kat():
+    """grid_to_particle.rs:57-77: with the same psi_pos = c on every particle the node ratio psi_momentum / psi_mass is c at every
+    node that received anything, the gather (partition of unity) returns c, and crack_energy = factor * h * c: a threshold just
+    below cracks every particle, one just above none."""
+    from oracle import Oracle
+    from sparkl_amd import abi, scenes
+    sc = scenes.elastic_cube(6)
+    sc.particles.velocity["vector"][:] = 0
+    c, h = 3.0, sc.cell_width
+    sc.particles.phase["psi_pos"][:] = c
+    sc.params.damage_model = abi.DAMAGE_MODIFIED_EIGENEROSION
+    n = len(sc.particles)
+    for factor, thr, want in ((2.0, 2.0 * h * c * 0.999, 0.0), (2.0, 2.0 * h * c * 1.001, 1.0), (0.0, 0.0, 1.0)):
+        o = Oracle(sc.cell_width, f64=True)
+        o.load_scene(sc)
+        o.set_fracture(np.tile(np.float32([factor, thr]), (n, 1)))
+        o.substep_fixed(sc.params, sc.gravity, 1.0e-5)
+        ph = o.get_particles().phase["phase"]
+        o.close()
+        assert (ph == want).all(), (factor, thr, np.unique(ph))
