@@ -93,9 +93,13 @@ SPK_DEV float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 // 1e-6 keeps them <= 5e-7 at every scale for 1 (undeformed) to ~3.5 (strained) sweeps.  The rotation tangent itself is
 // NOT a convergence measure (the first version used it and spun ~5 sweeps on undeformed particles).
 // (a rotation with two v_rsq_f32 and no v_rcp/v_sqrt was also tried: not faster, and 6x worse parity on the sand case)
+typedef float spk_f2 __attribute__((ext_vector_type(2)));
 SPK_DEV bool jacobi_pair(float* wp, float* wq, float* vp, float* vq) {
-    const float alpha = wp[0] * wp[0] + wp[1] * wp[1] + wp[2] * wp[2];
-    const float beta = wq[0] * wq[0] + wq[1] * wq[1] + wq[2] * wq[2];
+    // dot products two lanes at a time: (alpha, beta) = sum_i (wp_i^2, wq_i^2) as packed FMAs
+    spk_f2 ab2 = spk_f2{wp[0], wq[0]} * spk_f2{wp[0], wq[0]};
+    ab2 += spk_f2{wp[1], wq[1]} * spk_f2{wp[1], wq[1]};
+    ab2 += spk_f2{wp[2], wq[2]} * spk_f2{wp[2], wq[2]};
+    const float alpha = ab2.x, beta = ab2.y;
     const float gamma = wp[0] * wq[0] + wp[1] * wq[1] + wp[2] * wq[2];
     const float g2 = gamma * gamma, ab = alpha * beta;
     float c = 1.f, s = 0.f;
@@ -105,14 +109,15 @@ SPK_DEV bool jacobi_pair(float* wp, float* wq, float* vp, float* vq) {
         c = fast_rsq(1.f + t * t);
         s = c * t;
     }
+    // the rotation acts on (w, v) pairs: v_pk_mul / v_pk_fma retire the w and the v component together
+    const spk_f2 cc = {c, c}, ss = {s, s};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const float a = wp[i], b = wq[i];
-        wp[i] = c * a - s * b;
-        wq[i] = s * a + c * b;
-        const float va = vp[i], vb = vq[i];
-        vp[i] = c * va - s * vb;
-        vq[i] = s * va + c * vb;
+        const spk_f2 a = {wp[i], vp[i]}, b = {wq[i], vq[i]};
+        const spk_f2 np = cc * a - ss * b;
+        const spk_f2 nq = ss * a + cc * b;
+        wp[i] = np.x; vp[i] = np.y;
+        wq[i] = nq.x; vq[i] = nq.y;
     }
     return g2 > 1.0e-12f * ab;
 }

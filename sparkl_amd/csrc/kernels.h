@@ -159,13 +159,14 @@ SPK_DEV int xcd_remap(int bid, int n) {
     return (bid & 7) * per + (bid >> 3);
 }
 
-// round(x / h) as the reference computes it (sp_grid.rs:217), but through one multiply: the quotient is
-// only re-done with the exact division when x * (1/h) lands within a few ulp of a .5 tie.
+// round(x / h) as the reference computes it (sp_grid.rs:217: f32::round, half away from zero), but through one multiply and
+// v_rndne: the quotient is only re-done with the exact division when x * (1/h) lands within a few ulp of a .5 tie (away from
+// ties, round-to-nearest-even of the product and round-half-away of the exact quotient are the same integer).
 SPK_DEV float round_cell(float x, float h, float inv_h) {
     const float t = x * inv_h;
-    const float fr = t - floorf(t);
-    if (fabsf(fr - 0.5f) < 1.0e-6f * fmaxf(fabsf(t), 1.f)) return roundf(x / h);
-    return roundf(t);
+    const float r = rintf(t);
+    if (fabsf(t - r) > 0.5f - 1.0e-6f * fmaxf(fabsf(t), 1.f)) return roundf(x / h);
+    return r;
 }
 
 // DPP row shifts inside a 16-lane row: lane i reads lane i + N (zero beyond the row end).
@@ -229,14 +230,14 @@ struct Scatter {
 // `T` (fused kernel only): the corotated stress the Drucker-Prager return map of this very thread formed from the decomposition
 // of F it held (corotated_kirchhoff_from_svd) -- a rank-3 update instead of a polar iteration.
 SPK_DEV Scatter p2g_prepare(const DevModel& mo, uint32_t flags, const float px[3], const float v[3], const M3& C, const M3& F, float mass, float vol0, float eh,
-                            float phase, float fluid_jp, const int4& org, float h, float inv_h, float inv_d, float dt, const SymStress* T = nullptr) {
+                            float phase, float fluid_jp, const int4& org, float h, float inv_h, float inv_d, float dt, const SymStress* T = nullptr, const float* rcell = nullptr) {
     Scatter sc;
     float d0[3];
     int lc[3];
     const int orgv[3] = {org.x, org.y, org.z};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float r = round_cell(px[a], h, inv_h);
+        const float r = rcell ? rcell[a] : round_cell(px[a], h, inv_h);
         d0[a] = (r - 1.0f) * h - px[a];
         sc.fx[a] = -d0[a] * inv_h;
         lc[a] = (int)r - 1 - orgv[a] + 1;  // tile coordinate of the associated cell, in [0, 5]
@@ -1006,6 +1007,24 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
 
 // ------------------------------------------------------------------------------------------- G2P
 // Stage the 8^3 node values (vx, vy, vz, mass) of the tile into LDS from the 27 neighbour blocks.
+// The same tile as two arrays, (vx, vy) and vz: the gather then reads a node with ds_read_b64 + ds_read_b32 (2 + 2 LDS cycles per
+// wave) instead of the ds_read_b96 (8 cycles) a float4 tile whose w is unused compiles to, and the tile shrinks from 8 to 6 KB.
+struct VelTile {
+    float2 xy[TILE_N];
+    float z[TILE_N];
+};
+SPK_DEV void load_vel_tile(VelTile& vt, const GridArrays& G, int b, int tid) {
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) {
+        const int tx = n & 7, ty = (n >> 3) & 7, tz = n >> 6;
+        const int dx = tx == 0 ? -1 : (tx <= 4 ? 0 : 1), dy = ty == 0 ? -1 : (ty <= 4 ? 0 : 1), dz = tz == 0 ? -1 : (tz <= 4 ? 0 : 1);
+        const int cx = tx - 1 - 4 * dx, cy = ty - 1 - 4 * dy, cz = tz - 1 - 4 * dz;
+        const int nb = G.blk_nbr[b * 27 + (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1)];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nb >= 0) v = G.node_vel[(size_t)nb * 64 + cx + 4 * cy + 16 * cz];
+        vt.xy[n] = make_float2(v.x, v.y);
+        vt.z[n] = v.z;
+    }
+}
 SPK_DEV void load_vel_tile(float4* vt, const GridArrays& G, int b, int tid) {
     for (int n = tid; n < TILE_N; n += BLK_THREADS) {
         const int tx = n & 7, ty = (n >> 3) & 7, tz = n >> 6;
@@ -1112,6 +1131,7 @@ struct Advected {
     float alpha;
     bool newly_failed;   // flags word must be stored
     bool in_tile;        // the NEW position still scatters inside the home block's tile (and inside the domain)
+    float rnew[3];       // round(new position / h): computed once for the margin check, reused by the fused scatter
     SymStress T;         // corotated stress of the final F, formed by the Drucker-Prager return map (fused kernel: scattered next substep)
 };
 
@@ -1119,7 +1139,7 @@ struct Advected {
 // model of the set needs it, so the elastic / Drucker-Prager kernels keep their register budget (inlining that code,
 // or calling it out of line, cost the hot kernel 35 %).
 template <bool RARE, bool WANT_STRESS = false>
-SPK_DEV Advected g2p_update(const GridArrays& G, const float4* vt, const DevModel& mo, uint32_t flags, const float4& q0, const float4& q1, const float4& q2, const float4& dd,
+SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevModel& mo, uint32_t flags, const float4& q0, const float4& q1, const float4& q2, const float4& dd,
                             const float4& kk, const float4* kinvel_i, const float4* aux_i, float phase, const int4& org, const StepParams& S, float inv_h,
                             unsigned* num_invalid) {
     Advected o;
@@ -1147,8 +1167,9 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const float4* vt, const DevMode
         float Rz[3] = {0.f, 0.f, 0.f}, Rzx[3] = {0.f, 0.f, 0.f}, Rzy[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int sy = 0; sy < 3; ++sy) {
-            const float4* row = vt + base + TILE_W * sy + TILE_W * TILE_W * sz;
-            const float4 c0 = row[0], c1 = row[1], c2 = row[2];
+            const int row = base + TILE_W * sy + TILE_W * TILE_W * sz;
+            const float2 a0 = vt.xy[row], a1 = vt.xy[row + 1], a2 = vt.xy[row + 2];
+            const float4 c0 = make_float4(a0.x, a0.y, vt.z[row], 0.f), c1 = make_float4(a1.x, a1.y, vt.z[row + 1], 0.f), c2 = make_float4(a2.x, a2.y, vt.z[row + 2], 0.f);
             const float wy = wgt[1][sy];
             const float a1x = wx1 * c1.x, a1y = wx1 * c1.y, a1z = wx1 * c1.z;
             const float R[3] = {wx0 * c0.x + a1x + wx2 * c2.x, wx0 * c0.y + a1y + wx2 * c2.y, wx0 * c0.z + a1z + wx2 * c2.z};
@@ -1245,6 +1266,7 @@ mo, phase, eh, F, Jp, q, lvg, sv, sv_valid, o.T);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float r = round_cell(px[a], h, inv_h);
+        o.rnew[a] = r;
         const bool ok = (r >= 1.0f) && (r < (float)(S.dom - 4));   // 0 <= assoc, assoc + 5 < dom
         if (!ok) invalid = true;
         else {
@@ -1286,7 +1308,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
         if (blockIdx.x == 0 && tid == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
         return;
     }
-    __shared__ float4 vt[TILE_N];
+    __shared__ VelTile vt;
     const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int b = org.w, pfirst = rng.x, pcount = rng.y;
@@ -1346,33 +1368,24 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
 template <int REDUCE_STEPS, bool RARE, bool LDS_MODELS = true>
 __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
     const int tid = threadIdx.x;
-    if (ctl->abort_flag[S.parity]) {
-        if (blockIdx.x == 0 && tid == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
-        return;
-    }
-    __shared__ float4 vt[TILE_N];
+    __shared__ VelTile vt;
     __shared__ double tile[4][ACC_N];
     __shared__ int s_heads;
     __shared__ int s_runs[BLK_THREADS / 64][64];   // run list of each wave (run-task scatter)
     __shared__ float s_A[BLK_THREADS / 64][9][64]; // affine part of the scatter descriptors, per wave
     __shared__ DevModel s_models[LDS_MODELS ? MAX_LDS_MODELS : 1];
-    if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
 #ifdef SPK_EXP_LDS_PAD   // occupancy experiment: fewer resident workgroups per CU
     __shared__ float lds_pad[SPK_EXP_LDS_PAD / 4];
     if (S.h < 0.f) lds_pad[tid] = 1.f;
     if (S.h < -1.f) tile[0][0] = lds_pad[tid + 1];
 #endif
-    if (tid == 0) s_heads = 0;
-    // this launch scatters for substep s + 1: its heads go to [(parity + 1) & 1], the previous scatter's are at [parity]
-    if (blockIdx.x == 0 && tid == 0) disorder_policy(ctl, S.parity, S.parity);
     const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int b = org.w, pfirst = rng.x, pcount = rng.y;
     const int niter = (pcount + BLK_THREADS - 1) / BLK_THREADS;
-    // Software pipeline: the position stream (needed first: weights -> gather) and the constants (the flags decide whether the
-    // lane works at all) are carried in registers one batch ahead; F and the plastic scalars are requested at the top of their
-    // own batch and first used after the gather (~700 cycles later).  Carrying all five float4 ahead costs 12 more VGPRs than
-    // the 128 of 4 waves per SIMD leave.
+    // Software pipeline: the five float4 of the next batch are in flight while this batch computes.  The first batch is requested
+    // before anything else that touches memory (abort flag, model table, velocity tile): every vector load the wave waits for
+    // also waits for all older ones, so whatever is issued first pays the HBM latency for the rest.
 #if !defined(SPK_EXP_PF2) && !defined(SPK_EXP_PF3) && !defined(SPK_EXP_NO_PREFETCH)
     float4 n0, n1, n2, nd, nk;
     {
@@ -1388,7 +1401,17 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
 #elif defined(SPK_EXP_PF2)
     float4 n0 = P.q[0][pfirst + min(tid, pcount - 1)], nk = P.k[pfirst + min(tid, pcount - 1)];
 #endif
+    if (ctl->abort_flag[S.parity]) {   // sticky abort: keep every later substep a no-op until the host re-bins
+        if (blockIdx.x == 0 && tid == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
+        return;
+    }
+    if (tid == 0) s_heads = 0;
+    // this launch scatters for substep s + 1: its heads go to [(parity + 1) & 1], the previous scatter's are at [parity]
+    if (blockIdx.x == 0 && tid == 0) disorder_policy(ctl, S.parity, S.parity);
     for (int n = tid; n < ACC_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
+    // the particle loads above are already in flight: the L2 round trips of the model table and the velocity tile overlap
+    // with their HBM latency instead of preceding it
+    if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
     load_vel_tile(vt, G, b, tid);
     if (blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
     __syncthreads();
@@ -1435,7 +1458,7 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
                 dt_nan |= bnd != bnd;
                 dt_bound = fminf(dt_bound, bnd);
             }
-            if (live) { sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.F, kk.x, kk.y, o.eh, o.phase, o.Jp, org, h, inv_h, S.inv_d, S.dt_next, &o.T); shell_used |= sc.shell != 0; }
+            if (live) { sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.F, kk.x, kk.y, o.eh, o.phase, o.Jp, org, h, inv_h, S.inv_d, S.dt_next, &o.T, o.rnew); shell_used |= sc.shell != 0; }
         }
         // (a hybrid -- run tasks for regular waves, DPP for ragged ones -- was measured: the two paths in one kernel spill, +15 %)
         if (REDUCE_STEPS < 0) wave_heads += p2g_scatter_runs(tile, sc, live, tid, s_runs[tid >> 6], s_A[tid >> 6]);
@@ -1706,7 +1729,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
         if (blockIdx.x == 0 && tid == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
         return;
     }
-    __shared__ float4 vt[TILE_N];
+    __shared__ VelTile vt;
     __shared__ double mtile[TILE_N];
     __shared__ DevModel s_models[LDS_MODELS ? MAX_LDS_MODELS : 1];
     const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
