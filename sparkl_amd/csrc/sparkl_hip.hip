@@ -291,13 +291,16 @@ static int resort(SparklPipeline* p) {
         CHK(p->alt.reserve(p->cur.q[0].cap));
         hipLaunchKernelGGL(k_compute_keys, dim3(grid_for(n, 256)), dim3(256), 0, st, p->cur.arrays(), p->keys_a.p, p->idx_a.p, n, p->h, p->dom, p->slab_axis,
                            p->slab_on ? p->slab_lo : INT32_MIN, p->slab_on ? p->slab_hi : INT32_MAX);
-        // key bits: 3 * (block bits + 1 for the -1 bias) + 6 cell bits; invalid keys are all ones => sort all 64 if any
-        int end_bit = 64;
+        // key bits actually in use: Morton code of the block coordinate biased by +1 (3 x block_bits) + 6 cell bits; the tail
+        // classes (emigrants, out of domain, removed) are all-ones words, so ONE more bit keeps them behind every valid key and
+        // their two low bits order them among themselves.  dom = 256 (the default 2^30-byte grid): 28 bits = 4 radix passes
+        // instead of the 5 that the worst case (37 bits) needs.
+        int block_bits = 1;
+        while ((1 << block_bits) < p->dom / 4 + 2) ++block_bits;
+        const int end_bit = std::min(37, 3 * block_bits + 6 + 1);
         size_t tb = 0;
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, p->keys_a.p, p->keys_b.p, p->idx_a.p, p->idx_b.p, n, 0, end_bit, st));
         CHK(cub_reserve(p, tb));
-        // valid keys use <= 36 bits; KEY_INVALID has every bit set, so sorting bits [0,37) keeps them last
-        end_bit = 37;
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(p->cub_temp.p, tb, p->keys_a.p, p->keys_b.p, p->idx_a.p, p->idx_b.p, n, 0, end_bit, st));
         hipLaunchKernelGGL(k_permute, dim3(grid_for(n, 256)), dim3(256), 0, st, p->cur.arrays(), p->alt.arrays(), p->idx_b.p, n);
         std::swap(p->cur, p->alt);
@@ -323,11 +326,8 @@ static int resort(SparklPipeline* p) {
         HIPCHK(hipStreamSynchronize(st));
         // tail[k] = first index with class >= k; a missing class keeps the bound of the next one
         for (int k = 2; k >= 0; --k) tail[k] = std::min(tail[k], tail[k + 1]);
-        uint64_t last_key = 0;
-        if (h_runs > 0) {
-            HIPCHK(hipMemcpy(&last_key, p->pb_keys.p + (h_runs - 1), sizeof(uint64_t), hipMemcpyDeviceToHost));
-            if (last_key == (KEY_INVALID >> 6)) --h_runs;  // every tail class shares this block key: not a block
-        }
+        // every tail class shares one block key (all ones >> 6): if any such record exists, the last run is theirs, not a block
+        if (h_runs > 0 && tail[0] < n) --h_runs;
         p->emig_first[0] = tail[0]; p->n_emig[0] = tail[1] - tail[0];
         p->emig_first[1] = tail[1]; p->n_emig[1] = tail[2] - tail[1];
         p->n = (uint64_t)tail[3];   // particles already handed to a neighbour slab are dropped here
