@@ -1290,6 +1290,7 @@ int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* pa
         if (fuse) CHK(enqueue_fused_batch(p, params, gravity, dt, batch));
         else if (fuse_fluid) CHK(enqueue_fluid_batch(p, params, gravity, dt, batch));
         else for (uint32_t i = 0; i < batch; ++i) CHK(enqueue_substep(p, params, gravity, dt));
+        HIPCHK(hipGetLastError());   // a launch of this batch that failed (bad configuration, out of resources) surfaces here, not as a stalled re-bin loop
         CHK(read_ctl(p));
         if (p->clock_on) CHK(clock_collect(p));
         if (getenv("SPARKL_HIP_DEBUG"))
@@ -1388,6 +1389,7 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
         p->spec_prev_bound_bits = bound_bits;
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dt_bits, (int)init_bits, 1, p->stream));
         CHK(enqueue_adaptive_substep(p, params, gravity, dt, reuse, dt_guess));
+        HIPCHK(hipGetLastError());
         spec_tiles = dt_guess > 0.f && p->num_pblocks > 0;
         memcpy(&spec_dt_bits, &dt_guess, 4);
         have_bound = p->num_pblocks > 0;
@@ -1913,6 +1915,7 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
                 for (int side = 0; side < 2; ++side)
                     if (members[i]->x_nrecv[side]) CHK(sparkl_hip_halo_merge(members[i], side, members[i]->x_recv[side].p, members[i]->x_nrecv[side]));
             for (int i = 0; i < G.n; ++i) CHK(substep_finish_impl(members[i], j + 1 < batch));
+            HIPCHK(hipGetLastError());
         }
         // one host read per batch; the flag is global, so every member ran the same substeps
         long long need = 0;
