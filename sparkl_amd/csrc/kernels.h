@@ -1459,6 +1459,16 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
                 dt_bound = fminf(dt_bound, bnd);
             }
             if (live) { sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.F, kk.x, kk.y, o.eh, o.phase, o.Jp, org, h, inv_h, S.inv_d, S.dt_next, &o.T, o.rnew); shell_used |= sc.shell != 0; }
+#ifdef SPK_EXP_DUMMY_VALU   // sensitivity probe: N extra dependent-free VALU instructions per particle batch
+            {
+                float d0 = o.px[0], d1 = o.px[1], d2 = o.px[2], d3 = o.vel[0];
+#pragma unroll
+                for (int k = 0; k < SPK_EXP_DUMMY_VALU / 4; ++k) {
+                    asm volatile("v_fmac_f32 %0, %0, %1\n v_fmac_f32 %1, %1, %2\n v_fmac_f32 %2, %2, %3\n v_fmac_f32 %3, %3, %0" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+                }
+                if (d0 + d1 + d2 + d3 == 123.456f) sc.val_m += 1.f;
+            }
+#endif
         }
         // (a hybrid -- run tasks for regular waves, DPP for ragged ones -- was measured: the two paths in one kernel spill, +15 %)
         if (REDUCE_STEPS < 0) wave_heads += p2g_scatter_runs(tile, sc, live, tid, s_runs[tid >> 6], s_A[tid >> 6]);
