@@ -229,6 +229,7 @@ def main(args):
     comm_mode = os.environ.get("SPARKL_BENCH_COMM", "rccl" if backend == "nccl" else "torch")
     if world > 1:
         import torch.distributed as dist
+        default_pg_is_cpu = comm_mode == "rccl" or backend != "nccl"   # gloo carries the bootstrap / timing reductions then
         if comm_mode == "rccl":
             dist.init_process_group("gloo")
         elif backend == "nccl":
@@ -269,23 +270,46 @@ def main(args):
     pipe.load_scene(sc)
     upload_s = time.time() - t0
     in_library = mode == "slabs" and comm_mode == "rccl"
+    group = None
     if in_library:
-        ids = [MpmPipeline.comm_unique_id() if rank == 0 else None]
+        ok = 1
+        try:
+            ids = [MpmPipeline.comm_unique_id() if rank == 0 else None]
+        except Exception as e:                      # librccl missing or unusable: every rank sees the same library
+            print(f"bench.py: in-library RCCL unavailable ({e}); falling back to torch.distributed", file=sys.stderr)
+            ids, ok = [None], 0
         dist.broadcast_object_list(ids, src=0)
         # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the one JSON line
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            pipe.comm_init(ids[0], rank, world)
-            ranks = pipe.comm_allreduce_sum(1)      # counted over the RCCL communicator that carries the halo
+            if ok and ids[0] is not None:
+                pipe.comm_init(ids[0], rank, world)
+                ranks = pipe.comm_allreduce_sum(1)      # counted over the RCCL communicator that carries the halo
+            else:
+                ok = 0
+        except Exception as e:
+            print(f"bench.py: rank {rank}: sparkl_hip_comm_init failed ({e}); falling back to torch.distributed", file=sys.stderr)
+            ok = 0
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
-        assert ranks == dist.get_world_size() == world, (ranks, dist.get_world_size(), world)
-    elif mode == "slabs":
-        stepper = SlabStepper(HipSlabBackend(pipe, torch.device("cuda", device_id)), rank, world, chunk=16)
+        # all ranks use the in-library path or none does
+        agree = torch.tensor([ok], dtype=torch.int64)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if int(agree.item()) == 1:
+            assert ranks == dist.get_world_size() == world, (ranks, dist.get_world_size(), world)
+        else:
+            in_library = False
+            comm_mode = "torch"
+            group = dist.new_group(backend="nccl") if backend == "nccl" else None
+            ones = torch.ones(1, device="cuda" if backend == "nccl" else "cpu", dtype=torch.int64)
+            dist.all_reduce(ones, group=group)
+            ranks = int(ones.item())
+    if mode == "slabs" and not in_library:
+        stepper = SlabStepper(HipSlabBackend(pipe, torch.device("cuda", device_id)), rank, world, group=group, chunk=16)
 
     def run(n):
         if in_library:
@@ -314,7 +338,7 @@ def main(args):
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device="cuda" if (backend == "nccl" and comm_mode != "rccl") else "cpu", dtype=torch.float64)
+        tt = torch.tensor([elapsed], device="cpu" if default_pg_is_cpu else "cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     clock = None if args.no_kernel_clock else pipe.clock_read(reset=True)
