@@ -1386,20 +1386,12 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     // Software pipeline: the five float4 of the next batch are in flight while this batch computes.  The first batch is requested
     // before anything else that touches memory (abort flag, model table, velocity tile): every vector load the wave waits for
     // also waits for all older ones, so whatever is issued first pays the HBM latency for the rest.
-#if !defined(SPK_EXP_PF2) && !defined(SPK_EXP_PF3) && !defined(SPK_EXP_NO_PREFETCH)
+#ifndef SPK_EXP_NO_PREFETCH
     float4 n0, n1, n2, nd, nk;
     {
         const int i0 = pfirst + min(tid, pcount - 1);
         n0 = P.q[0][i0]; n1 = P.q[1][i0]; n2 = P.q[2][i0]; nd = P.d[i0]; nk = P.k[i0];
     }
-#elif defined(SPK_EXP_PF3)
-    float4 n0, n1, n2;
-    {
-        const int i0 = pfirst + min(tid, pcount - 1);
-        n0 = P.q[0][i0]; n1 = P.q[1][i0]; n2 = P.q[2][i0];
-    }
-#elif defined(SPK_EXP_PF2)
-    float4 n0 = P.q[0][pfirst + min(tid, pcount - 1)], nk = P.k[pfirst + min(tid, pcount - 1)];
 #endif
     if (ctl->abort_flag[S.parity]) {   // sticky abort: keep every later substep a no-op until the host re-bins
         if (blockIdx.x == 0 && tid == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
@@ -1424,23 +1416,14 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
         const int li = it * BLK_THREADS + tid;
         const bool active = li < pcount;
         const int i = pfirst + (active ? li : 0);
-#if defined(SPK_EXP_NO_PREFETCH)
+#ifdef SPK_EXP_NO_PREFETCH
         const float4 q0 = P.q[0][i], q1 = P.q[1][i], q2 = P.q[2][i], dd = P.d[i], kk = P.k[i];
-#elif !defined(SPK_EXP_PF2) && !defined(SPK_EXP_PF3)
+#else
         const float4 q0 = n0, q1 = n1, q2 = n2, dd = nd, kk = nk;
         if (it + 1 < niter) {
             const int inx = pfirst + min(li + BLK_THREADS, pcount - 1);
             n0 = P.q[0][inx]; n1 = P.q[1][inx]; n2 = P.q[2][inx]; nd = P.d[inx]; nk = P.k[inx];
         }
-#elif defined(SPK_EXP_PF3)
-        const float4 q0 = n0, q1 = n1, q2 = n2, kk = P.k[i], dd = P.d[i];
-        if (it + 1 < niter) {
-            const int inx = pfirst + min(li + BLK_THREADS, pcount - 1);
-            n0 = P.q[0][inx]; n1 = P.q[1][inx]; n2 = P.q[2][inx];
-        }
-#elif defined(SPK_EXP_PF2)
-        const float4 q0 = n0, kk = nk, q1 = P.q[1][i], q2 = P.q[2][i], dd = P.d[i];
-        if (it + 1 < niter) { const int inx = pfirst + min(li + BLK_THREADS, pcount - 1); n0 = P.q[0][inx]; nk = P.k[inx]; }
 #endif
         const uint32_t flags = __float_as_uint(kk.w);
         bool live = active && !(flags & FLAG_INVALID);
@@ -1459,6 +1442,15 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
                 dt_bound = fminf(dt_bound, bnd);
             }
             if (live) { sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.F, kk.x, kk.y, o.eh, o.phase, o.Jp, org, h, inv_h, S.inv_d, S.dt_next, &o.T, o.rnew); shell_used |= sc.shell != 0; }
+#ifdef SPK_EXP_DUMMY_LDS    // sensitivity probe: N extra LDS reads (ds_read_b32, one wave-wide 256 B access each) per particle batch
+            {
+                volatile float* vp = &s_A[tid >> 6][0][0];
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < SPK_EXP_DUMMY_LDS; ++k) acc += vp[((tid + 7 * k) & 63) + 64 * (k % 9)];
+                if (acc == 123.456f) sc.val_m += 1.f;
+            }
+#endif
 #ifdef SPK_EXP_DUMMY_VALU   // sensitivity probe: N extra dependent-free VALU instructions per particle batch
             {
                 float d0 = o.px[0], d1 = o.px[1], d2 = o.px[2], d3 = o.vel[0];
