@@ -454,6 +454,11 @@ int sparkl_hip_comm_allreduce_sum(SparklPipeline* p, long long* value);     /* h
 int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params,
                               const float gravity[3], float dt, uint32_t nsubsteps);
 uint64_t sparkl_hip_group_rebins(const SparklPipeline* p);                  /* collective re-bins this member has taken part in */
+/* Load re-balancing (on by default): at a collective re-bin the two ranks of a cut compare particle counts and occupied block
+ * planes and move the cut by one block plane towards the fuller side when that still leaves it the fuller one; the particles of
+ * the moved plane migrate like any emigrant.  sparkl_hip_slab_get returns the current range and how often a cut of this member moved. */
+int sparkl_hip_slab_balance(SparklPipeline* p, int enable);
+int sparkl_hip_slab_get(const SparklPipeline* p, SparklSlab* out, uint64_t* cut_moves_or_null);
 /* the hipStream_t the pipeline runs on (to create a second member on the same stream, or to order foreign work against it) */
 void* sparkl_hip_pipeline_stream(const SparklPipeline* p);
 

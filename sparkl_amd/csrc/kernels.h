@@ -2384,6 +2384,15 @@ __global__ __launch_bounds__(BLK_THREADS) void k_halo_merge(const HaloRecord* __
     v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
     halo_in[(size_t)b * 64 + lane] = v;
 }
+// extent of the particle blocks along the slab axis (block plane indices): out[0] = min, out[1] = max (preset to INT_MAX / INT_MIN)
+__global__ void k_plane_range(const int4* __restrict__ pb_info, int npb, int axis, int* out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= npb) return;
+    const int4 o = pb_info[2 * j];
+    const int plane = (axis == 0 ? o.x : (axis == 1 ? o.y : o.z)) >> 2;
+    atomicMin(&out[0], plane);
+    atomicMax(&out[1], plane);
+}
 // compact the nodes with mass != 0 for grid_read_nodes
 __global__ void k_dump_nodes(GridArrays G, SparklGridNode* out, unsigned long long cap, unsigned long long* count) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -124,7 +124,8 @@ struct SparklPipeline {
     uint64_t x_nsend[2] = {0, 0}, x_nrecv[2] = {0, 0};
     DevBuf<long long> x_dev;          // small device staging area for counts / flags
     long long* x_host = nullptr;     // pinned
-    uint64_t group_rebins = 0;
+    uint64_t group_rebins = 0, cut_moves = 0;
+    bool slab_balance = true;        // sparkl_hip_slab_balance
     bool all_plain_fluid = false;   // every model is a fluid without plastic / failure model: the FLUID_ONLY kernels apply
     bool mass_tiles_ready = false;  // k_g2p_mass of the previous substep already scattered the next volume sweep's masses
     DevBuf<DevCuboid> d_cuboids;
@@ -1670,6 +1671,7 @@ struct Group {
     SparklPipeline** m;
     int n;
     bool rccl;    // every member has a communicator
+    bool balance; // move the cuts towards equal particle counts at collective re-bins
     // neighbour of member i on `side` (0 = low, 1 = high): -2 none, -1 remote rank (RCCL), >= 0 local member index
     int nbr(int i, int side) const {
         SparklPipeline* p = m[i];
@@ -1772,8 +1774,52 @@ static int group_exchange(const Group& G, BufPair send, BufPair recv, const uint
     return SPARKL_OK;
 }
 
+// Load re-balancing at a collective re-bin (cuts re-chosen on the particle histogram).  Diffusive and local: the
+// two ranks of a cut see the same two (particle count, occupied block planes) pairs and move the cut by ONE block plane towards
+// the fuller side when that still leaves it the fuller one; the particles of the moved plane then travel as ordinary emigrants.
+static int group_rebalance(const Group& G) {
+    std::vector<std::array<uint64_t, 2>> mine(G.n), theirs_n(G.n), theirs_w(G.n), width(G.n);
+    for (int i = 0; i < G.n; ++i) {
+        SparklPipeline* p = G.m[i];
+        HIPCHK(hipSetDevice(p->device));
+        int range[2] = {INT32_MAX, INT32_MIN};
+        if (p->num_pblocks > 0) {
+            CHK(p->d_scalars.reserve(8));
+            HIPCHK(hipMemcpyAsync(p->d_scalars.p + 4, range, sizeof(range), hipMemcpyHostToDevice, p->stream));
+            hipLaunchKernelGGL(k_plane_range, dim3(grid_for(p->num_pblocks, 256)), dim3(256), 0, p->stream, p->pb_info.p, p->num_pblocks, p->slab_axis, p->d_scalars.p + 4);
+            HIPCHK(hipMemcpyAsync(range, p->d_scalars.p + 4, sizeof(range), hipMemcpyDeviceToHost, p->stream));
+            HIPCHK(hipStreamSynchronize(p->stream));
+        }
+        const uint64_t w = range[1] >= range[0] ? (uint64_t)(range[1] - range[0] + 1) : 0;
+        mine[i] = {p->n, p->n};
+        width[i] = {w, w};
+    }
+    CHK(group_swap_counts(G, (const uint64_t(*)[2])mine.data(), (uint64_t(*)[2])theirs_n.data()));
+    CHK(group_swap_counts(G, (const uint64_t(*)[2])width.data(), (uint64_t(*)[2])theirs_w.data()));
+    for (int i = 0; i < G.n; ++i) {
+        SparklPipeline* p = G.m[i];
+        for (int side = 0; side < 2; ++side) {
+            if (G.nbr(i, side) == -2) continue;
+            // (a, wa) = the low rank of this cut, (b, wb) = the high one: both ranks evaluate the same expression
+            const double a = side == 1 ? (double)p->n : (double)theirs_n[i][side], b = side == 1 ? (double)theirs_n[i][side] : (double)p->n;
+            const double wa = side == 1 ? (double)width[i][0] : (double)theirs_w[i][side], wb = side == 1 ? (double)theirs_w[i][side] : (double)width[i][0];
+            int shift = 0;
+            if (wa > 2.0 && a - b > 2.5 * (a / wa)) shift = -1;        // the low rank hands its top plane up
+            else if (wb > 2.0 && b - a > 2.5 * (b / wb)) shift = +1;   // the high rank hands its bottom plane down
+            if (shift == 0) continue;
+            if (side == 1) p->slab_hi += shift; else p->slab_lo += shift;
+            p->sorted = false;
+            p->cut_moves++;
+        }
+    }
+    return SPARKL_OK;
+}
+
 static int group_rebin(const Group& G) {
     const uint64_t mig_bytes = MIG_F4 * sizeof(float4), halo_bytes = sizeof(HaloRecord);
+    bool binned = true;
+    for (int i = 0; i < G.n; ++i) binned = binned && G.m[i]->group_rebins > 0;
+    if (binned && G.balance) CHK(group_rebalance(G));   // needs the block list of an earlier re-bin
     std::vector<std::array<uint64_t, 2>> n_out(G.n), n_in(G.n), b_out(G.n), b_in(G.n);
     std::vector<long long> total(G.n);
     for (int round = 0; round < 64; ++round) {
@@ -1856,7 +1902,8 @@ int sparkl_hip_comm_allreduce_sum(SparklPipeline* p, long long* value) {
 
 int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params, const float gravity[3], float dt, uint32_t nsubsteps) {
     if (!members || n_members == 0 || !params || !gravity) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
-    Group G{members, (int)n_members, true};
+    Group G{members, (int)n_members, true, true};
+    for (uint32_t i = 0; i < n_members; ++i) if (members[i]) G.balance = G.balance && members[i]->slab_balance;
     for (int i = 0; i < G.n; ++i) {
         if (!members[i] || !members[i]->slab_on) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "member %d is not a slab pipeline (sparkl_hip_slab_set)", i);
         G.rccl = G.rccl && members[i]->comm != nullptr;
@@ -1939,6 +1986,17 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
     return SPARKL_OK;
 }
 uint64_t sparkl_hip_group_rebins(const SparklPipeline* p) { return p ? p->group_rebins : 0; }
+int sparkl_hip_slab_balance(SparklPipeline* p, int enable) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    p->slab_balance = enable != 0;
+    return SPARKL_OK;
+}
+int sparkl_hip_slab_get(const SparklPipeline* p, SparklSlab* out, uint64_t* cut_moves) {
+    if (!p || !out) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    out->axis = p->slab_axis; out->block_lo = p->slab_lo; out->block_hi = p->slab_hi; out->_pad0 = 0; out->id_offset = p->id_offset;
+    if (cut_moves) *cut_moves = p->cut_moves;
+    return SPARKL_OK;
+}
 void* sparkl_hip_pipeline_stream(const SparklPipeline* p) { return p ? (void*)p->stream : nullptr; }
 
 }  // extern "C"

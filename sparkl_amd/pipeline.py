@@ -89,6 +89,16 @@ class MpmPipeline:
         g = (C.c_float * 3)(*[float(x) for x in gravity])
         check(members[0].L.sparkl_hip_group_substeps(arr, C.c_uint32(len(members)), C.byref(params), g, C.c_float(dt), C.c_uint32(n)))
 
+    def slab_balance(self, enable=True):
+        check(self.L.sparkl_hip_slab_balance(self.h, int(bool(enable))))
+
+    def slab_get(self):
+        """(axis, block_lo, block_hi, number of times a cut of this slab was moved by the re-balancing)."""
+        from .slab import SlabC
+        s, moves = SlabC(0, 0, 0, 0, 0), C.c_uint64(0)
+        check(self.L.sparkl_hip_slab_get(self.h, C.byref(s), C.byref(moves)))
+        return int(s.axis), int(s.block_lo), int(s.block_hi), int(moves.value)
+
     def group_rebins(self):
         return int(self.L.sparkl_hip_group_rebins(self.h))
 

@@ -283,3 +283,53 @@ def test_group_substeps_over_rccl_world_of_one():
     ev = np.abs(got.velocity["vector"][inv] - ref.velocity["vector"]).max() / np.abs(ref.velocity["vector"]).max()
     print("rccl world-1 group vs plain pipeline:", ex, ev, "re-bins", rebins)
     assert rebins >= 2 and ex < 2e-5 and ev < 2e-4
+
+
+def test_group_rebalancing_moves_the_cut_and_changes_nothing(tmp_path):
+    """Load re-balancing at collective re-bins: two slabs start 1 : 3 out of balance; the cut must walk towards the middle
+    (block planes migrate as ordinary emigrants) and the union must still equal the un-decomposed pipeline."""
+    from sparkl_amd.pipeline import MpmPipeline
+    from sparkl_amd.slab import INT32_MAX, INT32_MIN
+    sc, dt = _scene("spin")
+    nsteps = 80
+    h = sc.cell_width
+    cell = np.round(sc.particles.position["point"][:, 0] / np.float32(h)).astype(np.int64) - 1
+    blk = cell >> 2
+    cut0 = int(blk.min()) + 1                       # rank 0 owns only the first block plane
+    cuts = [INT32_MIN, cut0, INT32_MAX]
+    gids = [np.nonzero(blk < cut0)[0], np.nonzero(blk >= cut0)[0]]
+    assert 0 < len(gids[0]) < len(gids[1]) // 2
+    id_to_caller = np.concatenate(gids)
+    stream = torch.cuda.Stream()
+    pipes = []
+    for r in range(2):
+        comps = ParticleComponents(0)
+        for k in ParticleComponents.__slots__:
+            setattr(comps, k, np.ascontiguousarray(getattr(sc.particles, k)[gids[r]]))
+        pipe = MpmPipeline(h, device_id=0, domain_log2_bytes=sc.domain_log2_bytes, stream=stream.cuda_stream)
+        pipe.set_slab(0, cuts[r], cuts[r + 1], id_offset=int(sum(len(g) for g in gids[:r])))
+        pipe.set_models(sc.models)
+        pipe.set_colliders(sc.colliders)
+        pipe.upload_particles(comps)
+        pipes.append(pipe)
+    MpmPipeline.group_substeps(pipes, sc.params, sc.gravity, dt, nsteps)
+    slabs = [p.slab_get() for p in pipes]
+    n_after = [len(p) for p in pipes]
+    parts = [(p.read_particles(), id_to_caller[p.read_sorted_particle_ids()]) for p in pipes]
+    for p in pipes:
+        p.close()
+    print("re-balancing: cut", cut0, "->", slabs[0][2], "moves", slabs[0][3], "particles", [len(g) for g in gids], "->", n_after)
+    assert slabs[0][2] == slabs[1][1] and slabs[0][2] > cut0 and slabs[0][3] >= 1, slabs
+    assert abs(n_after[0] - n_after[1]) < abs(len(gids[0]) - len(gids[1])), "the split must be closer to even than it started"
+    caller = np.concatenate([c for _, c in parts])
+    assert np.array_equal(np.sort(caller), np.arange(len(sc.particles)))
+    inv = np.argsort(caller)
+    pos = np.concatenate([c.position["point"] for c, _ in parts])[inv]
+    vel = np.concatenate([c.velocity["vector"] for c, _ in parts])[inv]
+    with MpmPipeline(h, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, dt, nsteps)
+        ref = p.read_particles()
+    ex = np.abs(pos - ref.position["point"]).max() / h
+    ev = np.abs(vel - ref.velocity["vector"]).max() / np.abs(ref.velocity["vector"]).max()
+    assert ex < 2e-5 and ev < 2e-4, (ex, ev)
