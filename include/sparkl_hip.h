@@ -453,6 +453,10 @@ int sparkl_hip_comm_init(SparklPipeline* p, const void* unique_id_128_bytes, int
 int sparkl_hip_comm_allreduce_sum(SparklPipeline* p, long long* value);     /* host-synchronous; no-op without a communicator */
 int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params,
                               const float gravity[3], float dt, uint32_t nsubsteps);
+/* `MpmPipeline::step` across the slabs (adaptive substeps; the dt bound is the MIN over every member and rank, one host read per
+ * substep as in the reference); returns the simulated time (params->dt, or the substep length with stop_after_one_substep) */
+int sparkl_hip_group_step(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params,
+                          const float gravity[3], float* simulated_time, uint32_t* num_substeps_or_null);
 uint64_t sparkl_hip_group_rebins(const SparklPipeline* p);                  /* collective re-bins this member has taken part in */
 /* Load re-balancing (on by default): at a collective re-bin the two ranks of a cut compare particle counts and occupied block
  * planes and move the cut by one block plane towards the fuller side when that still leaves it the fuller one; the particles of

@@ -1985,6 +1985,60 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
     }
     return SPARKL_OK;
 }
+// `MpmPipeline::step` across the slabs: params->dt of simulated time in adaptive substeps whose length follows mls_solver.rs:33-59
+// with the dt bound (timestep_estimator.rs:10-51) taken over ALL members and ranks: per substep every member exports its local
+// bound, the MIN travels through RCCL (f32 bits of a non-negative float order like the float), one host read, then one lockstep
+// substep of that length through the same loop as sparkl_hip_group_substeps.
+int sparkl_hip_group_step(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params, const float gravity[3], float* simulated_time,
+                          uint32_t* num_substeps) {
+    if (!members || n_members == 0 || !params || !gravity) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    if (num_substeps) *num_substeps = 0;
+    if (simulated_time) *simulated_time = params->dt;
+    if (params->dt == 0.0f) return SPARKL_OK;
+    bool rccl = true;
+    for (uint32_t i = 0; i < n_members; ++i) {
+        if (!members[i]) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null member");
+        rccl = rccl && members[i]->comm != nullptr;
+    }
+    const float min_dt = params->dt / (float)params->max_num_substeps;
+    float remaining = params->dt;
+    uint32_t nsub = 0;
+    while (remaining > 0.0f) {
+        // a member that still has to bin its particles does so inside group_substeps(0 substeps are not possible): bin first
+        uint32_t bits = 0x7f7fffffu;
+        for (uint32_t i = 0; i < n_members; ++i) {
+            SparklPipeline* p = members[i];
+            HIPCHK(hipSetDevice(p->device));
+            CHK(x_staging(p));
+            CHK(sparkl_hip_dt_bound_export(p, p->x_dev.p + 16));
+        }
+        if (rccl) {
+            NCCLCHK(g_rccl.GroupStart());
+            for (uint32_t i = 0; i < n_members; ++i) NCCLCHK(g_rccl.AllReduce(members[i]->x_dev.p + 16, members[i]->x_dev.p + 16, 1, ncclUint32, ncclMin, members[i]->comm, members[i]->stream));
+            NCCLCHK(g_rccl.GroupEnd());
+        }
+        for (uint32_t i = 0; i < n_members; ++i) {
+            SparklPipeline* p = members[i];
+            HIPCHK(hipSetDevice(p->device));
+            HIPCHK(hipMemcpyAsync(p->x_host + 16, p->x_dev.p + 16, 4, hipMemcpyDeviceToHost, p->stream));
+            HIPCHK(hipStreamSynchronize(p->stream));
+            uint32_t b;
+            memcpy(&b, p->x_host + 16, 4);
+            bits = std::min(bits, b);
+        }
+        float bound;
+        memcpy(&bound, &bits, 4);
+        if (bound != bound) return set_error(SPARKL_ERR_NAN_TIMESTEP, "NaN timestep bound (the reference panics: timestep_estimator.rs:46)");
+        float dt = std::fmin(std::fmin(remaining, params->max_substep_dt), bound);   // timestep_estimator.rs:25,35,44
+        if (dt < min_dt && remaining > min_dt) dt = min_dt;                          // mls_solver.rs:57-59
+        CHK(sparkl_hip_group_substeps(members, n_members, params, gravity, dt, 1));
+        ++nsub;
+        remaining -= dt;
+        if (params->stop_after_one_substep) { if (simulated_time) *simulated_time = dt; break; }
+    }
+    if (num_substeps) *num_substeps = nsub;
+    return SPARKL_OK;
+}
 uint64_t sparkl_hip_group_rebins(const SparklPipeline* p) { return p ? p->group_rebins : 0; }
 int sparkl_hip_slab_balance(SparklPipeline* p, int enable) {
     if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");

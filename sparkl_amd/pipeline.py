@@ -89,6 +89,15 @@ class MpmPipeline:
         g = (C.c_float * 3)(*[float(x) for x in gravity])
         check(members[0].L.sparkl_hip_group_substeps(arr, C.c_uint32(len(members)), C.byref(params), g, C.c_float(dt), C.c_uint32(n)))
 
+    @staticmethod
+    def group_step(members, params, gravity):
+        """`MpmPipeline::step` across the slab pipelines `members`: returns (simulated time, number of substeps)."""
+        arr = (C.c_void_p * len(members))(*[m.h for m in members])
+        g = (C.c_float * 3)(*[float(x) for x in gravity])
+        sim, nsub = C.c_float(0.0), C.c_uint32(0)
+        check(members[0].L.sparkl_hip_group_step(arr, C.c_uint32(len(members)), C.byref(params), g, C.byref(sim), C.byref(nsub)))
+        return sim.value, int(nsub.value)
+
     def slab_balance(self, enable=True):
         check(self.L.sparkl_hip_slab_balance(self.h, int(bool(enable))))
 
