@@ -63,6 +63,9 @@ struct Ctl {
     float reorder_limit;     // 0 = off
     uint32_t reorder_request;
     uint32_t reorders;
+    // adaptive step, look-ahead: k_dt_reduce found a bound other than the one the already enqueued substeps were planned
+    // with and stopped them through the abort chain (the abort is NOT a re-bin request; the host clears both)
+    uint32_t dt_mismatch;
 };
 
 struct ParticleArrays {
@@ -1076,7 +1079,10 @@ SPK_DEV void dt_block_min_store(uint32_t* dt_partial, float dt_bound, bool dt_na
         dt_partial[blockIdx.x] = m;
     }
 }
-__global__ __launch_bounds__(1024) void k_dt_reduce(const uint32_t* __restrict__ dt_partial, int n, Ctl* ctl) {
+// `expect_bits` != 0: the substeps enqueued behind this launch were planned for that bound; any other value turns them
+// into no-ops (abort chain from `next_parity`) and the host re-plans.  A re-bin request already raised wins: dt_mismatch
+// is only set when this launch is the one that starts the chain.
+__global__ __launch_bounds__(1024) void k_dt_reduce(const uint32_t* __restrict__ dt_partial, int n, Ctl* ctl, uint32_t expect_bits = 0u, int next_parity = 0) {
     __shared__ uint32_t s[16];
     uint32_t m = 0x7f7fffffu;   // f32::MAX
     for (int i = threadIdx.x; i < n; i += 1024) m = min(m, dt_partial[i]);
@@ -1087,6 +1093,10 @@ __global__ __launch_bounds__(1024) void k_dt_reduce(const uint32_t* __restrict__
     if (threadIdx.x == 0) {
         for (int w = 1; w < 16; ++w) m = min(m, s[w]);
         ctl->dt_bits = m;
+        if (expect_bits != 0u && (m != expect_bits || ctl->dt_nan) && !ctl->abort_flag[next_parity]) {
+            ctl->abort_flag[next_parity] = 1u;
+            ctl->dt_mismatch = 1u;
+        }
     }
 }
 

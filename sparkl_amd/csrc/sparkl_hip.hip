@@ -175,6 +175,8 @@ struct SparklPipeline {
     // clock: per-kernel hipEvent spans on every clock_stride-th substep (events cost ~2 % when on every launch)
     uint32_t spec_prev_bound_bits = 0;   // adaptive step: speculative fusion bookkeeping (sparkl_hip_pipeline_step)
     uint64_t spec_hits = 0, spec_misses = 0;
+    bool lookahead = true;               // adaptive step: enqueue the rest of the frame while the bound repeats (SPARKL_HIP_LOOKAHEAD=0: off)
+    uint64_t lookahead_substeps = 0, lookahead_mismatches = 0;
     bool rare_models = false;      // some model needs the kernels that carry snow / Rankine / NACC / failure code
     bool fuse_fixed_dt = true;     // SPARKL_HIP_NO_FUSE=1 in the environment turns the fused schedule off (A/B)
     bool clock_on = false;
@@ -528,7 +530,7 @@ static int enqueue_substep(SparklPipeline* p, const SparklSolverParams* sp, cons
 // One substep of the adaptive loop.  `reuse_tiles`: the previous substep's fused kernel already scattered for exactly this dt.
 // `dt_guess` > 0: run G2P fused with the scatter of the next substep built for that step length (speculation, see
 // sparkl_hip_pipeline_step); otherwise the plain G2P.  Both reduce the next dt bound.
-static int enqueue_adaptive_substep(SparklPipeline* p, const SparklSolverParams* sp, const float g[3], float dt, bool reuse_tiles, float dt_guess) {
+static int enqueue_adaptive_substep(SparklPipeline* p, const SparklSolverParams* sp, const float g[3], float dt, bool reuse_tiles, float dt_guess, uint32_t expect_bound_bits = 0u) {
     if (p->num_pblocks == 0) { p->substep_index++; return SPARKL_OK; }
     hipStream_t st = p->stream;
     StepParams S = make_params(p, sp, g, dt);
@@ -559,7 +561,7 @@ static int enqueue_adaptive_substep(SparklPipeline* p, const SparklSolverParams*
         launch_g2p(p, P, G, S, st);
         CHK(clock_end(p, t2));
     }
-    hipLaunchKernelGGL(k_dt_reduce, dim3(1), dim3(1024), 0, st, p->dt_partial.p, p->num_pblocks, p->d_ctl);
+    hipLaunchKernelGGL(k_dt_reduce, dim3(1), dim3(1024), 0, st, p->dt_partial.p, p->num_pblocks, p->d_ctl, expect_bound_bits, (S.parity + 1) & 1);
     p->clock_on = was_on;
     p->substep_index++;
     return SPARKL_OK;
@@ -682,6 +684,7 @@ int sparkl_hip_pipeline_create(const SparklPipelineDesc* desc, SparklPipeline** 
     if (hipSetDevice(desc->device_id) != hipSuccess) return set_error(SPARKL_ERR_NO_DEVICE, "hipSetDevice(%d) failed", desc->device_id);
     SparklPipeline* p = new SparklPipeline;
     p->fuse_fixed_dt = getenv("SPARKL_HIP_NO_FUSE") == nullptr;
+    p->lookahead = !(getenv("SPARKL_HIP_LOOKAHEAD") && !strcmp(getenv("SPARKL_HIP_LOOKAHEAD"), "0"));
     p->device = desc->device_id;
     p->h = desc->cell_width;
     p->domain_log2 = bits;
@@ -1388,6 +1391,50 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
         float dt_guess = -1.f;
         if (may_fuse && rem_after > 0.0f && bound_bits == p->spec_prev_bound_bits) dt_guess = pick(rem_after);
         p->spec_prev_bound_bits = bound_bits;
+        // Look-ahead.  While the bound repeats, the rest of the frame is known: dt_k = pick(remaining_k) with the same bound.
+        // All of it is enqueued at once; every k_dt_reduce checks the bound it just produced against the planned one and, on
+        // a difference, turns the substeps behind it into no-ops.  One host sync per frame instead of one per substep in the
+        // stiffness-bound regime; the substep sequence stays the reference's (a mismatch re-plans from the exact state the
+        // per-substep loop would have had).
+        if (dt_guess > 0.f && p->lookahead && p->num_pblocks > 0) {
+            std::vector<float> plan;
+            float r = remaining;
+            while (r > 0.0f && plan.size() < 64) { const float d = pick(r); plan.push_back(d); r -= d; }
+            if (plan.size() >= 2) {
+                const uint32_t base_done = p->h_ctl->steps_done;
+                const uint32_t base_index = p->substep_index;
+                for (size_t k = 0; k < plan.size(); ++k) {
+                    const bool last = k + 1 == plan.size();
+                    const float guess_k = !last ? plan[k + 1] : (r > 0.0f ? pick(r) : -1.f);
+                    CHK(enqueue_adaptive_substep(p, params, gravity, plan[k], k == 0 ? reuse : true, guess_k, last ? 0u : bound_bits));
+                }
+                HIPCHK(hipGetLastError());
+                CHK(read_ctl(p));
+                const uint32_t executed = std::min<uint32_t>(p->h_ctl->steps_done - base_done, (uint32_t)plan.size());
+                for (uint32_t k = 0; k < executed; ++k) { remaining -= plan[k]; ++nsub; }
+                p->lookahead_substeps += executed;
+                have_bound = true;
+                if (executed == plan.size()) {
+                    spec_tiles = r > 0.0f;
+                    const float g_last = r > 0.0f ? pick(r) : -1.f;
+                    memcpy(&spec_dt_bits, &g_last, 4);
+                } else {
+                    // stopped early.  The tiles hold the scatter substep executed-1 built for plan[executed].
+                    spec_tiles = executed > 0;
+                    memcpy(&spec_dt_bits, &plan[executed], 4);
+                    p->substep_index = base_index + executed;   // parity continues as if the no-op substeps had not been enqueued
+                    if (p->h_ctl->dt_mismatch) {
+                        p->lookahead_mismatches++;
+                        HIPCHK(hipMemsetAsync(p->d_ctl, 0, 2 * sizeof(uint32_t), p->stream));
+                        HIPCHK(hipMemsetAsync(&p->d_ctl->dt_mismatch, 0, sizeof(uint32_t), p->stream));
+                        p->h_ctl->abort_flag[0] = p->h_ctl->abort_flag[1] = 0;
+                        p->h_ctl->dt_mismatch = 0;
+                    }
+                    // else: a real re-bin request; the loop head re-bins
+                }
+                continue;
+            }
+        }
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dt_bits, (int)init_bits, 1, p->stream));
         CHK(enqueue_adaptive_substep(p, params, gravity, dt, reuse, dt_guess));
         HIPCHK(hipGetLastError());
@@ -1400,6 +1447,9 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
     }
     CHK(read_ctl(p));
     if (p->h_ctl->abort_flag[0] || p->h_ctl->abort_flag[1]) p->sorted = false;  // re-bin lazily at the next call
+    if (getenv("SPARKL_HIP_DEBUG"))
+        fprintf(stderr, "[sparkl_hip] step: %u substeps; fused-scatter hits %llu misses %llu; look-ahead substeps %llu mismatches %llu\n", nsub, (unsigned long long)p->spec_hits,
+                (unsigned long long)p->spec_misses, (unsigned long long)p->lookahead_substeps, (unsigned long long)p->lookahead_mismatches);
     if (timings) {
         HIPCHK(hipEventRecord(e1, p->stream));
         HIPCHK(hipEventSynchronize(e1));
