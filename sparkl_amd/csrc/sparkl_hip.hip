@@ -176,6 +176,7 @@ struct SparklPipeline {
     uint32_t spec_prev_bound_bits = 0;   // adaptive step: speculative fusion bookkeeping (sparkl_hip_pipeline_step)
     uint64_t spec_hits = 0, spec_misses = 0;
     bool lookahead = true;               // adaptive step: enqueue the rest of the frame while the bound repeats (SPARKL_HIP_LOOKAHEAD=0: off)
+    bool lookahead_force = false;        // test hook (SPARKL_HIP_LOOKAHEAD=force): plan ahead even when the bound has not repeated, so the mismatch path runs
     uint64_t lookahead_substeps = 0, lookahead_mismatches = 0;
     bool rare_models = false;      // some model needs the kernels that carry snow / Rankine / NACC / failure code
     bool fuse_fixed_dt = true;     // SPARKL_HIP_NO_FUSE=1 in the environment turns the fused schedule off (A/B)
@@ -685,6 +686,7 @@ int sparkl_hip_pipeline_create(const SparklPipelineDesc* desc, SparklPipeline** 
     SparklPipeline* p = new SparklPipeline;
     p->fuse_fixed_dt = getenv("SPARKL_HIP_NO_FUSE") == nullptr;
     p->lookahead = !(getenv("SPARKL_HIP_LOOKAHEAD") && !strcmp(getenv("SPARKL_HIP_LOOKAHEAD"), "0"));
+    p->lookahead_force = getenv("SPARKL_HIP_LOOKAHEAD") && !strcmp(getenv("SPARKL_HIP_LOOKAHEAD"), "force");
     p->device = desc->device_id;
     p->h = desc->cell_width;
     p->domain_log2 = bits;
@@ -1389,7 +1391,7 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
         if (spec_tiles) { if (reuse) p->spec_hits++; else p->spec_misses++; }
         const float rem_after = remaining - dt;
         float dt_guess = -1.f;
-        if (may_fuse && rem_after > 0.0f && bound_bits == p->spec_prev_bound_bits) dt_guess = pick(rem_after);
+        if (may_fuse && rem_after > 0.0f && (bound_bits == p->spec_prev_bound_bits || p->lookahead_force)) dt_guess = pick(rem_after);
         p->spec_prev_bound_bits = bound_bits;
         // Look-ahead.  While the bound repeats, the rest of the frame is known: dt_k = pick(remaining_k) with the same bound.
         // All of it is enqueued at once; every k_dt_reduce checks the bound it just produced against the planned one and, on
@@ -1469,6 +1471,12 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
     }
     if (simulated_time) *simulated_time = result;
     return rc;
+}
+
+int sparkl_hip_pipeline_step_stats(SparklPipeline* p, uint64_t out[4]) {
+    if (!p || !out) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    out[0] = p->spec_hits; out[1] = p->spec_misses; out[2] = p->lookahead_substeps; out[3] = p->lookahead_mismatches;
+    return SPARKL_OK;
 }
 
 int sparkl_hip_pipeline_clock_enable(SparklPipeline* p, int enable) {

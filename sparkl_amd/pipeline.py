@@ -205,6 +205,12 @@ class MpmPipeline:
         """Limits in excess run heads: 0 = off, < 0 = built-in default (see sparkl_hip_reorder_policy_set)."""
         check(self.L.sparkl_hip_reorder_policy_set(self.h, C.c_float(reorder_limit), C.c_float(rebin_limit)))
 
+    def step_stats(self):
+        """Counters of the adaptive step: fused-scatter hits / misses, look-ahead substeps / mismatches."""
+        out = (C.c_uint64 * 4)()
+        check(self.L.sparkl_hip_pipeline_step_stats(self.h, out))
+        return {"fused_hits": out[0], "fused_misses": out[1], "lookahead_substeps": out[2], "lookahead_mismatches": out[3]}
+
     def reorder_policy_stats(self):
         st = abi.ReorderStatsC()
         check(self.L.sparkl_hip_reorder_policy_stats(self.h, C.byref(st)))

@@ -525,6 +525,38 @@ def test_adaptive_step_matches_oracle(Pipeline):
     assert not bad, (bad, rep)
 
 
+def test_adaptive_lookahead_mismatch_replans_to_the_same_substeps(Pipeline, monkeypatch):
+    """A velocity-bound scene (the dt bound changes every substep) with the look-ahead forced on: every plan is cut short by
+    the device-side bound check, the substeps behind the change run as no-ops and are re-planned.  Same substep lengths as
+    the oracle and the same particles (to roundoff) as the per-substep loop."""
+    sc = scenes.elastic_cube(16)
+    sc.particles.velocity["vector"] *= 40.0
+    sc.params.dt = 1.0 / 240.0
+    runs = {}
+    for mode in ("0", "force"):
+        monkeypatch.setenv("SPARKL_HIP_LOOKAHEAD", mode)
+        o = _oracle(sc)
+        with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+            p.load_scene(sc)
+            nsub = []
+            for frame in range(3):
+                t_ref = o.step(sc.params, sc.gravity)
+                t_got, tim = p.step(sc.params, sc.gravity, timings=True)
+                assert t_got == pytest.approx(t_ref, rel=1e-7)
+                assert tim.num_substeps == len(o.last_dts()), (mode, frame, tim.num_substeps, len(o.last_dts()))
+                nsub.append(tim.num_substeps)
+            runs[mode] = (p.read_particles(), p.step_stats(), nsub, particle_errors(p.read_particles(), o.get_particles(), sc.cell_width))
+    st = runs["force"][1]
+    _report("lookahead_mismatch", {"stats": {k: int(v) for k, v in st.items()}, "substeps": runs["force"][2], **runs["force"][3]})
+    assert runs["0"][1]["lookahead_substeps"] == 0
+    assert st["lookahead_mismatches"] >= 3 and st["lookahead_substeps"] >= 3
+    assert sum(runs["force"][2]) >= 9, "the scene should need several substeps per frame"
+    a, b = runs["0"][0], runs["force"][0]
+    e = particle_errors(b, a, sc.cell_width)   # different kernels for the same arithmetic (k_g2p vs k_g2p2g), f64 tile sums: roundoff only
+    assert e["eps_x"] <= 1e-5 and e["eps_v"] <= 1e-5 and e["failed_mismatch"] == 0, e
+    assert runs["force"][3]["eps_x"] <= TOL and runs["force"][3]["eps_v"] <= TOL
+
+
 def test_rebin_keeps_parity_and_ids(Pipeline):
     """A fast spinning cube crosses block boundaries: the re-bin must trigger and change nothing physically."""
     sc = scenes.elastic_cube(16)
