@@ -1,7 +1,8 @@
 """k_g2p2g per launch at the adaptive step length (1/360 s) but through the fixed-dt batch, next to MpmPipeline::step:
 separates the cost of the regime (larger displacements per substep) from the cost of the adaptive machinery."""
 import sys, time
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sparkl_amd import scenes
 from sparkl_amd.pipeline import MpmPipeline
 sc = scenes.sand_column(200, 250, 200)

@@ -1,7 +1,8 @@
 """Re-bin cost probe: a 10M sand column and a 20M fluid dam given a uniform drift so that re-bins recur; prints per-re-bin ms
 (SparklKernelClock.sort_ms / resorts, steady state: the first re-bin, which allocates, is excluded)."""
 import sys, time
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from sparkl_amd import scenes
 from sparkl_amd.pipeline import MpmPipeline

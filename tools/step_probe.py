@@ -1,6 +1,7 @@
 """ms per adaptive frame (MpmPipeline::step, dt = 1/60) on the 10M sand column and the 20M fluid dam."""
 import sys, time
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sparkl_amd import scenes
 from sparkl_amd.pipeline import MpmPipeline
 which = sys.argv[1] if len(sys.argv) > 1 else "sand"
