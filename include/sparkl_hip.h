@@ -354,13 +354,15 @@ typedef struct {
 } SparklReorderStats;
 int sparkl_hip_reorder_policy_stats(SparklPipeline* p, SparklReorderStats* out);
 
-/* Counters of the adaptive step (sparkl_hip_pipeline_step) since the pipeline was created: out[0] substeps that reused the
+/* Counters of the stepping loops since the pipeline was created.  Adaptive step (sparkl_hip_pipeline_step): out[0] substeps that reused the
  * scatter fused into the previous G2P, out[1] substeps that had to scatter again (the predicted step length was wrong),
  * out[2] substeps executed from a look-ahead plan (the rest of the frame enqueued at once while the dt bound repeats),
- * out[3] plans cut short because the bound changed (the substeps behind the change ran as no-ops and were re-planned).
+ * out[3] plans cut short because the bound changed (the substeps behind the change ran as no-ops and were re-planned),
+ * out[4] (fixed-dt batches, sparkl_hip_pipeline_substeps) times the deferred part of the velocity gradient was rebuilt
+ * because a batch stopped for a re-bin (k_regather_c; SPARKL_HIP_DEFER_C=0 stores it every substep instead).
  * SPARKL_HIP_LOOKAHEAD=0 in the environment at pipeline creation turns the look-ahead off; =force plans ahead even when
  * the bound has not repeated (test hook for the mismatch path). */
-int sparkl_hip_pipeline_step_stats(SparklPipeline* p, uint64_t out[4]);
+int sparkl_hip_pipeline_step_stats(SparklPipeline* p, uint64_t out[5]);
 /* Elapsed GPU time (ms, hipEvents on the pipeline's stream) and launch count of the
  * p2g / grid_update / g2p kernels accumulated since the last reset. */
 typedef struct {

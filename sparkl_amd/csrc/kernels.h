@@ -118,6 +118,10 @@ struct StepParams {
     int want_dt;      // G2P also reduces the next substep's dt bound into ctl->dt_bits (adaptive stepping)
     int num_models;   // entries of the model table (<= MAX_LDS_MODELS: the particle kernels stage it in LDS)
     float dt_next;    // k_g2p2g: the step length the fused scatter (P2G of the NEXT substep) is built for; = dt for fixed-dt batches
+    // k_g2p2g inside a fixed-dt batch: the next fused launch takes v and C from the grid, never from the particle, so C.m[1..8]
+    // (32 of the 112 B the kernel writes per particle) are only stored by the launch that ends the batch.  If the batch is cut
+    // short (re-bin request), k_regather_c rebuilds them from the node velocities of the last substep that ran.
+    int defer_c;
 };
 
 struct DevCuboid {
@@ -1145,25 +1149,23 @@ struct Advected {
     SymStress T;         // corotated stress of the final F, formed by the Drucker-Prager return map (fused kernel: scattered next substep)
 };
 
-// RARE: the instantiation that also carries snow / Rankine / NACC plasticity and the failure model; launched only when a
-// model of the set needs it, so the elastic / Drucker-Prager kernels keep their register budget (inlining that code,
-// or calling it out of line, cost the hot kernel 35 %).
-template <bool RARE, bool WANT_STRESS = false>
-SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevModel& mo, uint32_t flags, const float4& q0, const float4& q1, const float4& q2, const float4& dd,
-                            const float4& kk, const float4* kinvel_i, const float4* aux_i, float phase, const int4& org, const StepParams& S, float inv_h,
-                            unsigned* num_invalid) {
-    Advected o;
-    const float h = S.h, dt = S.dt;
-    float px[3] = {q0.x, q0.y, q0.z};
+// APIC gather of one particle from the staged velocity tile: v = sum w v_n, C = sum (w inv_d) v_n dpt^T
+// (grid_to_particle.rs:47-60).  `px` is the position the weights are evaluated at (the particle BEFORE advection).
+// CLAMP (k_regather_c only): `px` was reconstructed and may round into the cell next to the one the tile covers; the weights
+// are continuous across the cell face, so the covered cell is used.
+template <bool CLAMP = false>
+SPK_DEV void apic_gather(const VelTile& vt, const float px[3], const int4& org, const StepParams& S, float inv_h, float vel[3], M3& C) {
+    const float h = S.h;
     float d0[3], wgt[3][3];
     int lc[3];
     const int orgv[3] = {org.x, org.y, org.z};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float r = round_cell(px[a], h, inv_h);
+        float r = round_cell(px[a], h, inv_h);
+        lc[a] = (int)r - 1 - orgv[a] + 1;
+        if (CLAMP) { lc[a] = min(max(lc[a], 0), 5); r = (float)(lc[a] + orgv[a]); }
         d0[a] = (r - 1.0f) * h - px[a];
         eval_all(-d0[a] * inv_h, wgt[a]);
-        lc[a] = (int)r - 1 - orgv[a] + 1;
     }
     const int base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
     // APIC gather in separable form (grid_to_particle.rs:47-60):
@@ -1200,8 +1202,7 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
             Vz[e] += wzs * Rz[e];
         }
     }
-    float vel[3] = {V0[0], V0[1], V0[2]};
-    M3 C;
+    vel[0] = V0[0]; vel[1] = V0[1]; vel[2] = V0[2];
     const float hid = h * S.inv_d;
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
@@ -1209,6 +1210,22 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
         C.m[3 + e] = (S.inv_d * V0[e]) * d0[1] + hid * Vy[e];
         C.m[6 + e] = (S.inv_d * V0[e]) * d0[2] + hid * Vz[e];
     }
+}
+
+// RARE: the instantiation that also carries snow / Rankine / NACC plasticity and the failure model; launched only when a
+// model of the set needs it, so the elastic / Drucker-Prager kernels keep their register budget (inlining that code,
+// or calling it out of line, cost the hot kernel 35 %).
+template <bool RARE, bool WANT_STRESS = false>
+SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevModel& mo, uint32_t flags, const float4& q0, const float4& q1, const float4& q2, const float4& dd,
+                            const float4& kk, const float4* kinvel_i, const float4* aux_i, float phase, const int4& org, const StepParams& S, float inv_h,
+                            unsigned* num_invalid) {
+    Advected o;
+    const float h = S.h, dt = S.dt;
+    float px[3] = {q0.x, q0.y, q0.z};
+    const int orgv[3] = {org.x, org.y, org.z};
+    float vel[3];
+    M3 C;
+    apic_gather(vt, px, org, S, inv_h, vel, C);
     const float div = C.m[0] + C.m[4] + C.m[8];
     // kinematic override, advection (grid_to_particle.rs:82-86)
     {
@@ -1296,13 +1313,18 @@ mo, phase, eh, F, Jp, q, lvg, sv, sv_valid, o.T);
     o.eh = eh; o.phase = phase;
     return o;
 }
-SPK_DEV void g2p_store(const ParticleArrays& P, int i, const Advected& o) {
+// `defer_c`: q[4], q[5] (C.m[1..8]) are not written; k_regather_c recomputes them if anything but the next fused launch needs
+// them (see StepParams::defer_c)
+SPK_DEV void g2p_store(const ParticleArrays& P, int i, const Advected& o, int defer_c = 0) {
     P.q[0][i] = make_float4(o.px[0], o.px[1], o.px[2], o.F.m[0]);
     P.q[1][i] = make_float4(o.F.m[1], o.F.m[2], o.F.m[3], o.F.m[4]);
     P.q[2][i] = make_float4(o.F.m[5], o.F.m[6], o.F.m[7], o.F.m[8]);
     P.q[3][i] = make_float4(o.vel[0], o.vel[1], o.vel[2], o.C.m[0]);
-    P.q[4][i] = make_float4(o.C.m[1], o.C.m[2], o.C.m[3], o.C.m[4]);
-    P.q[5][i] = make_float4(o.C.m[5], o.C.m[6], o.C.m[7], o.C.m[8]);
+    // a particle that just left the domain is never touched again (k_regather_c included): its last C is stored now
+    if (!defer_c || (o.flags & FLAG_INVALID)) {
+        P.q[4][i] = make_float4(o.C.m[1], o.C.m[2], o.C.m[3], o.C.m[4]);
+        P.q[5][i] = make_float4(o.C.m[5], o.C.m[6], o.C.m[7], o.C.m[8]);
+    }
     P.d[i] = make_float4(o.q, o.lvg, o.Jp, o.psi);
     if (o.newly_failed) reinterpret_cast<uint32_t*>(&P.k[i])[3] = o.flags;
     if (o.store_k) reinterpret_cast<float*>(&P.k[i])[2] = o.eh;
@@ -1443,7 +1465,7 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
             const DevModel& mo = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
             const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
             const Advected o = g2p_update<RARE, true>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
-            g2p_store(P, i, o);
+                        g2p_store(P, i, o, S.defer_c);
             want_sort |= !o.in_tile;
             live = o.in_tile;
             if (S.want_dt) {  // the bound the next substep's estimator would compute from this state
@@ -1484,6 +1506,35 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     }
     if (S.want_dt) {
         dt_block_min_store(G.dt_partial, dt_bound, dt_nan, ctl, tid);
+    }
+}
+
+// Rebuilds C.m[1..8] (q[4], q[5]) after a fixed-dt batch was cut short behind a fused launch that deferred them
+// (StepParams::defer_c).  The node velocities of the last substep that ran are still in place (every later grid update was
+// a no-op), v is stored, so the position the gather was evaluated at is x - v dt (to one rounding of x: C comes back to
+// ~1e-6 relative, v and C.m[0] are the stored bits).  Static and failed particles carry C = 0 (grid_to_particle.rs:104-121).
+__global__ __launch_bounds__(BLK_THREADS) void k_regather_c(ParticleArrays P, GridArrays G, StepParams S) {
+    const int tid = threadIdx.x;
+    __shared__ VelTile vt;
+    const int pb = blockIdx.x;
+    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int b = org.w, pfirst = rng.x, pcount = rng.y;
+    load_vel_tile(vt, G, b, tid);
+    __syncthreads();
+    const float inv_h = 1.0f / S.h;
+    for (int li = tid; li < pcount; li += BLK_THREADS) {
+        const int i = pfirst + li;
+        const float4 q0 = P.q[0][i], q3 = P.q[3][i];
+        const uint32_t flags = __float_as_uint(P.k[i].w);
+        if (flags & FLAG_INVALID) continue;
+        M3 C = m3_zero();
+        if (!(flags & (FLAG_STATIC | FLAG_FAILED))) {
+            const float px[3] = {q0.x - q3.x * S.dt, q0.y - q3.y * S.dt, q0.z - q3.z * S.dt};
+            float vel[3];
+            apic_gather<true>(vt, px, org, S, inv_h, vel, C);
+        }
+        P.q[4][i] = make_float4(C.m[1], C.m[2], C.m[3], C.m[4]);
+        P.q[5][i] = make_float4(C.m[5], C.m[6], C.m[7], C.m[8]);
     }
 }
 

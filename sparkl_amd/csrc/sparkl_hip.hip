@@ -178,6 +178,10 @@ struct SparklPipeline {
     bool lookahead = true;               // adaptive step: enqueue the rest of the frame while the bound repeats (SPARKL_HIP_LOOKAHEAD=0: off)
     bool lookahead_force = false;        // test hook (SPARKL_HIP_LOOKAHEAD=force): plan ahead even when the bound has not repeated, so the mismatch path runs
     uint64_t lookahead_substeps = 0, lookahead_mismatches = 0;
+    bool defer_c = true;           // fused fixed-dt batches skip the store of C.m[1..8] (StepParams::defer_c); SPARKL_HIP_DEFER_C=0: off
+    bool c_stale = false;          // a batch was cut short behind such a launch: k_regather_c runs before the re-bin
+    StepParams c_stale_S{};
+    uint64_t c_regathers = 0;
     bool rare_models = false;      // some model needs the kernels that carry snow / Rankine / NACC / failure code
     bool fuse_fixed_dt = true;     // SPARKL_HIP_NO_FUSE=1 in the environment turns the fused schedule off (A/B)
     bool clock_on = false;
@@ -286,6 +290,12 @@ static int resort(SparklPipeline* p) {
     const int n = (int)p->n;
     size_t tok = 0;
     CHK(clock_begin(p, SPAN_SORT, &tok));
+    if (p->c_stale) {
+        // on the OLD binning: the node velocities and block ranges of the last substep that ran
+        if (p->num_pblocks > 0) hipLaunchKernelGGL(k_regather_c, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, p->cur.arrays(), grid_arrays(p), p->c_stale_S);
+        p->c_stale = false;
+        p->c_regathers++;
+    }
     p->num_blocks = p->num_pblocks = 0;
     if (n > 0) {
         CHK(p->keys_a.reserve(n)); CHK(p->keys_b.reserve(n)); CHK(p->idx_a.reserve(n)); CHK(p->idx_b.reserve(n));
@@ -415,7 +425,7 @@ static StepParams make_params(const SparklPipeline* p, const SparklSolverParams*
     S.h = p->h; S.inv_d = 4.0f / (p->h * p->h); S.dt = dt;
     S.gx = g[0]; S.gy = g[1]; S.gz = g[2];
     S.boundary_handling = sp->boundary_handling; S.dofs = sp->simulation_dofs;
-    S.parity = (int)(p->substep_index & 1u); S.dom = p->dom; S.num_cuboids = p->num_cuboids; S.num_heightfields = p->num_heightfields; S.num_trimeshes = p->num_trimeshes; S.want_dt = 0;
+    S.parity = (int)(p->substep_index & 1u); S.dom = p->dom; S.num_cuboids = p->num_cuboids; S.num_heightfields = p->num_heightfields; S.num_trimeshes = p->num_trimeshes; S.want_dt = 0; S.defer_c = 0;
     S.project_particles = sp->enable_boundary_particle_projection ? 1 : 0;
     S.dt_next = dt;
     S.num_models = (int)p->h_models.size();
@@ -594,8 +604,11 @@ static int enqueue_fused_batch(SparklPipeline* p, const SparklSolverParams* sp, 
         launch_grid_update(p, G, S, st);
         CHK(clock_end(p, tk));
         if (j + 1 < n) {
+            StepParams Sf = S;
+            Sf.defer_c = (p->defer_c && !p->rare_models && !S.project_particles) ? 1 : 0;
+            if (Sf.defer_c) p->c_stale_S = S;   // what k_regather_c needs should the batch stop here
             CHK(clock_begin(p, SPAN_FUSED, &tk));
-            launch_g2p2g(p, P, G, S, st);
+            launch_g2p2g(p, P, G, Sf, st);
             CHK(clock_end(p, tk));
         } else {
             CHK(clock_begin(p, SPAN_G2P, &tk));
@@ -685,6 +698,7 @@ int sparkl_hip_pipeline_create(const SparklPipelineDesc* desc, SparklPipeline** 
     if (hipSetDevice(desc->device_id) != hipSuccess) return set_error(SPARKL_ERR_NO_DEVICE, "hipSetDevice(%d) failed", desc->device_id);
     SparklPipeline* p = new SparklPipeline;
     p->fuse_fixed_dt = getenv("SPARKL_HIP_NO_FUSE") == nullptr;
+    p->defer_c = !(getenv("SPARKL_HIP_DEFER_C") && !strcmp(getenv("SPARKL_HIP_DEFER_C"), "0"));
     p->lookahead = !(getenv("SPARKL_HIP_LOOKAHEAD") && !strcmp(getenv("SPARKL_HIP_LOOKAHEAD"), "0"));
     p->lookahead_force = getenv("SPARKL_HIP_LOOKAHEAD") && !strcmp(getenv("SPARKL_HIP_LOOKAHEAD"), "force");
     p->device = desc->device_id;
@@ -1304,6 +1318,9 @@ int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* pa
                     base_done, p->h_ctl->abort_flag[0], p->h_ctl->abort_flag[1], p->h_ctl->num_invalid, (unsigned long long)p->n, p->num_pblocks, p->num_blocks, p->substep_index & 1u);
         const uint32_t now_done = p->num_pblocks ? (p->h_ctl->steps_done - base_done) : done + batch;
         const bool aborted = now_done < done + batch;
+        // cut short behind a fused launch that deferred C.m[1..8]: the last substep of a batch that runs to its end is a
+        // plain k_g2p, which stores everything
+        if (fuse && aborted && now_done > done && p->defer_c && !p->rare_models && !params->enable_boundary_particle_projection) p->c_stale = true;
         done = now_done;
         if (aborted || p->h_ctl->abort_flag[0] || p->h_ctl->abort_flag[1]) {
             CHK(resort(p));  // a particle left its tile margin: re-bin, then carry on from `done`
@@ -1473,9 +1490,10 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
     return rc;
 }
 
-int sparkl_hip_pipeline_step_stats(SparklPipeline* p, uint64_t out[4]) {
+int sparkl_hip_pipeline_step_stats(SparklPipeline* p, uint64_t out[5]) {
     if (!p || !out) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
     out[0] = p->spec_hits; out[1] = p->spec_misses; out[2] = p->lookahead_substeps; out[3] = p->lookahead_mismatches;
+    out[4] = p->c_regathers;
     return SPARKL_OK;
 }
 

@@ -207,9 +207,9 @@ class MpmPipeline:
 
     def step_stats(self):
         """Counters of the adaptive step: fused-scatter hits / misses, look-ahead substeps / mismatches."""
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 5)()
         check(self.L.sparkl_hip_pipeline_step_stats(self.h, out))
-        return {"fused_hits": out[0], "fused_misses": out[1], "lookahead_substeps": out[2], "lookahead_mismatches": out[3]}
+        return {"fused_hits": out[0], "fused_misses": out[1], "lookahead_substeps": out[2], "lookahead_mismatches": out[3], "c_regathers": out[4]}
 
     def reorder_policy_stats(self):
         st = abi.ReorderStatsC()

@@ -571,11 +571,36 @@ def test_rebin_keeps_parity_and_ids(Pipeline):
         p.substeps(sc.params, sc.gravity, dt, 60)
         k = p.clock_read()
         ids = p.read_sorted_particle_ids()
+        st = p.step_stats()
         e = particle_errors(p.read_particles(), o.get_particles(), sc.cell_width)
-    _report("rebin", {**e, "resorts": int(k.resorts), "substeps": int(k.substeps)})
+    _report("rebin", {**e, "resorts": int(k.resorts), "substeps": int(k.substeps), "c_regathers": int(st["c_regathers"])})
     assert k.resorts >= 2, "expected at least one re-bin beyond the initial one"
+    # every batch cut short by a re-bin request stopped behind a fused launch that had deferred C.m[1..8]: rebuilt each time
+    assert st["c_regathers"] >= 1
     assert sorted(ids.tolist()) == list(range(len(sc.particles)))
-    assert e["eps_x"] <= TOL and e["eps_v"] <= TOL
+    assert e["eps_x"] <= TOL and e["eps_v"] <= TOL and e["eps_C"] <= TOL
+
+
+def test_deferred_velocity_gradient_is_rebuilt_at_a_cut_batch(Pipeline, monkeypatch):
+    """StepParams::defer_c: inside a fixed-dt batch the fused kernel does not store C.m[1..8]; when a re-bin request cuts the
+    batch, k_regather_c rebuilds them from the node velocities of the last substep that ran.  Same particles (C included) as
+    with the store on every substep (SPARKL_HIP_DEFER_C=0), through several re-bins."""
+    sc = scenes.elastic_cube(16)
+    sc.particles.velocity["vector"] *= 40.0
+    sc.gravity = np.array([0.0, -9.81, 0.0], dtype=np.float32)
+    dt = 2.0e-4
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SPARKL_HIP_DEFER_C", mode)
+        with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+            p.load_scene(sc)
+            p.clock_enable(True)
+            p.substeps(sc.params, sc.gravity, dt, 90)
+            got[mode] = (p.read_particles(), p.step_stats()["c_regathers"], int(p.clock_read().resorts))
+    e = particle_errors(got["1"][0], got["0"][0], sc.cell_width)
+    _report("defer_c", {**e, "regathers": int(got["1"][1]), "resorts": got["1"][2]})
+    assert got["0"][1] == 0 and got["1"][1] >= 2 and got["1"][2] >= 3
+    assert e["eps_x"] <= 1e-5 and e["eps_v"] <= 1e-5 and e["eps_C"] <= 1e-4 and e["failed_mismatch"] == 0, e
 
 
 def test_async_readback_snapshots_the_state_at_the_call(Pipeline):
