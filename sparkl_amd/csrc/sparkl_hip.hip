@@ -541,7 +541,8 @@ static int enqueue_substep(SparklPipeline* p, const SparklSolverParams* sp, cons
 // One substep of the adaptive loop.  `reuse_tiles`: the previous substep's fused kernel already scattered for exactly this dt.
 // `dt_guess` > 0: run G2P fused with the scatter of the next substep built for that step length (speculation, see
 // sparkl_hip_pipeline_step); otherwise the plain G2P.  Both reduce the next dt bound.
-static int enqueue_adaptive_substep(SparklPipeline* p, const SparklSolverParams* sp, const float g[3], float dt, bool reuse_tiles, float dt_guess, uint32_t expect_bound_bits = 0u) {
+static int enqueue_adaptive_substep(SparklPipeline* p, const SparklSolverParams* sp, const float g[3], float dt, bool reuse_tiles, float dt_guess, uint32_t expect_bound_bits = 0u,
+                                    bool defer_c = false) {
     if (p->num_pblocks == 0) { p->substep_index++; return SPARKL_OK; }
     hipStream_t st = p->stream;
     StepParams S = make_params(p, sp, g, dt);
@@ -564,6 +565,8 @@ static int enqueue_adaptive_substep(SparklPipeline* p, const SparklSolverParams*
     if (psi_sweep_on(p, sp)) CHK(enqueue_psi_sweep(p, S));
     if (dt_guess > 0.f) {
         S.dt_next = dt_guess;
+        S.defer_c = (defer_c && p->defer_c && !p->rare_models && !S.project_particles) ? 1 : 0;   // look-ahead plans only (the caller rebuilds C if the plan is cut)
+        if (S.defer_c) p->c_stale_S = S;
         CHK(clock_begin(p, SPAN_FUSED, &t2));
         launch_g2p2g(p, P, G, S, st);
         CHK(clock_end(p, t2));
@@ -1425,7 +1428,8 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
                 for (size_t k = 0; k < plan.size(); ++k) {
                     const bool last = k + 1 == plan.size();
                     const float guess_k = !last ? plan[k + 1] : (r > 0.0f ? pick(r) : -1.f);
-                    CHK(enqueue_adaptive_substep(p, params, gravity, plan[k], k == 0 ? reuse : true, guess_k, last ? 0u : bound_bits));
+                    // every launch but the last may leave C.m[1..8] to the launch that ends the plan (StepParams::defer_c)
+                    CHK(enqueue_adaptive_substep(p, params, gravity, plan[k], k == 0 ? reuse : true, guess_k, last ? 0u : bound_bits, !last));
                 }
                 HIPCHK(hipGetLastError());
                 CHK(read_ctl(p));
@@ -1439,6 +1443,14 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
                     memcpy(&spec_dt_bits, &g_last, 4);
                 } else {
                     // stopped early.  The tiles hold the scatter substep executed-1 built for plan[executed].
+                    if (executed > 0 && p->defer_c && !p->rare_models && !params->enable_boundary_particle_projection) {
+                        // ... and the last launch that ran had deferred C.m[1..8]: rebuilt from the node velocities it used
+                        // (every grid update behind it was a no-op), before the next P2G or the re-bin reads them
+                        StepParams Sr = p->c_stale_S;
+                        Sr.dt = plan[executed - 1];
+                        hipLaunchKernelGGL(k_regather_c, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, p->stream, p->cur.arrays(), grid_arrays(p), Sr);
+                        p->c_regathers++;
+                    }
                     spec_tiles = executed > 0;
                     memcpy(&spec_dt_bits, &plan[executed], 4);
                     p->substep_index = base_index + executed;   // parity continues as if the no-op substeps had not been enqueued
@@ -1628,7 +1640,7 @@ int sparkl_hip_halo_merge(SparklPipeline* p, int side, const void* dev_in, uint6
     CHK(clock_end(p, tok));
     return SPARKL_OK;
 }
-static int substep_finish_impl(SparklPipeline* p, bool fuse_next) {
+static int substep_finish_impl(SparklPipeline* p, bool fuse_next, bool defer_c = false) {
     if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
     if (!p->in_substep) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "substep_finish without substep_begin");
     p->in_substep = false;
@@ -1648,8 +1660,13 @@ static int substep_finish_impl(SparklPipeline* p, bool fuse_next) {
     CHK(clock_end(p, t1));
     if (fuse_next && p->fuse_fixed_dt) {
         // G2P of this substep + P2G of the next one (same dt) in one kernel; the next substep_begin is then free
+        // defer_c: only from sparkl_hip_group_substeps, which owns the batch and rebuilds C if it is cut (the public
+        // substep_finish_fused leaves a complete particle state behind)
+        StepParams Sf = p->pending;
+        Sf.defer_c = (defer_c && p->defer_c && !p->rare_models && !Sf.project_particles) ? 1 : 0;
+        if (Sf.defer_c) p->c_stale_S = p->pending;
         CHK(clock_begin(p, SPAN_FUSED, &t2));
-        launch_g2p2g(p, p->cur.arrays(), G, p->pending, st);
+        launch_g2p2g(p, p->cur.arrays(), G, Sf, st);
         CHK(clock_end(p, t2));
         p->tiles_ready = true;
     } else {
@@ -2037,7 +2054,7 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
             for (int i = 0; i < G.n; ++i)
                 for (int side = 0; side < 2; ++side)
                     if (members[i]->x_nrecv[side]) CHK(sparkl_hip_halo_merge(members[i], side, members[i]->x_recv[side].p, members[i]->x_nrecv[side]));
-            for (int i = 0; i < G.n; ++i) CHK(substep_finish_impl(members[i], j + 1 < batch));
+            for (int i = 0; i < G.n; ++i) CHK(substep_finish_impl(members[i], j + 1 < batch, true));
             HIPCHK(hipGetLastError());
         }
         // one host read per batch; the flag is global, so every member ran the same substeps
@@ -2049,6 +2066,9 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
             CHK(read_ctl(members[i]));
             if (members[i]->clock_on) CHK(clock_collect(members[i]));
             const uint32_t r = members[i]->h_ctl->steps_done - base[i];
+            // cut short behind a fused launch that deferred C.m[1..8] (the last substep of a whole batch is a plain k_g2p)
+            if (r > done && r < done + batch && members[i]->fuse_fixed_dt && members[i]->defer_c && !members[i]->rare_models && !params->enable_boundary_particle_projection)
+                members[i]->c_stale = true;
             ran = i == 0 ? r : std::min(ran, r);
             needs[i] = (r < done + batch || members[i]->h_ctl->abort_flag[0] || members[i]->h_ctl->abort_flag[1]) ? 1 : 0;
         }

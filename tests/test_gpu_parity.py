@@ -553,7 +553,9 @@ def test_adaptive_lookahead_mismatch_replans_to_the_same_substeps(Pipeline, monk
     assert sum(runs["force"][2]) >= 9, "the scene should need several substeps per frame"
     a, b = runs["0"][0], runs["force"][0]
     e = particle_errors(b, a, sc.cell_width)   # different kernels for the same arithmetic (k_g2p vs k_g2p2g), f64 tile sums: roundoff only
-    assert e["eps_x"] <= 1e-5 and e["eps_v"] <= 1e-5 and e["failed_mismatch"] == 0, e
+    # eps_C: the cut plans stop behind launches that deferred C.m[1..8]; k_regather_c rebuilt them (7 times here)
+    assert e["eps_x"] <= 1e-5 and e["eps_v"] <= 1e-5 and e["eps_C"] <= 1e-4 and e["failed_mismatch"] == 0, e
+    assert st["c_regathers"] >= 3
     assert runs["force"][3]["eps_x"] <= TOL and runs["force"][3]["eps_v"] <= TOL
 
 

@@ -224,6 +224,7 @@ def test_group_substeps_two_slabs_in_the_library(kind, nsteps):
     MpmPipeline.group_substeps(pipes, sc.params, sc.gravity, dt, nsteps)
     parts = [(p.read_particles(), id_to_caller[p.read_sorted_particle_ids()]) for p in pipes]
     rebins = [p.group_rebins() for p in pipes]
+    regathers = [int(p.step_stats()["c_regathers"]) for p in pipes]
     n_after = [len(p) for p in pipes]
     for p in pipes:
         p.close()
@@ -241,8 +242,12 @@ def test_group_substeps_two_slabs_in_the_library(kind, nsteps):
     vmax = np.abs(ref.velocity["vector"]).max()
     ex = np.abs(got.position["point"] - ref.position["point"]).max() / h
     ev = np.abs(got.velocity["vector"] - ref.velocity["vector"]).max() / vmax
-    print(kind, "group slabs vs single pipeline:", ex, ev, "re-bins", rebins, "particles per slab", [len(g) for g in all_gids], "->", n_after)
-    assert ex < 2e-5 and ev < 2e-4
+    cmax = np.abs(ref.velocity_gradient.view(np.float32)).max()
+    ec = np.abs(got.velocity_gradient.view(np.float32) - ref.velocity_gradient.view(np.float32)).max() / cmax
+    print(kind, "group slabs vs single pipeline:", ex, ev, ec, "re-bins", rebins, "C rebuilt", regathers, "particles per slab", [len(g) for g in all_gids], "->", n_after)
+    assert ex < 2e-5 and ev < 2e-4 and ec < 1e-3
+    # batches cut by a re-bin request stop behind a fused launch that deferred C.m[1..8]: rebuilt before the migration packs it
+    assert all(r >= 1 for r in regathers), regathers
     assert all(r >= 2 for r in rebins) and n_after != [len(g) for g in all_gids], "the scene must migrate particles across the cut"
     if kind == "cube":
         from oracle import Oracle
