@@ -43,6 +43,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--clock-wake-n", type=int, default=4096)
+    ap.add_argument("--clock-wake-ms", type=float, default=250.0, help="untimed fp32 matmuls before the warmup substeps so that the run does not start in the power controller's load-onset clock dip (0 = off)")
     ap.add_argument("--no-copy-peak", action="store_true", help="skip the 1 GiB device-to-device copy that measures the stream peak")
     ap.add_argument("--config", choices=("sand10m", "neo1m", "fluid20m"), default="sand10m")
     ap.add_argument("--particles", type=float, default=None, help="particles per GPU (default: the configuration's own size)")
@@ -326,6 +328,21 @@ def main(args):
         torch.cuda.synchronize()
         pipe.sync()
 
+    if args.clock_wake_ms > 0:
+        # DVFS wake-up, untimed and before the W warmup substeps.  From idle, the first heavy launches make the power
+        # controller drop the shader clock from 2.4 to ~1.7 GHz and walk it back up over ~35 ms (sampled with a one-wave
+        # clock64 / wall_clock64 kernel: tools/debug/clock_probe.py, profiles/r02c_clock_probe.txt) -- exactly where the
+        # driver's `--warmup 5 --steps 20` window (3..15 ms after the first launch) sits.  A GPU that is already busy does not
+        # dip: a few plain fp32 matmuls on the bench stream are enough.  Nothing of the workload is skipped or moved.
+        with torch.cuda.stream(stream):
+            a = torch.randn(args.clock_wake_n, args.clock_wake_n, device="cuda")
+            b = torch.randn(args.clock_wake_n, args.clock_wake_n, device="cuda")
+            t_end = time.perf_counter() + args.clock_wake_ms * 1e-3
+            while time.perf_counter() < t_end:
+                for _ in range(4):
+                    c = a @ b
+                stream.synchronize()
+            del a, b, c
     run(args.warmup)
     # event spans on every launch of a short timed region (the driver's --steps 20), on every 4th substep of a long one
     # (<1 % perturbation)
@@ -411,6 +428,7 @@ def main(args):
             "step_gbs": step_bytes * world / (elapsed / args.steps) / 1e9,
             "step_frac_of_hbm_peak": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
             "setup_s": {"generate": gen_s, "upload_and_pack": upload_s},
+            "clock_wake_ms": args.clock_wake_ms,
         }
         if clock is not None and clock.sampled_substeps > 0:
             out["roofline"], avg_ms = roofline_of(clock, kb, n_particles, args.config)
