@@ -220,6 +220,11 @@ def main(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if world > 1:
+        # a rank that waits forever in a collective (a peer died, a link is down) must not hold the node: dump the stacks
+        # and exit after 15 minutes (a whole 8-rank run takes well under two)
+        import faulthandler
+        faulthandler.dump_traceback_later(900, exit=True)
     # test hook: SPARKL_BENCH_BACKEND=gloo + SPARKL_BENCH_ONE_DEVICE=1 runs the N-rank slab path on a single GPU
     backend = os.environ.get("SPARKL_BENCH_BACKEND", "nccl")
     device_id = 0 if os.environ.get("SPARKL_BENCH_ONE_DEVICE") else local_rank
