@@ -559,6 +559,48 @@ def test_adaptive_lookahead_mismatch_replans_to_the_same_substeps(Pipeline, monk
     assert runs["force"][3]["eps_x"] <= TOL and runs["force"][3]["eps_v"] <= TOL
 
 
+def test_model_table_longer_than_the_lds_copy(Pipeline):
+    """More models than the particle kernels stage in LDS (MAX_LDS_MODELS = 16): the instantiations that read the table from
+    global memory.  The same 16 active models once as a 16-entry table (LDS copy) and once as a 17-entry table (one unused
+    entry: global table): the arithmetic is the same, only the parameter source differs, so the particles must agree to
+    roundoff (they agree bit for bit) -- through a fixed-dt batch (fused kernels) and an adaptive frame (standalone kernels,
+    dt estimator).  Substep count and positions are also checked against the oracle; the velocity distances are reported, not
+    gated: 40 substeps of this 1200-particle stiff column move at 0.1 m/s, where one rounding of F is 6e-4 of the stress (HIP
+    6e-4, f32 oracle 3e-4..6e-4 from the f64 oracle depending on the run; the gated sand cases are in the tests above)."""
+    from sparkl_amd.models import ParticleModel, CorotatedLinearElasticity, DruckerPragerPlasticity
+    from tests.parity import particle_errors as perr
+
+    def build(n_table):
+        sc = scenes.sand_column(12, 10, 10)
+        for k in range(1, n_table):
+            E = 1.0e7 * (1.0 + 0.05 * k)
+            m = ParticleModel.with_plasticity(CorotatedLinearElasticity(E, 0.2), DruckerPragerPlasticity(E, 0.2)) if k % 2 else ParticleModel.new(CorotatedLinearElasticity(E, 0.2))
+            assert sc.models.insert(m) == k
+        sc.particles.status["model_index"] = (np.arange(len(sc.particles)) % 16).astype(sc.particles.status["model_index"].dtype)
+        return sc
+
+    dt = 2.5e-4
+    got = {}
+    for n_table in (16, 17):
+        sc = build(n_table)
+        with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+            p.load_scene(sc)
+            p.substeps(sc.params, sc.gravity, dt, 40)
+            t, tim = p.step(sc.params, sc.gravity, timings=True)
+            got[n_table] = (p.read_particles(), t, tim.num_substeps)
+    e = perr(got[17][0], got[16][0], sc.cell_width)
+    o32, o64 = _oracle(sc), _oracle(sc, f64=True)
+    for o in (o32, o64):
+        for _ in range(40):
+            o.substep_fixed(sc.params, sc.gravity, dt)
+        o.step(sc.params, sc.gravity)
+    assert got[17][2] == got[16][2] == len(o32.last_dts())
+    e_hip, e_floor = perr(got[17][0], o64.get_particles(), sc.cell_width), perr(o32.get_particles(), o64.get_particles(), sc.cell_width)
+    _report("many_models", {"table17_vs_table16": e, "vs_f64": e_hip, "oracle_f32_vs_f64": e_floor})
+    assert e["eps_x"] <= 1e-6 and e["eps_v"] <= 1e-6 and e["eps_C"] <= 1e-6 and e["eps_F"] <= 1e-6 and e["failed_mismatch"] == 0, e
+    assert e_hip["eps_x"] <= max(TOL, e_floor["eps_x"]) and e_hip["failed_mismatch"] == 0, (e_hip, e_floor)
+
+
 def test_rebin_keeps_parity_and_ids(Pipeline):
     """A fast spinning cube crosses block boundaries: the re-bin must trigger and change nothing physically."""
     sc = scenes.elastic_cube(16)
