@@ -206,20 +206,13 @@ SPK_DEV M3 polar_rotation(const M3& F) {
 
 // tau for the corotated model.  phase == 1 (every particle unless a damage model is active) only needs
 // the rotation R: U (S - I) V^T = F - R.
+SPK_DEV M3 corotated_kirchhoff_e(const DevModel& mo, float hardening, const M3& F);
 SPK_DEV M3 corotated_kirchhoff(const DevModel& mo, float phase, float hardening, const M3& F) {
     const float j = m3_det(F);
     const float sph = mo.lambda * hardening * (j - 1.f) * j;
     M3 tau;
     if (phase == 1.f) {
-        const M3 R = polar_rotation(F);
-        M3 m;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) m.m[i] = F.m[i] - R.m[i];
-        tau = m3_mul_bt(m, F);
-        const float k2 = 2.f * mo.mu * hardening;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) tau.m[i] *= k2;
-        tau.m[0] += sph; tau.m[4] += sph; tau.m[8] += sph;
+        return corotated_kirchhoff_e(mo, hardening, F);
     } else {
         const Svd3 d = svd3<SPK_SVD_SWEEPS>(F);
         float gp[3], gn[3];
@@ -345,6 +338,105 @@ SPK_DEV float expm1_small(float x) {
     return __expf(x) - 1.f;
 }
 
+// ------------------------------------------------------------------------------ strain-form arithmetic (E = F - I)
+// Why: the stiff examples sit at elastic strains of ~1e-4 (E = 1e7 sand under its own weight).  A singular value of F
+// computed in f32 carries ~1e-7 of absolute error whatever the algorithm (the one-sided Jacobi above: <= 5e-7), i.e.
+// 1e-3..5e-3 of sigma - 1, and the stress is proportional to sigma - 1: that, not the f32 STORAGE of F, is what separates an
+// f32 MPM step from the f64 one (measured on the CPU restatement: f64 arithmetic with F rounded to f32 after every substep
+// stays within 5e-5 of pure f64 on the sand case; f32 arithmetic is at 4.6e-4).  Everything below works on the small
+// quantities themselves -- E = F - I (exact in f32 for entries of F near 1), S = F^T F - I = E + E^T + E^T E, its
+// eigen-decomposition S = V diag(lam) V^T (sigma^2 - 1 = lam), ln sigma = log1p(lam) / 2 -- so that the strain keeps ~1e-7
+// RELATIVE precision.  U is never formed:  F' = U Sigma' V^T = F V diag(sigma'/sigma) V^T,  F - R = F V diag(1 - 1/sigma) V^T.
+SPK_DEV float log1p_small(float x) {   // ln(1 + x) = 2 atanh(x / (2 + x)); relative error ~1e-7 for |x| < 0.35
+    if (fabsf(x) < 0.35f) {
+        const float z = x * fast_rcp(2.f + x), z2 = z * z;
+        return 2.f * z * (1.f + z2 * (1.f / 3.f + z2 * (1.f / 5.f + z2 * (1.f / 7.f + z2 * (1.f / 9.f)))));
+    }
+    return log1pf(x);
+}
+// det(I + E) - 1 = tr E + (sum of the principal 2x2 minors) + det E
+SPK_DEV float det_minus_one(const M3& E) {
+    const float tr = E.m[0] + E.m[4] + E.m[8];
+    const float c2 = (E.m[0] * E.m[4] - E.m[3] * E.m[1]) + (E.m[0] * E.m[8] - E.m[6] * E.m[2]) + (E.m[4] * E.m[8] - E.m[7] * E.m[5]);
+    return tr + c2 + m3_det(E);
+}
+// S = E + E^T + E^T E as (xx, yy, zz, xy, xz, yz)
+SPK_DEV void strain_metric(const M3& E, float S[6]) {
+    const int ii[6] = {0, 1, 2, 0, 0, 1}, jj[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+        const int a = ii[e], b = jj[e];
+        S[e] = (E.m[a + 3 * b] + E.m[b + 3 * a]) + (E.m[3 * a] * E.m[3 * b] + E.m[3 * a + 1] * E.m[3 * b + 1] + E.m[3 * a + 2] * E.m[3 * b + 2]);
+    }
+}
+#ifndef SPK_EIG_TOL
+#define SPK_EIG_TOL 1.0e-5f
+#endif
+struct Eig3 {
+    M3 v;          // eigenvectors (columns)
+    float lam[3];
+};
+// One Jacobi rotation of the symmetric 3x3 (pp, qq, pq; rp, rq couple the third index) and of the columns vp, vq of V.
+SPK_DEV void jacobi_sym(float& pp, float& qq, float& pq, float& rp, float& rq, float* vp, float* vq, float skip) {
+    const bool rot = fabsf(pq) > skip;
+    if (!__any(rot)) return;              // wave-uniform: the converged tail costs three compares per sweep
+    // branch-free per lane (a lane that does not rotate gets t = 0: c = 1, s = 0): no exec-masked copies of the twelve outputs
+    const float pqs = rot ? pq : 1.f;
+    const float zeta = (qq - pp) * fast_rcp(2.f * pqs);
+    float t = copysignf(1.f, zeta) * fast_rcp(fabsf(zeta) + fast_sqrt(1.f + zeta * zeta));
+    t = rot ? t : 0.f;
+    const float c = fast_rsq(1.f + t * t), sn = c * t;
+    pp -= t * pq; qq += t * pq;
+    pq = rot ? 0.f : pq;
+    const float nrp = c * rp - sn * rq;
+    rq = sn * rp + c * rq;
+    rp = nrp;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float a = vp[i], b = vq[i];
+        vp[i] = c * a - sn * b;
+        vq[i] = sn * a + c * b;
+    }
+}
+// Cyclic Jacobi on S.  Stops after the sweep that leaves every off-diagonal entry of every lane below SPK_EIG_TOL of the
+// largest entry S had (wave-uniform branch; the test comes AFTER the sweep, so a converged matrix is not swept once more):
+// an off-diagonal residue r shifts an eigenvalue by at most r -- r^2 / gap when the eigenvalues are apart -- so the strains
+// are good to 1e-5 of the strain at worst, typically 1e-7 (the convergence is quadratic: 1e-1 -> 1e-3 -> 1e-7 per sweep).
+SPK_DEV Eig3 sym_eig3(const float S[6]) {
+    Eig3 r;
+    r.v = m3_identity();
+    float s00 = S[0], s11 = S[1], s22 = S[2], s01 = S[3], s02 = S[4], s12 = S[5];
+    const float scale = fmaxf(fmaxf(fmaxf(fabsf(s00), fabsf(s11)), fmaxf(fabsf(s22), fabsf(s01))), fmaxf(fabsf(s02), fabsf(s12)));
+    // no squares of the thresholds (they underflow for the strains of a particle that barely left F = I); a strain below
+    // 1e-30 is zero
+    const float tol = fmaxf(SPK_EIG_TOL * scale, 1.0e-30f), skip = 1.0e-3f * tol;
+    bool more = fmaxf(fabsf(s01), fmaxf(fabsf(s02), fabsf(s12))) > tol;
+    for (int sweep = 0; sweep < SPK_SVD_SWEEPS && __any(more); ++sweep) {
+        jacobi_sym(s00, s11, s01, s02, s12, r.v.m + 0, r.v.m + 3, skip);
+        jacobi_sym(s00, s22, s02, s01, s12, r.v.m + 0, r.v.m + 6, skip);
+        jacobi_sym(s11, s22, s12, s01, s02, r.v.m + 3, r.v.m + 6, skip);
+        more = fmaxf(fabsf(s01), fabsf(s02)) > tol;    // s12 was just annihilated
+    }
+    r.lam[0] = s00; r.lam[1] = s11; r.lam[2] = s22;
+    return r;
+}
+// V diag(g) V^T as (xx, yy, zz, xy, xz, yz)
+SPK_DEV void sym_compose(const M3& v, const float g[3], float out[6]) {
+    const int ii[6] = {0, 1, 2, 0, 0, 1}, jj[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+    for (int e = 0; e < 6; ++e) out[e] = g[0] * v.m[ii[e]] * v.m[jj[e]] + g[1] * v.m[3 + ii[e]] * v.m[3 + jj[e]] + g[2] * v.m[6 + ii[e]] * v.m[6 + jj[e]];
+}
+SPK_DEV M3 sym6_to_m3(const float t[6]) { return M3{{t[0], t[3], t[4], t[3], t[1], t[5], t[4], t[5], t[2]}}; }
+// ln sigma_k of F = I + E and the eigenvectors of F^T F
+SPK_DEV Eig3 log_stretch(const M3& E, float eps[3]) {
+    float S[6];
+    strain_metric(E, S);
+    const Eig3 d = sym_eig3(S);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) eps[k] = 0.5f * log1p_small(fmaxf(d.lam[k], -0.99999988f));
+    return d;
+}
+
 // Corotated Kirchhoff stress (phase == 1) of the particle's final F = U diag(sigma') V^T, formed by the return map itself from
 // the decomposition it holds (the fused kernel scatters it one substep later; see corotated_kirchhoff_from_svd).  Symmetric:
 // (xx, yy, zz, xy, xz, yz).
@@ -387,6 +479,104 @@ SPK_DEV SymStress corotated_kirchhoff_from_svd(const DevModel& mo, float hardeni
 // DruckerPragerPlasticity::update_particle.  Updates F, Jp, q, lvg in place and returns the singular
 // values of the (possibly projected) F through sv[] for the pos-energy bookkeeping.
 // `T` (want_stress): the corotated stress of the final F for the fused kernel (eh = elastic hardening), left invalid when the model / phase do not qualify.
+// Corotated Kirchhoff stress (phase == 1) of F = I + E from the eigenvectors of F^T F and eps_k = ln sigma_k:
+//   2 mu (F - R) F^T + lambda (J - 1) J I  =  2 mu F [V diag((sigma - 1)/sigma) V^T] F^T + lambda (J - 1) J I
+// (elasticity_corotated_linear.rs:31-78; R = U V^T, U = F V Sigma^-1).  (sigma - 1)/sigma = -expm1(-eps) and J - 1 =
+// det(I + E) - 1 enter without cancellation.
+SPK_DEV SymStress corotated_tau_e(const DevModel& mo, float hardening, const M3& E, const M3& V, const float eps[3]) {
+    float g[3], m6[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g[k] = -expm1_small(-eps[k]);
+    sym_compose(V, g, m6);
+    const M3 M = sym6_to_m3(m6);
+    M3 A = m3_mul(E, M);                 // A = F M = M + E M
+#pragma unroll
+    for (int e = 0; e < 9; ++e) A.m[e] += M.m[e];
+    const float jm1 = det_minus_one(E);
+    const float sph = mo.lambda * hardening * jm1 * (1.f + jm1);
+    const float k2 = 2.f * mo.mu * hardening;
+    SymStress S;
+    const int ii[6] = {0, 1, 2, 0, 0, 1}, jj[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+        const int a = ii[e], b = jj[e];
+        // (A F^T)_ab = A_ab + sum_k A_ak E_bk
+        S.t[e] = k2 * (A.m[a + 3 * b] + (A.m[a] * E.m[b] + A.m[a + 3] * E.m[b + 3] + A.m[a + 6] * E.m[b + 6]));
+    }
+    S.t[0] += sph; S.t[1] += sph; S.t[2] += sph;
+    S.valid = true;
+    return S;
+}
+
+SPK_DEV M3 corotated_kirchhoff_e(const DevModel& mo, float hardening, const M3& F) {
+    M3 E = F;
+    E.m[0] -= 1.f; E.m[4] -= 1.f; E.m[8] -= 1.f;
+    float eps[3];
+    const Eig3 d = log_stretch(E, eps);
+    return sym_to_m3(corotated_tau_e(mo, hardening, E, d.v, eps));
+}
+
+// DruckerPragerPlasticity::update_particle (plasticity_drucker_prager.rs:68-104) on E = F_trial - I, in place.
+// `sm1` returns sigma' - 1 of the mapped F (for the positive-energy bookkeeping), T the corotated stress of the mapped F.
+template <bool WANT_STRESS>
+SPK_DEV void dp_update_e(const DevModel& mo, float phase, float eh, M3& E, float& Jp, float& q, float& lvg, float sm1[3], bool& sv_valid, SymStress& T) {
+    sv_valid = false;
+    T.valid = false;
+    if (mo.only_active_when_failed && phase != 0.f) return;
+    float eps[3];
+    const Eig3 d = log_stretch(E, eps);
+    const float alpha = dp_alpha(mo, q);
+    float strain[3], dev[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) strain[i] = eps[i] + lvg * (1.f / 3.f);
+    const float tr = strain[0] + strain[1] + strain[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dev[i] = strain[i] - tr * (1.f / 3.f);
+    // three outcomes: tensile (sigma' = 1), inside the yield surface (F stays), projection onto the cone; folded into one
+    // straight line (`neps` = ln sigma', `moved`) so that the stress below is formed once per wave, not once per divergent branch
+    float neps[3] = {eps[0], eps[1], eps[2]}, dq = 0.f;
+    bool moved = false;
+    if ((dev[0] == 0.f && dev[1] == 0.f && dev[2] == 0.f) || tr > 0.f) {
+        neps[0] = neps[1] = neps[2] = 0.f;
+        dq = fast_sqrt(strain[0] * strain[0] + strain[1] * strain[1] + strain[2] * strain[2]);
+        moved = true;
+    } else {
+        const float dn = fast_sqrt(dev[0] * dev[0] + dev[1] * dev[1] + dev[2] * dev[2]);
+        const float gamma = dn + mo.p_k * tr * alpha;   // p_k = (3 lambda + 2 mu) / (2 mu), precomputed on the host
+        if (gamma > 0.f) {                              // otherwise inside the yield surface
+            const float gdn = gamma * fast_rcp(dn);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) neps[i] = strain[i] - gdn * dev[i];
+            dq = gamma;
+            moved = true;
+        }
+    }
+    if (moved) {
+        // prev_det = prod sigma = exp(sum eps), new_det = prod sigma' = exp(sum neps)
+        const float so = eps[0] + eps[1] + eps[2], sn = neps[0] + neps[1] + neps[2];
+        const float pm1 = expm1_small(so);
+        float nm1 = expm1_small(sn), lnew = sn;
+        const float diff = nm1 - pm1;
+        if (!(diff > 0.f) && mo.volume_correction != 1.f) { nm1 = pm1 + diff * mo.volume_correction; lnew = log1p_small(nm1); }
+        Jp *= (1.f + pm1) * fast_rcp(1.f + nm1);
+        lvg += so - lnew;
+        q += dq;
+        // F' = F V diag(sigma'/sigma) V^T = F (I + G),  G = V diag(expm1(neps - eps)) V^T  =>  E' = E + G + E G
+        float kap[3], g6[6];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) kap[i] = expm1_small(neps[i] - eps[i]);
+        sym_compose(d.v, kap, g6);
+        const M3 G = sym6_to_m3(g6);
+        const M3 EG = m3_mul(E, G);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) E.m[e] += G.m[e] + EG.m[e];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sm1[i] = expm1_small(neps[i]);
+    sv_valid = true;
+    if (WANT_STRESS && mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR && phase == 1.f) T = corotated_tau_e(mo, eh, E, d.v, neps);
+}
+
 template <bool WANT_STRESS>
 SPK_DEV void dp_update(const DevModel& mo, float phase, float eh, M3& F, float& Jp, float& q, float& lvg, float sv[3], bool& sv_valid, SymStress& T) {
     sv_valid = false;
@@ -561,18 +751,26 @@ SPK_DEV bool maximum_stress_failed(const DevModel& mo, const M3& t) {
 }
 
 // constitutive_model.pos_energy(particle)
-SPK_DEV float model_pos_energy(const DevModel& mo, float phase, float eh, const M3& F, const float sv[3], bool sv_valid) {
+SPK_DEV float model_pos_energy(const DevModel& mo, float phase, float eh, const M3& F, const float sm1[3], bool sv_valid) {
     if (mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR) {
-        const float j = m3_det(F);
+        // elasticity_corotated_linear.rs:105-118 on the small quantities: sigma_k - 1 (`sm1` when the return map already holds
+        // them) and J - 1
+        M3 E = F;
+        E.m[0] -= 1.f; E.m[4] -= 1.f; E.m[8] -= 1.f;
+        const float jm1 = det_minus_one(E);
         float s[3];
-        if (sv_valid) { s[0] = sv[0]; s[1] = sv[1]; s[2] = sv[2]; }
-        else { const Svd3 d = svd3<SPK_SVD_SWEEPS>(F); s[0] = d.s[0]; s[1] = d.s[1]; s[2] = d.s[2]; }
+        if (sv_valid) { s[0] = sm1[0]; s[1] = sm1[1]; s[2] = sm1[2]; }
+        else {
+            float eps[3];
+            (void)log_stretch(E, eps);
+            s[0] = expm1_small(eps[0]); s[1] = expm1_small(eps[1]); s[2] = expm1_small(eps[2]);
+        }
         float nsq = 0.f;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { const float e = fmaxf(s[i] - 1.f, 0.f); nsq += e * e; }
+        for (int i = 0; i < 3; ++i) { const float e = fmaxf(s[i], 0.f); nsq += e * e; }
         const float pos_dev = mo.mu * eh * nsq;
-        const float sph = mo.lambda * eh / 2.f * (j - 1.f) * (j - 1.f);
-        return j < 1.f ? pos_dev : pos_dev + sph;
+        const float sph = mo.lambda * eh / 2.f * jm1 * jm1;
+        return jm1 < 0.f ? pos_dev : pos_dev + sph;
     }
     if (mo.ctag == SPARKL_CONSTITUTIVE_NEO_HOOKEAN) {
         const float pc = nh_phase_coeff(phase);

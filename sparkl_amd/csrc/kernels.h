@@ -1236,13 +1236,18 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
     px[0] += vel[0] * dt; px[1] += vel[1] * dt; px[2] += vel[2] * dt;
     // deformation gradient update (:91-100)
     M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
+    // Drucker-Prager particles carry E = F - I through the update and the return map (device_math.h, "strain-form arithmetic"):
+    // F is only rounded once, when it is stored
+    const bool dp_e = !mo.is_fluid && mo.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER;
+    M3 E = F;
+    E.m[0] -= 1.f; E.m[4] -= 1.f; E.m[8] -= 1.f;
     if (!mo.is_fluid) {
         M3 Cdt;
 #pragma unroll
         for (int e = 0; e < 9; ++e) Cdt.m[e] = C.m[e] * dt;
         const M3 dF = m3_mul(Cdt, F);
 #pragma unroll
-        for (int e = 0; e < 9; ++e) F.m[e] += dF.m[e];
+        for (int e = 0; e < 9; ++e) { F.m[e] += dF.m[e]; E.m[e] += dF.m[e]; }
     } else {
         F.m[0] += (div * dt) * F.m[0];
     }
@@ -1261,11 +1266,19 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
         o.alpha = alpha;
     }
 #ifdef SPK_EXP_NO_PLASTICITY
-    if (mo.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER && Jp == 123.456f) dp_update<WANT_STRESS>(
+    if (dp_e && Jp == 123.456f) {
 #else
-    if (mo.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER) dp_update<WANT_STRESS>(
+    if (dp_e) {
 #endif
-mo, phase, eh, F, Jp, q, lvg, sv, sv_valid, o.T);
+#ifdef SPK_DP_F_FORM   // A/B: the round-1 arithmetic on F itself (one-sided Jacobi SVD of F)
+        dp_update<WANT_STRESS>(mo, phase, eh, F, Jp, q, lvg, sv, sv_valid, o.T);
+        if (sv_valid) { sv[0] -= 1.f; sv[1] -= 1.f; sv[2] -= 1.f; }
+#else
+        dp_update_e<WANT_STRESS>(mo, phase, eh, E, Jp, q, lvg, sv, sv_valid, o.T);   // sv: sigma' - 1
+        F = E;
+        F.m[0] += 1.f; F.m[4] += 1.f; F.m[8] += 1.f;
+#endif
+    }
     if (flags & FLAG_STATIC) { vel[0] = vel[1] = vel[2] = 0.f; C = m3_zero(); }
     // fail guards (:111-121); density_def_grad() == 0  <=>  mass/volume0 == 0 or det(F) overflowed
     const bool zero_density = (kk.x == 0.f) || !(fabsf(m3_det(F)) < 1.0e30f);
