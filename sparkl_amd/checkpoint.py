@@ -4,8 +4,9 @@ Two formats:
 
 * **native** (`save` / `load`): one `.npz` holding the seven SoA component arrays exactly as the C ABI exchanges them,
   the `SparklParticleModel` array as raw bytes and a JSON header (cell width, solver parameters, simulated time).
-  Loss-free; `load` + `MpmPipeline.upload_particles` resumes a run (the sorted order is rebuilt by the next re-bin, so
-  the continuation matches an uninterrupted run to f32 summation order, not bit for bit).
+  Loss-free at the precision of the ABI (the deformation gradient crosses it as f32 F; the device keeps F - I, which is
+  rounded once when F is formed for the read-back); `load` + `MpmPipeline.upload_particles` resumes a run (the sorted
+  order is rebuilt by the next re-bin, so the continuation matches an uninterrupted run to f32 rounding, not bit for bit).
 
 * **sparkl serde layout** (`dump_bincode` / `load_bincode`): what `bincode 1` (default options: little endian,
   fixed-width integers, u64 sequence lengths, u32 enum variant index, u8 `Option` tag) writes for the reference's

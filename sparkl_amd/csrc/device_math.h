@@ -369,8 +369,11 @@ SPK_DEV void strain_metric(const M3& E, float S[6]) {
         S[e] = (E.m[a + 3 * b] + E.m[b + 3 * a]) + (E.m[3 * a] * E.m[3 * b] + E.m[3 * a + 1] * E.m[3 * b + 1] + E.m[3 * a + 2] * E.m[3 * b + 2]);
     }
 }
-#ifndef SPK_EIG_TOL
-#define SPK_EIG_TOL 1.0e-5f
+#ifndef SPK_EIG_TOL_ABS
+#define SPK_EIG_TOL_ABS 1.0e-6f
+#endif
+#ifndef SPK_EIG_FLOOR
+#define SPK_EIG_FLOOR 1.0e-10f   // off-diagonal strains below this are noise: (f32 rounding of F)^2 is 1e-14
 #endif
 struct Eig3 {
     M3 v;          // eigenvectors (columns)
@@ -398,18 +401,20 @@ SPK_DEV void jacobi_sym(float& pp, float& qq, float& pq, float& rp, float& rq, f
         vq[i] = sn * a + c * b;
     }
 }
-// Cyclic Jacobi on S.  Stops after the sweep that leaves every off-diagonal entry of every lane below SPK_EIG_TOL of the
-// largest entry S had (wave-uniform branch; the test comes AFTER the sweep, so a converged matrix is not swept once more):
-// an off-diagonal residue r shifts an eigenvalue by at most r -- r^2 / gap when the eigenvalues are apart -- so the strains
-// are good to 1e-5 of the strain at worst, typically 1e-7 (the convergence is quadratic: 1e-1 -> 1e-3 -> 1e-7 per sweep).
+// Cyclic Jacobi on S.  Stops after the sweep that leaves every off-diagonal entry of every lane below the tolerance
+// (wave-uniform branch; the test comes AFTER the sweep, so a converged matrix is not swept once more).
+// What the tolerance has to be: the callers take the part of every matrix function that is LINEAR in S from S itself and
+// only the remainder (second order in the strain) from V diag(.) V^T, so an off-diagonal residue r -- a misalignment of V by
+// r / gap -- costs r / gap x (second-order term) ~ r in RELATIVE terms whatever the strain.  r <= 1e-6 absolute is therefore
+// enough (1e-3 of a 1e-3 strain: two sweeps; 1e-5 of a 0.1 strain: three or four), never looser than 1e-2 of the matrix.
 SPK_DEV Eig3 sym_eig3(const float S[6]) {
     Eig3 r;
     r.v = m3_identity();
     float s00 = S[0], s11 = S[1], s22 = S[2], s01 = S[3], s02 = S[4], s12 = S[5];
     const float scale = fmaxf(fmaxf(fmaxf(fabsf(s00), fabsf(s11)), fmaxf(fabsf(s22), fabsf(s01))), fmaxf(fabsf(s02), fabsf(s12)));
-    // no squares of the thresholds (they underflow for the strains of a particle that barely left F = I); a strain below
-    // 1e-30 is zero
-    const float tol = fmaxf(SPK_EIG_TOL * scale, 1.0e-30f), skip = 1.0e-3f * tol;
+    // no squares of the thresholds (they underflow for the strains of a particle that barely left F = I).  The floor: a
+    // particle in free fall carries S = (rounding of F)^2 ~ 1e-12 of arbitrary structure -- three sweeps for nothing
+    const float tol = fmaxf(fminf(1.0e-2f * scale, fmaxf(SPK_EIG_TOL_ABS, 1.0e-5f * scale)), SPK_EIG_FLOOR), skip = 1.0e-3f * tol;
     bool more = fmaxf(fabsf(s01), fmaxf(fabsf(s02), fabsf(s12))) > tol;
     for (int sweep = 0; sweep < SPK_SVD_SWEEPS && __any(more); ++sweep) {
         jacobi_sym(s00, s11, s01, s02, s12, r.v.m + 0, r.v.m + 3, skip);
@@ -427,13 +432,32 @@ SPK_DEV void sym_compose(const M3& v, const float g[3], float out[6]) {
     for (int e = 0; e < 6; ++e) out[e] = g[0] * v.m[ii[e]] * v.m[jj[e]] + g[1] * v.m[3 + ii[e]] * v.m[3 + jj[e]] + g[2] * v.m[6 + ii[e]] * v.m[6 + jj[e]];
 }
 SPK_DEV M3 sym6_to_m3(const float t[6]) { return M3{{t[0], t[3], t[4], t[3], t[1], t[5], t[4], t[5], t[2]}}; }
-// ln sigma_k of F = I + E and the eigenvectors of F^T F
-SPK_DEV Eig3 log_stretch(const M3& E, float eps[3]) {
+// x -> e^x - 1 - x and x -> ln(1 + x) - x: the second-order remainders, without the cancellation of the differences
+SPK_DEV float expm1_rem(float x) {
+    if (fabsf(x) < 0.1f) return x * x * (0.5f + x * (1.f / 6.f + x * (1.f / 24.f + x * (1.f / 120.f + x * (1.f / 720.f)))));
+    return __expf(x) - 1.f - x;
+}
+SPK_DEV float log1p_rem(float x) {
+    if (fabsf(x) < 0.1f) return x * x * (-0.5f + x * (1.f / 3.f + x * (-0.25f + x * (0.2f + x * (-1.f / 6.f + x * (1.f / 7.f + x * -0.125f))))));
+    return log1pf(x) - x;
+}
+// Hencky strain of F = I + E:  eps = ln(F^T F) / 2  as a matrix (xx, yy, zz, xy, xz, yz) and in the eigenbasis of F^T F
+// (e_k = ln sigma_k).  The matrix takes S / 2 from S itself and only the remainder from the eigen-decomposition (see
+// sym_eig3).
+SPK_DEV Eig3 log_stretch(const M3& E, float e[3], float eps6[6]) {
     float S[6];
     strain_metric(E, S);
     const Eig3 d = sym_eig3(S);
+    float re[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) eps[k] = 0.5f * log1p_small(fmaxf(d.lam[k], -0.99999988f));
+    for (int k = 0; k < 3; ++k) {
+        const float lam = fmaxf(d.lam[k], -0.99999988f);
+        re[k] = 0.5f * log1p_rem(lam);
+        e[k] = 0.5f * lam + re[k];
+    }
+    sym_compose(d.v, re, eps6);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) eps6[k] += 0.5f * S[k];
     return d;
 }
 
@@ -479,41 +503,47 @@ SPK_DEV SymStress corotated_kirchhoff_from_svd(const DevModel& mo, float hardeni
 // DruckerPragerPlasticity::update_particle.  Updates F, Jp, q, lvg in place and returns the singular
 // values of the (possibly projected) F through sv[] for the pos-energy bookkeeping.
 // `T` (want_stress): the corotated stress of the final F for the fused kernel (eh = elastic hardening), left invalid when the model / phase do not qualify.
-// Corotated Kirchhoff stress (phase == 1) of F = I + E from the eigenvectors of F^T F and eps_k = ln sigma_k:
-//   2 mu (F - R) F^T + lambda (J - 1) J I  =  2 mu F [V diag((sigma - 1)/sigma) V^T] F^T + lambda (J - 1) J I
-// (elasticity_corotated_linear.rs:31-78; R = U V^T, U = F V Sigma^-1).  (sigma - 1)/sigma = -expm1(-eps) and J - 1 =
-// det(I + E) - 1 enter without cancellation.
-SPK_DEV SymStress corotated_tau_e(const DevModel& mo, float hardening, const M3& E, const M3& V, const float eps[3]) {
+// Corotated Kirchhoff stress (phase == 1) of F = I + E from the Hencky strain (matrix `eps6`, eigenbasis V / `e`):
+//   2 mu (F - R) F^T + lambda (J - 1) J I  =  2 mu F M F^T + lambda (J - 1) J I,   M = V diag((sigma - 1)/sigma) V^T = I - exp(-eps)
+// (elasticity_corotated_linear.rs:31-78; R = U V^T, U = F V Sigma^-1).  M = eps + V diag(-expm1(-e) - e) V^T: first order from
+// the matrix, remainder from the eigenbasis; J - 1 = det(I + E) - 1 without cancellation.
+SPK_DEV SymStress corotated_tau_e(const DevModel& mo, float hardening, const M3& E, const M3& V, const float e[3], const float eps6[6]) {
     float g[3], m6[6];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) g[k] = -expm1_small(-eps[k]);
+    for (int k = 0; k < 3; ++k) g[k] = -expm1_rem(-e[k]);
     sym_compose(V, g, m6);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) m6[k] += eps6[k];
     const M3 M = sym6_to_m3(m6);
     M3 A = m3_mul(E, M);                 // A = F M = M + E M
 #pragma unroll
-    for (int e = 0; e < 9; ++e) A.m[e] += M.m[e];
+    for (int k = 0; k < 9; ++k) A.m[k] += M.m[k];
     const float jm1 = det_minus_one(E);
     const float sph = mo.lambda * hardening * jm1 * (1.f + jm1);
     const float k2 = 2.f * mo.mu * hardening;
     SymStress S;
     const int ii[6] = {0, 1, 2, 0, 0, 1}, jj[6] = {0, 1, 2, 1, 2, 2};
 #pragma unroll
-    for (int e = 0; e < 6; ++e) {
-        const int a = ii[e], b = jj[e];
-        // (A F^T)_ab = A_ab + sum_k A_ak E_bk
-        S.t[e] = k2 * (A.m[a + 3 * b] + (A.m[a] * E.m[b] + A.m[a + 3] * E.m[b + 3] + A.m[a + 6] * E.m[b + 6]));
+    for (int k = 0; k < 6; ++k) {
+        const int a = ii[k], b = jj[k];
+        // (A F^T)_ab = A_ab + sum_c A_ac E_bc
+        S.t[k] = k2 * (A.m[a + 3 * b] + (A.m[a] * E.m[b] + A.m[a + 3] * E.m[b + 3] + A.m[a + 6] * E.m[b + 6]));
     }
     S.t[0] += sph; S.t[1] += sph; S.t[2] += sph;
     S.valid = true;
     return S;
 }
 
+// phase == 1 corotated stress of F = I + E
+SPK_DEV M3 corotated_kirchhoff_fe(const DevModel& mo, float hardening, const M3& E) {
+    float e[3], eps6[6];
+    const Eig3 d = log_stretch(E, e, eps6);
+    return sym_to_m3(corotated_tau_e(mo, hardening, E, d.v, e, eps6));
+}
 SPK_DEV M3 corotated_kirchhoff_e(const DevModel& mo, float hardening, const M3& F) {
     M3 E = F;
     E.m[0] -= 1.f; E.m[4] -= 1.f; E.m[8] -= 1.f;
-    float eps[3];
-    const Eig3 d = log_stretch(E, eps);
-    return sym_to_m3(corotated_tau_e(mo, hardening, E, d.v, eps));
+    return corotated_kirchhoff_fe(mo, hardening, E);
 }
 
 // DruckerPragerPlasticity::update_particle (plasticity_drucker_prager.rs:68-104) on E = F_trial - I, in place.
@@ -523,37 +553,46 @@ SPK_DEV void dp_update_e(const DevModel& mo, float phase, float eh, M3& E, float
     sv_valid = false;
     T.valid = false;
     if (mo.only_active_when_failed && phase != 0.f) return;
-    float eps[3];
-    const Eig3 d = log_stretch(E, eps);
+    float e[3], eps6[6];
+    const Eig3 d = log_stretch(E, e, eps6);
     const float alpha = dp_alpha(mo, q);
-    float strain[3], dev[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) strain[i] = eps[i] + lvg * (1.f / 3.f);
-    const float tr = strain[0] + strain[1] + strain[2];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) dev[i] = strain[i] - tr * (1.f / 3.f);
+    // strain = eps + (lvg / 3) I; its trace, deviator and norms from the MATRIX (first order exact in S)
+    const float tre = eps6[0] + eps6[1] + eps6[2];
+    const float tr = tre + lvg;
+    const float dev6[6] = {eps6[0] - tre * (1.f / 3.f), eps6[1] - tre * (1.f / 3.f), eps6[2] - tre * (1.f / 3.f), eps6[3], eps6[4], eps6[5]};
+    const float dn2 = (dev6[0] * dev6[0] + dev6[1] * dev6[1] + dev6[2] * dev6[2]) + 2.f * (dev6[3] * dev6[3] + dev6[4] * dev6[4] + dev6[5] * dev6[5]);
     // three outcomes: tensile (sigma' = 1), inside the yield surface (F stays), projection onto the cone; folded into one
-    // straight line (`neps` = ln sigma', `moved`) so that the stress below is formed once per wave, not once per divergent branch
-    float neps[3] = {eps[0], eps[1], eps[2]}, dq = 0.f;
+    // straight line (K = ln(Sigma' / Sigma) as a matrix and in the eigenbasis, `moved`) so that the stress below is formed once
+    // per wave, not once per divergent branch
+    float K6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, k[3] = {0.f, 0.f, 0.f}, dq = 0.f;
     bool moved = false;
-    if ((dev[0] == 0.f && dev[1] == 0.f && dev[2] == 0.f) || tr > 0.f) {
-        neps[0] = neps[1] = neps[2] = 0.f;
-        dq = fast_sqrt(strain[0] * strain[0] + strain[1] * strain[1] + strain[2] * strain[2]);
+    if (dn2 == 0.f || tr > 0.f) {
+        // |strain|^2 = |dev eps|^2 + (tr eps + lvg)^2 / 3
+        dq = fast_sqrt(dn2 + tr * tr * (1.f / 3.f));
+#pragma unroll
+        for (int i = 0; i < 6; ++i) K6[i] = -eps6[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) k[i] = -e[i];
         moved = true;
     } else {
-        const float dn = fast_sqrt(dev[0] * dev[0] + dev[1] * dev[1] + dev[2] * dev[2]);
+        const float dn = fast_sqrt(dn2);
         const float gamma = dn + mo.p_k * tr * alpha;   // p_k = (3 lambda + 2 mu) / (2 mu), precomputed on the host
         if (gamma > 0.f) {                              // otherwise inside the yield surface
             const float gdn = gamma * fast_rcp(dn);
+            // ln sigma' = strain - gdn dev  =>  K = (lvg / 3) I - gdn dev(eps)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) neps[i] = strain[i] - gdn * dev[i];
+            for (int i = 0; i < 6; ++i) K6[i] = -gdn * dev6[i];
+            K6[0] += lvg * (1.f / 3.f); K6[1] += lvg * (1.f / 3.f); K6[2] += lvg * (1.f / 3.f);
+            const float em = (e[0] + e[1] + e[2]) * (1.f / 3.f);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) k[i] = lvg * (1.f / 3.f) - gdn * (e[i] - em);
             dq = gamma;
             moved = true;
         }
     }
     if (moved) {
-        // prev_det = prod sigma = exp(sum eps), new_det = prod sigma' = exp(sum neps)
-        const float so = eps[0] + eps[1] + eps[2], sn = neps[0] + neps[1] + neps[2];
+        // prev_det = prod sigma = exp(tr eps), new_det = prod sigma' = exp(tr eps + tr K)
+        const float so = tre, sn = tre + (K6[0] + K6[1] + K6[2]);
         const float pm1 = expm1_small(so);
         float nm1 = expm1_small(sn), lnew = sn;
         const float diff = nm1 - pm1;
@@ -561,20 +600,24 @@ SPK_DEV void dp_update_e(const DevModel& mo, float phase, float eh, M3& E, float
         Jp *= (1.f + pm1) * fast_rcp(1.f + nm1);
         lvg += so - lnew;
         q += dq;
-        // F' = F V diag(sigma'/sigma) V^T = F (I + G),  G = V diag(expm1(neps - eps)) V^T  =>  E' = E + G + E G
-        float kap[3], g6[6];
+        // F' = F V diag(sigma'/sigma) V^T = F (I + G),  G = exp(K) - I = K + V diag(expm1(k) - k) V^T  =>  E' = E + G + E G
+        float kr[3], g6[6];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) kap[i] = expm1_small(neps[i] - eps[i]);
-        sym_compose(d.v, kap, g6);
+        for (int i = 0; i < 3; ++i) kr[i] = expm1_rem(k[i]);
+        sym_compose(d.v, kr, g6);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { g6[i] += K6[i]; eps6[i] += K6[i]; }
         const M3 G = sym6_to_m3(g6);
         const M3 EG = m3_mul(E, G);
 #pragma unroll
-        for (int e = 0; e < 9; ++e) E.m[e] += G.m[e] + EG.m[e];
+        for (int i = 0; i < 9; ++i) E.m[i] += G.m[i] + EG.m[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) e[i] += k[i];
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) sm1[i] = expm1_small(neps[i]);
+    for (int i = 0; i < 3; ++i) sm1[i] = expm1_small(e[i]);
     sv_valid = true;
-    if (WANT_STRESS && mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR && phase == 1.f) T = corotated_tau_e(mo, eh, E, d.v, neps);
+    if (WANT_STRESS && mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR && phase == 1.f) T = corotated_tau_e(mo, eh, E, d.v, e, eps6);
 }
 
 template <bool WANT_STRESS>
@@ -751,18 +794,16 @@ SPK_DEV bool maximum_stress_failed(const DevModel& mo, const M3& t) {
 }
 
 // constitutive_model.pos_energy(particle)
-SPK_DEV float model_pos_energy(const DevModel& mo, float phase, float eh, const M3& F, const float sm1[3], bool sv_valid) {
+SPK_DEV float model_pos_energy(const DevModel& mo, float phase, float eh, const M3& F, const M3& E, const float sm1[3], bool sv_valid) {
     if (mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR) {
         // elasticity_corotated_linear.rs:105-118 on the small quantities: sigma_k - 1 (`sm1` when the return map already holds
-        // them) and J - 1
-        M3 E = F;
-        E.m[0] -= 1.f; E.m[4] -= 1.f; E.m[8] -= 1.f;
+        // them) and J - 1; E = F - I
         const float jm1 = det_minus_one(E);
         float s[3];
         if (sv_valid) { s[0] = sm1[0]; s[1] = sm1[1]; s[2] = sm1[2]; }
         else {
-            float eps[3];
-            (void)log_stretch(E, eps);
+            float eps[3], eps6[6];
+            (void)log_stretch(E, eps, eps6);
             s[0] = expm1_small(eps[0]); s[1] = expm1_small(eps[1]); s[2] = expm1_small(eps[2]);
         }
         float nsq = 0.f;

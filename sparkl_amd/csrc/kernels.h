@@ -236,9 +236,12 @@ struct Scatter {
 // particle_to_grid.rs:42-59: stress, affine, weights.  `org` = cell origin of the home block.
 // `T` (fused kernel only): the corotated stress the Drucker-Prager return map of this very thread formed from the decomposition
 // of F it held (corotated_kirchhoff_from_svd) -- a rank-3 update instead of a polar iteration.
-SPK_DEV Scatter p2g_prepare(const DevModel& mo, uint32_t flags, const float px[3], const float v[3], const M3& C, const M3& F, float mass, float vol0, float eh,
+// `Fe` = F - I, as the particle stores it.
+SPK_DEV Scatter p2g_prepare(const DevModel& mo, uint32_t flags, const float px[3], const float v[3], const M3& C, const M3& Fe, float mass, float vol0, float eh,
                             float phase, float fluid_jp, const int4& org, float h, float inv_h, float inv_d, float dt, const SymStress* T = nullptr, const float* rcell = nullptr) {
     Scatter sc;
+    M3 F = Fe;
+    F.m[0] += 1.f; F.m[4] += 1.f; F.m[8] += 1.f;
     float d0[3];
     int lc[3];
     const int orgv[3] = {org.x, org.y, org.z};
@@ -262,7 +265,7 @@ SPK_DEV Scatter p2g_prepare(const DevModel& mo, uint32_t flags, const float px[3
             if (T != nullptr && T->valid && phase == 1.f) tau = sym_to_m3(*T);
             else
 #endif
-                tau = corotated_kirchhoff(mo, phase, eh, F);
+                tau = phase == 1.f ? corotated_kirchhoff_fe(mo, eh, Fe) : corotated_kirchhoff(mo, phase, eh, F);
         } else if (mo.ctag == SPARKL_CONSTITUTIVE_NEO_HOOKEAN) tau = neo_hookean_kirchhoff(mo, phase, eh, F);
         else if (mo.ctag == SPARKL_CONSTITUTIVE_EOS_MONAGHAN_SPH) tau = monaghan_kirchhoff(mo, mass, vol0, F.m[0], fluid_jp, C);
     }
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
         scatter_clear(sc);
         if (live) {
             const float px[3] = {q0.x, q0.y, q0.z}, v[3] = {q3.x, q3.y, q3.z};
-            const M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
+            const M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};   // F - I as stored
             const M3 C = {{q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
             const DevModel& mo = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
             const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
@@ -735,7 +738,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_pair(ParticleArrays P, Grid
             scatter_clear(sc[k]);
             if (live[k]) {
                 const float px[3] = {q0.x, q0.y, q0.z}, v[3] = {q3.x, q3.y, q3.z};
-                const M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
+                const M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};   // F - I as stored
                 const M3 C = {{q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
                 const DevModel& mo = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
                 const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
@@ -1136,7 +1139,7 @@ SPK_DEV void project_particle_on_colliders(const GridArrays& G, const StepParams
 // State of one particle after grid_to_particle.rs:62-164 (gather .. psi_pos), before it is written back.
 struct Advected {
     float px[3], vel[3];
-    M3 C, F;
+    M3 C, Fe;            // Fe = F - I: what the particle stores
     float q, lvg, Jp, psi;
     float eh, phase;     // elastic hardening (snow changes it) and phase (a failure model zeroes it) as P2G must see them
     uint32_t flags;
@@ -1235,12 +1238,12 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
     }
     px[0] += vel[0] * dt; px[1] += vel[1] * dt; px[2] += vel[2] * dt;
     // deformation gradient update (:91-100)
-    M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
-    // Drucker-Prager particles carry E = F - I through the update and the return map (device_math.h, "strain-form arithmetic"):
-    // F is only rounded once, when it is stored
+    // the particle stores E = F - I; Drucker-Prager particles carry E through the update and the return map (device_math.h,
+    // "strain-form arithmetic"), everything else works on F and hands F - I back
     const bool dp_e = !mo.is_fluid && mo.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER;
-    M3 E = F;
-    E.m[0] -= 1.f; E.m[4] -= 1.f; E.m[8] -= 1.f;
+    M3 E = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
+    M3 F = E;
+    F.m[0] += 1.f; F.m[4] += 1.f; F.m[8] += 1.f;
     if (!mo.is_fluid) {
         M3 Cdt;
 #pragma unroll
@@ -1249,7 +1252,8 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
 #pragma unroll
         for (int e = 0; e < 9; ++e) { F.m[e] += dF.m[e]; E.m[e] += dF.m[e]; }
     } else {
-        F.m[0] += (div * dt) * F.m[0];
+        const float dj = (div * dt) * F.m[0];
+        F.m[0] += dj; E.m[0] += dj;
     }
     float q = dd.x, lvg = dd.y, Jp = dd.z, psi = dd.w;
     float eh = kk.z;
@@ -1261,6 +1265,8 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
         float alpha = mo.ptag == SPARKL_PLASTIC_NACC ? aux_i->z : 0.f;
         const float eh0 = eh, alpha0 = alpha;
         rare_plastic_update(mo, F, Jp, q, eh, alpha);
+        E = F;
+        E.m[0] -= 1.f; E.m[4] -= 1.f; E.m[8] -= 1.f;
         o.store_k = eh != eh0;
         o.store_aux = alpha != alpha0;
         o.alpha = alpha;
@@ -1287,12 +1293,13 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
         newly_failed = !(flags & FLAG_FAILED);
         flags |= FLAG_FAILED;
         F = m3_identity();
+        E = m3_zero();
         C = m3_zero();
         sv_valid = false;
         o.T.valid = false;
     }
     // positive energy bookkeeping (:127-132)
-    psi = fmaxf(psi, model_pos_energy(mo, phase, eh, F, sv, sv_valid));
+    psi = fmaxf(psi, model_pos_energy(mo, phase, eh, F, E, sv, sv_valid));
     // failure model (:134-144): stress of the updated particle; a failed particle keeps phase = 0 from now on
     if (RARE && mo.has_failure && phase != 0.f && failure_check(mo, phase, eh, F, kk.x, kk.y, Jp, C)) {
         phase = 0.f;
@@ -1322,16 +1329,16 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) { o.px[a] = px[a]; o.vel[a] = vel[a]; }
-    o.C = C; o.F = F; o.q = q; o.lvg = lvg; o.Jp = Jp; o.psi = psi; o.flags = flags; o.newly_failed = newly_failed; o.in_tile = in_tile;
+    o.C = C; o.Fe = E; o.q = q; o.lvg = lvg; o.Jp = Jp; o.psi = psi; o.flags = flags; o.newly_failed = newly_failed; o.in_tile = in_tile;
     o.eh = eh; o.phase = phase;
     return o;
 }
 // `defer_c`: q[4], q[5] (C.m[1..8]) are not written; k_regather_c recomputes them if anything but the next fused launch needs
 // them (see StepParams::defer_c)
 SPK_DEV void g2p_store(const ParticleArrays& P, int i, const Advected& o, int defer_c = 0) {
-    P.q[0][i] = make_float4(o.px[0], o.px[1], o.px[2], o.F.m[0]);
-    P.q[1][i] = make_float4(o.F.m[1], o.F.m[2], o.F.m[3], o.F.m[4]);
-    P.q[2][i] = make_float4(o.F.m[5], o.F.m[6], o.F.m[7], o.F.m[8]);
+    P.q[0][i] = make_float4(o.px[0], o.px[1], o.px[2], o.Fe.m[0]);
+    P.q[1][i] = make_float4(o.Fe.m[1], o.Fe.m[2], o.Fe.m[3], o.Fe.m[4]);
+    P.q[2][i] = make_float4(o.Fe.m[5], o.Fe.m[6], o.Fe.m[7], o.Fe.m[8]);
     P.q[3][i] = make_float4(o.vel[0], o.vel[1], o.vel[2], o.C.m[0]);
     // a particle that just left the domain is never touched again (k_regather_c included): its last C is stored now
     if (!defer_c || (o.flags & FLAG_INVALID)) {
@@ -1387,7 +1394,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
         g2p_store(P, i, o);
         want_sort |= !o.in_tile;
         if (S.want_dt) {  // the bound the next substep's estimator would compute from this state
-            const float b = particle_dt_bound(mo, o.flags, o.vel, o.C, kk.x, kk.y, o.eh, o.F.m[0], S.h);
+            const float b = particle_dt_bound(mo, o.flags, o.vel, o.C, kk.x, kk.y, o.eh, 1.f + o.Fe.m[0], S.h);
             dt_nan |= b != b;
             dt_bound = fminf(dt_bound, b);
         }
@@ -1482,11 +1489,11 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
             want_sort |= !o.in_tile;
             live = o.in_tile;
             if (S.want_dt) {  // the bound the next substep's estimator would compute from this state
-                const float bnd = particle_dt_bound(mo, o.flags, o.vel, o.C, kk.x, kk.y, o.eh, o.F.m[0], S.h);
+                const float bnd = particle_dt_bound(mo, o.flags, o.vel, o.C, kk.x, kk.y, o.eh, 1.f + o.Fe.m[0], S.h);
                 dt_nan |= bnd != bnd;
                 dt_bound = fminf(dt_bound, bnd);
             }
-            if (live) { sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.F, kk.x, kk.y, o.eh, o.phase, o.Jp, org, h, inv_h, S.inv_d, S.dt_next, &o.T, o.rnew); shell_used |= sc.shell != 0; }
+            if (live) { sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.Fe, kk.x, kk.y, o.eh, o.phase, o.Jp, org, h, inv_h, S.inv_d, S.dt_next, &o.T, o.rnew); shell_used |= sc.shell != 0; }
 #ifdef SPK_EXP_DUMMY_LDS    // sensitivity probe: N extra LDS reads (ds_read_b32, one wave-wide 256 B access each) per particle batch
             {
                 volatile float* vp = &s_A[tid >> 6][0][0];
@@ -1743,7 +1750,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p_volume(ParticleArrays P, Gr
                     new_mass += (wgt[0][sx] * wgt[1][sy] * wgt[2][sz]) * vt[base + sx + TILE_W * sy + TILE_W * TILE_W * sz].w;
         const float new_density = new_mass / (h * h * h);
         const float new_volume = kk.x / new_density;
-        reinterpret_cast<float*>(&P.q[0][i])[3] = new_volume / kk.y;
+        reinterpret_cast<float*>(&P.q[0][i])[3] = new_volume / kk.y - 1.f;   // stored as F00 - 1
     }
 }
 
@@ -1848,7 +1855,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
             const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
             const Advected o = g2p_update<false>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
             if (FLUID_ONLY) {
-                P.q[0][i] = make_float4(o.px[0], o.px[1], o.px[2], o.F.m[0]);
+                P.q[0][i] = make_float4(o.px[0], o.px[1], o.px[2], o.Fe.m[0]);
                 P.q[3][i] = make_float4(o.vel[0], o.vel[1], o.vel[2], o.C.m[0]);
                 P.q[4][i] = make_float4(o.C.m[1], o.C.m[2], o.C.m[3], o.C.m[4]);
                 P.q[5][i] = make_float4(o.C.m[5], o.C.m[6], o.C.m[7], o.C.m[8]);
@@ -1860,7 +1867,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
             live = o.in_tile;
             npx[0] = o.px[0]; npx[1] = o.px[1]; npx[2] = o.px[2];
             if (S.want_dt) {
-                const float bnd = particle_dt_bound(mo, o.flags, o.vel, o.C, kk.x, kk.y, o.eh, o.F.m[0], S.h);
+                const float bnd = particle_dt_bound(mo, o.flags, o.vel, o.C, kk.x, kk.y, o.eh, 1.f + o.Fe.m[0], S.h);
                 dt_nan |= bnd != bnd;
                 dt_bound = fminf(dt_bound, bnd);
             }
@@ -1948,10 +1955,10 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
                                 new_mass += (wgt[0][sx] * wgt[1][sy] * wgt[2][sz]) * vm[vb + sx + TILE_W * sy + TILE_W * TILE_W * sz];
                     const float new_density = new_mass / (h * h * h);
                     const float new_volume = kk.x / new_density;
-                    q0.w = new_volume / kk.y;
+                    q0.w = new_volume / kk.y - 1.f;   // stored as F00 - 1
                     P.q[0][i] = q0;
                 }
-                const M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
+                const M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};   // F - I as stored
                 const M3 C = {{q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
                 const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
                 const float jp = mo.is_fluid ? jp_stored : 1.f;
@@ -2081,7 +2088,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_estimate_dt(ParticleArrays P, c
         const DevModel& mo = models[flags >> FLAG_MODEL_SHIFT];
         const float v[3] = {q3.x, q3.y, q3.z};
         const M3 C = {{q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
-        dt = particle_dt_bound(mo, flags, v, C, kk.x, kk.y, kk.z, mo.is_fluid ? P.q[0][i].w : 1.f, h);
+        dt = particle_dt_bound(mo, flags, v, C, kk.x, kk.y, kk.z, mo.is_fluid ? 1.f + P.q[0][i].w : 1.f, h);
         nan = dt != dt;
     }
     dt_block_min_store(dt_partial, dt, nan, ctl, threadIdx.x);
@@ -2281,9 +2288,11 @@ __global__ void k_pack_upload(ParticleArrays P, int first, int n, uint32_t id_ba
     const float* D = data + 4 * (size_t)j;       // nacc_alpha, plastic_hardening, elastic_hardening, log_vol_gain
     float C[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (vg) for (int e = 0; e < 9; ++e) C[e] = vg[9 * (size_t)j + e];
-    P.q[0][i] = make_float4(X[0], X[1], X[2], V[3]);
-    P.q[1][i] = make_float4(V[4], V[5], V[6], V[7]);
-    P.q[2][i] = make_float4(V[8], V[9], V[10], V[11]);
+    // the deformation gradient is STORED as F - I (diagonal entries minus one, exact for 0.5 <= F_kk <= 2): the strain of a stiff
+    // particle keeps its relative precision from one substep to the next (device_math.h, "strain-form arithmetic")
+    P.q[0][i] = make_float4(X[0], X[1], X[2], V[3] - 1.f);
+    P.q[1][i] = make_float4(V[4], V[5], V[6], V[7] - 1.f);
+    P.q[2][i] = make_float4(V[8], V[9], V[10], V[11] - 1.f);
     P.q[3][i] = make_float4(U[0], U[1], U[2], C[0]);
     P.q[4][i] = make_float4(C[1], C[2], C[3], C[4]);
     P.q[5][i] = make_float4(C[5], C[6], C[7], C[8]);
@@ -2308,7 +2317,7 @@ __global__ void k_read_struct(ParticleArrays P, uint32_t* out, int n, long long 
         const float4 q0 = P.q[0][i], q1 = P.q[1][i], q2 = P.q[2][i], dd = P.d[i], kk = P.k[i], ax = P.aux[i];
         float* w = reinterpret_cast<float*>(out) + 13 * o;
         w[0] = kk.x; w[1] = kk.y; w[2] = ax.y;
-        w[3] = q0.w; w[4] = q1.x; w[5] = q1.y; w[6] = q1.z; w[7] = q1.w; w[8] = q2.x; w[9] = q2.y; w[10] = q2.z; w[11] = q2.w;
+        w[3] = 1.f + q0.w; w[4] = q1.x; w[5] = q1.y; w[6] = q1.z; w[7] = 1.f + q1.w; w[8] = q2.x; w[9] = q2.y; w[10] = q2.z; w[11] = 1.f + q2.w;   // stored as F - I
         w[12] = dd.z;
     } else if (what == 1) {   // SparklParticleStatus: failed, is_static, kinematic_vel_enabled, pad | kinematic_vel[3] | model_index u64
         const float4 kk = P.k[i], kv = P.kinvel[i];

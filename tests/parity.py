@@ -24,11 +24,13 @@ TOL = 1.0e-4   # BASELINE.json north_star: <= 1e-4 relative particle-state diver
 def parity_verdict(got, ref32, ref64, h):
     """The parity gate.  The arbiter is the oracle evaluated in f64 (the exact trajectory of the reference's algorithm):
 
-        eps(HIP vs f64 oracle)  <=  max(1e-4, eps(f32 oracle vs f64 oracle))      for positions and for velocities,
+        eps(HIP vs f64 oracle)  <=  1e-4      for positions (in h) and for velocities (relative to max |v|), no exceptions.
 
-    i.e. the HIP path meets the 1e-4 target outright, or -- on materials where the reference's own f32 arithmetic cannot
-    (stiff sand: E = 1e7, |v| <= 0.25 m/s) -- is at least as close to the exact trajectory as the reference's f32 path is.
-    No multiplier on the floor.  Returns the three error dictionaries (max and p99.9 in each) and a list of violations."""
+    The reference's own f32 arithmetic (the f32 oracle) does NOT meet this on the stiff sand cases (3e-4 .. 6e-4: a singular value
+    of F in f32 carries 1e-7 of absolute error against a strain of 1e-4 .. 1e-3); its distance from the f64 trajectory is
+    reported beside ours (`oracle_f32_vs_f64`) but is no longer part of the gate: the HIP path works on F - I (strain-form
+    arithmetic, sparkl_amd/csrc/device_math.h) and sits at 1e-6 .. 3e-5 in every case of the suite.
+    Returns the three error dictionaries (max, mean and p99.9 in each) and a list of violations."""
     vs32 = particle_errors(got, ref32, h)
     vs64 = particle_errors(got, ref64, h)
     floor = particle_errors(ref32, ref64, h)
@@ -36,9 +38,8 @@ def parity_verdict(got, ref32, ref64, h):
     if vs64["failed_mismatch"] or vs32["failed_mismatch"]:
         bad.append(f"failed flags differ ({vs32['failed_mismatch']} vs f32, {vs64['failed_mismatch']} vs f64)")
     for k in ("eps_x", "eps_v"):
-        bound = max(TOL, floor[k])
-        if not vs64[k] <= bound:
-            bad.append(f"{k} vs f64 oracle {vs64[k]:.3e} > max(1e-4, f32-oracle-vs-f64 {floor[k]:.3e})")
+        if not vs64[k] <= TOL:
+            bad.append(f"{k} vs f64 oracle {vs64[k]:.3e} > 1e-4 (f32 oracle vs f64: {floor[k]:.3e})")
     return {"vs_f32": vs32, "vs_f64": vs64, "oracle_f32_vs_f64": floor}, bad
 
 

@@ -3,7 +3,8 @@ as `*_f64`, with the same algorithm evaluated in f64).
 
 CPU: the oracle still reproduces them bit-for-bit (guards the checker against accidental edits) and the scene generators
 still produce the same seeded inputs.  GPU: the HIP path matches them under the parity gate of tests/parity.py:
-eps(HIP vs f64 golden) <= max(1e-4, eps(f32 golden vs f64 golden)), positions in h, velocities relative to max |v|."""
+eps(HIP vs f64 golden) <= 1e-4, positions in h, velocities relative to max |v| (the f32 golden columns -- the reference's own
+arithmetic -- are printed beside it)."""
 import os
 
 import numpy as np
@@ -80,7 +81,7 @@ def test_hip_matches_golden(name):
             fx, fv = eps(g[f"pos{k}"], g[f"vel{k}"])          # the reference's own f32 arithmetic against the same arbiter
             eF = np.abs(c.volume["deformation_gradient"] - g[f"F{k}"]).max()
             print(f"golden {name} k={k}: eps_x {ex:.3e} (f32 oracle {fx:.3e})  eps_v {ev:.3e} (f32 oracle {fv:.3e})  eps_F {eF:.3e}")
-            assert ex <= max(1e-4, fx) and ev <= max(1e-4, fv), (name, k, ex, fx, ev, fv)
+            assert ex <= 1e-4 and ev <= 1e-4, (name, k, ex, fx, ev, fv)
             # NACC snaps particles onto the tips / the yield surface by thresholds: a particle sitting on one may take the other
             # branch (the f32 and f64 oracles differ by 6e-3 in F there, test_rare_material_models_parity)
             assert eF <= (1e-2 if name == "nacc" else 1e-3 if k >= 100 else 1e-4), (name, k, eF)
