@@ -180,30 +180,6 @@ SPK_DEV float powi_f(float x, int n) {
     return r;
 }
 
-// Rotation factor of F (polar decomposition) by Newton's iteration R <- (R + R^-T) / 2.
-// Quadratically convergent and self-correcting; 3-4 iterations for MPM-sized strains.
-SPK_DEV M3 polar_rotation(const M3& F) {
-    M3 R = F;
-    for (int it = 0; it < 12; ++it) {
-        // cofactor matrix = det * R^-T; columns are cross products of R's columns
-        M3 cof;
-        cof.m[0] = R.m[4] * R.m[8] - R.m[5] * R.m[7]; cof.m[1] = R.m[5] * R.m[6] - R.m[3] * R.m[8]; cof.m[2] = R.m[3] * R.m[7] - R.m[4] * R.m[6];
-        cof.m[3] = R.m[7] * R.m[2] - R.m[8] * R.m[1]; cof.m[4] = R.m[8] * R.m[0] - R.m[6] * R.m[2]; cof.m[5] = R.m[6] * R.m[1] - R.m[7] * R.m[0];
-        cof.m[6] = R.m[1] * R.m[5] - R.m[2] * R.m[4]; cof.m[7] = R.m[2] * R.m[3] - R.m[0] * R.m[5]; cof.m[8] = R.m[0] * R.m[4] - R.m[1] * R.m[3];
-        const float det = R.m[0] * cof.m[0] + R.m[1] * cof.m[1] + R.m[2] * cof.m[2];
-        const float hid = 0.5f * fast_rcp(det);
-        float delta = 0.f;
-#pragma unroll
-        for (int e = 0; e < 9; ++e) {
-            const float n = 0.5f * R.m[e] + hid * cof.m[e];
-            delta = fmaxf(delta, fabsf(n - R.m[e]));
-            R.m[e] = n;
-        }
-        if (!__any(delta > 3.0e-4f)) break;  // next update would be ~delta^2 < 1e-7
-    }
-    return R;
-}
-
 // tau for the corotated model.  phase == 1 (every particle unless a damage model is active) only needs
 // the rotation R: U (S - I) V^T = F - R.
 SPK_DEV M3 corotated_kirchhoff_e(const DevModel& mo, float hardening, const M3& F);
@@ -462,43 +438,13 @@ SPK_DEV Eig3 log_stretch(const M3& E, float e[3], float eps6[6]) {
 }
 
 // Corotated Kirchhoff stress (phase == 1) of the particle's final F = U diag(sigma') V^T, formed by the return map itself from
-// the decomposition it holds (the fused kernel scatters it one substep later; see corotated_kirchhoff_from_svd).  Symmetric:
+// the decomposition it holds (the fused kernel scatters it one substep later; see corotated_tau_e).  Symmetric:
 // (xx, yy, zz, xy, xz, yz).
 struct SymStress {
     float t[6];
     bool valid;
 };
 SPK_DEV M3 sym_to_m3(const SymStress& s) { return M3{{s.t[0], s.t[3], s.t[4], s.t[3], s.t[1], s.t[5], s.t[4], s.t[5], s.t[2]}}; }
-
-// Corotated Kirchhoff stress (phase == 1) of F = U diag(sigma') V^T straight from the decomposition the return map holds:
-//   2 mu (F - R) F^T + lambda (J - 1) J I  =  U diag(2 mu (sigma' - 1) sigma') U^T + lambda (J - 1) J I,   R = U V^T,
-// (elasticity_corotated_linear.rs:31-78) with u_k = w_k / sigma_k.  No polar iteration, and sigma' - 1, J - 1 enter without
-// the cancellation they suffer once F has been rounded to f32 entries.  `em1` = sigma' - 1.  The one-sided Jacobi keeps
-// det V = +1, so det U carries the sign of det F: J = sign * prod sigma'.
-SPK_DEV SymStress corotated_kirchhoff_from_svd(const DevModel& mo, float hardening, const Svd3& d, const float em1[3]) {
-    const float e0 = em1[0], e1 = em1[1], e2 = em1[2];
-    float jm1 = (e0 + e1 + e2) + (e0 * e1 + e0 * e2 + e1 * e2) + e0 * e1 * e2;    // prod(1 + e_k) - 1
-    float j = 1.f + jm1;
-    // det W = det F (W = F V, det V = 1)
-    const float detw = d.w.m[0] * (d.w.m[4] * d.w.m[8] - d.w.m[5] * d.w.m[7]) - d.w.m[3] * (d.w.m[1] * d.w.m[8] - d.w.m[2] * d.w.m[7]) +
-                       d.w.m[6] * (d.w.m[1] * d.w.m[5] - d.w.m[2] * d.w.m[4]);
-    if (detw < 0.f) { j = -j; jm1 = j - 1.f; }
-    const float sph = mo.lambda * hardening * jm1 * j;
-    const float k2 = 2.f * mo.mu * hardening;
-    float c[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float is = d.s[k] == 0.f ? 0.f : fast_rcp(d.s[k]);
-        c[k] = k2 * em1[k] * (1.f + em1[k]) * is * is;
-    }
-    SymStress S;
-    const int ii[6] = {0, 1, 2, 0, 0, 1}, jj[6] = {0, 1, 2, 1, 2, 2};
-#pragma unroll
-    for (int e = 0; e < 6; ++e) S.t[e] = c[0] * d.w.m[ii[e]] * d.w.m[jj[e]] + c[1] * d.w.m[3 + ii[e]] * d.w.m[3 + jj[e]] + c[2] * d.w.m[6 + ii[e]] * d.w.m[6 + jj[e]];
-    S.t[0] += sph; S.t[1] += sph; S.t[2] += sph;
-    S.valid = true;
-    return S;
-}
 
 // DruckerPragerPlasticity::update_particle.  Updates F, Jp, q, lvg in place and returns the singular
 // values of the (possibly projected) F through sv[] for the pos-energy bookkeeping.
@@ -618,58 +564,6 @@ SPK_DEV void dp_update_e(const DevModel& mo, float phase, float eh, M3& E, float
     for (int i = 0; i < 3; ++i) sm1[i] = expm1_small(e[i]);
     sv_valid = true;
     if (WANT_STRESS && mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR && phase == 1.f) T = corotated_tau_e(mo, eh, E, d.v, e, eps6);
-}
-
-template <bool WANT_STRESS>
-SPK_DEV void dp_update(const DevModel& mo, float phase, float eh, M3& F, float& Jp, float& q, float& lvg, float sv[3], bool& sv_valid, SymStress& T) {
-    sv_valid = false;
-    T.valid = false;
-    if (mo.only_active_when_failed && phase != 0.f) return;
-    const Svd3 d = svd3<SPK_SVD_SWEEPS>(F);
-    sv[0] = d.s[0]; sv[1] = d.s[1]; sv[2] = d.s[2];
-    sv_valid = true;
-    const float alpha = dp_alpha(mo, q);
-    float strain[3], dev[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) strain[i] = log_near_one(d.s[i]) + lvg * (1.f / 3.f);
-    const float tr = strain[0] + strain[1] + strain[2];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) dev[i] = strain[i] - tr * (1.f / 3.f);
-    // three outcomes: tensile (sigma' = 1), inside the yield surface (F stays), projection onto the cone.  They are folded into one
-    // straight line (em1 = sigma' - 1, `moved`) so that the stress below is formed once per wave, not once per divergent branch.
-    float em1[3] = {d.s[0] - 1.f, d.s[1] - 1.f, d.s[2] - 1.f}, dq = 0.f;
-    bool moved = false;
-    if ((dev[0] == 0.f && dev[1] == 0.f && dev[2] == 0.f) || tr > 0.f) {
-        em1[0] = em1[1] = em1[2] = 0.f;
-        dq = fast_sqrt(strain[0] * strain[0] + strain[1] * strain[1] + strain[2] * strain[2]);
-        moved = true;
-    } else {
-        const float dn = fast_sqrt(dev[0] * dev[0] + dev[1] * dev[1] + dev[2] * dev[2]);
-        const float gamma = dn + mo.p_k * tr * alpha;   // p_k = (3 lambda + 2 mu) / (2 mu), precomputed on the host
-        if (gamma > 0.f) {                              // otherwise inside the yield surface
-            const float gdn = gamma * fast_rcp(dn);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) em1[i] = expm1_small(strain[i] - gdn * dev[i]);
-            dq = gamma;
-            moved = true;
-        }
-    }
-    if (moved) {
-        const float nsv[3] = {1.f + em1[0], 1.f + em1[1], 1.f + em1[2]};
-        const float prev_det = d.s[0] * d.s[1] * d.s[2];
-        float new_det = nsv[0] * nsv[1] * nsv[2];
-        const float diff = new_det - prev_det;
-        new_det = diff > 0.f ? new_det : prev_det + diff * mo.volume_correction;
-        Jp *= prev_det * fast_rcp(new_det);
-        lvg += log_near_one(prev_det) - log_near_one(new_det);
-        q += dq;
-        float g[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) g[i] = d.s[i] == 0.f ? 0.f : nsv[i] * fast_rcp(d.s[i]);
-        F = svd_compose_scaled(d, g);
-        sv[0] = nsv[0]; sv[1] = nsv[1]; sv[2] = nsv[2];
-    }
-    if (WANT_STRESS && mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR && phase == 1.f) T = corotated_kirchhoff_from_svd(mo, eh, d, em1);
 }
 
 // SnowPlasticity::update_particle (plasticity_snow.rs:26-48)

@@ -235,7 +235,7 @@ struct Scatter {
 
 // particle_to_grid.rs:42-59: stress, affine, weights.  `org` = cell origin of the home block.
 // `T` (fused kernel only): the corotated stress the Drucker-Prager return map of this very thread formed from the decomposition
-// of F it held (corotated_kirchhoff_from_svd) -- a rank-3 update instead of a polar iteration.
+// of F it held (corotated_tau_e) -- no second decomposition.
 // `Fe` = F - I, as the particle stores it.
 SPK_DEV Scatter p2g_prepare(const DevModel& mo, uint32_t flags, const float px[3], const float v[3], const M3& C, const M3& Fe, float mass, float vol0, float eh,
                             float phase, float fluid_jp, const int4& org, float h, float inv_h, float inv_d, float dt, const SymStress* T = nullptr, const float* rcell = nullptr) {
@@ -1276,14 +1276,9 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
 #else
     if (dp_e) {
 #endif
-#ifdef SPK_DP_F_FORM   // A/B: the round-1 arithmetic on F itself (one-sided Jacobi SVD of F)
-        dp_update<WANT_STRESS>(mo, phase, eh, F, Jp, q, lvg, sv, sv_valid, o.T);
-        if (sv_valid) { sv[0] -= 1.f; sv[1] -= 1.f; sv[2] -= 1.f; }
-#else
         dp_update_e<WANT_STRESS>(mo, phase, eh, E, Jp, q, lvg, sv, sv_valid, o.T);   // sv: sigma' - 1
         F = E;
         F.m[0] += 1.f; F.m[4] += 1.f; F.m[8] += 1.f;
-#endif
     }
     if (flags & FLAG_STATIC) { vel[0] = vel[1] = vel[2] = 0.f; C = m3_zero(); }
     // fail guards (:111-121); density_def_grad() == 0  <=>  mass/volume0 == 0 or det(F) overflowed
