@@ -564,9 +564,8 @@ def test_model_table_longer_than_the_lds_copy(Pipeline):
     global memory.  The same 16 active models once as a 16-entry table (LDS copy) and once as a 17-entry table (one unused
     entry: global table): the arithmetic is the same, only the parameter source differs, so the particles must agree to
     roundoff (they agree bit for bit) -- through a fixed-dt batch (fused kernels) and an adaptive frame (standalone kernels,
-    dt estimator).  Substep count and positions are also checked against the oracle; the velocity distances are reported, not
-    gated: 40 substeps of this 1200-particle stiff column move at 0.1 m/s, where one rounding of F is 6e-4 of the stress (HIP
-    6e-4, f32 oracle 3e-4..6e-4 from the f64 oracle depending on the run; the gated sand cases are in the tests above)."""
+    dt estimator).  The 17-entry run is also held to the parity gate against the f64 oracle (this 1 200-particle stiff column at
+    0.1 m/s was at 6e-4 with the F-form arithmetic; the f32 oracle is at 3e-4)."""
     from sparkl_amd.models import ParticleModel, CorotatedLinearElasticity, DruckerPragerPlasticity
     from tests.parity import particle_errors as perr
 
@@ -598,7 +597,7 @@ def test_model_table_longer_than_the_lds_copy(Pipeline):
     e_hip, e_floor = perr(got[17][0], o64.get_particles(), sc.cell_width), perr(o32.get_particles(), o64.get_particles(), sc.cell_width)
     _report("many_models", {"table17_vs_table16": e, "vs_f64": e_hip, "oracle_f32_vs_f64": e_floor})
     assert e["eps_x"] <= 1e-6 and e["eps_v"] <= 1e-6 and e["eps_C"] <= 1e-6 and e["eps_F"] <= 1e-6 and e["failed_mismatch"] == 0, e
-    assert e_hip["eps_x"] <= max(TOL, e_floor["eps_x"]) and e_hip["failed_mismatch"] == 0, (e_hip, e_floor)
+    assert e_hip["eps_x"] <= TOL and e_hip["eps_v"] <= TOL and e_hip["failed_mismatch"] == 0, (e_hip, e_floor)
 
 
 def test_rebin_keeps_parity_and_ids(Pipeline):
