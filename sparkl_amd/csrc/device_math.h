@@ -360,9 +360,10 @@ SPK_DEV void jacobi_sym(float& pp, float& qq, float& pq, float& rp, float& rq, f
     const bool rot = fabsf(pq) > skip;
     if (!__any(rot)) return;              // wave-uniform: the converged tail costs three compares per sweep
     // branch-free per lane (a lane that does not rotate gets t = 0: c = 1, s = 0): no exec-masked copies of the twelve outputs
-    const float pqs = rot ? pq : 1.f;
-    const float zeta = (qq - pp) * fast_rcp(2.f * pqs);
-    float t = copysignf(1.f, zeta) * fast_rcp(fabsf(zeta) + fast_sqrt(1.f + zeta * zeta));
+    // t = tan(theta) = sgn(tau) 2 pq / (|tau| + sqrt(tau^2 + 4 pq^2)),  tau = qq - pp: one v_sqrt and one v_rcp (the textbook
+    // zeta = tau / (2 pq) form takes two reciprocals)
+    const float tau = qq - pp, p2 = pq + pq;
+    float t = copysignf(p2, tau * pq) * fast_rcp(fabsf(tau) + fast_sqrt(tau * tau + p2 * p2));
     t = rot ? t : 0.f;
     const float c = fast_rsq(1.f + t * t), sn = c * t;
     pp -= t * pq; qq += t * pq;

@@ -534,13 +534,10 @@ SPK_DEV int p2g_scatter_runs(double (*tile)[ACC_N], const Scatter& sc, bool live
         // this task's z-weight is  za + zb (x - zg)^2  (eval_all: 0.5 (1.5 - x)^2 | 0.75 - (x - 1)^2 | 0.5 (x - 0.5)^2)
         const float za = z == 1 ? 0.75f : 0.f, zb = z == 1 ? -1.f : 0.5f, zg = 1.5f - 0.5f * fz;
         f2v acc01[9], acc23[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { acc01[k] = f2v{0.f, 0.f}; acc23[k] = f2v{0.f, 0.f}; }
-#ifdef SPK_EXP_RUNS_NO_LOOP
-        for (int j = 0; j < 0; ++j) {
-#else
-        for (int j = 0; j < maxcnt; ++j) {
-#endif
+        // one particle of the task: its 9 nodes x (m, px, py, pz).  FIRST: the sums start from this particle's products (no zero
+        // fill of the 36 accumulators, no add to zero)
+        auto visit = [&](int j, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             const bool on = j < cnt;
             const int src = on ? first + j : start;                             // an idle iteration re-reads a lane of its own run
             const int addr = src << 2;
@@ -566,11 +563,17 @@ SPK_DEV int p2g_scatter_runs(double (*tile)[ACC_N], const Scatter& sc, bool live
                 for (int sx = 0; sx < 3; ++sx) {
                     if (sx > 0) { Q01 += X01; Q23 += X23; }
                     const float w = wx[sx] * wyz;
-                    acc01[3 * sy + sx] += Q01 * w;
-                    acc23[3 * sy + sx] += Q23 * w;
+                    if (FIRST) { acc01[3 * sy + sx] = Q01 * w; acc23[3 * sy + sx] = Q23 * w; }
+                    else { acc01[3 * sy + sx] += Q01 * w; acc23[3 * sy + sx] += Q23 * w; }
                 }
             }
-        }
+        };
+        visit(0, std::true_type{});
+#ifdef SPK_EXP_RUNS_NO_LOOP
+        for (int j = 1; j < 1; ++j) visit(j, std::false_type{});
+#else
+        for (int j = 1; j < maxcnt; ++j) visit(j, std::false_type{});
+#endif
         // the two halves of a run sit in neighbouring lanes (sub = 2 z + half): add the odd lane's sums into the even one, so
         // that one lane deposits per (run, plane) -- two lanes adding to the SAME address serialise in the LDS
         bool deposit = cnt > 0;
