@@ -240,11 +240,15 @@ SPK_DEV float monaghan_pressure(const DevModel& mo, float mass, float volume0, f
     const float density0 = mass / volume0;
     return fmaxf(mo.pressure0 * (powi_f(density_fluid / density0, mo.gamma) - 1.f), -mo.max_neg_pressure);
 }
+// the same with the density ratio rho / rho0 = 1 / F00 given directly (the reference forms (m / V0) / F00 / (m / V0): the same
+// number to 1e-7, three divisions)
+SPK_DEV float monaghan_pressure_ratio(const DevModel& mo, float ratio) {
+    return fmaxf(mo.pressure0 * (powi_f(ratio, mo.gamma) - 1.f), -mo.max_neg_pressure);
+}
 // NB: the reference glue passes plastic_deformation_gradient_det as `fluid_j`
 // (src/dynamics/models/eos_monaghan_sph.rs:12-20)
 SPK_DEV M3 monaghan_kirchhoff(const DevModel& mo, float mass, float volume0, float f00, float fluid_j, const M3& C) {
-    const float density_fluid = (mass / volume0) / f00;
-    const float p = -monaghan_pressure(mo, mass, volume0, density_fluid) * fluid_j;
+    const float p = -monaghan_pressure_ratio(mo, 1.0f / f00) * fluid_j;
     M3 tau = m3_zero();
     tau.m[0] = tau.m[4] = tau.m[8] = p;
     if (mo.viscosity != 0.f) {
@@ -253,7 +257,7 @@ SPK_DEV M3 monaghan_kirchhoff(const DevModel& mo, float mass, float volume0, flo
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int i = 0; i < 3; ++i) sr.m[i + 3 * j] = (C.m[i + 3 * j] + C.m[j + 3 * i]) * 0.5f;
-        const float sph = (sr.m[0] + sr.m[4] + sr.m[8]) / 3.f;
+        const float sph = (sr.m[0] + sr.m[4] + sr.m[8]) * (1.f / 3.f);
         sr.m[0] -= sph; sr.m[4] -= sph; sr.m[8] -= sph;
         const float k = 2.f * mo.viscosity * fluid_j;
 #pragma unroll

@@ -1768,11 +1768,12 @@ SPK_DEV void mass_scatter(double* mtile, const float px[3], float mass, bool liv
     const int orgv[3] = {org.x, org.y, org.z};
     float wgt[3][3];
     int lc[3];
+    const float inv_h = 1.0f / h;   // wave-uniform: one division, not six per particle
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float rc = roundf(px[a] / h);
+        const float rc = round_cell(px[a], h, inv_h);
         const float d0 = (rc - 1.0f) * h - px[a];
-        eval_all(-d0 / h, wgt[a]);
+        eval_all(-d0 * inv_h, wgt[a]);
         lc[a] = (int)rc - 1 - orgv[a] + 1;
     }
     const int base = live ? lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2] : 0;
@@ -1838,7 +1839,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
         const int i = pfirst + (active ? li : 0);
         const float4 q0 = n0, kk = nk;
         // a plain fluid keeps F1..F8 = identity and never reads its plastic scalars
-        const float4 q1 = FLUID_ONLY ? make_float4(0.f, 0.f, 0.f, 1.f) : n1, q2 = FLUID_ONLY ? make_float4(0.f, 0.f, 0.f, 1.f) : n2;
+        const float4 q1 = FLUID_ONLY ? make_float4(0.f, 0.f, 0.f, 0.f) : n1, q2 = FLUID_ONLY ? make_float4(0.f, 0.f, 0.f, 0.f) : n2;   // F - I
         const float4 dd = FLUID_ONLY ? make_float4(1.f, 0.f, 1.f, 0.f) : nd;
         if (it + 1 < niter) {
             const int inx = pfirst + min(li + BLK_THREADS, pcount - 1);
@@ -1923,7 +1924,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
             const int i = pfirst + (active ? li : 0);
             float4 q0 = P.q[0][i];
             const float4 q3 = P.q[3][i], q4 = P.q[4][i], q5 = P.q[5][i], kk = P.k[i];
-            const float4 q1 = FLUID_ONLY ? make_float4(0.f, 0.f, 0.f, 1.f) : P.q[1][i], q2 = FLUID_ONLY ? make_float4(0.f, 0.f, 0.f, 1.f) : P.q[2][i];
+            const float4 q1 = FLUID_ONLY ? make_float4(0.f, 0.f, 0.f, 0.f) : P.q[1][i], q2 = FLUID_ONLY ? make_float4(0.f, 0.f, 0.f, 0.f) : P.q[2][i];   // F - I
             const float jp_stored = P.d[i].z;
             const uint32_t flags = __float_as_uint(kk.w);
             live[k] = active && !(flags & FLAG_INVALID);
@@ -1937,9 +1938,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
                     int lc[3];
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
-                        const float r = roundf(px[a] / h);
+                        const float r = round_cell(px[a], h, inv_h);
                         const float d0 = (r - 1.0f) * h - px[a];
-                        eval_all(-d0 / h, wgt[a]);
+                        eval_all(-d0 * inv_h, wgt[a]);
                         lc[a] = (int)r - 1 - orgv[a] + 1;
                     }
                     const int vb = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
@@ -1951,9 +1952,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
 #pragma unroll
                             for (int sx = 0; sx < 3; ++sx)
                                 new_mass += (wgt[0][sx] * wgt[1][sy] * wgt[2][sz]) * vm[vb + sx + TILE_W * sy + TILE_W * TILE_W * sz];
-                    const float new_density = new_mass / (h * h * h);
-                    const float new_volume = kk.x / new_density;
-                    q0.w = new_volume / kk.y - 1.f;   // stored as F00 - 1
+                    // F00 = (m / (M / h^3)) / V0 as one quotient (the reference divides three times: the same number to 1e-7)
+                    q0.w = (kk.x * (h * h * h)) / (new_mass * kk.y) - 1.f;   // stored as F00 - 1
                     P.q[0][i] = q0;
                 }
                 const M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};   // F - I as stored
