@@ -219,9 +219,10 @@ SPK_DEV M3 neo_hookean_kirchhoff(const DevModel& mo, float phase, float hardenin
     const float j = m3_det(F);
     const float k = 2.f / 3.f * mo.mu * hardening + mo.lambda * hardening;
     M3 cg = m3_mul_bt(F, F);
-    const float sphp = (cg.m[0] + cg.m[4] + cg.m[8]) / 3.f;
+    const float sphp = (cg.m[0] + cg.m[4] + cg.m[8]) * (1.f / 3.f);
     cg.m[0] -= sphp; cg.m[4] -= sphp; cg.m[8] -= sphp;
-    const float kd = (mo.mu * hardening) * powf(j, -2.f / 3.f);
+    // J^(-2/3) = exp2(-2/3 log2 J) on the hardware exp / log units (J > 0 for any particle that has not failed; 1e-7 relative)
+    const float kd = (mo.mu * hardening) * (j > 0.f ? __builtin_amdgcn_exp2f((-2.f / 3.f) * __builtin_amdgcn_logf(j)) : powf(j, -2.f / 3.f));
     const float vol = k / 2.f * (j * j - 1.f);
     M3 tau;
     if (j >= 1.f) {
