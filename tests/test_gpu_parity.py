@@ -600,6 +600,33 @@ def test_model_table_longer_than_the_lds_copy(Pipeline):
     assert e_hip["eps_x"] <= TOL and e_hip["eps_v"] <= TOL and e_hip["failed_mismatch"] == 0, (e_hip, e_floor)
 
 
+@pytest.mark.parametrize("omega", [3.0, 30.0])
+def test_rotating_stiff_block_keeps_the_gate(Pipeline, omega):
+    """The strain-form arithmetic (E = F - I) is at its best when the rotation is small.  A stiff Drucker-Prager / corotated block
+    (E = 1e7) spinning about z in free flight for 200 substeps turns by 0.15 rad (omega = 3) or 1.5 rad (omega = 30): E becomes
+    O(theta) while the elastic strain stays ~1e-4 (centrifugal load), i.e. S = E + E^T + E^T E is a small difference of O(theta^2)
+    terms.  The gate must hold through that ("Limits")."""
+    from sparkl_amd.models import CorotatedLinearElasticity, DruckerPragerPlasticity
+    sc = scenes.block_on_floor(10, CorotatedLinearElasticity(1.0e7, 0.2), DruckerPragerPlasticity(1.0e7, 0.2), density=2700.0, v0=(0.0, 0.0, 0.0),
+                               gravity=(0.0, 0.0, 0.0), dt=2.5e-4, name="spinning_sand")
+    pos = sc.particles.position["point"]
+    c = pos.mean(axis=0, dtype=np.float64).astype(np.float32)
+    d = pos - c
+    sc.particles.velocity["vector"] = np.cross(np.broadcast_to(np.float32([0.0, 0.0, omega]), d.shape), d).astype(np.float32)
+    sc.particles.position["point"] = pos + np.float32([0.0, 3.0 * sc.cell_width, 0.0])     # clear of the floor for the whole run
+    dt = 2.5e-4
+    o32, o64 = _oracle(sc), _oracle(sc, f64=True)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        for _ in range(200):
+            o32.substep_fixed(sc.params, sc.gravity, dt)
+            o64.substep_fixed(sc.params, sc.gravity, dt)
+        p.substeps(sc.params, sc.gravity, dt, 200)
+        rep, bad = parity_verdict(p.read_particles(), o32.get_particles(), o64.get_particles(), sc.cell_width)
+    _report(f"rotating_block_omega{omega:g}", rep)
+    assert not bad, (bad, rep)
+
+
 def test_rebin_keeps_parity_and_ids(Pipeline):
     """A fast spinning cube crosses block boundaries: the re-bin must trigger and change nothing physically."""
     sc = scenes.elastic_cube(16)
