@@ -339,15 +339,19 @@ def main(args):
         # clock64 / wall_clock64 kernel: tools/debug/clock_probe.py, profiles/r02c_clock_probe.txt) -- exactly where the
         # driver's `--warmup 5 --steps 20` window (3..15 ms after the first launch) sits.  A GPU that is already busy does not
         # dip: a few plain fp32 matmuls on the bench stream are enough.  Nothing of the workload is skipped or moved.
-        with torch.cuda.stream(stream):
-            a = torch.randn(args.clock_wake_n, args.clock_wake_n, device="cuda")
-            b = torch.randn(args.clock_wake_n, args.clock_wake_n, device="cuda")
-            t_end = time.perf_counter() + args.clock_wake_ms * 1e-3
-            while time.perf_counter() < t_end:
-                for _ in range(4):
-                    c = a @ b
-                stream.synchronize()
-            del a, b, c
+        try:
+            with torch.cuda.stream(stream):
+                a = torch.randn(args.clock_wake_n, args.clock_wake_n, device="cuda")
+                b = torch.randn(args.clock_wake_n, args.clock_wake_n, device="cuda")
+                t_end = time.perf_counter() + args.clock_wake_ms * 1e-3
+                while time.perf_counter() < t_end:
+                    for _ in range(4):
+                        c = a @ b
+                    stream.synchronize()
+                del a, b, c
+        except Exception as e:   # the wake-up is a convenience: a missing BLAS must not cost the measurement
+            print(f"bench.py: clock wake-up skipped ({e})", file=sys.stderr)
+            args.clock_wake_ms = 0.0
     run(args.warmup)
     # event spans on every launch of a short timed region (the driver's --steps 20), on every 4th substep of a long one
     # (<1 % perturbation)
