@@ -129,6 +129,7 @@ SPK_DEV Svd3 svd3(const M3& a) {
     Svd3 r;
     r.w = a;
     r.v = m3_identity();
+#pragma unroll 1
     for (int sweep = 0; sweep < MAX_SWEEPS; ++sweep) {
         bool more = jacobi_pair(r.w.m + 0, r.w.m + 3, r.v.m + 0, r.v.m + 3);
         more |= jacobi_pair(r.w.m + 0, r.w.m + 6, r.v.m + 0, r.v.m + 6);
@@ -398,6 +399,7 @@ SPK_DEV Eig3 sym_eig3(const float S[6]) {
     // particle in free fall carries S = (rounding of F)^2 ~ 1e-12 of arbitrary structure -- three sweeps for nothing
     const float tol = fmaxf(fminf(1.0e-2f * scale, fmaxf(SPK_EIG_TOL_ABS, 1.0e-5f * scale)), SPK_EIG_FLOOR), skip = 1.0e-3f * tol;
     bool more = fmaxf(fabsf(s01), fmaxf(fabsf(s02), fabsf(s12))) > tol;
+#pragma unroll 1   // rolled: eight unrolled sweeps of three instances were 25 KB of a kernel that is 60 KB long
     for (int sweep = 0; sweep < SPK_SVD_SWEEPS && __any(more); ++sweep) {
         jacobi_sym(s00, s11, s01, s02, s12, r.v.m + 0, r.v.m + 3, skip);
         jacobi_sym(s00, s22, s02, s01, s12, r.v.m + 0, r.v.m + 6, skip);
