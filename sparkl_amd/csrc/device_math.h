@@ -425,23 +425,19 @@ SPK_DEV float log1p_rem(float x) {
     if (fabsf(x) < 0.1f) return x * x * (-0.5f + x * (1.f / 3.f + x * (-0.25f + x * (0.2f + x * (-1.f / 6.f + x * (1.f / 7.f + x * -0.125f))))));
     return log1pf(x) - x;
 }
-// Hencky strain of F = I + E:  eps = ln(F^T F) / 2  as a matrix (xx, yy, zz, xy, xz, yz) and in the eigenbasis of F^T F
-// (e_k = ln sigma_k).  The matrix takes S / 2 from S itself and only the remainder from the eigen-decomposition (see
-// sym_eig3).
-SPK_DEV Eig3 log_stretch(const M3& E, float e[3], float eps6[6]) {
-    float S[6];
+// Hencky strain of F = I + E,  eps = ln(F^T F) / 2,  in two parts: the matrix S / 2 (first order, exact) and, in the eigenbasis V of
+// S, the remainders re_k = (log1p(lam_k) - lam_k) / 2; e_k = ln sigma_k = lam_k / 2 + re_k.  eps = S / 2 + V diag(re) V^T is never
+// composed on its own: every consumer adds its own first-order matrix and its own remainders and composes once (see sym_eig3 for
+// why the split matters).
+SPK_DEV Eig3 log_stretch(const M3& E, float S[6], float e[3], float re[3]) {
     strain_metric(E, S);
     const Eig3 d = sym_eig3(S);
-    float re[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float lam = fmaxf(d.lam[k], -0.99999988f);
         re[k] = 0.5f * log1p_rem(lam);
         e[k] = 0.5f * lam + re[k];
     }
-    sym_compose(d.v, re, eps6);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) eps6[k] += 0.5f * S[k];
     return d;
 }
 
@@ -457,17 +453,11 @@ SPK_DEV M3 sym_to_m3(const SymStress& s) { return M3{{s.t[0], s.t[3], s.t[4], s.
 // DruckerPragerPlasticity::update_particle.  Updates F, Jp, q, lvg in place and returns the singular
 // values of the (possibly projected) F through sv[] for the pos-energy bookkeeping.
 // `T` (want_stress): the corotated stress of the final F for the fused kernel (eh = elastic hardening), left invalid when the model / phase do not qualify.
-// Corotated Kirchhoff stress (phase == 1) of F = I + E from the Hencky strain (matrix `eps6`, eigenbasis V / `e`):
+// Corotated Kirchhoff stress (phase == 1) of F = I + E:
 //   2 mu (F - R) F^T + lambda (J - 1) J I  =  2 mu F M F^T + lambda (J - 1) J I,   M = V diag((sigma - 1)/sigma) V^T = I - exp(-eps)
-// (elasticity_corotated_linear.rs:31-78; R = U V^T, U = F V Sigma^-1).  M = eps + V diag(-expm1(-e) - e) V^T: first order from
-// the matrix, remainder from the eigenbasis; J - 1 = det(I + E) - 1 without cancellation.
-SPK_DEV SymStress corotated_tau_e(const DevModel& mo, float hardening, const M3& E, const M3& V, const float e[3], const float eps6[6]) {
-    float g[3], m6[6];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) g[k] = -expm1_rem(-e[k]);
-    sym_compose(V, g, m6);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) m6[k] += eps6[k];
+// (elasticity_corotated_linear.rs:31-78; R = U V^T, U = F V Sigma^-1).  The caller hands M over as (xx, yy, zz, xy, xz, yz):
+// first order of eps as a matrix, remainder -expm1_rem(-e_k) in the eigenbasis.  J - 1 = det(I + E) - 1 without cancellation.
+SPK_DEV SymStress corotated_tau_e(const DevModel& mo, float hardening, const M3& E, const float m6[6]) {
     const M3 M = sym6_to_m3(m6);
     M3 A = m3_mul(E, M);                 // A = F M = M + E M
 #pragma unroll
@@ -490,9 +480,14 @@ SPK_DEV SymStress corotated_tau_e(const DevModel& mo, float hardening, const M3&
 
 // phase == 1 corotated stress of F = I + E
 SPK_DEV M3 corotated_kirchhoff_fe(const DevModel& mo, float hardening, const M3& E) {
-    float e[3], eps6[6];
-    const Eig3 d = log_stretch(E, e, eps6);
-    return sym_to_m3(corotated_tau_e(mo, hardening, E, d.v, e, eps6));
+    float S[6], e[3], re[3], g[3], m6[6];
+    const Eig3 d = log_stretch(E, S, e, re);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g[k] = re[k] - expm1_rem(-e[k]);
+    sym_compose(d.v, g, m6);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) m6[k] += 0.5f * S[k];
+    return sym_to_m3(corotated_tau_e(mo, hardening, E, m6));
 }
 SPK_DEV M3 corotated_kirchhoff_e(const DevModel& mo, float hardening, const M3& F) {
     M3 E = F;
@@ -507,46 +502,45 @@ SPK_DEV void dp_update_e(const DevModel& mo, float phase, float eh, M3& E, float
     sv_valid = false;
     T.valid = false;
     if (mo.only_active_when_failed && phase != 0.f) return;
-    float e[3], eps6[6];
-    const Eig3 d = log_stretch(E, e, eps6);
+    // eps = lin + V diag(dv) V^T throughout: `lin` the first-order matrix, `dv` the remainders in the eigenbasis, e_k its eigenvalues
+    float lin[6], e[3], dv[3];
+    const Eig3 d = log_stretch(E, lin, e, dv);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lin[i] *= 0.5f;
     const float alpha = dp_alpha(mo, q);
-    // strain = eps + (lvg / 3) I; its trace, deviator and norms from the MATRIX (first order exact in S)
-    const float tre = eps6[0] + eps6[1] + eps6[2];
+    // strain = eps + (lvg / 3) I.  Its invariants from the eigenvalues: tr and |dev|^2 miss only the SQUARE of the off-diagonal residue
+    const float tre = e[0] + e[1] + e[2], em = tre * (1.f / 3.f);
     const float tr = tre + lvg;
-    const float dev6[6] = {eps6[0] - tre * (1.f / 3.f), eps6[1] - tre * (1.f / 3.f), eps6[2] - tre * (1.f / 3.f), eps6[3], eps6[4], eps6[5]};
-    const float dn2 = (dev6[0] * dev6[0] + dev6[1] * dev6[1] + dev6[2] * dev6[2]) + 2.f * (dev6[3] * dev6[3] + dev6[4] * dev6[4] + dev6[5] * dev6[5]);
-    // three outcomes: tensile (sigma' = 1), inside the yield surface (F stays), projection onto the cone; folded into one
-    // straight line (K = ln(Sigma' / Sigma) as a matrix and in the eigenbasis, `moved`) so that the stress below is formed once
-    // per wave, not once per divergent branch
-    float K6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, k[3] = {0.f, 0.f, 0.f}, dq = 0.f;
+    const float dn2 = (e[0] - em) * (e[0] - em) + (e[1] - em) * (e[1] - em) + (e[2] - em) * (e[2] - em);
+    // three outcomes: tensile (sigma' = 1), inside the yield surface (F stays), projection onto the cone; folded into one straight
+    // line: K = ln(Sigma' / Sigma) = klin + V diag(kd) V^T with eigenvalues k, `moved`
+    float klin[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, kd[3] = {0.f, 0.f, 0.f}, k[3] = {0.f, 0.f, 0.f}, dq = 0.f;
     bool moved = false;
     if (dn2 == 0.f || tr > 0.f) {
-        // |strain|^2 = |dev eps|^2 + (tr eps + lvg)^2 / 3
-        dq = fast_sqrt(dn2 + tr * tr * (1.f / 3.f));
+        dq = fast_sqrt(dn2 + tr * tr * (1.f / 3.f));     // |strain|^2 = |dev eps|^2 + (tr eps + lvg)^2 / 3
 #pragma unroll
-        for (int i = 0; i < 6; ++i) K6[i] = -eps6[i];
+        for (int i = 0; i < 6; ++i) klin[i] = -lin[i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) k[i] = -e[i];
+        for (int i = 0; i < 3; ++i) { kd[i] = -dv[i]; k[i] = -e[i]; }
         moved = true;
     } else {
         const float dn = fast_sqrt(dn2);
         const float gamma = dn + mo.p_k * tr * alpha;   // p_k = (3 lambda + 2 mu) / (2 mu), precomputed on the host
         if (gamma > 0.f) {                              // otherwise inside the yield surface
             const float gdn = gamma * fast_rcp(dn);
-            // ln sigma' = strain - gdn dev  =>  K = (lvg / 3) I - gdn dev(eps)
+            // ln sigma' = strain - gdn dev(strain)  =>  K = (lvg / 3) I - gdn dev(eps)
+            const float lm = (lin[0] + lin[1] + lin[2]) * (1.f / 3.f), dm = (dv[0] + dv[1] + dv[2]) * (1.f / 3.f), c = lvg * (1.f / 3.f);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) K6[i] = -gdn * dev6[i];
-            K6[0] += lvg * (1.f / 3.f); K6[1] += lvg * (1.f / 3.f); K6[2] += lvg * (1.f / 3.f);
-            const float em = (e[0] + e[1] + e[2]) * (1.f / 3.f);
+            for (int i = 0; i < 3; ++i) { klin[i] = c - gdn * (lin[i] - lm); kd[i] = -gdn * (dv[i] - dm); k[i] = c - gdn * (e[i] - em); }
 #pragma unroll
-            for (int i = 0; i < 3; ++i) k[i] = lvg * (1.f / 3.f) - gdn * (e[i] - em);
+            for (int i = 3; i < 6; ++i) klin[i] = -gdn * lin[i];
             dq = gamma;
             moved = true;
         }
     }
     if (moved) {
         // prev_det = prod sigma = exp(tr eps), new_det = prod sigma' = exp(tr eps + tr K)
-        const float so = tre, sn = tre + (K6[0] + K6[1] + K6[2]);
+        const float so = tre, sn = tre + (k[0] + k[1] + k[2]);
         const float pm1 = expm1_small(so);
         float nm1 = expm1_small(sn), lnew = sn;
         const float diff = nm1 - pm1;
@@ -554,24 +548,33 @@ SPK_DEV void dp_update_e(const DevModel& mo, float phase, float eh, M3& E, float
         Jp *= (1.f + pm1) * fast_rcp(1.f + nm1);
         lvg += so - lnew;
         q += dq;
-        // F' = F V diag(sigma'/sigma) V^T = F (I + G),  G = exp(K) - I = K + V diag(expm1(k) - k) V^T  =>  E' = E + G + E G
-        float kr[3], g6[6];
+        // F' = F V diag(sigma'/sigma) V^T = F (I + G),  G = exp(K) - I = klin + V diag(kd + expm1_rem(k)) V^T  =>  E' = E + G + E G
+        float gr[3], g6[6];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) kr[i] = expm1_rem(k[i]);
-        sym_compose(d.v, kr, g6);
+        for (int i = 0; i < 3; ++i) gr[i] = kd[i] + expm1_rem(k[i]);
+        sym_compose(d.v, gr, g6);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { g6[i] += K6[i]; eps6[i] += K6[i]; }
+        for (int i = 0; i < 6; ++i) { g6[i] += klin[i]; lin[i] += klin[i]; }
         const M3 G = sym6_to_m3(g6);
         const M3 EG = m3_mul(E, G);
 #pragma unroll
         for (int i = 0; i < 9; ++i) E.m[i] += G.m[i] + EG.m[i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) e[i] += k[i];
+        for (int i = 0; i < 3; ++i) { e[i] += k[i]; dv[i] += kd[i]; }
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) sm1[i] = expm1_small(e[i]);
     sv_valid = true;
-    if (WANT_STRESS && mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR && phase == 1.f) T = corotated_tau_e(mo, eh, E, d.v, e, eps6);
+    if (WANT_STRESS && mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR && phase == 1.f) {
+        // M = I - exp(-eps') = eps' - V diag(expm1_rem(-e')) V^T = lin + V diag(dv - expm1_rem(-e')) V^T: one composition
+        float mr[3], m6[6];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) mr[i] = dv[i] - expm1_rem(-e[i]);
+        sym_compose(d.v, mr, m6);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m6[i] += lin[i];
+        T = corotated_tau_e(mo, eh, E, m6);
+    }
 }
 
 // SnowPlasticity::update_particle (plasticity_snow.rs:26-48)
@@ -704,8 +707,8 @@ SPK_DEV float model_pos_energy(const DevModel& mo, float phase, float eh, const 
         float s[3];
         if (sv_valid) { s[0] = sm1[0]; s[1] = sm1[1]; s[2] = sm1[2]; }
         else {
-            float eps[3], eps6[6];
-            (void)log_stretch(E, eps, eps6);
+            float S6[6], eps[3], re[3];
+            (void)log_stretch(E, S6, eps, re);
             s[0] = expm1_small(eps[0]); s[1] = expm1_small(eps[1]); s[2] = expm1_small(eps[2]);
         }
         float nsq = 0.f;
