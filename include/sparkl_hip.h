@@ -354,6 +354,22 @@ typedef struct {
 } SparklReorderStats;
 int sparkl_hip_reorder_policy_stats(SparklPipeline* p, SparklReorderStats* out);
 
+/* Structure check of the binning, the counterpart of the reference's debug validator `check_active_blocks`
+ * (src/cuda/cuda_sparse_grid.rs:492-650; its call at :479-486 is commented out there): particle ids unique and in range
+ * (single-device pipelines), every node block resolved by the hash and the block list Morton-sorted, every particle inside the
+ * tile of the particle block that holds it (its associated cell at most one cell outside the 4x4x4 block), all 27 neighbour
+ * blocks of a particle block present, block ranges contiguous, disjoint and covering exactly the valid particles.  Re-bins first
+ * if the particle set changed.  Every counter is 0 on a healthy pipeline. */
+typedef struct {
+    uint64_t bad_particle_ids;
+    uint64_t blocks_not_in_hash;
+    uint64_t particles_outside_their_block;
+    uint64_t missing_neighbour_blocks;
+    uint64_t coverage_errors;
+    uint64_t node_blocks, particle_blocks;   /* sizes checked */
+} SparklGridCheck;
+int sparkl_hip_grid_check(SparklPipeline* p, SparklGridCheck* out);
+
 /* Counters of the stepping loops since the pipeline was created.  Adaptive step (sparkl_hip_pipeline_step): out[0] substeps that reused the
  * scatter fused into the previous G2P, out[1] substeps that had to scatter again (the predicted step length was wrong),
  * out[2] substeps executed from a look-ahead plan (the rest of the frame enqueued at once while the dt bound repeats),

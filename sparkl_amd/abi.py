@@ -196,6 +196,11 @@ class KernelClockC(C.Structure):
                 ("p2g_mass_launches", C.c_uint64), ("grid_update_mass_launches", C.c_uint64), ("g2p_volume_launches", C.c_uint64)]
 
 
+class GridCheckC(C.Structure):
+    _fields_ = [("bad_particle_ids", C.c_uint64), ("blocks_not_in_hash", C.c_uint64), ("particles_outside_their_block", C.c_uint64),
+                ("missing_neighbour_blocks", C.c_uint64), ("coverage_errors", C.c_uint64), ("node_blocks", C.c_uint64), ("particle_blocks", C.c_uint64)]
+
+
 class ReorderStatsC(C.Structure):
     _fields_ = [("last_heads", C.c_uint32), ("base_heads", C.c_uint32), ("reorders", C.c_uint32), ("policy_rebins", C.c_uint32)]
 

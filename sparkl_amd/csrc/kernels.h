@@ -2474,6 +2474,58 @@ __global__ void k_plane_range(const int4* __restrict__ pb_info, int npb, int axi
     atomicMin(&out[0], plane);
     atomicMax(&out[1], plane);
 }
+// ---- structure validator (cuda_sparse_grid.rs:492-650 `check_active_blocks`, the reference's debug check of the binning) ----
+// counters: [0] particle ids out of range or duplicated, [1] node blocks the hash does not resolve to themselves,
+//           [2] particles whose associated cell is outside the tile of the particle block that holds them (or outside the domain
+//               without being flagged), [3] missing blocks in the 27-neighbourhood of a particle block, [4] dispatch coverage errors
+//               (block ranges not contiguous / not disjoint)
+__global__ void k_check_ids(ParticleArrays P, int n, uint32_t id_base, uint32_t* seen, unsigned long long* cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t id = particle_id(P, i) - id_base;
+    if (id >= (uint32_t)n || atomicAdd(&seen[id], 1u) != 0u) atomicAdd(&cnt[0], 1ull);
+}
+__global__ void k_check_blocks(const uint32_t* __restrict__ blk_keys, int nb, HashTable H, unsigned long long* cnt) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    if (hash_lookup(H, (uint64_t)blk_keys[b]) != b) atomicAdd(&cnt[1], 1ull);
+    if (b > 0 && !(blk_keys[b - 1] < blk_keys[b])) atomicAdd(&cnt[1], 1ull);      // Morton-sorted, unique
+}
+__global__ void k_check_pblocks(GridArrays G, int n_valid, unsigned long long* cnt) {
+    const int pb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pb >= G.num_pblocks) return;
+    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int b = org.w;
+    if (b < 0 || b >= G.num_blocks) { atomicAdd(&cnt[3], 27ull); return; }
+    for (int k = 0; k < 27; ++k) if (G.blk_nbr[b * 27 + k] < 0) atomicAdd(&cnt[3], 1ull);
+    const int4 o = G.blk_origin[b];
+    if (o.x != org.x || o.y != org.y || o.z != org.z || o.w != pb) atomicAdd(&cnt[4], 1ull);   // block <-> tile cross links
+    const int expect = pb == 0 ? 0 : G.pb_info[2 * (pb - 1) + 1].x + G.pb_info[2 * (pb - 1) + 1].y;
+    if (rng.x != expect || rng.y <= 0) atomicAdd(&cnt[4], 1ull);
+    if (pb == G.num_pblocks - 1 && rng.x + rng.y != n_valid) atomicAdd(&cnt[4], 1ull);
+}
+__global__ __launch_bounds__(BLK_THREADS) void k_check_particles(ParticleArrays P, GridArrays G, float h, int dom, unsigned long long* cnt) {
+    const int pb = blockIdx.x;
+    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int orgv[3] = {org.x, org.y, org.z};
+    for (int li = threadIdx.x; li < rng.y; li += BLK_THREADS) {
+        const int i = rng.x + li;
+        const float4 q0 = P.q[0][i];
+        const uint32_t flags = reinterpret_cast<const uint32_t*>(&P.k[i])[3];
+        if (flags & FLAG_INVALID) continue;
+        const float px[3] = {q0.x, q0.y, q0.z};
+        bool bad = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float r = roundf(px[a] / h);
+            if (!((r >= 1.0f) && (r < (float)(dom - 4)))) { bad = true; continue; }
+            const int nl = (int)r - 1 - orgv[a];
+            if (nl < -1 || nl > 4) bad = true;     // one cell of drift around the block is what the tile covers
+        }
+        if (bad) atomicAdd(&cnt[2], 1ull);
+    }
+}
+
 // compact the nodes with mass != 0 for grid_read_nodes
 __global__ void k_dump_nodes(GridArrays G, SparklGridNode* out, unsigned long long cap, unsigned long long* count) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

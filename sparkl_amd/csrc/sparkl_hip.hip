@@ -1502,6 +1502,53 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
     return rc;
 }
 
+// cuda_sparse_grid.rs:492-650 (`check_active_blocks`, the reference's debug validator of the binning), on the current state
+int sparkl_hip_grid_check(SparklPipeline* p, SparklGridCheck* out) {
+    if (!p || !out) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    memset(out, 0, sizeof(*out));
+    HIPCHK(hipSetDevice(p->device));
+    CHK(validate_models(p));
+    if (!p->sorted) CHK(resort(p));
+    hipStream_t st = p->stream;
+    const int n = (int)p->n;
+    DevBuf<unsigned long long> cnt;
+    DevBuf<uint32_t> seen;
+    CHK(cnt.reserve(8));
+    HIPCHK(hipMemsetAsync(cnt.p, 0, 8 * sizeof(unsigned long long), st));
+    if (n > 0) {
+        CHK(seen.reserve((size_t)n));
+        HIPCHK(hipMemsetAsync(seen.p, 0, (size_t)n * sizeof(uint32_t), st));
+        if (!p->slab_on) hipLaunchKernelGGL(k_check_ids, dim3(grid_for(n, 256)), dim3(256), 0, st, p->cur.arrays(), n, (uint32_t)p->id_offset, seen.p, cnt.p);
+    }
+    if (p->num_blocks > 0) {
+        HashTable H{p->hash_keys.p, p->hash_vals.p, p->hash_mask};
+        hipLaunchKernelGGL(k_check_blocks, dim3(grid_for(p->num_blocks, 256)), dim3(256), 0, st, p->blk_keys.p, p->num_blocks, H, cnt.p);
+    }
+    if (p->num_pblocks > 0) {
+        // particles flagged out of the domain sit behind the last block range
+        int n_valid = 0;
+        {
+            std::vector<int4> last(2);
+            HIPCHK(hipMemcpyAsync(last.data(), p->pb_info.p + 2 * (size_t)(p->num_pblocks - 1), 2 * sizeof(int4), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            n_valid = last[1].x + last[1].y;
+            if (n_valid > n) n_valid = -1;    // reported as a coverage error by the kernel
+        }
+        const GridArrays G = grid_arrays(p);
+        hipLaunchKernelGGL(k_check_pblocks, dim3(grid_for(p->num_pblocks, 256)), dim3(256), 0, st, G, n_valid, cnt.p);
+        hipLaunchKernelGGL(k_check_particles, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, st, p->cur.arrays(), G, p->h, p->dom, cnt.p);
+    }
+    unsigned long long h[8] = {0};
+    HIPCHK(hipMemcpyAsync(h, cnt.p, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    out->bad_particle_ids = h[0]; out->blocks_not_in_hash = h[1]; out->particles_outside_their_block = h[2];
+    out->missing_neighbour_blocks = h[3]; out->coverage_errors = h[4];
+    out->node_blocks = (uint64_t)p->num_blocks; out->particle_blocks = (uint64_t)p->num_pblocks;
+    cnt.release(); seen.release();
+    return SPARKL_OK;
+}
+
 int sparkl_hip_pipeline_step_stats(SparklPipeline* p, uint64_t out[5]) {
     if (!p || !out) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
     out[0] = p->spec_hits; out[1] = p->spec_misses; out[2] = p->lookahead_substeps; out[3] = p->lookahead_mismatches;

@@ -211,6 +211,12 @@ class MpmPipeline:
         check(self.L.sparkl_hip_pipeline_step_stats(self.h, out))
         return {"fused_hits": out[0], "fused_misses": out[1], "lookahead_substeps": out[2], "lookahead_mismatches": out[3], "c_regathers": out[4]}
 
+    def grid_check(self):
+        """The reference's `check_active_blocks` (cuda_sparse_grid.rs:492-650) on the current binning: a dict of violation counts."""
+        k = abi.GridCheckC()
+        check(self.L.sparkl_hip_grid_check(self.h, C.byref(k)))
+        return {name: int(getattr(k, name)) for name, _ in abi.GridCheckC._fields_}
+
     def reorder_policy_stats(self):
         st = abi.ReorderStatsC()
         check(self.L.sparkl_hip_reorder_policy_stats(self.h, C.byref(st)))

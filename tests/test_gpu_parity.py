@@ -627,6 +627,41 @@ def test_rotating_stiff_block_keeps_the_gate(Pipeline, omega):
     assert not bad, (bad, rep)
 
 
+def test_grid_structure_check_like_the_reference_validator(Pipeline):
+    """`sparkl_hip_grid_check` = the reference's `check_active_blocks` (cuda_sparse_grid.rs:492-650): ids unique and in range, every node
+    block in the hash, particles inside the tile of their particle block, the 27-neighbourhood of every particle block present,
+    block ranges contiguous and covering the particles -- on a spinning cube through a dozen re-bins, on the sand column with its
+    floor (particles drift inside their tiles between re-bins), after an append / remove_range, and on an empty set."""
+    keys = ("bad_particle_ids", "blocks_not_in_hash", "particles_outside_their_block", "missing_neighbour_blocks", "coverage_errors")
+    sc = scenes.elastic_cube(16)
+    sc.particles.velocity["vector"] *= 40.0
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        assert all(v == 0 for v in p.grid_check().values())          # empty pipeline
+        p.load_scene(sc)
+        p.clock_enable(True)
+        for _ in range(6):
+            p.substeps(sc.params, sc.gravity, 2.0e-4, 10)
+            c = p.grid_check()
+            assert all(c[k] == 0 for k in keys), c
+            assert c["particle_blocks"] > 0 and c["node_blocks"] >= c["particle_blocks"]
+        assert p.clock_read().resorts >= 4
+        # the particles that left the domain are flagged, not miscounted
+        n = len(p)
+        p.remove_range(10, 200)
+        extra = scenes.elastic_cube(6).particles
+        p.append_particles(extra)
+        c = p.grid_check()
+        assert all(c[k] == 0 for k in keys), c
+        assert len(p) == n - 190 + len(extra)
+    sc = scenes.sand_column(16, 10, 12, with_block=True)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, 2.5e-4, 150)
+        c = p.grid_check()
+        _report("grid_check", c)
+        assert all(c[k] == 0 for k in keys), c
+
+
 def test_rebin_keeps_parity_and_ids(Pipeline):
     """A fast spinning cube crosses block boundaries: the re-bin must trigger and change nothing physically."""
     sc = scenes.elastic_cube(16)
