@@ -312,6 +312,12 @@ public:
         for (auto* m : members) raw.push_back(m->h_);
         check(sparkl_hip_group_substeps(raw.data(), (uint32_t)raw.size(), &params, gravity.data(), dt, n));
     }
+    // `check_active_blocks` of the reference (cuda_sparse_grid.rs:492-650): every counter of the result is 0 on a healthy pipeline
+    SparklGridCheck grid_check() { SparklGridCheck c; check(sparkl_hip_grid_check(h_, &c)); return c; }
+    bool grid_is_consistent() {
+        const SparklGridCheck c = grid_check();
+        return !(c.bad_particle_ids | c.blocks_not_in_hash | c.particles_outside_their_block | c.missing_neighbour_blocks | c.coverage_errors);
+    }
     // device order of a slab pipeline: positions / velocities as stored, plus the global id of every record
     void read_device_order(std::vector<SparklParticlePosition>& pos, std::vector<SparklParticleVelocity>& vel, std::vector<uint32_t>& ids) {
         const size_t n = len();

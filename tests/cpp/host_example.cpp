@@ -107,6 +107,8 @@ int main(int argc, char** argv) {
             const bool ok = total == all.len() && std::fabs(got[0] - ref[0]) <= 1e-6 * std::fabs(ref[0]) && std::fabs(got[1] - ref[1]) <= 2e-3 * std::fabs(ref[1]);
             std::printf("slabs: %zu + %zu particles, sum_y %.9g vs %.9g, sum_vy %.9g vs %.9g, %s\n", lo.len(), hi.len(), got[0], ref[0], got[1], ref[1], ok ? "ok" : "MISMATCH");
         }
+        // the reference's debug validator of the binning (check_active_blocks), through the library
+        std::printf("grid check: %s\n", pipeline.grid_is_consistent() ? "ok" : "INCONSISTENT");
         // error behaviour: Custom models cannot cross the C ABI
         ParticleModelSet bad;
         ParticleModel custom;

@@ -39,6 +39,7 @@ def test_cpp_host_matches_python_host():
     assert "custom: rejected code 2" in out
     assert "slabs:" in out and out.split("slabs:")[1].splitlines()[0].rstrip().endswith("ok")   # two slabs stepped inside the library, no Python
     assert "readback: snapshot" in out and out.split("readback:")[1].splitlines()[0].rstrip().endswith("ok")
+    assert "grid check: ok" in out    # sparkl_hip_grid_check (the reference's check_active_blocks) through the C++ mirror
     # same scene through the Python mirror
     h, r = 0.2, 0.05
     models = ParticleModelSet()
