@@ -277,6 +277,8 @@ def main(args):
     t0 = time.time()
     pipe.load_scene(sc)
     upload_s = time.time() - t0
+    if os.environ.get("SPARKL_BENCH_REORDER_HEADS"):   # experiments: in-place reorder threshold in run heads per particle (library default 0.6)
+        pipe.reorder_policy_set(float(os.environ["SPARKL_BENCH_REORDER_HEADS"]) * n_particles, 0.0)
     in_library = mode == "slabs" and comm_mode == "rccl"
     group = None
     if in_library:
