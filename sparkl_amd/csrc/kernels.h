@@ -1390,7 +1390,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
         const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
         const Advected o = g2p_update<RARE>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
         g2p_store(P, i, o);
-        want_sort |= !o.in_tile;
+        want_sort |= !o.in_tile && !(o.flags & FLAG_INVALID);   // a particle that left the DOMAIN is dead (skipped from now on): no re-bin for it
         if (S.want_dt) {  // the bound the next substep's estimator would compute from this state
             const float b = particle_dt_bound(mo, o.flags, o.vel, o.C, kk.x, kk.y, o.eh, 1.f + o.Fe.m[0], S.h);
             dt_nan |= b != b;
@@ -1484,7 +1484,7 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
             const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
             const Advected o = g2p_update<RARE, true>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
                         g2p_store(P, i, o, S.defer_c);
-            want_sort |= !o.in_tile;
+            want_sort |= !o.in_tile && !(o.flags & FLAG_INVALID);   // a particle that left the DOMAIN is dead (skipped from now on): no re-bin for it
             live = o.in_tile;
             if (S.want_dt) {  // the bound the next substep's estimator would compute from this state
                 const float bnd = particle_dt_bound(mo, o.flags, o.vel, o.C, kk.x, kk.y, o.eh, 1.f + o.Fe.m[0], S.h);
@@ -1862,7 +1862,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
             } else {
                 g2p_store(P, i, o);
             }
-            want_sort |= !o.in_tile;
+            want_sort |= !o.in_tile && !(o.flags & FLAG_INVALID);   // a particle that left the DOMAIN is dead (skipped from now on): no re-bin for it
             live = o.in_tile;
             npx[0] = o.px[0]; npx[1] = o.px[1]; npx[2] = o.px[2];
             if (S.want_dt) {

@@ -818,6 +818,35 @@ def test_out_of_domain_particles_fail_like_reference(Pipeline):
     np.testing.assert_array_equal(pos["point"][:2], sc.particles.position["point"][:2])  # frozen
 
 
+def test_particles_trickling_out_of_the_domain_do_not_force_a_rebin_each(Pipeline):
+    """A block flying through the low face of the SPGrid loses a layer of particles every few substeps.  Each of them is flagged
+    failed (particle_set.rs:129-136) and frozen -- and that is all: it is dead weight in its block until the next regular re-bin
+    sorts it behind the valid particles.  (Requesting a re-bin for every particle that leaves the domain cost one re-bin per
+    substep: the 10M column went from 0.88 to 6.9 ms per substep once its foot reached the wall, tools/debug/soak.py.)  The
+    survivors must still match the oracle."""
+    sc = scenes.elastic_cube(12)
+    sc.particles.velocity["vector"][:] = np.float32([-20.0, 0.0, 0.0])
+    dt = 2.5e-4
+    o32, o64 = _oracle(sc), _oracle(sc, f64=True)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.clock_enable(True)
+        for _ in range(240):
+            o32.substep_fixed(sc.params, sc.gravity, dt)
+            o64.substep_fixed(sc.params, sc.gravity, dt)
+        p.substeps(sc.params, sc.gravity, dt, 240)
+        k = p.clock_read()
+        got, chk = p.read_particles(), p.grid_check()
+    ref = o64.get_particles()
+    failed = got.status["failed"] == 1
+    _report("trickle_out", {"failed": int(failed.sum()), "failed_oracle": int((ref.status["failed"] == 1).sum()), "resorts": int(k.resorts), "n": len(failed)})
+    assert failed.sum() >= 200 and (~failed).sum() >= 200, "the scene must lose part of the block through the wall"
+    assert k.resorts <= 16, f"{int(k.resorts)} re-bins in 240 substeps: particles leaving the domain must not force one each"
+    assert all(chk[c] == 0 for c in ("bad_particle_ids", "blocks_not_in_hash", "particles_outside_their_block", "missing_neighbour_blocks", "coverage_errors")), chk
+    rep, bad = parity_verdict(got, o32.get_particles(), ref, sc.cell_width)
+    assert not bad, (bad, rep)
+
+
 def test_unsupported_models_are_rejected(Pipeline):
     from sparkl_amd._lib import SparklHipError
     from sparkl_amd.models import ParticleModelSet
