@@ -5,11 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 from sparkl_amd import scenes
 from sparkl_amd.pipeline import MpmPipeline
-sc = scenes.sand_column(200, 250, 200)
+which = sys.argv[1] if len(sys.argv) > 1 else "sand"
+sc = scenes.sand_column(200, 250, 200) if which == "sand" else (scenes.fluid_dam(344, 240, 244) if which == "fluid" else scenes.elastic_cube(100))
+nchunks = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
     p.load_scene(sc)
     p.clock_enable(True, stride=8)
-    for chunk in range(8):
+    for chunk in range(nchunks):
         p.clock_read(reset=True)
         p.sync(); t0 = time.perf_counter()
         p.substeps(sc.params, sc.gravity, sc.fixed_dt, 500)
