@@ -138,6 +138,7 @@ struct DevHeightField {
     float t[3];
     float friction;
     int below_is_solid;
+    float ymin, ymax;       // range of heights * scale[1] (local frame): a point farther above than the search reach cannot be near the surface
 };
 
 // Triangle mesh: 30 floats per triangle (a, b, c | pseudo-normals of a, b, c | of the edges ab, ac, bc | face normal; the
@@ -877,6 +878,10 @@ SPK_DEV bool heightfield_project(const DevHeightField& hf, const float ptw[3], f
     float rel[3] = {ptw[0] - hf.t[0], ptw[1] - hf.t[1], ptw[2] - hf.t[2]};
     float lp[3];
     quat_rot(hf.q, rel, -1.f, lp);
+    // vertical early-out: no triangle within `reach` of a point that is more than `reach` above the highest sample or below the lowest
+    // one (the search below returns false for those as well, after visiting up to 128 triangles).  In a 25 m column this is 99 % of the
+    // grid nodes: the grid update with the sand3 ground went 0.124 -> 0.05 ms at 10M particles.
+    if (lp[1] > hf.ymax + reach || lp[1] < hf.ymin - reach) return false;
     const float cw = 1.f / (float)(hf.ncols - 1), ch = 1.f / (float)(hf.nrows - 1);
     const float ux = lp[0] / hf.scale[0] + 0.5f, uz = lp[2] / hf.scale[2] + 0.5f;
     const float rx = reach / fabsf(hf.scale[0]), rz = reach / fabsf(hf.scale[2]);

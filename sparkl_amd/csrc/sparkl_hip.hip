@@ -894,6 +894,11 @@ int sparkl_hip_colliders_set_heightfields(SparklPipeline* p, uint32_t n, const S
         for (int a = 0; a < 3; ++a) { dh[i].scale[a] = c[i].scale[a]; dh[i].t[a] = c[i].translation[a]; }
         for (int a = 0; a < 4; ++a) dh[i].q[a] = c[i].rotation[a];
         dh[i].friction = c[i].friction; dh[i].below_is_solid = c[i].below_is_solid;
+        {
+            float lo = c[i].heights[0] * c[i].scale[1], hi = lo;
+            for (size_t k = 1; k < cnt; ++k) { const float y = c[i].heights[k] * c[i].scale[1]; lo = std::min(lo, y); hi = std::max(hi, y); }
+            dh[i].ymin = lo; dh[i].ymax = hi;
+        }
     }
     CHK(p->d_heightfields.reserve(std::max<uint32_t>(n, 1)));
     if (n) HIPCHK(hipMemcpy(p->d_heightfields.p, dh.data(), n * sizeof(DevHeightField), hipMemcpyHostToDevice));
