@@ -375,10 +375,13 @@ int sparkl_hip_grid_check(SparklPipeline* p, SparklGridCheck* out);
  * out[2] substeps executed from a look-ahead plan (the rest of the frame enqueued at once while the dt bound repeats),
  * out[3] plans cut short because the bound changed (the substeps behind the change ran as no-ops and were re-planned),
  * out[4] (fixed-dt batches, sparkl_hip_pipeline_substeps) times the deferred part of the velocity gradient was rebuilt
- * because a batch stopped for a re-bin (k_regather_c; SPARKL_HIP_DEFER_C=0 stores it every substep instead).
+ * because a batch stopped for a re-bin (k_regather_c; SPARKL_HIP_DEFER_C=0 stores it every substep instead),
+ * out[5] / out[6] (adaptive step with force_fluids_volume_recomputation) substeps that ran with the volume sweep fused into the
+ * substep kernels on a predicted step length, and predictions the estimator refuted (those substeps were repeated in the
+ * reference's order; SPARKL_HIP_FLUID_STEP_FUSE=0 turns the prediction off).
  * SPARKL_HIP_LOOKAHEAD=0 in the environment at pipeline creation turns the look-ahead off; =force plans ahead even when
  * the bound has not repeated (test hook for the mismatch path). */
-int sparkl_hip_pipeline_step_stats(SparklPipeline* p, uint64_t out[5]);
+int sparkl_hip_pipeline_step_stats(SparklPipeline* p, uint64_t out[7]);
 /* Elapsed GPU time (ms, hipEvents on the pipeline's stream) and launch count of the
  * p2g / grid_update / g2p kernels accumulated since the last reset. */
 typedef struct {

@@ -1115,6 +1115,20 @@ __global__ __launch_bounds__(1024) void k_dt_reduce(const uint32_t* __restrict__
     }
 }
 
+// Adaptive stepping with the fluid volume sweep fused (sparkl_hip_pipeline_step): the scatter of k_vol_p2g was built for a step length
+// the host PREDICTED; this runs right behind the estimator pass on the recomputed volumes and checks the prediction against
+// min(remaining, max_substep_dt, bound) with the min_dt rule of mls_solver.rs:57-59.  A different value turns the rest of THIS
+// substep (grid update, G2P) into no-ops; the host repeats it the long way.
+__global__ void k_dt_check(Ctl* ctl, float remaining, float max_substep_dt, float min_dt, uint32_t expect_dt_bits, int parity) {
+    const float bound = __uint_as_float(ctl->dt_bits);
+    float d = fminf(fminf(remaining, max_substep_dt), bound);
+    if (d < min_dt && remaining > min_dt) d = min_dt;
+    if ((__float_as_uint(d) != expect_dt_bits || ctl->dt_nan) && !ctl->abort_flag[parity]) {
+        ctl->abort_flag[parity] = 1u;
+        ctl->dt_mismatch = 1u;
+    }
+}
+
 // grid_to_particle.rs:146-163 (enable_boundary_particle_projection): a particle found inside a collider is put back on its
 // surface and its velocity corrected by the displacement / dt.  Colliders in the order of the grid update.
 SPK_DEV void project_particle_on_colliders(const GridArrays& G, const StepParams& S, float px[3], float vel[3]) {

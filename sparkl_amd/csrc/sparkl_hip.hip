@@ -128,6 +128,9 @@ struct SparklPipeline {
     bool slab_balance = true;        // sparkl_hip_slab_balance
     bool all_plain_fluid = false;   // every model is a fluid without plastic / failure model: the FLUID_ONLY kernels apply
     bool mass_tiles_ready = false;  // k_g2p_mass of the previous substep already scattered the next volume sweep's masses
+    bool fluid_bound_valid = false; // adaptive step with the volume sweep: the last dt bound seen (predicts the next step length)
+    float fluid_bound = 0.f;
+    uint64_t fluid_fused_substeps = 0, fluid_fused_mismatches = 0;
     DevBuf<DevCuboid> d_cuboids;
     int num_cuboids = 0;
     DevBuf<DevHeightField> d_heightfields;
@@ -627,7 +630,9 @@ static int enqueue_fused_batch(SparklPipeline* p, const SparklSolverParams* sp, 
 // Fixed-dt batch with force_fluids_volume_recomputation:  M ; { GUm ; V+P ; GU ; G+M } x n  (see k_g2p_mass / k_vol_p2g).
 // Same arithmetic as the unfused sweep (mass scatter, mass merge, volume gather, P2G, grid update, G2P), two passes over the
 // particles per substep instead of four.
-static int enqueue_fluid_batch(SparklPipeline* p, const SparklSolverParams* sp, const float g[3], float dt, uint32_t n) {
+// `check` (adaptive step, n == 1): {remaining, min_dt}; the estimator runs on the recomputed volumes right behind k_vol_p2g and
+// k_dt_check validates `dt` against it (see k_dt_check)
+static int enqueue_fluid_batch(SparklPipeline* p, const SparklSolverParams* sp, const float g[3], float dt, uint32_t n, const float* check = nullptr) {
     if (p->num_pblocks == 0) { p->substep_index += n; return SPARKL_OK; }
     hipStream_t st = p->stream;
     GridArrays G = grid_arrays(p);
@@ -656,6 +661,15 @@ static int enqueue_fluid_batch(SparklPipeline* p, const SparklSolverParams* sp, 
         CHK(clock_begin(p, SPAN_P2G, &tk));
         if (fluid_only) SPK_LAUNCH_MODELS(k_vol_p2g, true); else SPK_LAUNCH_MODELS(k_vol_p2g, false);
         CHK(clock_end(p, tk));
+        if (check) {
+            uint32_t dt_bits;
+            memcpy(&dt_bits, &dt, 4);
+            CHK(clock_begin(p, SPAN_DT, &tk));
+            hipLaunchKernelGGL(k_estimate_dt, dim3(grid_for(p->n, BLK_THREADS)), block, 0, st, P, p->d_models.p, p->d_ctl, (int)p->n, p->h, p->dt_partial.p);
+            hipLaunchKernelGGL(k_dt_reduce, dim3(1), dim3(1024), 0, st, p->dt_partial.p, (int)grid_for(p->n, BLK_THREADS), p->d_ctl, 0u, 0);
+            hipLaunchKernelGGL(k_dt_check, dim3(1), dim3(1), 0, st, p->d_ctl, check[0], sp->max_substep_dt, check[1], dt_bits, S.parity);
+            CHK(clock_end(p, tk));
+        }
         CHK(maybe_reorder(p, S.parity));
         CHK(clock_begin(p, SPAN_GRID, &tk));
         launch_grid_update(p, G, S, st);
@@ -1375,7 +1389,51 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
     // the dt estimate of every substep, so the bound G2P left behind (computed from the volumes before the recompute) is not
     // the reference's: the estimator pass runs every substep in that mode.
     const bool fluid_volumes = params->force_fluids_volume_recomputation && p->any_fluid;
+    // With force_fluids_volume_recomputation the step length of a substep is only known after ITS volume sweep, which sits in
+    // front of ITS scatter -- the unfused order costs seven kernels (2.5 ms at 20M particles).  The fused sweep of the fixed-dt
+    // batches (k_g2p_mass / k_vol_p2g) is used here too: the scatter is built for the PREDICTED length min(remaining,
+    // max_substep_dt, last bound), the estimator runs right behind the volume gather and k_dt_check compares; a wrong prediction
+    // no-ops the rest of the substep, which is then repeated in the reference's order.  Still one host read per substep.
+    const bool fluid_fused = fluid_volumes && p->fuse_fixed_dt && !p->rare_models && !psi_sweep_on(p, params) && !(getenv("SPARKL_HIP_FLUID_STEP_FUSE") && !strcmp(getenv("SPARKL_HIP_FLUID_STEP_FUSE"), "0"));
+    if (fluid_fused) CHK(read_ctl(p));   // steps_done as of now
+    uint32_t pending = 0;                // substeps enqueued since the last read of the control block (they always run: the read before them found no re-bin request)
     while (remaining > 0.0f) {
+        // ... and only when the prediction does not hinge on the bound itself: a step limited by `remaining` or max_substep_dt survives a
+        // bound that moves a little, a bound-limited one is refuted whenever the bound changes in its last bit (every substep of an
+        // accelerating flow), and a refuted attempt costs 60 % of a substep
+        float d = p->fluid_bound_valid ? std::fmin(std::fmin(remaining, params->max_substep_dt), p->fluid_bound) : 0.f;
+        if (fluid_fused && p->fluid_bound_valid && d < p->fluid_bound && p->num_pblocks > 0 && !(p->h_ctl->abort_flag[0] || p->h_ctl->abort_flag[1])) {
+            if (d < min_dt && remaining > min_dt) d = min_dt;
+            const float chk[2] = {remaining, min_dt};
+            const uint32_t idx0 = p->substep_index, done0 = p->h_ctl->steps_done + pending;
+            pending = 0;
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dt_bits, (int)init_bits, 1, p->stream));
+            CHK(enqueue_fluid_batch(p, params, gravity, d, 1, chk));
+            HIPCHK(hipGetLastError());
+            CHK(read_ctl(p));
+            if (p->h_ctl->steps_done == done0 + 1) {          // the substep ran: the prediction held
+                memcpy(&p->fluid_bound, &p->h_ctl->dt_bits, 4);
+                p->fluid_fused_substeps++;
+                ++nsub;
+                remaining -= d;
+                have_bound = false;
+                if (p->h_ctl->abort_flag[0] || p->h_ctl->abort_flag[1]) { CHK(resort(p)); CHK(read_ctl(p)); }   // it also asked for a re-bin
+                if (params->stop_after_one_substep) { result = d; break; }
+                continue;
+            }
+            p->substep_index = idx0;
+            p->mass_tiles_ready = false;
+            if (!p->h_ctl->dt_mismatch) {                     // a re-bin request stopped it
+                CHK(resort(p));
+                CHK(read_ctl(p));
+                continue;
+            }
+            // wrong prediction (or a NaN bound): clear the chain, take this substep in the reference's order
+            p->fluid_fused_mismatches++;
+            HIPCHK(hipMemsetAsync(p->d_ctl, 0, 2 * sizeof(uint32_t), p->stream));
+            HIPCHK(hipMemsetAsync(&p->d_ctl->dt_mismatch, 0, sizeof(uint32_t), p->stream));
+            HIPCHK(hipMemsetAsync(&p->d_ctl->dt_nan, 0, sizeof(uint32_t), p->stream));
+        }
         // one host sync per substep, as in the reference (cuda_mpm_pipeline.rs:393-398)
         if (fluid_volumes) have_bound = false;
         for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1393,6 +1451,7 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
                 CHK(clock_end(p, tok));
             }
             CHK(read_ctl(p));
+            pending = 0;
             if (!(p->h_ctl->abort_flag[0] || p->h_ctl->abort_flag[1])) break;
             CHK(resort(p));
             spec_tiles = false;
@@ -1403,6 +1462,7 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
         if (p->h_ctl->dt_nan) { rc = set_error(SPARKL_ERR_NAN_TIMESTEP, "NaN timestep bound (the reference panics: timestep_estimator.rs:46)"); break; }
         float bound;
         memcpy(&bound, &p->h_ctl->dt_bits, 4);
+        if (fluid_volumes) { p->fluid_bound = bound; p->fluid_bound_valid = true; p->mass_tiles_ready = false; }
         auto pick = [&](float rem) {
             float d = std::fmin(std::fmin(rem, params->max_substep_dt), bound);   // timestep_estimator.rs:25,35,44
             if (d < min_dt && rem > min_dt) d = min_dt;                              // mls_solver.rs:57-59
@@ -1474,6 +1534,7 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dt_bits, (int)init_bits, 1, p->stream));
         CHK(enqueue_adaptive_substep(p, params, gravity, dt, reuse, dt_guess));
         HIPCHK(hipGetLastError());
+        pending = 1;
         spec_tiles = dt_guess > 0.f && p->num_pblocks > 0;
         memcpy(&spec_dt_bits, &dt_guess, 4);
         have_bound = p->num_pblocks > 0;
@@ -1554,10 +1615,11 @@ int sparkl_hip_grid_check(SparklPipeline* p, SparklGridCheck* out) {
     return SPARKL_OK;
 }
 
-int sparkl_hip_pipeline_step_stats(SparklPipeline* p, uint64_t out[5]) {
+int sparkl_hip_pipeline_step_stats(SparklPipeline* p, uint64_t out[7]) {
     if (!p || !out) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
     out[0] = p->spec_hits; out[1] = p->spec_misses; out[2] = p->lookahead_substeps; out[3] = p->lookahead_mismatches;
     out[4] = p->c_regathers;
+    out[5] = p->fluid_fused_substeps; out[6] = p->fluid_fused_mismatches;
     return SPARKL_OK;
 }
 

@@ -207,9 +207,10 @@ class MpmPipeline:
 
     def step_stats(self):
         """Counters of the adaptive step: fused-scatter hits / misses, look-ahead substeps / mismatches."""
-        out = (C.c_uint64 * 5)()
+        out = (C.c_uint64 * 7)()
         check(self.L.sparkl_hip_pipeline_step_stats(self.h, out))
-        return {"fused_hits": out[0], "fused_misses": out[1], "lookahead_substeps": out[2], "lookahead_mismatches": out[3], "c_regathers": out[4]}
+        return {"fused_hits": out[0], "fused_misses": out[1], "lookahead_substeps": out[2], "lookahead_mismatches": out[3], "c_regathers": out[4],
+                "fluid_fused_substeps": out[5], "fluid_fused_mismatches": out[6]}
 
     def grid_check(self):
         """The reference's `check_active_blocks` (cuda_sparse_grid.rs:492-650) on the current binning: a dict of violation counts."""

@@ -136,12 +136,17 @@ def test_config1_sand3_50k_parity(Pipeline):
         assert not bad, (bad, rep)
 
 
-def test_adaptive_step_on_fluid_recomputes_volumes(Pipeline):
+@pytest.mark.parametrize("frame_dt,max_substep_dt", [(2.0e-3, None), (2.0e-2, 6.0e-3), (0.1, 1.0)])
+def test_adaptive_step_on_fluid_recomputes_volumes(Pipeline, frame_dt, max_substep_dt):
     """`MpmPipeline::step` on a fluid scene: mls_solver.rs:46-48 recomputes the fluid volumes after the sort and before the dt
     estimate of EVERY adaptive substep (force_fluids_volume_recomputation, set by fluids3)."""
     sc = scenes.fluid_dam(24, 16, 16)
     assert sc.params.force_fluids_volume_recomputation
-    sc.params.dt = 2.0e-3            # a few adaptive substeps per call
+    # one substep per call | four per call, all predictable (max_substep_dt binds) | the estimator's bound binds and moves from
+    # substep to substep: the predictions are refuted and the substeps repeated in the reference's order
+    sc.params.dt = frame_dt
+    if max_substep_dt is not None:
+        sc.params.max_substep_dt = max_substep_dt
     o32, o64 = _oracle(sc), _oracle(sc, f64=True)
     with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
         p.load_scene(sc)
@@ -152,9 +157,16 @@ def test_adaptive_step_on_fluid_recomputes_volumes(Pipeline):
             assert t_got == pytest.approx(t_ref, rel=1e-7)
             assert tim.num_substeps == len(o32.last_dts()), (frame, tim.num_substeps, o32.last_dts())
         rep, bad = parity_verdict(p.read_particles(), o32.get_particles(), o64.get_particles(), sc.cell_width)
-    _report("adaptive_step_fluid", rep)
+        st = p.step_stats()
+    _report(f"adaptive_step_fluid_{frame_dt:g}", {**rep, "substeps_last_frame": int(tim.num_substeps), "fluid_fused_substeps": int(st["fluid_fused_substeps"]), "fluid_fused_mismatches": int(st["fluid_fused_mismatches"])})
     assert not bad, (bad, rep)
     assert rep["vs_f32"]["eps_F"] < 1e-4     # the recompute really ran: F00 = rho0 / rho_grid follows the oracle's
+    # the volume sweep ran fused into the substep kernels on predicted step lengths (the first substep of the first frame has no
+    # bound to predict from); refuted predictions were repeated in the reference's order -- either way the substep lengths above are
+    # the oracle's
+    assert st["fluid_fused_substeps"] + st["fluid_fused_mismatches"] >= 1, st
+    if max_substep_dt == 6.0e-3:
+        assert tim.num_substeps == 4 and st["fluid_fused_substeps"] >= 8, (tim.num_substeps, st)
 
 
 def test_step_in_a_spreading_sparse_scene_regrows_its_buffers(Pipeline):
