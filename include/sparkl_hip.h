@@ -47,7 +47,8 @@ typedef struct {                                                     /* :64-72, 
     float mass;
     float volume0;
     float radius0;
-    float deformation_gradient[9];            /* column-major (nalgebra Matrix3) */
+    float deformation_gradient[9];            /* column-major (nalgebra Matrix3).  The library keeps F - I per particle (exact on upload for
+                                               * 0.5 <= F_kk <= 2, one rounding when F is formed for a read-back): DESIGN.md 5 */
     float plastic_deformation_gradient_det;
 } SparklParticleVolume;
 typedef struct {                                                     /* :114-122, 24 B */
