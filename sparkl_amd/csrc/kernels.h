@@ -66,6 +66,10 @@ struct Ctl {
     // adaptive step, look-ahead: k_dt_reduce found a bound other than the one the already enqueued substeps were planned
     // with and stopped them through the abort chain (the abort is NOT a re-bin request; the host clears both)
     uint32_t dt_mismatch;
+    // velocity bound h / (|v| + 6 sqrt(3) (h^2/4) |C| / h) of the particles that left the domain (float bits, min): the reference keeps
+    // them in the set with their last v and C, so `adaptive_timestep_length` (timestep_estimator.rs:25-35) still sees them, while no
+    // kernel here visits them any more.  Rebuilt at every re-bin, extended by G2P when a particle dies; k_dt_reduce folds it in.
+    uint32_t dead_dt_bits;
 };
 
 struct ParticleArrays {
@@ -1058,6 +1062,11 @@ SPK_DEV void load_vel_tile(float4* vt, const GridArrays& G, int b, int tid) {
 }
 
 // timestep_estimator.rs:21-44: velocity (APIC) bound and constitutive-model bound of one particle
+SPK_DEV float velocity_dt_bound(const float v[3], const M3& C, float h) {
+    const float d = (h * h) / 4.f;
+    const float apic_v = (d * m3_frob(C)) * 6.f * sqrtf(3.f) / h;
+    return fminf(3.402823466e+38f, h / (sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) + apic_v));
+}
 SPK_DEV float particle_dt_bound(const DevModel& mo, uint32_t flags, const float v[3], const M3& C, float mass, float vol0, float eh, float f00, float h) {
     const float d = (h * h) / 4.f;
     const float apic_v = (d * m3_frob(C)) * 6.f * sqrtf(3.f) / h;
@@ -1109,6 +1118,7 @@ __global__ __launch_bounds__(1024) void k_dt_reduce(const uint32_t* __restrict__
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 16; ++w) m = min(m, s[w]);
+        m = min(m, ctl->dead_dt_bits);
         ctl->dt_bits = m;
         if (expect_bits != 0u && (m != expect_bits || ctl->dt_nan) && !ctl->abort_flag[next_parity]) {
             ctl->abort_flag[next_parity] = 1u;
@@ -1345,6 +1355,8 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
         flags |= FLAG_FAILED | FLAG_INVALID;
         in_tile = false;
         atomicAdd(num_invalid, 1u);
+        // num_invalid sits in Ctl: the dead particles' dt bound is its neighbour (see Ctl::dead_dt_bits)
+        atomicMin(num_invalid + (offsetof(Ctl, dead_dt_bits) - offsetof(Ctl, num_invalid)) / 4, __float_as_uint(velocity_dt_bound(vel, C, h)));
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) { o.px[a] = px[a]; o.vel[a] = vel[a]; }
@@ -2139,7 +2151,7 @@ constexpr uint64_t KEY_EMIG_HI = ~0ull - 2;      // home block beyond the slab's
 constexpr uint64_t KEY_INVALID = ~0ull - 1;      // outside the SPGrid domain (frozen, failed)
 constexpr uint64_t KEY_REMOVED = ~0ull;          // already handed to a neighbour slab: dropped by this re-bin
 
-__global__ void k_compute_keys(ParticleArrays P, uint64_t* keys, uint32_t* idx, int n, float h, int dom, int slab_axis, int slab_lo, int slab_hi) {
+__global__ void k_compute_keys(ParticleArrays P, uint64_t* keys, uint32_t* idx, int n, float h, int dom, int slab_axis, int slab_lo, int slab_hi, Ctl* ctl) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 q0 = P.q[0][i];
@@ -2166,6 +2178,12 @@ __global__ void k_compute_keys(ParticleArrays P, uint64_t* keys, uint32_t* idx, 
     } else if ((flags & (FLAG_INVALID | FLAG_FAILED)) != (FLAG_INVALID | FLAG_FAILED)) {
         flags |= FLAG_INVALID | FLAG_FAILED;  // particle_set.rs:132-135
         reinterpret_cast<uint32_t*>(&P.k[i])[3] = flags;
+    }
+    if (key == KEY_INVALID) {   // outside the domain: only its velocity bound still takes part in the adaptive step (Ctl::dead_dt_bits)
+        const float4 q3 = P.q[3][i], q4 = P.q[4][i], q5 = P.q[5][i];
+        const float v[3] = {q3.x, q3.y, q3.z};
+        const M3 C = {{q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
+        atomicMin(&ctl->dead_dt_bits, __float_as_uint(velocity_dt_bound(v, C, h)));
     }
     keys[i] = key;
     idx[i] = (uint32_t)i;

@@ -306,8 +306,9 @@ static int resort(SparklPipeline* p) {
         CHK(p->d_scalars.reserve(4));
         p->alt.has_frac = p->cur.has_frac;
         CHK(p->alt.reserve(p->cur.q[0].cap));
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dead_dt_bits, 0x7f7fffff, 1, st));   // rebuilt from the particles that are outside the domain now
         hipLaunchKernelGGL(k_compute_keys, dim3(grid_for(n, 256)), dim3(256), 0, st, p->cur.arrays(), p->keys_a.p, p->idx_a.p, n, p->h, p->dom, p->slab_axis,
-                           p->slab_on ? p->slab_lo : INT32_MIN, p->slab_on ? p->slab_hi : INT32_MAX);
+                           p->slab_on ? p->slab_lo : INT32_MIN, p->slab_on ? p->slab_hi : INT32_MAX, p->d_ctl);
         // key bits actually in use: Morton code of the block coordinate biased by +1 (3 x block_bits) + 6 cell bits; the tail
         // classes (emigrants, out of domain, removed) are all-ones words, so ONE more bit keeps them behind every valid key and
         // their two low bits order them among themselves.  dom = 256 (the default 2^30-byte grid): 28 bits = 4 radix passes
@@ -732,6 +733,7 @@ int sparkl_hip_pipeline_create(const SparklPipelineDesc* desc, SparklPipeline** 
         return set_error(SPARKL_ERR_OUT_OF_MEMORY, "control block allocation failed");
     }
     (void)hipMemset(p->d_ctl, 0, sizeof(Ctl));
+    (void)hipMemsetD32((hipDeviceptr_t)&p->d_ctl->dead_dt_bits, 0x7f7fffff, 1);
     memset(p->h_ctl, 0, sizeof(Ctl));
     *out = p;
     return SPARKL_OK;

@@ -859,6 +859,41 @@ def test_particles_trickling_out_of_the_domain_do_not_force_a_rebin_each(Pipelin
     assert not bad, (bad, rep)
 
 
+def test_dead_particles_still_bound_the_adaptive_step(Pipeline):
+    """The reference keeps particles that left the SPGrid in the set, failed and frozen with their last velocity, and
+    `adaptive_timestep_length` (timestep_estimator.rs:25-35) applies the velocity bound h / |v| to every particle: a fast particle that
+    died keeps limiting dt for the rest of the run.  No kernel visits dead particles here, so their bound is carried in the control block
+    (Ctl::dead_dt_bits).  Twelve particles shot through the wall at 120 m/s: substep counts and state must follow the oracle frame after
+    frame (without the carried bound the step length jumps back to the stiffness bound as soon as they are gone: 6 substeps per frame)."""
+    sc = scenes.sand_column(12, 8, 8)
+    # twelve particles of the column become a small free-flying cluster between the column (x >= 4 h) and the low wall, two and a half
+    # cells away from everything else, heading for the wall at 120 m/s: they are gone within the first frame
+    shot = np.arange(12)
+    h = sc.cell_width
+    mid = sc.particles.position["point"].mean(axis=0)
+    k = np.arange(12)
+    sc.particles.position["point"][shot] = np.stack([np.float32(1.5 * h) + np.float32(0.25 * h) * (k % 2), mid[1] + np.float32(0.25 * h) * ((k // 2) % 2),
+                                                     mid[2] + np.float32(0.25 * h) * (k // 4)], axis=1).astype(np.float32)
+    sc.particles.velocity["vector"][shot] = np.float32([-120.0, 0.0, 0.0])
+    o32, o64 = _oracle(sc), _oracle(sc, f64=True)
+    counts = []
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        for frame in range(3):
+            t_ref = o32.step(sc.params, sc.gravity)
+            o64.step(sc.params, sc.gravity)
+            t_got, tim = p.step(sc.params, sc.gravity, timings=True)
+            counts.append((int(tim.num_substeps), len(o32.last_dts())))
+            assert t_got == pytest.approx(t_ref, rel=1e-7)
+            assert tim.num_substeps == len(o32.last_dts()), counts
+        got = p.read_particles()
+    _report("dead_particles_dt", {"substeps_hip_oracle": counts, "failed": int((got.status["failed"] == 1).sum())})
+    assert (got.status["failed"][shot] == 1).all() and got.status["failed"].sum() == len(shot)
+    assert counts[-1][0] >= 10, "the dead particles' velocity must still bound the step (6 substeps per frame without it)"
+    rep, bad = parity_verdict(got, o32.get_particles(), o64.get_particles(), sc.cell_width)
+    assert not bad, (bad, rep)
+
+
 def test_unsupported_models_are_rejected(Pipeline):
     from sparkl_amd._lib import SparklHipError
     from sparkl_amd.models import ParticleModelSet
