@@ -143,6 +143,8 @@ struct DevHeightField {
     float friction;
     int below_is_solid;
     float ymin, ymax;       // range of heights * scale[1] (local frame): a point farther above than the search reach cannot be near the surface
+    const float2* coarse;   // [(nrows + 2) / 4][(ncols + 2) / 4] (min, max) of heights * scale[1] over blocks of 4 x 4 heightfield cells, column-major like `heights`
+    int crows, ccols;
 };
 
 // Triangle mesh: 30 floats per triangle (a, b, c | pseudo-normals of a, b, c | of the edges ab, ac, bc | face normal; the
@@ -894,6 +896,18 @@ SPK_DEV bool heightfield_project(const DevHeightField& hf, const float ptw[3], f
     // bounded work even for heightfield cells much finer than the MPM grid: an 8 x 8 window centred on the point
     if (j1 - j0 > 7) { j0 = min(max((int)floorf(ux / cw) - 3, 0), max(hf.ncols - 9, 0)); j1 = min(j0 + 7, hf.ncols - 2); }
     if (i1 - i0 > 7) { i0 = min(max((int)floorf(uz / ch) - 3, 0), max(hf.nrows - 9, 0)); i1 = min(i0 + 7, hf.nrows - 2); }
+    if (i1 < i0 || j1 < j0) return false;
+    // the same vertical test against the height range of the window only (blocks of 4 x 4 cells): under a sinusoidal ground most nodes
+    // of the band |y - ground range| < reach are still too far from the piece of ground below them
+    if (hf.coarse) {
+        float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
+        for (int ci = i0 >> 2; ci <= (i1 >> 2); ++ci)
+            for (int cj = j0 >> 2; cj <= (j1 >> 2); ++cj) {
+                const float2 r = hf.coarse[ci + hf.crows * cj];
+                lo = fminf(lo, r.x); hi = fmaxf(hi, r.y);
+            }
+        if (lp[1] > hi + reach || lp[1] < lo - reach) return false;
+    }
     float best = 3.402823466e+38f, bp[3] = {0.f, 0.f, 0.f};
     for (int i = i0; i <= i1; ++i)
         for (int j = j0; j <= j1; ++j) {

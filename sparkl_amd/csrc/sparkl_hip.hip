@@ -914,6 +914,25 @@ int sparkl_hip_colliders_set_heightfields(SparklPipeline* p, uint32_t n, const S
             float lo = c[i].heights[0] * c[i].scale[1], hi = lo;
             for (size_t k = 1; k < cnt; ++k) { const float y = c[i].heights[k] * c[i].scale[1]; lo = std::min(lo, y); hi = std::max(hi, y); }
             dh[i].ymin = lo; dh[i].ymax = hi;
+            // (min, max) over blocks of 4 x 4 cells = 5 x 5 samples; cell (r, c) spans samples r..r+1, c..c+1
+            const int nr = (int)c[i].nrows, nc = (int)c[i].ncols;
+            const int cr = (nr - 1 + 3) / 4, cc = (nc - 1 + 3) / 4;
+            std::vector<float2> coarse((size_t)cr * cc);
+            for (int bj = 0; bj < cc; ++bj)
+                for (int bi = 0; bi < cr; ++bi) {
+                    float l = std::numeric_limits<float>::max(), h2 = -l;
+                    for (int cj = 4 * bj; cj <= std::min(4 * bj + 4, nc - 1); ++cj)
+                        for (int ri = 4 * bi; ri <= std::min(4 * bi + 4, nr - 1); ++ri) {
+                            const float y = c[i].heights[ri + (size_t)nr * cj] * c[i].scale[1];
+                            l = std::min(l, y); h2 = std::max(h2, y);
+                        }
+                    coarse[bi + (size_t)cr * bj] = make_float2(l, h2);
+                }
+            float2* dc = nullptr;
+            HIPCHK(hipMalloc((void**)&dc, coarse.size() * sizeof(float2)));
+            p->d_heights.push_back(reinterpret_cast<float*>(dc));     // freed with the height arrays
+            HIPCHK(hipMemcpy(dc, coarse.data(), coarse.size() * sizeof(float2), hipMemcpyHostToDevice));
+            dh[i].coarse = dc; dh[i].crows = cr; dh[i].ccols = cc;
         }
     }
     CHK(p->d_heightfields.reserve(std::max<uint32_t>(n, 1)));
