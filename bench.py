@@ -255,7 +255,7 @@ def main(args):
     from sparkl_amd.slab import INT32_MAX, INT32_MIN, HipSlabBackend, SlabStepper
 
     # weak scaling: rank k owns the k-th x-slab of a column `world` times longer (config 5's decomposition);
-    # each slab holds `particles` particles, cut on block planes, ghost node-block planes swapped every substep
+    # each slab holds `particles` particles, cut on block planes, the shared node planes swapped every substep
     mode = os.environ.get("SPARKL_BENCH_MODE", "slabs" if world > 1 else "single")
     t0 = time.time()
     sc, material, desc, nx = build_scene(args, rank, world, mode)
@@ -433,7 +433,7 @@ def main(args):
             "config": {"workload": desc, "name": args.config, "particles_per_gpu": n_particles,
                        "active_node_blocks": n_blocks, "particle_blocks": n_pblocks,
                        "parallelism": "single GPU" if world == 1 else (
-                           f"{world} x-slabs of one {world * nx}-long column, ghost node-block planes swapped with both neighbours every substep "
+                           f"{world} x-slabs of one {world * nx}-long column, the four shared node planes of every cut swapped with both neighbours every substep "
                            f"({'RCCL send/recv inside libsparkl_hip.so (sparkl_hip_group_substeps)' if in_library else backend + ' send/recv from the Python SlabStepper'}), "
                            f"re-bin flag all-reduce" if mode == "slabs" else f"{world} independent replicas")},
             "step_gbs": step_bytes * world / (elapsed / args.steps) / 1e9,

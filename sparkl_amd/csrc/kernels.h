@@ -2460,29 +2460,31 @@ __global__ void k_tail_bounds(const uint64_t* __restrict__ keys, int n, int* out
         if (a >= T[k] && (i == 0 || b < T[k])) atomicMin(&out[k], i);
 }
 
-// Halo record: key + 64 x (mass, px, py, pz) of one node block (1040 B, 16-B aligned payload)
+// Halo record: the 64 nodes two slabs share in ONE column of blocks across a cut.  A particle sits at most one cell outside its home
+// block (the tile margin), so the slab below the cut reaches the first three node planes of the block above it (nodes 4 cut .. 4 cut + 2)
+// and the slab above reaches the last plane of the block below (node 4 cut - 1): 16 + 48 nodes, not the 2 x 64 of both blocks.
+//   nodes[0..15]  = plane 3 of the LOWER block (axis coordinate 3; the other two coordinates u + 4 v)
+//   nodes[16..63] = planes 0, 1, 2 of the UPPER block (16 each)
+// `key` = block key of the UPPER block position (whether or not that block is active on the sender).  1040 B, 16-B aligned payload.
 struct HaloRecord {
     unsigned long long key;
     unsigned long long pad;
     float4 nodes[64];
 };
-// node blocks in the two block planes adjacent to a cut (plane indices cut-1 and cut along slab_axis)
-__global__ void k_halo_list(const int4* __restrict__ blk_origin, int nb, int axis, int cut, int* list, int* count) {
+SPK_DEV int nbr_slot(int axis, int d) { return axis == 0 ? (d + 1) + 3 + 9 : (axis == 1 ? 1 + 3 * (d + 1) + 9 : 1 + 3 + 9 * (d + 1)); }
+SPK_DEV int plane_node(int axis, int c, int u, int v) { return axis == 0 ? c + 4 * u + 16 * v : (axis == 1 ? u + 4 * c + 16 * v : u + 4 * v + 16 * c); }
+// columns with an active block on either side of the cut.  Entry = (upper block << 1), or (lower block << 1) | 1 when the block above it
+// is not active here (a column is listed once)
+__global__ void k_halo_list(const int4* __restrict__ blk_origin, const int* __restrict__ blk_nbr, int nb, int axis, int cut, int* list, int* count) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     const int4 o = blk_origin[b];
     const int bs = (axis == 0 ? o.x : (axis == 1 ? o.y : o.z)) >> 2;
-    if (bs == cut - 1 || bs == cut) list[atomicAdd(count, 1)] = b;
+    if (bs == cut) list[atomicAdd(count, 1)] = b << 1;
+    else if (bs == cut - 1 && blk_nbr[b * 27 + nbr_slot(axis, +1)] < 0) list[atomicAdd(count, 1)] = (b << 1) | 1;
 }
-// one wave per listed block: this slab's partial (mass, momentum) of its 64 nodes, gathered from own tiles
-__global__ __launch_bounds__(BLK_THREADS) void k_halo_pack(GridArrays G, const uint32_t* __restrict__ blk_keys, const int* __restrict__ list, int n,
-                                                            HaloRecord* out, const Ctl* __restrict__ ctl, int parity) {
-    if (ctl->abort_flag[parity]) return;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n) return;
-    const int b = list[r];
-    const int lane = threadIdx.x & 63;
-    const int cx = lane & 3, cy = (lane >> 2) & 3, cz = lane >> 4;
+// this slab's partial (mass, momentum) of node (cx, cy, cz) of block b, gathered from its own tiles
+SPK_DEV float4 halo_node_sum(const GridArrays& G, int b, int cx, int cy, int cz) {
     const int dx0 = cx <= 2 ? -1 : 0, dy0 = cy <= 2 ? -1 : 0, dz0 = cz <= 2 ? -1 : 0;
     float m = 0.f, px = 0.f, py = 0.f, pz = 0.f;
 #pragma unroll
@@ -2500,23 +2502,59 @@ __global__ __launch_bounds__(BLK_THREADS) void k_halo_pack(GridArrays G, const u
                 const float4 v = tile_read(G, t, tx, ty, tz);
                 m += v.x; px += v.y; py += v.z; pz += v.w;
             }
-    out[r].nodes[lane] = make_float4(m, px, py, pz);
-    if (lane == 0) { out[r].key = (unsigned long long)blk_keys[b]; out[r].pad = 0ull; }
+    return make_float4(m, px, py, pz);
 }
-// add the neighbour's partial sums into halo_in (zeroed every substep); unknown blocks are ignored: no local
-// particle touches them
-__global__ __launch_bounds__(BLK_THREADS) void k_halo_merge(const HaloRecord* __restrict__ in, int n, HashTable H, float4* halo_in,
+// one wave per listed column
+__global__ __launch_bounds__(BLK_THREADS) void k_halo_pack(GridArrays G, const uint32_t* __restrict__ blk_keys, const int* __restrict__ list, int n, int axis,
+                                                            HaloRecord* out, const Ctl* __restrict__ ctl, int parity) {
+    if (ctl->abort_flag[parity]) return;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int e = list[r];
+    const int lane = threadIdx.x & 63;
+    int upper = (e & 1) ? -1 : (e >> 1), lower = (e & 1) ? (e >> 1) : G.blk_nbr[(e >> 1) * 27 + nbr_slot(axis, -1)];
+    const bool lo_part = lane < 16;
+    const int b = lo_part ? lower : upper;
+    const int c = lo_part ? 3 : (lane - 16) >> 4, uv = lo_part ? lane : (lane - 16) & 15;
+    const int node = plane_node(axis, c, uv & 3, uv >> 2);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b >= 0) v = halo_node_sum(G, b, node & 3, (node >> 2) & 3, node >> 4);
+    out[r].nodes[lane] = v;
+    if (lane == 0) {
+        unsigned long long key;
+        if (upper >= 0) key = (unsigned long long)blk_keys[upper];
+        else {
+            const int4 o = G.blk_origin[lower];
+            int bc[3] = {o.x >> 2, o.y >> 2, o.z >> 2};
+            bc[axis] += 1;
+            key = (unsigned long long)block_key(bc[0], bc[1], bc[2]);
+        }
+        out[r].key = key; out[r].pad = 0ull;
+    }
+}
+// add the neighbour's partial sums into halo_in (zeroed every substep); blocks unknown here are ignored: no local particle touches them
+__global__ __launch_bounds__(BLK_THREADS) void k_halo_merge(const HaloRecord* __restrict__ in, int n, int axis, HashTable H, float4* halo_in,
                                                              const Ctl* __restrict__ ctl, int parity) {
     if (ctl->abort_flag[parity]) return;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n) return;
     const int lane = threadIdx.x & 63;
-    const int b = hash_lookup(H, (uint64_t)in[r].key);
+    const uint32_t key = (uint32_t)in[r].key;
+    const bool lo_part = lane < 16;
+    int b;
+    if (!lo_part) b = hash_lookup(H, (uint64_t)key);
+    else {
+        int bc[3] = {(int)compact10(key) - 1, (int)compact10(key >> 1) - 1, (int)compact10(key >> 2) - 1};
+        bc[axis] -= 1;
+        b = bc[axis] >= -1 ? hash_lookup(H, (uint64_t)block_key(bc[0], bc[1], bc[2])) : -1;
+    }
     if (b < 0) return;
-    float4 v = halo_in[(size_t)b * 64 + lane];
+    const int c = lo_part ? 3 : (lane - 16) >> 4, uv = lo_part ? lane : (lane - 16) & 15;
+    const int node = plane_node(axis, c, uv & 3, uv >> 2);
+    float4 v = halo_in[(size_t)b * 64 + node];
     const float4 a = in[r].nodes[lane];
     v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-    halo_in[(size_t)b * 64 + lane] = v;
+    halo_in[(size_t)b * 64 + node] = v;
 }
 // extent of the particle blocks along the slab axis (block plane indices): out[0] = min, out[1] = max (preset to INT_MAX / INT_MIN)
 __global__ void k_plane_range(const int4* __restrict__ pb_info, int npb, int axis, int* out) {

@@ -401,7 +401,7 @@ static int resort(SparklPipeline* p) {
                     if (cut == INT32_MIN || cut == INT32_MAX) continue;
                     CHK(p->halo_list[side].reserve(nb));
                     HIPCHK(hipMemsetAsync(p->d_scalars.p + 2 + side, 0, sizeof(int), st));
-                    hipLaunchKernelGGL(k_halo_list, dim3(grid_for(nb, 256)), dim3(256), 0, st, p->blk_origin.p, nb, p->slab_axis, cut, p->halo_list[side].p, p->d_scalars.p + 2 + side);
+                    hipLaunchKernelGGL(k_halo_list, dim3(grid_for(nb, 256)), dim3(256), 0, st, p->blk_origin.p, p->blk_nbr.p, nb, p->slab_axis, cut, p->halo_list[side].p, p->d_scalars.p + 2 + side);
                     HIPCHK(hipMemcpyAsync(&p->halo_count[side], p->d_scalars.p + 2 + side, sizeof(int), hipMemcpyDeviceToHost, st));
                 }
                 HIPCHK(hipStreamSynchronize(st));
@@ -1757,8 +1757,8 @@ int sparkl_hip_halo_pack(SparklPipeline* p, int side, void* dev_out) {
     if (!dev_out) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null buffer");
     size_t tok = 0;
     CHK(clock_begin(p, SPAN_HALO, &tok));
-    hipLaunchKernelGGL(k_halo_pack, dim3((n + 3) / 4), dim3(BLK_THREADS), 0, p->stream, grid_arrays(p), p->blk_keys.p, p->halo_list[side].p, n, (HaloRecord*)dev_out,
-                       p->d_ctl, p->pending.parity);
+    hipLaunchKernelGGL(k_halo_pack, dim3((n + 3) / 4), dim3(BLK_THREADS), 0, p->stream, grid_arrays(p), p->blk_keys.p, p->halo_list[side].p, n, p->slab_axis,
+                       (HaloRecord*)dev_out, p->d_ctl, p->pending.parity);
     CHK(clock_end(p, tok));
     return SPARKL_OK;
 }
@@ -1770,8 +1770,8 @@ int sparkl_hip_halo_merge(SparklPipeline* p, int side, const void* dev_in, uint6
     HashTable H{p->hash_keys.p, p->hash_vals.p, p->hash_mask};
     size_t tok = 0;
     CHK(clock_begin(p, SPAN_HALO, &tok));
-    hipLaunchKernelGGL(k_halo_merge, dim3((unsigned)((n + 3) / 4)), dim3(BLK_THREADS), 0, p->stream, (const HaloRecord*)dev_in, (int)n, H, p->halo_in.p, p->d_ctl,
-                       p->pending.parity);
+    hipLaunchKernelGGL(k_halo_merge, dim3((unsigned)((n + 3) / 4)), dim3(BLK_THREADS), 0, p->stream, (const HaloRecord*)dev_in, (int)n, p->slab_axis, H, p->halo_in.p,
+                       p->d_ctl, p->pending.parity);
     CHK(clock_end(p, tok));
     return SPARKL_OK;
 }
