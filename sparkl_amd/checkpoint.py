@@ -35,12 +35,23 @@ NATIVE_VERSION = 1
 
 
 # ------------------------------------------------------------------------------------------------ native
-def save(path, components, model_set_or_array, cell_width, params=None, simulated_time=0.0, extra=None):
+def save(path, components, model_set_or_array, cell_width, params=None, simulated_time=0.0, extra=None, fracture=None):
+    """`fracture`: the optional `ParticleFracture` component (abi.FRACTURE_DTYPE, `MpmPipeline.read_fracture()`), in the particles'
+    order.  `DamageModel::ModifiedEigenerosion` only runs its crack sweep while that component is uploaded, so a checkpoint of such
+    a run WITHOUT it would resume with damage silently off: refused."""
     models = model_set_or_array.to_c_array() if hasattr(model_set_or_array, "to_c_array") else model_set_or_array
     n_models = len(model_set_or_array)
+    if fracture is None and params is not None and int(params.damage_model) == abi.DAMAGE_MODIFIED_EIGENEROSION:
+        raise ValueError("checkpoint.save: params.damage_model is ModifiedEigenerosion but no `fracture` component was given "
+                         "(pass MpmPipeline.read_fracture(): the crack sweep needs it after the resume)")
     header = {"format": "sparkl_amd-checkpoint", "version": NATIVE_VERSION, "cell_width": float(cell_width), "n_models": int(n_models),
-              "simulated_time": float(simulated_time), "extra": extra or {}}
+              "simulated_time": float(simulated_time), "extra": extra or {}, "has_fracture": fracture is not None}
     arrays = {k: getattr(components, k) for k in ParticleComponents.__slots__}
+    if fracture is not None:
+        fracture = np.ascontiguousarray(fracture, dtype=abi.FRACTURE_DTYPE)
+        if len(fracture) != len(components):
+            raise ValueError(f"checkpoint.save: {len(fracture)} fracture records for {len(components)} particles")
+        arrays["fracture"] = fracture
     arrays["models"] = np.frombuffer(bytes(models), dtype=np.uint8)[: n_models * abi.C.sizeof(abi.ParticleModelC)].copy()
     if params is not None:
         arrays["params"] = np.frombuffer(bytes(params), dtype=np.uint8).copy()
@@ -63,7 +74,9 @@ class ModelArray:
 
 
 def load(path):
-    """-> (ParticleComponents, ModelArray, header dict, SolverParameters or None)"""
+    """-> (ParticleComponents, ModelArray, header dict, SolverParameters or None).  header["fracture"] is the `ParticleFracture`
+    component (abi.FRACTURE_DTYPE array) when the checkpoint carries one, else None: hand it to `MpmPipeline.set_fracture` after
+    `upload_particles` (`resume` below does)."""
     z = np.load(path)
     header = json.loads(bytes(z["header"]).decode())
     if header.get("format") != "sparkl_amd-checkpoint" or header.get("version") != NATIVE_VERSION:
@@ -75,6 +88,12 @@ def load(path):
         if a.dtype != want:
             raise ValueError(f"{path}: component {k} has dtype {a.dtype}, expected {want}")
         setattr(c, k, a)
+    header["fracture"] = None
+    if header.get("has_fracture"):
+        fr = z["fracture"]
+        if fr.dtype != abi.FRACTURE_DTYPE or len(fr) != len(c):
+            raise ValueError(f"{path}: fracture component has dtype {fr.dtype} / length {len(fr)}, expected {abi.FRACTURE_DTYPE} / {len(c)}")
+        header["fracture"] = fr
     n = header["n_models"]
     arr = (abi.ParticleModelC * max(n, 1))()
     raw = bytes(z["models"])
@@ -84,6 +103,24 @@ def load(path):
         params = abi.SolverParameters()
         abi.C.memmove(abi.C.byref(params), bytes(z["params"]), abi.C.sizeof(params))
     return c, ModelArray(arr, n), header, params
+
+
+def save_pipeline(path, pipe, model_set_or_array, params=None, simulated_time=0.0, extra=None):
+    """Checkpoint of a live `MpmPipeline`: particle state, and the `ParticleFracture` component if the caller had uploaded one."""
+    fr = pipe.read_fracture()   # never uploaded: every record is the default (factor 0, threshold f32::MAX) -- not worth a component
+    if len(fr) == 0 or (not fr["crack_propagation_factor"].any() and (fr["crack_threshold"] == np.finfo(np.float32).max).all()):
+        fr = None
+    save(path, pipe.read_particles(), model_set_or_array, pipe.cell_width, params=params, simulated_time=simulated_time, extra=extra, fracture=fr)
+
+
+def resume(pipe, path):
+    """Load `path` into `pipe` (models, particles, fracture component); colliders are the caller's.  -> (header, params)"""
+    c, models, header, params = load(path)
+    pipe.set_models(models)
+    pipe.upload_particles(c)
+    if header["fracture"] is not None:
+        pipe.set_fracture(header["fracture"])
+    return header, params
 
 
 # ------------------------------------------------------------------------------------- sparkl serde layout (bincode 1)

@@ -429,8 +429,7 @@ SPK_DEV float log1p_rem(float x) {
 // S, the remainders re_k = (log1p(lam_k) - lam_k) / 2; e_k = ln sigma_k = lam_k / 2 + re_k.  eps = S / 2 + V diag(re) V^T is never
 // composed on its own: every consumer adds its own first-order matrix and its own remainders and composes once (see sym_eig3 for
 // why the split matters).
-SPK_DEV Eig3 log_stretch(const M3& E, float S[6], float e[3], float re[3]) {
-    strain_metric(E, S);
+SPK_DEV Eig3 log_stretch_s(const float S[6], float e[3], float re[3]) {
     const Eig3 d = sym_eig3(S);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -440,6 +439,79 @@ SPK_DEV Eig3 log_stretch(const M3& E, float S[6], float e[3], float re[3]) {
     }
     return d;
 }
+SPK_DEV Eig3 log_stretch(const M3& E, float S[6], float e[3], float re[3]) {
+    strain_metric(E, S);
+    return log_stretch_s(S, e, re);
+}
+
+// ------------------------------------------------------------------------------ series path (no eigenvectors)
+// While the Frobenius norm of S = F^T F - I (a bound on its eigenvalues sigma^2 - 1) and the pending volume gain stay below
+// SPK_SERIES_MAX -- stiff materials for most of their life: the E = 1e7 sand column of the benchmark passes it at its foot
+// ~0.1 s after release -- every matrix function the return map and the corotated stress need is a short polynomial in a SYMMETRIC matrix that
+// commutes with S:   ln(I + S) / 2 = S/2 - S^2/4 + S^3/6 - S^4/8,   exp(D) - I = D + D^2/2 + D^3/6,   I - exp(-e) = e - e^2/2 + e^3/6.
+// The part linear in the strain is the strain matrix itself, exactly as in the eigenbasis form above, so the relative precision of
+// the strain is kept (truncation: |S|^4 / 5 and |e|^3 / 24 relative, < 2e-7 at the switch-over); two Jacobi sweeps with their
+// eigenvector accumulation (2 x 128 instructions, 18 transcendentals) and two eigenbasis compositions become seven symmetric
+// products of 18 FMAs.  Only the positive-energy bookkeeping needs eigenVALUES (sum of max(sigma_k - 1, 0)^2): closed form below.
+#ifndef SPK_SERIES_MAX
+#define SPK_SERIES_MAX 0.03f
+#endif
+// a * b for two commuting symmetric matrices (the product is symmetric), (xx, yy, zz, xy, xz, yz)
+SPK_DEV void sym_mul(const float a[6], const float b[6], float o[6]) {
+    o[0] = a[0] * b[0] + a[3] * b[3] + a[4] * b[4];
+    o[1] = a[3] * b[3] + a[1] * b[1] + a[5] * b[5];
+    o[2] = a[4] * b[4] + a[5] * b[5] + a[2] * b[2];
+    o[3] = a[0] * b[3] + a[3] * b[1] + a[4] * b[5];
+    o[4] = a[0] * b[4] + a[3] * b[5] + a[4] * b[2];
+    o[5] = a[3] * b[4] + a[1] * b[5] + a[5] * b[2];
+}
+// Eigenvalues of a symmetric 3x3 in closed form (trigonometric solution of the characteristic cubic of the deviator; the
+// trisection cos(acos(r) / 3) as two Newton steps on 4 c^3 - 3 c = |r| from the chord, c in [cos(pi/6), 1] where the root is
+// simple; r < 0 is the mirrored problem).  Errors: ~1e-7 |A| on the isolated eigenvalue; a near-degenerate pair is split
+// symmetrically by up to ~5e-4 |dev A| -- second order in every symmetric function of the pair, which is all the callers form.
+SPK_DEV void sym_eigvals(const float a[6], float e[3]) {
+    const float q = (a[0] + a[1] + a[2]) * (1.f / 3.f);
+    const float d0 = a[0] - q, d1 = a[1] - q, d2 = a[2] - q;
+    const float p2 = (d0 * d0 + d1 * d1 + d2 * d2 + 2.f * (a[3] * a[3] + a[4] * a[4] + a[5] * a[5])) * (1.f / 6.f);
+    if (!(p2 > 1.0e-36f)) { e[0] = e[1] = e[2] = q; return; }
+    const float ip = fast_rsq(p2), p = p2 * ip;
+    const float det = d0 * (d1 * d2 - a[5] * a[5]) - a[3] * (a[3] * d2 - a[5] * a[4]) + a[4] * (a[3] * a[5] - d1 * a[4]);
+    const float r = fminf(fmaxf(0.5f * det * (ip * ip * ip), -1.f), 1.f);
+    const float ar = fabsf(r);
+    float c = 0.8660254f + 0.1339746f * ar;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const float c2 = c * c;
+        c -= ((4.f * c2 - 3.f) * c - ar) * fast_rcp(12.f * c2 - 3.f);
+    }
+    const float sn = fast_sqrt(fmaxf(1.f - c * c, 0.f)) * 0.8660254f;   // (sqrt(3) / 2) sin(phi)
+    const float sg = r < 0.f ? -p : p;
+    e[0] = q + sg * (2.f * c);
+    e[1] = q + sg * (-c + 2.f * sn);
+    e[2] = q + sg * (-c - 2.f * sn);
+}
+// eps = ln(I + S) / 2 by its series (quartic: the next term is |S|^4 / 5 of the first)
+SPK_DEV void hencky_series(const float S[6], float eps[6]) {
+    float P2[6], P3[6], P4[6];
+    sym_mul(S, S, P2);
+    sym_mul(S, P2, P3);
+    sym_mul(P2, P2, P4);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) eps[i] = 0.5f * S[i] + (-0.25f * P2[i] + ((1.f / 6.f) * P3[i] - 0.125f * P4[i]));
+}
+// x - x^2/2 + x^3/6 = I - exp(-x) to |x|^3 / 24 relative
+SPK_DEV void one_minus_exp_neg_series(const float x[6], float m[6]) {
+    float X2[6], X3[6];
+    sym_mul(x, x, X2);
+    sym_mul(x, X2, X3);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) m[i] = x[i] + (-0.5f * X2[i] + (1.f / 6.f) * X3[i]);
+}
+// squared Frobenius norm: bounds every eigenvalue of the symmetric matrix
+SPK_DEV float sym_frob2(const float S[6]) {
+    return (S[0] * S[0] + S[1] * S[1] + S[2] * S[2]) + 2.f * (S[3] * S[3] + S[4] * S[4] + S[5] * S[5]);
+}
+SPK_DEV bool series_ok(const float S[6], float extra = 0.f) { return fmaxf(sym_frob2(S), extra * extra) < SPK_SERIES_MAX * SPK_SERIES_MAX; }
 
 // Corotated Kirchhoff stress (phase == 1) of the particle's final F = U diag(sigma') V^T, formed by the return map itself from
 // the decomposition it holds (the fused kernel scatters it one substep later; see corotated_tau_e).  Symmetric:
@@ -481,7 +553,18 @@ SPK_DEV SymStress corotated_tau_e(const DevModel& mo, float hardening, const M3&
 // phase == 1 corotated stress of F = I + E
 SPK_DEV M3 corotated_kirchhoff_fe(const DevModel& mo, float hardening, const M3& E) {
     float S[6], e[3], re[3], g[3], m6[6];
-    const Eig3 d = log_stretch(E, S, e, re);
+    strain_metric(E, S);
+    if (SPK_SERIES_MAX > 0.f && __all(series_ok(S))) {   // wave-uniform; series path: M = I - (I + S)^(-1/2)
+        float P2[6], P3[6], P4[6], P5[6];
+        sym_mul(S, S, P2);
+        sym_mul(S, P2, P3);
+        sym_mul(P2, P2, P4);
+        sym_mul(P2, P3, P5);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) m6[k] = 0.5f * S[k] + (-0.375f * P2[k] + (0.3125f * P3[k] + (-0.2734375f * P4[k] + 0.24609375f * P5[k])));
+        return sym_to_m3(corotated_tau_e(mo, hardening, E, m6));
+    }
+    const Eig3 d = log_stretch_s(S, e, re);
 #pragma unroll
     for (int k = 0; k < 3; ++k) g[k] = re[k] - expm1_rem(-e[k]);
     sym_compose(d.v, g, m6);
@@ -497,6 +580,72 @@ SPK_DEV M3 corotated_kirchhoff_e(const DevModel& mo, float hardening, const M3& 
 
 // DruckerPragerPlasticity::update_particle (plasticity_drucker_prager.rs:68-104) on E = F_trial - I, in place.
 // `sm1` returns sigma' - 1 of the mapped F (for the positive-energy bookkeeping), T the corotated stress of the mapped F.
+// The same return map on the series path (see "series path" above): `S` = F_trial^T F_trial - I with every entry, and the pending
+// log_vol_gain, below SPK_SERIES_MAX.  K = ln(Sigma' / Sigma) = c I + D with D = g dev(eps) traceless, so
+// exp(K) - I = expm1(c) I + e^c (D + D^2/2 + D^3/6).
+template <bool WANT_STRESS>
+SPK_DEV void dp_update_series(const DevModel& mo, float phase, float eh, const float S[6], M3& E, float& Jp, float& q, float& lvg, float sm1[3], bool& sv_valid,
+                              SymStress& T) {
+    float eps[6];
+    hencky_series(S, eps);
+    const float alpha = dp_alpha(mo, q);
+    const float tre = eps[0] + eps[1] + eps[2], em = tre * (1.f / 3.f);
+    const float tr = tre + lvg;
+    const float dev[6] = {eps[0] - em, eps[1] - em, eps[2] - em, eps[3], eps[4], eps[5]};
+    const float dn2 = (dev[0] * dev[0] + dev[1] * dev[1] + dev[2] * dev[2]) + 2.f * (dev[3] * dev[3] + dev[4] * dev[4] + dev[5] * dev[5]);
+    float c = 0.f, g = 0.f, dq = 0.f;
+    bool moved = false;
+    if (dn2 == 0.f || tr > 0.f) {            // tensile: sigma' = 1, K = -eps
+        dq = fast_sqrt(dn2 + tr * tr * (1.f / 3.f));
+        c = -em; g = -1.f;
+        moved = true;
+    } else {
+        const float dn = fast_sqrt(dn2);
+        const float gamma = dn + mo.p_k * tr * alpha;
+        if (gamma > 0.f) {                   // onto the cone: K = (lvg / 3) I - gdn dev(eps)
+            c = lvg * (1.f / 3.f); g = -gamma * fast_rcp(dn);
+            dq = gamma;
+            moved = true;
+        }
+    }
+    if (moved) {
+        const float so = tre, sn = tre + 3.f * c;
+        const float pm1 = expm1_small(so);
+        float nm1 = expm1_small(sn), lnew = sn;
+        const float diff = nm1 - pm1;
+        if (!(diff > 0.f) && mo.volume_correction != 1.f) { nm1 = pm1 + diff * mo.volume_correction; lnew = log1p_small(nm1); }
+        Jp *= (1.f + pm1) * fast_rcp(1.f + nm1);
+        lvg += so - lnew;
+        q += dq;
+        float D[6], D2[6], D3[6], G6[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) D[i] = g * dev[i];
+        sym_mul(D, D, D2);
+        sym_mul(D, D2, D3);
+        const float xc = expm1_small(c), ec = 1.f + xc;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) G6[i] = ec * (D[i] + (0.5f * D2[i] + (1.f / 6.f) * D3[i]));
+        G6[0] += xc; G6[1] += xc; G6[2] += xc;
+        const M3 G = sym6_to_m3(G6);
+        const M3 EG = m3_mul(E, G);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) E.m[i] += G.m[i] + EG.m[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) eps[i] += D[i];
+        eps[0] += c; eps[1] += c; eps[2] += c;
+    }
+    float e[3];
+    sym_eigvals(eps, e);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sm1[i] = expm1_small(e[i]);
+    sv_valid = true;
+    if (WANT_STRESS && mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR && phase == 1.f) {
+        float m6[6];
+        one_minus_exp_neg_series(eps, m6);
+        T = corotated_tau_e(mo, eh, E, m6);
+    }
+}
+
 template <bool WANT_STRESS>
 SPK_DEV void dp_update_e(const DevModel& mo, float phase, float eh, M3& E, float& Jp, float& q, float& lvg, float sm1[3], bool& sv_valid, SymStress& T) {
     sv_valid = false;
@@ -504,7 +653,12 @@ SPK_DEV void dp_update_e(const DevModel& mo, float phase, float eh, M3& E, float
     if (mo.only_active_when_failed && phase != 0.f) return;
     // eps = lin + V diag(dv) V^T throughout: `lin` the first-order matrix, `dv` the remainders in the eigenbasis, e_k its eigenvalues
     float lin[6], e[3], dv[3];
-    const Eig3 d = log_stretch(E, lin, e, dv);
+    strain_metric(E, lin);
+    if (SPK_SERIES_MAX > 0.f && __all(series_ok(lin, lvg))) {   // wave-uniform
+        dp_update_series<WANT_STRESS>(mo, phase, eh, lin, E, Jp, q, lvg, sm1, sv_valid, T);
+        return;
+    }
+    const Eig3 d = log_stretch_s(lin, e, dv);
 #pragma unroll
     for (int i = 0; i < 6; ++i) lin[i] *= 0.5f;
     const float alpha = dp_alpha(mo, q);
@@ -708,7 +862,14 @@ SPK_DEV float model_pos_energy(const DevModel& mo, float phase, float eh, const 
         if (sv_valid) { s[0] = sm1[0]; s[1] = sm1[1]; s[2] = sm1[2]; }
         else {
             float S6[6], eps[3], re[3];
-            (void)log_stretch(E, S6, eps, re);
+            strain_metric(E, S6);
+            if (SPK_SERIES_MAX > 0.f && __all(series_ok(S6))) {   // wave-uniform; series path
+                float eps6[6];
+                hencky_series(S6, eps6);
+                sym_eigvals(eps6, eps);
+            } else {
+                (void)log_stretch_s(S6, eps, re);
+            }
             s[0] = expm1_small(eps[0]); s[1] = expm1_small(eps[1]); s[2] = expm1_small(eps[2]);
         }
         float nsq = 0.f;

@@ -492,8 +492,16 @@ SPK_DEV int wave_max_i32(int v) {
 }
 SPK_DEV int wave_shr1_i(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false); }
 
-// `s_run`: this wave's 64-entry run list in LDS.  Every lane of the wave must call this (cross-lane operations inside).
+// `s_run`: this wave's 64-entry chunk list in LDS.  Every lane of the wave must call this (cross-lane operations inside).
 // Returns the number of live runs of the wave (wave-uniform): the disorder measure of the re-order policy.
+//
+// Balance.  A task walks its particles one per iteration and the wave iterates as long as its longest task, so the chunk a task
+// gets must be short: a run longer than L particles is split into two halves -- two chunks, neighbours in the list, whose sums
+// are added with one v_fmac_f32_dpp per value before ONE lane deposits (two lanes adding to the same address serialise in the
+// LDS).  L is the smallest of 4, 5, 6, 8, 12 whose chunks still fit the rounds of 64 tasks the runs need anyway (wave-uniform):
+// the lattice (8 runs of 8) splits every run (48 tasks, 4 iterations), the flowing column (10-25 ragged runs of 1-12) splits the
+// long ones only (5-6 iterations where whole-run tasks took 8-12).  Task t = (plane z, chunk c) = z * C + c.
+#define SPK_FMAC_WSHL(R) "v_fmac_f32_dpp " R ", " R ", %4 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
 SPK_DEV int p2g_scatter_runs(double (*tile)[ACC_N], const Scatter& sc, bool live, int tid, int* s_run, float (*s_A)[64]) {
     if (!__any(live)) return 0;   // wave-uniform
     const int lane = tid & 63;
@@ -501,39 +509,45 @@ SPK_DEV int p2g_scatter_runs(double (*tile)[ACC_N], const Scatter& sc, bool live
     // the task phase is where the kernel's register pressure peaks, and those 9 pay for carrying the whole next batch in flight
 #pragma unroll
     for (int e = 0; e < 9; ++e) s_A[e][lane] = sc.A.m[e];
-    const int key = live ? sc.base : -1;                       // dead lanes form runs of their own, skipped below
+    const int key = live ? sc.base : -1;                       // dead lanes form runs of their own, never listed
     const int prev = wave_shr1_i(key, -2);
     const bool head = (lane == 0) | (prev != key);
     const unsigned long long hb = __ballot(head);
-    const int nruns = (int)__popcll(hb);
-    const int nheads = (int)__popcll(__ballot(head & live));
+    const bool lhead = head & live;
+    const unsigned long long hl = __ballot(lhead);
+    const int nruns = (int)__popcll(hl);
+    const unsigned long long above = (lane == 63) ? 0ull : (hb >> (lane + 1));
+    const int len = above ? (int)__ffsll((long long)above) : (64 - lane);  // distance to the next head
+    // split threshold: the smallest L whose chunks fit the task slots of the rounds the runs need anyway
+    const int slots = ((3 * nruns + 63) >> 6) << 6;
+    unsigned long long sb = 0ull;
     {
-        const int rank = (int)__popcll(hb & ((1ull << lane) - 1ull));          // heads strictly below this lane
-        const unsigned long long above = (lane == 63) ? 0ull : (hb >> (lane + 1));
-        const int len = above ? (int)__ffsll((long long)above) : (64 - lane);  // distance to the next head
-        if (head) s_run[rank] = lane | (len << 8) | (key < 0 ? 0x10000 : 0);
+        const unsigned long long b4 = __ballot(lhead & (len > 4)), b5 = __ballot(lhead & (len > 5)), b6 = __ballot(lhead & (len > 6)),
+                                 b8 = __ballot(lhead & (len > 8)), b12 = __ballot(lhead & (len > 12));
+        const int room = slots / 3 - nruns;   // chunks that may be added
+        sb = (int)__popcll(b4) <= room ? b4 : (int)__popcll(b5) <= room ? b5 : (int)__popcll(b6) <= room ? b6 : (int)__popcll(b8) <= room ? b8 : (int)__popcll(b12) <= room ? b12 : 0ull;
+    }
+    const int C = nruns + (int)__popcll(sb);
+    if (lhead) {
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const int c = (int)__popcll(hl & lt) + (int)__popcll(sb & lt);
+        const bool split = (sb >> lane) & 1ull;
+        const int n0 = split ? (len + 1) >> 1 : len;
+        s_run[c] = lane | (n0 << 8) | (split ? 0x10000 : 0);                       // bit 16: the next chunk is this run's second half
+        if (split) s_run[c + 1] = (lane + n0) | ((len - n0) << 8) | 0x20000;        // bit 17: second half
     }
     __builtin_amdgcn_wave_barrier();   // LDS operations of one wave execute in order: the list is visible to its lanes
-    // tasks per run: 3 z-planes x S particle halves; the halves keep the 64 lanes busy while the runs are long
-#ifdef SPK_EXP_RUNS_S1
-    const int S = 1;
-#else
-    const int S = (6 * nruns <= 64) ? 2 : 1;
-#endif
-    const int TPR = 3 * S;
-    const int ntasks = nruns * TPR;
+    const int ntasks = 3 * C;
+    const bool any_split = sb != 0ull;
     for (int t0 = 0; t0 < ntasks; t0 += 64) {
         const int t = t0 + lane;
         const bool valid = t < ntasks;
-        const int r = valid ? ((t * (S == 2 ? 10923 : 21846)) >> 16) : 0;     // t / TPR for t < 4096
-        const int sub = t - r * TPR;
-        const int z = (S == 2) ? (sub >> 1) : sub;
-        const int half = (S == 2) ? (sub & 1) : 0;
-        const int info = s_run[r];
-        const int start = info & 63, len = (info >> 8) & 127;
-        int first = start, cnt = len;
-        if (S == 2) { const int n0 = (len + 1) >> 1; first = half ? start + n0 : start; cnt = half ? len - n0 : n0; }
-        if (!valid || (info & 0x10000)) cnt = 0;
+        const int z = (t >= C ? 1 : 0) + (t >= 2 * C ? 1 : 0);
+        const int c = valid ? t - z * C : 0;
+        const int info = s_run[c];
+        const int start = info & 63;
+        const int cnt = valid ? (info >> 8) & 127 : 0;
+        const int first = start;
         const int run_base = __builtin_amdgcn_ds_bpermute(start << 2, sc.base);
         // trip count of the wave (scalar): the longest task
         const int maxcnt = wave_max_i32(cnt);
@@ -576,27 +590,23 @@ SPK_DEV int p2g_scatter_runs(double (*tile)[ACC_N], const Scatter& sc, bool live
             }
         };
         visit(0, std::true_type{});
-#ifdef SPK_EXP_RUNS_NO_LOOP
-        for (int j = 1; j < 1; ++j) visit(j, std::false_type{});
-#else
         for (int j = 1; j < maxcnt; ++j) visit(j, std::false_type{});
-#endif
-        // the two halves of a run sit in neighbouring lanes (sub = 2 z + half): add the odd lane's sums into the even one, so
-        // that one lane deposits per (run, plane) -- two lanes adding to the SAME address serialise in the LDS
+        // the halves of a split run sit in neighbouring lanes: add the second half's sums into the first, so that one lane
+        // deposits per (run, plane).  A pair cut by the end of a round (first half in lane 63) deposits on both sides: different
+        // instructions, no same-address conflict.
         bool deposit = cnt > 0;
-        if (S == 2) {
+        if (any_split) {   // wave-uniform
+            const bool paired = (info & 0x10000) && valid && lane != 63;
+            const float f = paired ? 1.f : 0.f;
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                acc01[k].x += dpp_shl<1>(acc01[k].x); acc01[k].y += dpp_shl<1>(acc01[k].y);
-                acc23[k].x += dpp_shl<1>(acc23[k].x); acc23[k].y += dpp_shl<1>(acc23[k].y);
+                float a0 = acc01[k].x, a1 = acc01[k].y, a2 = acc23[k].x, a3 = acc23[k].y;
+                asm volatile("s_nop 1\n" SPK_FMAC_WSHL("%0") SPK_FMAC_WSHL("%1") SPK_FMAC_WSHL("%2") SPK_FMAC_WSHL("%3") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(f));
+                acc01[k].x = a0; acc01[k].y = a1; acc23[k].x = a2; acc23[k].y = a3;
             }
-            deposit = deposit && half == 0;
+            deposit = deposit && (!(info & 0x20000) || lane == 0);
         }
-#ifdef SPK_EXP_RUNS_NO_ATOMICS
-        if (deposit && fz == 123.f) {
-#else
         if (deposit) {
-#endif
             const int p = (run_base >> 6) + z;
             const int n0 = run_base + TILE_W * TILE_W * z + 8 * p - 4 * (p & 1);      // acc_slot of the plane's (0, 0) node
 #pragma unroll
@@ -611,7 +621,7 @@ SPK_DEV int p2g_scatter_runs(double (*tile)[ACC_N], const Scatter& sc, bool live
                 }
         }
     }
-    return nheads;
+    return nruns;
 }
 
 // Tile write-out (ends with the workgroup barrier the caller needs anyway).  Most blocks have no particle in the drift

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "probes.h"
 
 using namespace spk;
 
@@ -1690,6 +1691,7 @@ int sparkl_hip_dt_bound_export(SparklPipeline* p, void* dev_u32) {
     uint32_t bits;
     memcpy(&bits, &fmax, 4);
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dt_bits, (int)bits, 1, p->stream));
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dt_nan, 0, 1, p->stream));
     if (p->n > 0) {
         const int nblk = (int)grid_for(p->n, BLK_THREADS);
         CHK(p->dt_partial.reserve(std::max<size_t>(nblk, (size_t)std::max(p->num_pblocks, 1))));
@@ -2259,9 +2261,13 @@ int sparkl_hip_group_step(SparklPipeline** members, uint32_t n_members, const Sp
         }
         float bound;
         memcpy(&bound, &bits, 4);
-        if (bound != bound) return set_error(SPARKL_ERR_NAN_TIMESTEP, "NaN timestep bound (the reference panics: timestep_estimator.rs:46)");
+        // A NaN bound never wins an integer MIN of float bits (0x7fc00000 > 0x7f7fffff): the estimator exports it as 0 (and sets
+        // Ctl::dt_nan), so the word that travels is 0 on EVERY rank -- all of them return here, in step, like sparkl_hip_pipeline_step
+        // does (the reference panics: timestep_estimator.rs:46).  A true bound of 0 (infinite speed) is no more steppable.
+        if (!(bound > 0.0f)) return set_error(SPARKL_ERR_NAN_TIMESTEP, "NaN timestep bound (the reference panics: timestep_estimator.rs:46)");
         float dt = std::fmin(std::fmin(remaining, params->max_substep_dt), bound);   // timestep_estimator.rs:25,35,44
         if (dt < min_dt && remaining > min_dt) dt = min_dt;                          // mls_solver.rs:57-59
+        if (!(dt > 0.0f)) return set_error(SPARKL_ERR_NAN_TIMESTEP, "substep length %g: the step cannot make progress", (double)dt);
         CHK(sparkl_hip_group_substeps(members, n_members, params, gravity, dt, 1));
         ++nsub;
         remaining -= dt;
@@ -2322,3 +2328,17 @@ int sparkl_hip_grid_read_nodes(SparklPipeline* p, SparklGridNode* out, uint64_t 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------- diagnostics (probes.h)
+extern "C" int sparkl_hip_debug_run_stats(SparklPipeline* p, unsigned long long* out, uint64_t cap) {
+    if (!p || !out || cap < (uint64_t)RS_HISTS * RS_BINS) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "run_stats: need %d counters", RS_HISTS * RS_BINS);
+    HIPCHK(hipSetDevice(p->device));
+    memset(out, 0, sizeof(unsigned long long) * RS_HISTS * RS_BINS);
+    if (p->num_pblocks == 0) return SPARKL_OK;
+    CHK(p->d_count.reserve((size_t)RS_HISTS * RS_BINS));
+    HIPCHK(hipMemsetAsync(p->d_count.p, 0, sizeof(unsigned long long) * RS_HISTS * RS_BINS, p->stream));
+    hipLaunchKernelGGL(k_run_stats, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, p->stream, p->cur.arrays(), grid_arrays(p), p->h, p->d_count.p);
+    HIPCHK(hipMemcpyAsync(out, p->d_count.p, sizeof(unsigned long long) * RS_HISTS * RS_BINS, hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return SPARKL_OK;
+}

@@ -96,6 +96,72 @@ def test_bincode_layout_round_trip_and_sizes():
         checkpoint.load_bincode(pb + b"\\0", mb)
 
 
+def test_native_checkpoint_carries_the_fracture_component(tmp_path):
+    """ParticleFracture (crack_propagation_factor, crack_threshold) rides in the native checkpoint; a ModifiedEigenerosion checkpoint
+    without it is refused (it would resume with the crack sweep silently off)."""
+    rng = np.random.default_rng(4)
+    sc = scenes.sand_column(6, 5, 6, with_block=False)
+    n = len(sc.particles)
+    frac = np.zeros(n, dtype=abi.FRACTURE_DTYPE)
+    frac["crack_propagation_factor"] = rng.random(n).astype(np.float32)
+    frac["crack_threshold"] = rng.random(n).astype(np.float32)
+    params = abi.SolverParameters.from_buffer_copy(bytes(sc.params))
+    params.damage_model = abi.DAMAGE_MODIFIED_EIGENEROSION
+    with pytest.raises(ValueError, match="ModifiedEigenerosion"):
+        checkpoint.save(tmp_path / "bad.npz", sc.particles, sc.models, sc.cell_width, params=params)
+    with pytest.raises(ValueError, match="fracture records"):
+        checkpoint.save(tmp_path / "bad.npz", sc.particles, sc.models, sc.cell_width, params=params, fracture=frac[:-1])
+    checkpoint.save(tmp_path / "ok.npz", sc.particles, sc.models, sc.cell_width, params=params, fracture=frac)
+    c, models, header, p2 = checkpoint.load(tmp_path / "ok.npz")
+    assert header["has_fracture"] and p2.damage_model == abi.DAMAGE_MODIFIED_EIGENEROSION
+    np.testing.assert_array_equal(header["fracture"], frac)
+    checkpoint.save(tmp_path / "plain.npz", sc.particles, sc.models, sc.cell_width, params=sc.params)
+    assert checkpoint.load(tmp_path / "plain.npz")[2]["fracture"] is None
+
+
+@pytest.mark.gpu
+def test_resume_under_modified_eigenerosion_keeps_cracking(tmp_path):
+    """A ModifiedEigenerosion run checkpointed half way (checkpoint.save_pipeline / resume) ends where the uninterrupted run ends:
+    same cracked set (threshold decisions on the line may flip), same particle state to f32 rounding."""
+    from sparkl_amd.models import CorotatedLinearElasticity
+    from sparkl_amd.pipeline import MpmPipeline
+    from tests.parity import particle_errors
+    sc = scenes.block_on_floor(12, CorotatedLinearElasticity(1.0e6, 0.3), expand=6.0, v0=(0.0, 0.0, 0.0), gravity=(0.0, 0.0, 0.0), name="eigenerosion")
+    dt, n = sc.fixed_dt, len(sc.particles)
+    with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, dt, 60)
+        psi60 = p.read_particles().phase["psi_pos"]
+    frac = np.zeros(n, dtype=abi.FRACTURE_DTYPE)
+    frac["crack_propagation_factor"] = 1.0
+    frac["crack_threshold"] = np.float32(sc.cell_width * np.percentile(psi60, 70))
+    sc.params.damage_model = abi.DAMAGE_MODIFIED_EIGENEROSION
+    with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.set_fracture(frac)
+        p.substeps(sc.params, sc.gravity, dt, 100)
+        ref = p.read_particles()
+    with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.set_fracture(frac)
+        p.substeps(sc.params, sc.gravity, dt, 50)
+        checkpoint.save_pipeline(tmp_path / "mid.npz", p, sc.models, params=sc.params, simulated_time=50 * dt)
+    with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        header, params = checkpoint.resume(p, tmp_path / "mid.npz")
+        assert header["has_fracture"] and params.damage_model == abi.DAMAGE_MODIFIED_EIGENEROSION
+        p.set_colliders(sc.colliders)
+        p.substeps(params, sc.gravity, dt, 50)
+        got = p.read_particles()
+        np.testing.assert_array_equal(p.read_fracture(), frac)
+    cracked_ref, cracked = ref.phase["phase"] == 0.0, got.phase["phase"] == 0.0
+    assert n // 20 < int(cracked_ref.sum()) < n - n // 20, "the crack front must pass through part of the block"
+    assert int((cracked != cracked_ref).sum()) <= max(2, int(cracked_ref.sum()) // 100)
+    c_mid = checkpoint.load(tmp_path / "mid.npz")[0]
+    assert int(cracked.sum()) > int((c_mid.phase["phase"] == 0.0).sum()), "cracking must go on after the resume"
+    e = particle_errors(got, ref, sc.cell_width)
+    assert e["eps_x"] < 1e-4 and e["eps_v"] < 1e-3, e
+
+
 @pytest.mark.gpu
 def test_resume_from_checkpoint_matches_uninterrupted_run(tmp_path):
     from sparkl_amd.pipeline import MpmPipeline
