@@ -4,10 +4,13 @@
 One "step" = one substep (P2G -> grid update -> G2P, re-bin when a particle leaves its tile margin) of fixed length on
 synthetic, HBM-resident particles.  Prints ONE JSON line.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config sand10m|neo1m|fluid20m] [--particles P] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config sand10m|neo1m|fluid20m|cube80m] [--scaling weak|strong] [--particles P] [--no-cpu-baseline]
 
 --config sand10m (default) is BASELINE.json's metric: the 10 M-particle Drucker-Prager column (configs[2]);
-neo1m = configs[1] (1 M neo-Hookean cube), fluid20m = configs[3] (20 M fluid particles, volume recompute sweep).
+neo1m = configs[1] (1 M neo-Hookean cube), fluid20m = configs[3] (20 M fluid particles, volume recompute sweep),
+cube80m = configs[4] (cube_through_sand3, ONE 80 M-particle scene: on N GPUs it is cut into N x-slabs -- strong scaling).
+--scaling weak (default for sand10m): every rank owns a 10 M column of an N x longer scene, so N = 1 is the headline line;
+--scaling strong: the configured size is the whole job (sand10m: 192 x 260 x 200 = 9.98 M whatever N).
 --gpus N > 1 with no WORLD_SIZE in the environment starts N ranks by itself (one process per GPU, RCCL); under
 torch.distributed.run the ranks come from the environment.  See DESIGN.md "Multi-GPU".
 """
@@ -34,6 +37,10 @@ NODE_BYTES = {"p2g": 16, "grid_update": 28, "g2p": 12}
 # config 4's volume-recompute sweep (+48 B/particle, +12 B/node): mass-only P2G 20 B, its gather 24 + 4 B
 VOLUME_BYTES = {"p2g_mass": 20, "g2p_volume": 28}
 VOLUME_NODE_BYTES = {"p2g_mass": 4, "grid_update_mass": 8}
+# the parity gate of tests/parity.py (TOLERANCE_STATEMENT), stated beside every number this file prints
+PARITY_TOLERANCE = ("arbiter = the reference's algorithm evaluated in f64 (oracle/): eps_x (in h) and eps_v (relative to max |v|) of the HIP path "
+                    "vs that trajectory <= 1e-4; vs the reference's own f32 arithmetic (f32 oracle): eps_x <= 1e-4 and "
+                    "eps_v <= eps_v(f32 oracle vs f64 oracle) + 1e-4 -- the f32 oracle itself sits 1e-4..6e-4 from the f64 trajectory on stiff sand")
 KERNEL_NAMES = {"p2g": "k_p2g_pair", "g2p": "k_g2p", "grid_update": "k_grid_update", "g2p2g": "k_g2p2g", "p2g_mass": "k_p2g_mass",
                 "grid_update_mass": "k_grid_update<mass>", "g2p_volume": "k_g2p_volume"}
 
@@ -46,12 +53,22 @@ def parse_args(argv=None):
     ap.add_argument("--clock-wake-n", type=int, default=4096)
     ap.add_argument("--clock-wake-ms", type=float, default=250.0, help="untimed fp32 matmuls before the warmup substeps so that the run does not start in the power controller's load-onset clock dip (0 = off)")
     ap.add_argument("--no-copy-peak", action="store_true", help="skip the 1 GiB device-to-device copy that measures the stream peak")
-    ap.add_argument("--config", choices=("sand10m", "neo1m", "fluid20m"), default="sand10m")
-    ap.add_argument("--particles", type=float, default=None, help="particles per GPU (default: the configuration's own size)")
+    ap.add_argument("--config", choices=("sand10m", "neo1m", "fluid20m", "cube80m"), default="sand10m")
+    ap.add_argument("--particles", type=float, default=None, help="particles per GPU with --scaling weak, in the whole job with --scaling strong (default: the configuration's own size)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="weak (default for sand10m): every rank owns a column of the configured size, the job grows with N; strong (default and only mode of cube80m): "
+                         "the whole job is the configured size -- 80 M for cube80m, 10 M for sand10m -- cut into N x-slabs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-clock", action="store_true", help="skip the per-kernel hipEvent spans")
-    ap.add_argument("--no-late-phase", dest="late_phase", action="store_false", help="skip the flowing-phase measurement (sand10m, N = 1)")
-    return ap.parse_args(argv)
+    ap.add_argument("--no-late-phase", dest="late_phase", action="store_false", help="skip the flowing-phase measurements (late_collapse, deep_collapse; sand10m, N = 1)")
+    args = ap.parse_args(argv)
+    if args.scaling is None:
+        args.scaling = "strong" if args.config == "cube80m" else "weak"
+    if args.config == "cube80m" and args.scaling != "strong":
+        ap.error("cube80m is BASELINE configs[4]: ONE 80 M-particle scene cut into slabs (--scaling strong)")
+    if args.scaling == "strong" and args.config not in ("cube80m", "sand10m"):
+        ap.error("--scaling strong cuts the sand scenes (sand10m, cube80m) into x-slabs")
+    return args
 
 
 # ------------------------------------------------------------------------------------------ N > 1: launcher
@@ -92,19 +109,46 @@ def column_dims(n_particles):
     return max(8, int(round(200 * f))), max(8, int(round(250 * f))), max(8, int(round(200 * f)))
 
 
+def strong_dims(total, world, base=(200, 250, 200)):
+    """Lattice of ~`total` particles with the aspect of `base`, its x size a whole number of 4-cell blocks (8 particles) per rank
+    for every world size up to 8 -- the SAME lattice whatever N, so that the job is fixed."""
+    f = (total / float(base[0] * base[1] * base[2])) ** (1.0 / 3.0)
+    nx = max(64, int(round(base[0] * f / 64.0)) * 64)
+    nz = max(8, int(round(base[2] * f)))
+    ny = max(8, int(round(total / float(nx * nz))))
+    assert nx % (8 * world) == 0, f"{world} ranks do not divide the {nx // 8} block planes of the scene"
+    return nx, ny, nz
+
+
 def build_scene(args, rank, world, mode):
-    """Returns (scene, material key of BYTES, description, x-lattice size)."""
+    """Returns (scene, material key of BYTES, description, x-lattice size of this rank's slab)."""
     from sparkl_amd import scenes
+    slab = (rank, world) if mode == "slabs" else (0, 1)
+    if args.config == "cube80m":
+        # BASELINE configs[4]: cube_through_sand3 (examples3d/cube_through_sand3.rs:40-81), 800 x 250 x 400 bed = 80 M + the kinematic cube
+        total = args.particles or 80.0e6
+        nx, ny, nz = strong_dims(total, world, base=(800, 250, 400))
+        cube_n = max(2, int(round(25 * (total / 80.0e6) ** (1.0 / 3.0))))
+        sc = scenes.cube_through_sand(nx // slab[1], ny, nz, cube_n=cube_n, name="config5_cube_through_sand", x_slab=slab)
+        desc = (f"cube_through_sand3: Drucker-Prager sand bed {nx}x{ny}x{nz} = {nx * ny * nz} particles + kinematic cube {cube_n}^3 at (10,0,0) m/s "
+                f"(8 ppc, h=0.2, E=1e7 nu=0.2 rho=2700, cuboid friction floor), fixed dt={sc.fixed_dt}; {len(sc.particles)} particles on this rank")
+        return sc, "sand", desc, nx // slab[1]
+    if args.config == "sand10m" and args.scaling == "strong":
+        nx, ny, nz = strong_dims(args.particles or 10.0e6, world)
+        sc = scenes.sand_column(nx // slab[1], ny, nz, name="config3_drucker_prager_column", x_slab=slab)
+        desc = (f"3D Drucker-Prager sand column collapse, {nx}x{ny}x{nz} = {nx * ny * nz} particles in the whole job, {len(sc.particles)} on this rank (8 ppc, h=0.2, "
+                f"E=1e7 nu=0.2 rho=2700, cuboid friction floor), fixed dt={sc.fixed_dt}")
+        return sc, "sand", desc, nx // slab[1]
     if args.config == "sand10m":
         nx, ny, nz = column_dims(args.particles or 10.0e6)
         if mode == "slabs":
             nx = max(8, int(round(nx / 8.0)) * 8)          # whole 4-cell blocks per slab (200 at the 10M default)
-        sc = scenes.sand_column(nx, ny, nz, name="config3_drucker_prager_column", x_slab=(rank, world) if mode == "slabs" else (0, 1))
+        sc = scenes.sand_column(nx, ny, nz, name="config3_drucker_prager_column", x_slab=slab)
         desc = (f"3D Drucker-Prager sand column collapse, {len(sc.particles)} particles/GPU ({nx}x{ny}x{nz} lattice, 8 ppc, h=0.2, "
                 f"E=1e7 nu=0.2 rho=2700, cuboid friction floor), fixed dt={sc.fixed_dt}")
         return sc, "sand", desc, nx
     if mode == "slabs":
-        raise SystemExit("--gpus > 1 runs the slab decomposition of the sand column only (BASELINE configs[2] / configs[4])")
+        raise SystemExit("--gpus > 1 runs the slab decomposition of the sand scenes only (sand10m = BASELINE configs[2], cube80m = configs[4])")
     if args.config == "neo1m":
         n = max(8, int(round((args.particles or 1.0e6) ** (1.0 / 3.0))))
         sc = scenes.elastic_cube(n, name="config2_neo_hookean_cube")
@@ -119,36 +163,56 @@ def build_scene(args, rank, world, mode):
     return sc, "fluid", desc, nx
 
 
-def cpu_baseline(max_threads, seconds_budget=20.0):
-    """The oracle (restated sparkl CPU path, f32, OpenMP) on a bounded sample of the sand workload.
+def cpu_baseline(max_threads, sc=None, desc=None):
+    """The oracle (restated sparkl CPU path, f32, OpenMP, `kind: "port"`) on the benchmark's OWN configuration: 2 substeps of
+    the scene the GPU just ran (the 10 M column at the default), timed phase by phase (sort / P2G / grid update / G2P as
+    BASELINE.md section 2 lists them) after one untimed substep (first touch of the mmap'd grid).
 
-    Like the reference (serial region loop, particle_set.rs:171-253) it stops scaling early: the thread count is probed
-    on one substep each and the best one is used and reported."""
+    Like the reference (serial region loop, particle_set.rs:171-253) the port stops scaling early: the thread count is probed
+    on one substep of a 400 k-particle column each (~1 s in all) and the best one is used and reported as `cores`."""
     from sparkl_amd import scenes
     from oracle import Oracle
     nx, ny, nz = column_dims(400_000)
-    sc = scenes.sand_column(nx, ny, nz, name="cpu_sample")
-    n = len(sc.particles)
-    best_t, best_rate = 1, 0.0
+    probe = scenes.sand_column(nx, ny, nz, name="cpu_thread_probe")
+    n = len(probe.particles)
+    best_t, best_rate, rates = 1, 0.0, {}
     for t in (8, 16, 32, 64, 128):
         if t > max_threads:
             break
-        o = Oracle(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes, threads=t)
-        o.load_scene(sc)
-        o.substep_fixed(sc.params, sc.gravity, sc.fixed_dt)   # first touch of the mmap'd grid
-        rate = n / o.timed_substeps(sc.params, sc.gravity, sc.fixed_dt, 1)
+        o = Oracle(probe.cell_width, domain_log2_bytes=probe.domain_log2_bytes, threads=t)
+        o.load_scene(probe)
+        o.substep_fixed(probe.params, probe.gravity, probe.fixed_dt)   # first touch of the mmap'd grid
+        rate = n / o.timed_substeps(probe.params, probe.gravity, probe.fixed_dt, 1)
         o.close()
+        rates[t] = rate
         if rate > best_rate:
             best_t, best_rate = t, rate
+    if sc is None:
+        sc, desc = probe, f"{n}-particle Drucker-Prager column ({nx}x{ny}x{nz})"
+    n = len(sc.particles)
     o = Oracle(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes, threads=best_t)
     o.load_scene(sc)
-    o.substep_fixed(sc.params, sc.gravity, sc.fixed_dt)
-    nsub = int(max(2, min(100, (seconds_budget - 5.0) * best_rate / n)))
-    t = o.timed_substeps(sc.params, sc.gravity, sc.fixed_dt, nsub)
+    dt = sc.fixed_dt
+    o.substep_fixed(sc.params, sc.gravity, dt)
+    nsub = 2 if n > 2_000_000 else int(max(2, min(50, 10.0 * best_rate / n)))
+    phases = {"sort": 0.0, "p2g": 0.0, "grid_update": 0.0, "g2p": 0.0}
+    if sc.params.force_fluids_volume_recomputation:
+        phases["fluid_volumes"] = 0.0
+    t_all = time.perf_counter()
+    for _ in range(nsub):   # the order of oracle_substep_fixed (mls_solver.rs:33-139 at a fixed step length)
+        t0 = time.perf_counter(); o.sort(); phases["sort"] += time.perf_counter() - t0
+        if "fluid_volumes" in phases:
+            t0 = time.perf_counter(); o.recompute_fluids_volumes(); phases["fluid_volumes"] += time.perf_counter() - t0
+        t0 = time.perf_counter(); o.p2g(dt, sc.gravity); phases["p2g"] += time.perf_counter() - t0
+        t0 = time.perf_counter(); o.grid_update(dt, int(sc.params.boundary_handling), int(sc.params.simulation_dofs)); phases["grid_update"] += time.perf_counter() - t0
+        t0 = time.perf_counter(); o.g2p(dt); phases["g2p"] += time.perf_counter() - t0
+    t = time.perf_counter() - t_all
     o.close()
     return {"value": n * nsub / t, "unit": "particle-steps/s", "cores": best_t, "kind": "port",
-            "sample": f"{n}-particle Drucker-Prager column ({nx}x{ny}x{nz}), {nsub} substeps of dt=2.5e-4, f32 oracle (oracle/mpm_oracle.hpp), OpenMP, "
-                      f"best of 8/16/32/64/128 threads on a {max_threads}-thread host"}
+            "ms_per_substep": 1e3 * t / nsub, "phase_ms_per_substep": {k: 1e3 * v / nsub for k, v in phases.items()},
+            "thread_probe_particle_steps_per_s": {str(k): v for k, v in rates.items()},
+            "sample": f"{nsub} substeps (after one untimed) of the benchmark's own configuration: {desc}; f32 oracle (oracle/mpm_oracle.hpp: restated sparkl CPU "
+                      f"path), OpenMP with {best_t} threads = the best of 8/16/32/64/128 probed on a {len(probe.particles)}-particle column, on a {max_threads}-thread host"}
 
 
 def recorded_traffic(kernel, n_particles, config):
@@ -273,7 +337,7 @@ def main(args):
         first_block = 1                                # the column starts at cell 4
         lo = INT32_MIN if rank == 0 else first_block + rank * (cells_per_rank // 4)
         hi = INT32_MAX if rank == world - 1 else first_block + (rank + 1) * (cells_per_rank // 4)
-        pipe.set_slab(0, lo, hi, id_offset=rank * n_particles)
+        pipe.set_slab(0, lo, hi, id_offset=getattr(sc, "id_offset", rank * n_particles))
     t0 = time.time()
     pipe.load_scene(sc)
     upload_s = time.time() - t0
@@ -370,6 +434,11 @@ def main(args):
         tt = torch.tensor([elapsed], device="cpu" if default_pg_is_cpu else "cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    total_particles = n_particles
+    if world > 1:   # ranks of a strong-scaling job own different counts (the kinematic cube sits on rank 0; slabs re-balance)
+        tn = torch.tensor([n_particles], device="cpu" if default_pg_is_cpu else "cuda", dtype=torch.int64)
+        dist.all_reduce(tn)
+        total_particles = int(tn.item())
     clock = None if args.no_kernel_clock else pipe.clock_read(reset=True)
     n_blocks, n_pblocks = pipe.num_active_blocks(), pipe.num_particle_blocks()
     kb, step_bytes = kernel_bytes(material, n_particles, n_blocks * 64, fluid_volumes)
@@ -377,30 +446,40 @@ def main(args):
     # The same column once it flows (cells hold uneven particle counts, re-bins and in-place reorders happen): outside the
     # timed region and never part of `value`, but measured the same way -- wall clock over 128 substeps and the dominant
     # kernel's hipEvent spans -> `roofline_late` (see profiles/r01_reorder_policy.txt)
-    late = None
-    if world == 1 and args.late_phase and args.config == "sand10m":
-        before = max(0, 640 - args.steps - args.warmup)
-        pipe.clock_enable(False)
-        run(before)
-        if not args.no_kernel_clock:
-            pipe.clock_enable(True, stride=4)
-            pipe.clock_read(reset=True)
-        pipe.sync()
-        t1 = time.perf_counter()
-        run(128)
-        pipe.sync()
-        late_ms = 1e3 * (time.perf_counter() - t1) / 128
-        late = {"substeps_before": args.steps + args.warmup + before, "substeps_timed": 128, "ms_per_step": late_ms}
-        if not args.no_kernel_clock:
-            lclock = pipe.clock_read(reset=True)
-            nb_late = pipe.num_active_blocks()
-            kb_late, step_bytes_late = kernel_bytes(material, n_particles, nb_late * 64, fluid_volumes)
-            late["roofline"], late_avg = roofline_of(lclock, kb_late, n_particles, args.config, kernel="g2p2g")
-            late["kernels_avg_launch_ms"] = late_avg
-            late["step_frac_of_hbm_peak"] = step_bytes_late / (late_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-            late["resorts"] = int(lclock.resorts)
-            late["reorder_ms_total"] = lclock.reorder_ms
-            late["active_node_blocks"] = nb_late
+    late, deep = None, None
+    if world == 1 and args.late_phase and args.config == "sand10m" and args.scaling == "weak":
+        substeps_run = [args.steps + args.warmup]
+
+        def phase(start):
+            """128 substeps from substep `start` on, timed like the headline region (wall clock + the dominant kernel's spans)."""
+            before = max(0, start - substeps_run[0])
+            pipe.clock_enable(False)
+            run(before)
+            if not args.no_kernel_clock:
+                pipe.clock_enable(True, stride=4)
+                pipe.clock_read(reset=True)
+            pipe.sync()
+            t1 = time.perf_counter()
+            run(128)
+            pipe.sync()
+            ms = 1e3 * (time.perf_counter() - t1) / 128
+            out = {"substeps_before": substeps_run[0] + before, "substeps_timed": 128, "ms_per_step": ms}
+            substeps_run[0] += before + 128
+            if not args.no_kernel_clock:
+                lclock = pipe.clock_read(reset=True)
+                nb = pipe.num_active_blocks()
+                kb_l, step_bytes_l = kernel_bytes(material, n_particles, nb * 64, fluid_volumes)
+                out["roofline"], avg = roofline_of(lclock, kb_l, n_particles, args.config, kernel="g2p2g")
+                out["kernels_avg_launch_ms"] = avg
+                out["step_frac_of_hbm_peak"] = step_bytes_l / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                out["resorts"] = int(lclock.resorts)
+                out["noop_launches"] = int(lclock.noop_launches)   # launches behind a re-bin request (returned at once): not in the averages
+                out["reorder_ms_total"] = lclock.reorder_ms
+                out["active_node_blocks"] = nb
+            return out
+
+        late = phase(640)      # 0.16 s after release: the column flows
+        deep = phase(2000)     # 0.5 s: deep in the collapse (cells hold uneven counts, the foot spreads, re-bins every ~100 substeps)
 
     # SURVEY.md §8(d): the achieved rate is also reported against a MEASURED stream peak, not only the 8 TB/s of the
     # data sheet: a device-to-device copy of 1 GiB (read + write = 2 GiB of traffic per copy), hipEvent-timed, after the run
@@ -421,23 +500,24 @@ def main(args):
             del src, dst
 
     if rank == 0:
-        total_particles = n_particles * world
         value = total_particles * args.steps / elapsed
-        metric = "particle-steps/sec (whole node) + achieved HBM GB/s, 3D sand 10M particles" if args.config == "sand10m" else \
-            f"particle-steps/sec (whole node) + achieved HBM GB/s, {args.config} (not BASELINE.json's headline metric)"
+        headline = args.config == "sand10m" and (args.scaling == "weak" or world == 1)
+        metric = "particle-steps/sec (whole node) + achieved HBM GB/s, 3D sand 10M particles" if headline else \
+            f"particle-steps/sec (whole node) + achieved HBM GB/s, {args.config} {args.scaling} scaling (not BASELINE.json's headline metric)"
         out = {
             "metric": metric,
             "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "ranks": ranks,
-            "config": {"workload": desc, "name": args.config, "particles_per_gpu": n_particles,
+            "config": {"workload": desc, "name": args.config, "particles_per_gpu": n_particles, "particles_total": total_particles,
+                       "parity_tolerance": PARITY_TOLERANCE,
                        "active_node_blocks": n_blocks, "particle_blocks": n_pblocks,
                        "parallelism": "single GPU" if world == 1 else (
-                           f"{world} x-slabs of one {world * nx}-long column, the four shared node planes of every cut swapped with both neighbours every substep "
+                           f"{world} x-slabs of one {world * nx}-particle-long scene ({'fixed total, strong scaling' if args.scaling == 'strong' else 'one configured column per rank, weak scaling'}), the four shared node planes of every cut swapped with both neighbours every substep "
                            f"({'RCCL send/recv inside libsparkl_hip.so (sparkl_hip_group_substeps)' if in_library else backend + ' send/recv from the Python SlabStepper'}), "
                            f"re-bin flag all-reduce" if mode == "slabs" else f"{world} independent replicas")},
-            "step_gbs": step_bytes * world / (elapsed / args.steps) / 1e9,
-            "step_frac_of_hbm_peak": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+            "step_gbs": step_bytes * (total_particles / n_particles) / (elapsed / args.steps) / 1e9,
+            "step_frac_of_hbm_peak": step_bytes * (total_particles / n_particles) / world / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
             "setup_s": {"generate": gen_s, "upload_and_pack": upload_s},
             "clock_wake_ms": args.clock_wake_ms,
         }
@@ -460,9 +540,14 @@ def main(args):
             out["late_collapse"] = late
             if late.get("roofline"):
                 out["roofline_late"] = late["roofline"]
+        if deep is not None:
+            out["deep_collapse"] = deep
+            if deep.get("roofline"):
+                out["roofline_deep"] = deep["roofline"]
         if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only: the other ranks would sit in the final barrier
             threads = len(os.sched_getaffinity(0))
-            out["cpu_baseline"] = cpu_baseline(threads)
+            # the port does 10 M particles in ~4 s per substep; an 80 M scene would take minutes: the thread-probe column stands in
+            out["cpu_baseline"] = cpu_baseline(threads, sc, desc) if n_particles <= 12_000_000 else cpu_baseline(threads)
         print(json.dumps(out), flush=True)
     pipe.close()
     if world > 1:

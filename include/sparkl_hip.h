@@ -330,11 +330,15 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
 /* Run `nsubsteps` substeps of fixed length `dt` with NO host synchronisation inside
  * (the dt estimator is skipped; equivalent to the reference when max_substep_dt == dt
  * is the binding bound).  Only params->{boundary_handling, simulation_dofs,
- * force_fluids_volume_recomputation, enable_boundary_particle_projection, damage_model} are read;
- * damage_model other than SPARKL_DAMAGE_NONE returns SPARKL_ERR_UNSUPPORTED (here, in
- * sparkl_hip_pipeline_step and in sparkl_hip_substep_begin).  Substeps are enqueued in batches; the
- * host reads the 64-byte control block back once per batch (a stream sync) to learn whether a re-bin
- * is needed, so the call returns when the last batch has been read. */
+ * force_fluids_volume_recomputation, enable_boundary_particle_projection, damage_model} are read.
+ * damage_model: SPARKL_DAMAGE_NONE and SPARKL_DAMAGE_MODIFIED_EIGENEROSION are implemented here and in
+ * sparkl_hip_pipeline_step (the latter runs its psi_mass / psi_momentum sweep only while a ParticleFracture
+ * component is uploaded -- sparkl_hip_particles_set_fracture -- and turns the fused G2P->P2G schedule off);
+ * SPARKL_DAMAGE_CDMPM / SPARKL_DAMAGE_EIGENEROSION return SPARKL_ERR_UNSUPPORTED everywhere, and the
+ * split-phase / slab entry points (sparkl_hip_substep_begin, sparkl_hip_group_substeps, sparkl_hip_group_step)
+ * accept SPARKL_DAMAGE_NONE only.  Substeps are enqueued in batches; the host reads the control block
+ * (72 bytes) back once per batch (a stream sync) to learn whether a re-bin is needed, so the call returns
+ * when the last batch has been read. */
 int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* params,
                                  const float gravity[3], float dt, uint32_t nsubsteps);
 int sparkl_hip_pipeline_sync(SparklPipeline* p);
@@ -397,6 +401,10 @@ typedef struct {
     /* force_fluids_volume_recomputation sweep (fluids_volume.rs:9-115): mass-only scatter, mass-only node merge, volume gather */
     double p2g_mass_ms, grid_update_mass_ms, g2p_volume_ms;
     uint64_t p2g_mass_launches, grid_update_mass_launches, g2p_volume_launches;
+    /* launches that returned at once behind a raised abort flag (the rest of a batch cut by a re-bin request): spans shorter than
+     * a quarter of the longest span of the same kernel; NOT part of the *_ms sums and *_launches counts above */
+    double noop_ms;
+    uint64_t noop_launches;
 } SparklKernelClock;
 /* enable: 0 = off, 1 = spans on every substep, N > 1 = spans on every N-th substep */
 int sparkl_hip_pipeline_clock_enable(SparklPipeline* p, int enable);

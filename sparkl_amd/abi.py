@@ -193,7 +193,8 @@ class KernelClockC(C.Structure):
                 ("p2g_launches", C.c_uint64), ("grid_update_launches", C.c_uint64), ("g2p_launches", C.c_uint64), ("g2p2g_launches", C.c_uint64),
                 ("reorder_ms", C.c_double), ("reorder_launches", C.c_uint64),
                 ("p2g_mass_ms", C.c_double), ("grid_update_mass_ms", C.c_double), ("g2p_volume_ms", C.c_double),
-                ("p2g_mass_launches", C.c_uint64), ("grid_update_mass_launches", C.c_uint64), ("g2p_volume_launches", C.c_uint64)]
+                ("p2g_mass_launches", C.c_uint64), ("grid_update_mass_launches", C.c_uint64), ("g2p_volume_launches", C.c_uint64),
+                ("noop_ms", C.c_double), ("noop_launches", C.c_uint64)]
 
 
 class GridCheckC(C.Structure):

@@ -17,6 +17,12 @@
 #include "../../include/sparkl_hip.h"
 
 #define SPK_DEV __device__ __forceinline__
+// section markers in the ISA of an analysis build (-DSPK_MARKS): tools/isa_sections.py counts the instructions between them
+#ifdef SPK_MARKS
+#define SPK_MARK(name) asm volatile("; SPKMARK " name)
+#else
+#define SPK_MARK(name) ((void)0)
+#endif
 
 namespace spk {
 
@@ -518,6 +524,7 @@ SPK_DEV bool series_ok(const float S[6], float extra = 0.f) { return fmaxf(sym_f
 // (xx, yy, zz, xy, xz, yz).
 struct SymStress {
     float t[6];
+    float jm1;     // det(F) - 1 of the same F (the callers' guards and the energy bookkeeping need it too)
     bool valid;
 };
 SPK_DEV M3 sym_to_m3(const SymStress& s) { return M3{{s.t[0], s.t[3], s.t[4], s.t[3], s.t[1], s.t[5], s.t[4], s.t[5], s.t[2]}}; }
@@ -546,6 +553,7 @@ SPK_DEV SymStress corotated_tau_e(const DevModel& mo, float hardening, const M3&
         S.t[k] = k2 * (A.m[a + 3 * b] + (A.m[a] * E.m[b] + A.m[a + 3] * E.m[b + 3] + A.m[a + 6] * E.m[b + 6]));
     }
     S.t[0] += sph; S.t[1] += sph; S.t[2] += sph;
+    S.jm1 = jm1;
     S.valid = true;
     return S;
 }
@@ -587,8 +595,11 @@ template <bool WANT_STRESS>
 SPK_DEV void dp_update_series(const DevModel& mo, float phase, float eh, const float S[6], M3& E, float& Jp, float& q, float& lvg, float sm1[3], bool& sv_valid,
                               SymStress& T) {
     float eps[6];
+    SPK_MARK("dp_series_log");
     hencky_series(S, eps);
+    SPK_MARK("dp_alpha");
     const float alpha = dp_alpha(mo, q);
+    SPK_MARK("dp_cases");
     const float tre = eps[0] + eps[1] + eps[2], em = tre * (1.f / 3.f);
     const float tr = tre + lvg;
     const float dev[6] = {eps[0] - em, eps[1] - em, eps[2] - em, eps[3], eps[4], eps[5]};
@@ -618,6 +629,7 @@ SPK_DEV void dp_update_series(const DevModel& mo, float phase, float eh, const f
         lvg += so - lnew;
         q += dq;
         float D[6], D2[6], D3[6], G6[6];
+        SPK_MARK("dp_exp");
 #pragma unroll
         for (int i = 0; i < 6; ++i) D[i] = g * dev[i];
         sym_mul(D, D, D2);
@@ -635,10 +647,12 @@ SPK_DEV void dp_update_series(const DevModel& mo, float phase, float eh, const f
         eps[0] += c; eps[1] += c; eps[2] += c;
     }
     float e[3];
+    SPK_MARK("dp_eigvals");
     sym_eigvals(eps, e);
 #pragma unroll
     for (int i = 0; i < 3; ++i) sm1[i] = expm1_small(e[i]);
     sv_valid = true;
+    SPK_MARK("dp_stress");
     if (WANT_STRESS && mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR && phase == 1.f) {
         float m6[6];
         one_minus_exp_neg_series(eps, m6);
@@ -853,11 +867,11 @@ SPK_DEV bool maximum_stress_failed(const DevModel& mo, const M3& t) {
 }
 
 // constitutive_model.pos_energy(particle)
-SPK_DEV float model_pos_energy(const DevModel& mo, float phase, float eh, const M3& F, const M3& E, const float sm1[3], bool sv_valid) {
+// `jm1` = det(F) - 1 (det_minus_one(E)), which the caller holds anyway
+SPK_DEV float model_pos_energy(const DevModel& mo, float phase, float eh, const M3& F, const M3& E, const float sm1[3], bool sv_valid, float jm1) {
     if (mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR) {
         // elasticity_corotated_linear.rs:105-118 on the small quantities: sigma_k - 1 (`sm1` when the return map already holds
         // them) and J - 1; E = F - I
-        const float jm1 = det_minus_one(E);
         float s[3];
         if (sv_valid) { s[0] = sm1[0]; s[1] = sm1[1]; s[2] = sm1[2]; }
         else {

@@ -98,6 +98,7 @@ struct GridArrays {
     float4* node_vel;          // [B][64]  (vx, vy, vz, mass)
     float4* node_mom;          // [B][64]  (px, py, pz, -) debug capture or NULL
     const float4* halo_in;     // [B][64]  (mass, px, py, pz) received from neighbour slabs, or NULL
+    int halo_axis, halo_lo, halo_hi;   // slab cuts (block planes): only the node blocks of planes lo - 1, lo, hi - 1, hi receive
     uint32_t* dt_partial;      // [gridDim] per-workgroup minimum of the dt bound (float bits), reduced by k_dt_reduce
     const DevCuboid* cuboids;  // the collider arrays, for enable_boundary_particle_projection (G2P tail)
     const DevHeightField* heightfields;
@@ -1013,8 +1014,12 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
         }
     }
     if (G.halo_in) {  // partial sums of the neighbour slab(s): a + b is bit-identical on both sides of a cut
-        const float4 hv = G.halo_in[(size_t)b * 64 + lane];
-        m += hv.x; px += hv.y; py += hv.z; pz += hv.w;
+        const int4 ob = G.blk_origin[b];
+        const int bp = (G.halo_axis == 0 ? ob.x : (G.halo_axis == 1 ? ob.y : ob.z)) >> 2;
+        if (bp == G.halo_lo || bp == G.halo_hi || bp + 1 == G.halo_lo || bp + 1 == G.halo_hi) {   // wave-uniform: one block per wave
+            const float4 hv = G.halo_in[(size_t)b * 64 + lane];
+            m += hv.x; px += hv.y; py += hv.z; pz += hv.w;
+        }
     }
     if (MASS_ONLY) {
         G.node_vel[(size_t)b * 64 + lane] = make_float4(0.f, 0.f, 0.f, m);
@@ -1232,37 +1237,39 @@ SPK_DEV void apic_gather(const VelTile& vt, const float px[3], const int4& org, 
     // APIC gather in separable form (grid_to_particle.rs:47-60):
     //   v = sum w v_n ;  C = inv_d * sum w v_n (d0 + s h)^T = inv_d * (v d0^T + h [Vx Vy Vz]),  V_a = sum w s_a v_n
     //   velocity_gradient_det = sum w (v_n . dpt) inv_d = trace(C)
-    float V0[3] = {0.f, 0.f, 0.f}, Vx[3] = {0.f, 0.f, 0.f}, Vy[3] = {0.f, 0.f, 0.f}, Vz[3] = {0.f, 0.f, 0.f};
+    // The (x, y) components travel as packed pairs -- the velocity tile holds them as float2, so a ds_read_b64 lands in an aligned
+    // register pair and every step of the separable sum is one v_pk_fma_f32 for both -- the z component as scalars beside them:
+    // 2 instead of 3 VALU operations per 3-vector step (the kernel is VALU-issue bound).
+    f2v V0p = {0.f, 0.f}, Vxp = {0.f, 0.f}, Vyp = {0.f, 0.f}, Vzp = {0.f, 0.f};
+    float V0z = 0.f, Vxz = 0.f, Vyz = 0.f, Vzz = 0.f;
     const float wx0 = wgt[0][0], wx1 = wgt[0][1], wx2 = wgt[0][2], wx2d = 2.f * wgt[0][2];
 #pragma unroll 1
     for (int sz = 0; sz < 3; ++sz) {
         const float wz = sz == 0 ? wgt[2][0] : (sz == 1 ? wgt[2][1] : wgt[2][2]);  // no dynamic register indexing
-        float Rz[3] = {0.f, 0.f, 0.f}, Rzx[3] = {0.f, 0.f, 0.f}, Rzy[3] = {0.f, 0.f, 0.f};
+        f2v Rzp = {0.f, 0.f}, Rzxp = {0.f, 0.f}, Rzyp = {0.f, 0.f};
+        float Rzz = 0.f, Rzxz = 0.f, Rzyz = 0.f;
 #pragma unroll
         for (int sy = 0; sy < 3; ++sy) {
             const int row = base + TILE_W * sy + TILE_W * TILE_W * sz;
             const float2 a0 = vt.xy[row], a1 = vt.xy[row + 1], a2 = vt.xy[row + 2];
-            const float4 c0 = make_float4(a0.x, a0.y, vt.z[row], 0.f), c1 = make_float4(a1.x, a1.y, vt.z[row + 1], 0.f), c2 = make_float4(a2.x, a2.y, vt.z[row + 2], 0.f);
+            const f2v c0 = {a0.x, a0.y}, c1 = {a1.x, a1.y}, c2 = {a2.x, a2.y};
+            const float z0 = vt.z[row], z1 = vt.z[row + 1], z2 = vt.z[row + 2];
             const float wy = wgt[1][sy];
-            const float a1x = wx1 * c1.x, a1y = wx1 * c1.y, a1z = wx1 * c1.z;
-            const float R[3] = {wx0 * c0.x + a1x + wx2 * c2.x, wx0 * c0.y + a1y + wx2 * c2.y, wx0 * c0.z + a1z + wx2 * c2.z};
-            const float Rx[3] = {a1x + wx2d * c2.x, a1y + wx2d * c2.y, a1z + wx2d * c2.z};
-#pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                Rz[e] += wy * R[e];
-                Rzx[e] += wy * Rx[e];
-                if (sy > 0) Rzy[e] += (wy * (float)sy) * R[e];
-            }
+            const f2v A1 = c1 * wx1;
+            const float a1z = wx1 * z1;
+            const f2v R = c0 * wx0 + A1 + c2 * wx2, Rx = A1 + c2 * wx2d;
+            const float Rz_ = wx0 * z0 + a1z + wx2 * z2, Rxz = a1z + wx2d * z2;
+            Rzp += R * wy; Rzz += wy * Rz_;
+            Rzxp += Rx * wy; Rzxz += wy * Rxz;
+            if (sy > 0) { const float wys = wy * (float)sy; Rzyp += R * wys; Rzyz += wys * Rz_; }
         }
         const float wzs = wz * (float)sz;
-#pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            V0[e] += wz * Rz[e];
-            Vx[e] += wz * Rzx[e];
-            Vy[e] += wz * Rzy[e];
-            Vz[e] += wzs * Rz[e];
-        }
+        V0p += Rzp * wz; V0z += wz * Rzz;
+        Vxp += Rzxp * wz; Vxz += wz * Rzxz;
+        Vyp += Rzyp * wz; Vyz += wz * Rzyz;
+        Vzp += Rzp * wzs; Vzz += wzs * Rzz;
     }
+    const float V0[3] = {V0p.x, V0p.y, V0z}, Vx[3] = {Vxp.x, Vxp.y, Vxz}, Vy[3] = {Vyp.x, Vyp.y, Vyz}, Vz[3] = {Vzp.x, Vzp.y, Vzz};
     vel[0] = V0[0]; vel[1] = V0[1]; vel[2] = V0[2];
     const float hid = h * S.inv_d;
 #pragma unroll
@@ -1286,7 +1293,9 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
     const int orgv[3] = {org.x, org.y, org.z};
     float vel[3];
     M3 C;
+    SPK_MARK("gather");
     apic_gather(vt, px, org, S, inv_h, vel, C);
+    SPK_MARK("advect_F");
     const float div = C.m[0] + C.m[4] + C.m[8];
     // kinematic override, advection (grid_to_particle.rs:82-86)
     {
@@ -1318,7 +1327,7 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
     float sv[3] = {1.f, 1.f, 1.f};
     bool sv_valid = false;
     o.store_k = false; o.store_aux = false; o.alpha = 0.f;
-    o.T.valid = false;
+    o.T.valid = false; o.T.jm1 = 0.f;
     if (RARE && mo.ptag > SPARKL_PLASTIC_DRUCKER_PRAGER) {   // snow / Rankine / NACC (plastic_model.update_particle, :102-104)
         float alpha = mo.ptag == SPARKL_PLASTIC_NACC ? aux_i->z : 0.f;
         const float eh0 = eh, alpha0 = alpha;
@@ -1334,13 +1343,18 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
 #else
     if (dp_e) {
 #endif
+        SPK_MARK("dp_update");
         dp_update_e<WANT_STRESS>(mo, phase, eh, E, Jp, q, lvg, sv, sv_valid, o.T);   // sv: sigma' - 1
+        SPK_MARK("post_dp");
         F = E;
         F.m[0] += 1.f; F.m[4] += 1.f; F.m[8] += 1.f;
     }
     if (flags & FLAG_STATIC) { vel[0] = vel[1] = vel[2] = 0.f; C = m3_zero(); }
     // fail guards (:111-121); density_def_grad() == 0  <=>  mass/volume0 == 0 or det(F) overflowed
-    const bool zero_density = (kk.x == 0.f) || !(fabsf(m3_det(F)) < 1.0e30f);
+    // det(F) - 1 without cancellation, once: from the return map when it formed the stress of this very F, else by minors
+    float jm1 = o.T.jm1;
+    if (!o.T.valid) jm1 = det_minus_one(E);
+    const bool zero_density = (kk.x == 0.f) || !(fabsf(jm1) < 1.0e30f);
     bool newly_failed = false;
     if (zero_density || (flags & FLAG_FAILED) || (!mo.is_fluid && fabsf(F.m[0]) > 1.0e4f)) {
         newly_failed = !(flags & FLAG_FAILED);
@@ -1350,9 +1364,12 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
         C = m3_zero();
         sv_valid = false;
         o.T.valid = false;
+        jm1 = 0.f;
     }
     // positive energy bookkeeping (:127-132)
-    psi = fmaxf(psi, model_pos_energy(mo, phase, eh, F, E, sv, sv_valid));
+    SPK_MARK("pos_energy");
+    psi = fmaxf(psi, model_pos_energy(mo, phase, eh, F, E, sv, sv_valid, jm1));
+    SPK_MARK("tile_checks");
     // failure model (:134-144): stress of the updated particle; a failed particle keeps phase = 0 from now on
     if (RARE && mo.has_failure && phase != 0.f && failure_check(mo, phase, eh, F, kk.x, kk.y, Jp, C)) {
         phase = 0.f;
@@ -1540,7 +1557,8 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
             const DevModel& mo = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
             const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
             const Advected o = g2p_update<RARE, true>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
-                        g2p_store(P, i, o, S.defer_c);
+            SPK_MARK("store");
+            g2p_store(P, i, o, S.defer_c);
             want_sort |= !o.in_tile && !(o.flags & FLAG_INVALID);   // a particle that left the DOMAIN is dead (skipped from now on): no re-bin for it
             live = o.in_tile;
             if (S.want_dt) {  // the bound the next substep's estimator would compute from this state
@@ -1548,7 +1566,9 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
                 dt_nan |= bnd != bnd;
                 dt_bound = fminf(dt_bound, bnd);
             }
+            SPK_MARK("p2g_prepare");
             if (live) { sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.Fe, kk.x, kk.y, o.eh, o.phase, o.Jp, org, h, inv_h, S.inv_d, S.dt_next, &o.T, o.rnew); shell_used |= sc.shell != 0; }
+            SPK_MARK("scatter");
 #ifdef SPK_EXP_DUMMY_LDS    // sensitivity probe: N extra LDS reads (ds_read_b32, one wave-wide 256 B access each) per particle batch
             {
                 volatile float* vp = &s_A[tid >> 6][0][0];
@@ -2565,6 +2585,74 @@ __global__ __launch_bounds__(BLK_THREADS) void k_halo_merge(const HaloRecord* __
     const float4 a = in[r].nodes[lane];
     v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
     halo_in[(size_t)b * 64 + node] = v;
+}
+// Both cuts of a slab in one launch each (sparkl_hip_group_substeps): waves [0, n0) serve the low cut, [n0, n0 + n1) the high one.
+// The merge STORES: between two re-bins the same (block, node) pairs receive a record every substep, each from exactly one
+// neighbour (the last node plane of the block below a cut, the first three of the block above it), and halo_in is zeroed by the
+// re-bin -- no per-substep memset of the whole array (28 MB at 10 M particles).
+struct HaloSides {
+    const int* list[2];
+    int n[2];
+    HaloRecord* out[2];
+    const HaloRecord* in[2];
+    int nin[2];
+};
+__global__ __launch_bounds__(BLK_THREADS) void k_halo_pack2(GridArrays G, const uint32_t* __restrict__ blk_keys, HaloSides hs, int axis, const Ctl* __restrict__ ctl, int parity) {
+    if (ctl->abort_flag[parity]) return;
+    int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int side = r >= hs.n[0] ? 1 : 0;
+    if (side) r -= hs.n[0];
+    if (r >= hs.n[side]) return;
+    const int e = hs.list[side][r];
+    HaloRecord* out = hs.out[side];
+    const int lane = threadIdx.x & 63;
+    int upper = (e & 1) ? -1 : (e >> 1), lower = (e & 1) ? (e >> 1) : G.blk_nbr[(e >> 1) * 27 + nbr_slot(axis, -1)];
+    const bool lo_part = lane < 16;
+    const int b = lo_part ? lower : upper;
+    const int c = lo_part ? 3 : (lane - 16) >> 4, uv = lo_part ? lane : (lane - 16) & 15;
+    const int node = plane_node(axis, c, uv & 3, uv >> 2);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b >= 0) v = halo_node_sum(G, b, node & 3, (node >> 2) & 3, node >> 4);
+    out[r].nodes[lane] = v;
+    if (lane == 0) {
+        unsigned long long key;
+        if (upper >= 0) key = (unsigned long long)blk_keys[upper];
+        else {
+            const int4 o = G.blk_origin[lower];
+            int bc[3] = {o.x >> 2, o.y >> 2, o.z >> 2};
+            bc[axis] += 1;
+            key = (unsigned long long)block_key(bc[0], bc[1], bc[2]);
+        }
+        out[r].key = key; out[r].pad = 0ull;
+    }
+}
+__global__ __launch_bounds__(BLK_THREADS) void k_halo_merge2(HaloSides hs, int axis, HashTable H, float4* halo_in, const Ctl* __restrict__ ctl, int parity) {
+    if (ctl->abort_flag[parity]) return;
+    int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int side = r >= hs.nin[0] ? 1 : 0;
+    if (side) r -= hs.nin[0];
+    if (r >= hs.nin[side]) return;
+    const HaloRecord* in = hs.in[side];
+    const int lane = threadIdx.x & 63;
+    const uint32_t key = (uint32_t)in[r].key;
+    const bool lo_part = lane < 16;
+    int b;
+    if (!lo_part) b = hash_lookup(H, (uint64_t)key);
+    else {
+        int bc[3] = {(int)compact10(key) - 1, (int)compact10(key >> 1) - 1, (int)compact10(key >> 2) - 1};
+        bc[axis] -= 1;
+        b = bc[axis] >= -1 ? hash_lookup(H, (uint64_t)block_key(bc[0], bc[1], bc[2])) : -1;
+    }
+    if (b < 0) return;
+    const int c = lo_part ? 3 : (lane - 16) >> 4, uv = lo_part ? lane : (lane - 16) & 15;
+    halo_in[(size_t)b * 64 + plane_node(axis, c, uv & 3, uv >> 2)] = in[r].nodes[lane];
+}
+// MAX of the members' abort flags of the upcoming substep, written back to all of them (members of one process on one stream)
+struct CtlList { Ctl* c[16]; int n; };
+__global__ void k_flags_max(CtlList L, int parity) {
+    uint32_t m = 0u;
+    for (int i = 0; i < L.n; ++i) m = max(m, L.c[i]->abort_flag[parity]);
+    for (int i = 0; i < L.n; ++i) L.c[i]->abort_flag[parity] = m;
 }
 // extent of the particle blocks along the slab axis (block plane indices): out[0] = min, out[1] = max (preset to INT_MAX / INT_MIN)
 __global__ void k_plane_range(const int4* __restrict__ pb_info, int npb, int axis, int* out) {

@@ -113,6 +113,7 @@ struct SparklPipeline {
     bool in_substep = false;
     bool pending_clock_saved = false;
     bool tiles_ready = false;      // the previous substep_finish_fused already scattered this substep's tiles
+    bool halo_store_mode = false;  // inside sparkl_hip_group_substeps: halo records are stored, not added (no per-substep memset)
 
     // models / colliders
     DevBuf<DevModel> d_models;
@@ -196,6 +197,7 @@ struct SparklPipeline {
     struct Span { size_t a, b; int kind; };
     std::vector<Span> spans;
     SparklKernelClock clock{};
+    float span_ref_ms[16] = {0.f};       // duration of a working launch per span kind (see clock_collect)
     uint64_t total_resorts = 0;
 };
 
@@ -221,22 +223,37 @@ static int clock_end(SparklPipeline* p, size_t tok) {
     return SPARKL_OK;
 }
 // requires the stream to be idle
+// A launch that found the abort flag raised (the substeps of a batch behind a re-bin request) returns at once: ~8 us against the
+// 50-700 us of a working launch.  Averaged in, such spans would make the kernel look faster than it is (the deep collapse re-bins
+// every ~100 substeps and leaves up to 127 of them per cut batch), so a span shorter than a quarter of the longest recent span of the
+// same kernel is counted as a no-op launch (SparklKernelClock::noop_*), not as a launch of the kernel.
 static int clock_collect(SparklPipeline* p) {
-    for (auto& s : p->spans) {
-        float ms = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms, p->ev_pool[s.a], p->ev_pool[s.b]));
+    std::vector<float> ms(p->spans.size(), 0.f);
+    float* longest = p->span_ref_ms;   // decays slowly across collections: a chunk that lies wholly behind a re-bin request holds no-ops only
+    for (int k = 0; k < 16; ++k) longest[k] *= 0.9f;
+    for (size_t i = 0; i < p->spans.size(); ++i) {
+        const auto& s = p->spans[i];
+        HIPCHK(hipEventElapsedTime(&ms[i], p->ev_pool[s.a], p->ev_pool[s.b]));
+        if (s.kind >= 0 && s.kind < 16) longest[s.kind] = std::max(longest[s.kind], ms[i]);
+    }
+    for (size_t i = 0; i < p->spans.size(); ++i) {
+        const auto& s = p->spans[i];
+        const float t = ms[i];
+        const bool kernel_span = s.kind == SPAN_P2G || s.kind == SPAN_GRID || s.kind == SPAN_G2P || s.kind == SPAN_FUSED || s.kind == SPAN_P2G_MASS || s.kind == SPAN_GRID_MASS ||
+                                 s.kind == SPAN_G2P_VOLUME;
+        if (kernel_span && t < 0.25f * longest[s.kind]) { p->clock.noop_ms += t; p->clock.noop_launches++; continue; }
         switch (s.kind) {
-            case SPAN_P2G: p->clock.p2g_ms += ms; p->clock.p2g_launches++; break;
-            case SPAN_GRID: p->clock.grid_update_ms += ms; p->clock.grid_update_launches++; break;
-            case SPAN_G2P: p->clock.g2p_ms += ms; p->clock.g2p_launches++; break;
-            case SPAN_FUSED: p->clock.g2p2g_ms += ms; p->clock.g2p2g_launches++; break;
-            case SPAN_SORT: p->clock.sort_ms += ms; break;
-            case SPAN_REORDER: p->clock.reorder_ms += ms; p->clock.reorder_launches++; break;
-            case SPAN_DT: p->clock.dt_ms += ms; break;
-            case SPAN_P2G_MASS: p->clock.p2g_mass_ms += ms; p->clock.p2g_mass_launches++; break;
-            case SPAN_GRID_MASS: p->clock.grid_update_mass_ms += ms; p->clock.grid_update_mass_launches++; break;
-            case SPAN_G2P_VOLUME: p->clock.g2p_volume_ms += ms; p->clock.g2p_volume_launches++; break;
-            default: p->clock.halo_ms += ms; break;
+            case SPAN_P2G: p->clock.p2g_ms += t; p->clock.p2g_launches++; break;
+            case SPAN_GRID: p->clock.grid_update_ms += t; p->clock.grid_update_launches++; break;
+            case SPAN_G2P: p->clock.g2p_ms += t; p->clock.g2p_launches++; break;
+            case SPAN_FUSED: p->clock.g2p2g_ms += t; p->clock.g2p2g_launches++; break;
+            case SPAN_SORT: p->clock.sort_ms += t; break;
+            case SPAN_REORDER: p->clock.reorder_ms += t; p->clock.reorder_launches++; break;
+            case SPAN_DT: p->clock.dt_ms += t; break;
+            case SPAN_P2G_MASS: p->clock.p2g_mass_ms += t; p->clock.p2g_mass_launches++; break;
+            case SPAN_GRID_MASS: p->clock.grid_update_mass_ms += t; p->clock.grid_update_mass_launches++; break;
+            case SPAN_G2P_VOLUME: p->clock.g2p_volume_ms += t; p->clock.g2p_volume_launches++; break;
+            default: p->clock.halo_ms += t; break;
         }
     }
     p->spans.clear();
@@ -260,6 +277,7 @@ static GridArrays grid_arrays(const SparklPipeline* p) {
     g.cuboids = p->d_cuboids.p; g.heightfields = p->d_heightfields.p; g.trimeshes = p->d_trimeshes.p;
     g.pblk = p->pblk.p; g.pb_info = p->pb_info.p; g.tile_mode = p->tile_mode.p; g.tiles = p->tiles.p; g.node_vel = p->node_vel.p; g.node_mom = p->capture_mom ? p->node_mom.p : nullptr;
     g.halo_in = (p->slab_on && p->num_blocks) ? p->halo_in.p : nullptr;
+    g.halo_axis = p->slab_axis; g.halo_lo = p->slab_lo; g.halo_hi = p->slab_hi;
     g.num_blocks = p->num_blocks; g.num_pblocks = p->num_pblocks;
     return g;
 }
@@ -1318,8 +1336,9 @@ int sparkl_hip_particles_truncate(SparklPipeline* p, uint64_t new_len) {
 }
 
 // ------------------------------------------------------------------------------------------ stepping
-// DamageModel::{CdMpm, Eigenerosion, ModifiedEigenerosion} (mls_solver.rs:68-83) are not built: refuse instead of silently
-// stepping with DamageModel::None.
+// DamageModel::{CdMpm, Eigenerosion} (mls_solver.rs:68-83) are not built: refuse instead of silently stepping with
+// DamageModel::None.  ModifiedEigenerosion is built for the single-pipeline entry points (enqueue_psi_sweep); the split-phase
+// and slab-group entry points refuse it (the psi planes are not exchanged across cuts).
 static int unsupported_damage_model(const SparklSolverParams* params) {
     return set_error(SPARKL_ERR_UNSUPPORTED, "damage_model %d is not implemented (SPARKL_DAMAGE_NONE and SPARKL_DAMAGE_MODIFIED_EIGENEROSION are)", (int)params->damage_model);
 }
@@ -1737,7 +1756,9 @@ int sparkl_hip_substep_begin(SparklPipeline* p, const SparklSolverParams* params
     if (p->num_pblocks == 0) return SPARKL_OK;
     hipStream_t st = p->stream;
     const GridArrays G = grid_arrays(p);
-    if (G.halo_in) HIPCHK(hipMemsetAsync(p->halo_in.p, 0, (size_t)p->num_blocks * 64 * sizeof(float4), st));
+    // split-phase callers ADD their records (sparkl_hip_halo_merge, any number of calls per substep): start from zero.  The group
+    // loop stores its records instead (k_halo_merge2) and relies on the zero fill of the re-bin.
+    if (G.halo_in && !p->halo_store_mode) HIPCHK(hipMemsetAsync(p->halo_in.p, 0, (size_t)p->num_blocks * 64 * sizeof(float4), st));
     if (p->tiles_ready) { p->tiles_ready = false; return SPARKL_OK; }   // scattered by the fused kernel of the previous substep
     if (params->force_fluids_volume_recomputation && p->any_fluid) CHK(enqueue_fluid_volumes(p, p->pending));
     size_t t0 = 0;
@@ -1894,7 +1915,6 @@ static void comm_destroy(SparklPipeline* p) {
     p->comm = nullptr;
 }
 
-__global__ void k_max_i32(int* dst, const int* src) { *dst = max(*dst, *src); }
 
 namespace {
 struct Group {
@@ -1919,30 +1939,40 @@ static int x_staging(SparklPipeline* p) {
     return SPARKL_OK;
 }
 
-// MAX over all members and ranks of one host value per member (host-synchronous: only used around re-bins)
-static int group_max(const Group& G, const long long* per_member, long long* out) {
-    long long mx = 0;
-    for (int i = 0; i < G.n; ++i) mx = std::max(mx, per_member[i]);
+// MAX over all members and ranks of one host value per member (host-synchronous: only used around re-bins).  `veto` (optional)
+// travels in the same all-reduce: out_veto = MAX of every member's veto[i] on every rank.
+static int group_max(const Group& G, const long long* per_member, long long* out, const long long* veto = nullptr, long long* out_veto = nullptr) {
+    long long mx = 0, vx = 0;
+    for (int i = 0; i < G.n; ++i) { mx = std::max(mx, per_member[i]); if (veto) vx = std::max(vx, veto[i]); }
     if (G.rccl) {
         for (int i = 0; i < G.n; ++i) {
             SparklPipeline* p = G.m[i];
             HIPCHK(hipSetDevice(p->device));
-            p->x_host[0] = mx;
-            HIPCHK(hipMemcpyAsync(p->x_dev.p, p->x_host, sizeof(long long), hipMemcpyHostToDevice, p->stream));
+            p->x_host[0] = mx; p->x_host[1] = vx;
+            HIPCHK(hipMemcpyAsync(p->x_dev.p, p->x_host, 2 * sizeof(long long), hipMemcpyHostToDevice, p->stream));
         }
         NCCLCHK(g_rccl.GroupStart());
-        for (int i = 0; i < G.n; ++i) NCCLCHK(g_rccl.AllReduce(G.m[i]->x_dev.p, G.m[i]->x_dev.p, 1, ncclInt64, ncclMax, G.m[i]->comm, G.m[i]->stream));
+        for (int i = 0; i < G.n; ++i) NCCLCHK(g_rccl.AllReduce(G.m[i]->x_dev.p, G.m[i]->x_dev.p, 2, ncclInt64, ncclMax, G.m[i]->comm, G.m[i]->stream));
         NCCLCHK(g_rccl.GroupEnd());
         for (int i = 0; i < G.n; ++i) {
             SparklPipeline* p = G.m[i];
             HIPCHK(hipSetDevice(p->device));
-            HIPCHK(hipMemcpyAsync(p->x_host, p->x_dev.p, sizeof(long long), hipMemcpyDeviceToHost, p->stream));
+            HIPCHK(hipMemcpyAsync(p->x_host, p->x_dev.p, 2 * sizeof(long long), hipMemcpyDeviceToHost, p->stream));
             HIPCHK(hipStreamSynchronize(p->stream));
-            mx = std::max(mx, p->x_host[0]);
+            mx = std::max(mx, p->x_host[0]); vx = std::max(vx, p->x_host[1]);
         }
     }
     *out = mx;
+    if (out_veto) *out_veto = vx;
     return SPARKL_OK;
+}
+// Whether the coming collective re-bin may also move the cuts (group_rebalance: two more count exchanges).  Every rank must take
+// the same branch or the Send / Recv pairs of those exchanges stay unmatched: the decision is rank-local state (a re-bin has
+// happened before, sparkl_hip_slab_balance), so it travels as a veto in the all-reduce that decides the re-bin itself.
+static long long balance_veto(const Group& G) {
+    bool ok = G.balance;
+    for (int i = 0; i < G.n; ++i) ok = ok && G.m[i]->group_rebins > 0 && G.m[i]->slab_balance;
+    return ok ? 0 : 1;
 }
 
 // counts[i][side] announced to the neighbour on that side -> what the neighbours announced (host-synchronous)
@@ -2045,11 +2075,10 @@ static int group_rebalance(const Group& G) {
     return SPARKL_OK;
 }
 
-static int group_rebin(const Group& G) {
+// `balance`: agreed by every rank (balance_veto through group_max); needs the block list of an earlier re-bin
+static int group_rebin(const Group& G, bool balance) {
     const uint64_t mig_bytes = MIG_F4 * sizeof(float4), halo_bytes = sizeof(HaloRecord);
-    bool binned = true;
-    for (int i = 0; i < G.n; ++i) binned = binned && G.m[i]->group_rebins > 0;
-    if (binned && G.balance) CHK(group_rebalance(G));   // needs the block list of an earlier re-bin
+    if (balance) CHK(group_rebalance(G));
     std::vector<std::array<uint64_t, 2>> n_out(G.n), n_in(G.n), b_out(G.n), b_in(G.n);
     std::vector<long long> total(G.n);
     for (int round = 0; round < 64; ++round) {
@@ -2151,11 +2180,16 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
     bool need_rebin = false;
     for (int i = 0; i < G.n; ++i) need_rebin |= !members[i]->sorted || members[i]->group_rebins == 0;
     {   // a member that still has to (re-)bin makes the whole job do it: the re-bin is collective
-        std::vector<long long> v(G.n, need_rebin ? 1 : 0);
-        long long any = 0;
-        CHK(group_max(G, v.data(), &any));
-        if (any) CHK(group_rebin(G));
+        std::vector<long long> v(G.n, need_rebin ? 1 : 0), veto(G.n, balance_veto(G));
+        long long any = 0, no_balance = 0;
+        CHK(group_max(G, v.data(), &any, veto.data(), &no_balance));
+        if (any) CHK(group_rebin(G, no_balance == 0));
     }
+    struct StoreMode {   // halo records are stored, not added, while this loop owns the substeps (see k_halo_merge2)
+        const Group& g;
+        explicit StoreMode(const Group& gg) : g(gg) { for (int i = 0; i < g.n; ++i) g.m[i]->halo_store_mode = true; }
+        ~StoreMode() { for (int i = 0; i < g.n; ++i) g.m[i]->halo_store_mode = false; }
+    } store_mode(G);
     std::vector<uint32_t> base(G.n);
     for (int i = 0; i < G.n; ++i) { HIPCHK(hipSetDevice(members[i]->device)); CHK(read_ctl(members[i])); base[i] = members[i]->h_ctl->steps_done; }
     uint32_t done = 0;
@@ -2164,33 +2198,61 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
     while (done < nsubsteps) {
         const uint32_t batch = std::min<uint32_t>(16, nsubsteps - done);
         for (uint32_t j = 0; j < batch; ++j) {
-            // 1. the re-bin request of the upcoming substep, MAX over every slab: all ranks skip the same substeps
-            for (int i = 0; i < G.n; ++i) { HIPCHK(hipSetDevice(members[i]->device)); CHK(sparkl_hip_flags_export(members[i], members[i]->x_dev.p + 8)); }
+            // 1. the re-bin request of the upcoming substep, MAX over every slab: all ranks skip the same substeps.  In place on the
+            //    control blocks: one 4-byte all-reduce (RCCL) or one single-thread kernel (members of one process)
             if (G.rccl) {
                 NCCLCHK(g_rccl.GroupStart());
-                for (int i = 0; i < G.n; ++i) NCCLCHK(g_rccl.AllReduce(members[i]->x_dev.p + 8, members[i]->x_dev.p + 8, 1, ncclInt32, ncclMax, members[i]->comm, members[i]->stream));
+                for (int i = 0; i < G.n; ++i) {
+                    uint32_t* flag = &members[i]->d_ctl->abort_flag[members[i]->substep_index & 1u];
+                    NCCLCHK(g_rccl.AllReduce(flag, flag, 1, ncclUint32, ncclMax, members[i]->comm, members[i]->stream));
+                }
                 NCCLCHK(g_rccl.GroupEnd());
             } else if (G.n > 1) {
-                for (int i = 1; i < G.n; ++i) hipLaunchKernelGGL(k_max_i32, dim3(1), dim3(1), 0, members[0]->stream, (int*)(members[0]->x_dev.p + 8), (const int*)(members[i]->x_dev.p + 8));
-                for (int i = 1; i < G.n; ++i) HIPCHK(hipMemcpyAsync(members[i]->x_dev.p + 8, members[0]->x_dev.p + 8, 4, hipMemcpyDeviceToDevice, members[0]->stream));
+                // up to 16 control blocks per launch; longer groups chain chunks through members[0] and run the chain twice
+                const int parity = (int)(members[0]->substep_index & 1u);
+                for (int pass = 0; pass < (G.n > 16 ? 2 : 1); ++pass)
+                    for (int i0 = 1; i0 < G.n; i0 += 15) {
+                        CtlList L;
+                        L.n = 0;
+                        L.c[L.n++] = members[0]->d_ctl;
+                        for (int i = i0; i < G.n && L.n < 16; ++i) L.c[L.n++] = members[i]->d_ctl;
+                        hipLaunchKernelGGL(k_flags_max, dim3(1), dim3(1), 0, members[0]->stream, L, parity);
+                    }
             }
-            for (int i = 0; i < G.n; ++i) { HIPCHK(hipSetDevice(members[i]->device)); CHK(sparkl_hip_flags_import(members[i], members[i]->x_dev.p + 8)); }
-            // 2. scatter, pack the shared planes, swap, merge, finish
+            // 2. scatter (nothing when the previous fused kernel already did), pack the shared planes of both cuts, swap, store
             for (int i = 0; i < G.n; ++i) CHK(sparkl_hip_substep_begin(members[i], params, gravity, dt));
-            for (int i = 0; i < G.n; ++i)
-                for (int side = 0; side < 2; ++side) {
-                    bs[i][side] = members[i]->x_nsend[side] * sizeof(HaloRecord); br[i][side] = members[i]->x_nrecv[side] * sizeof(HaloRecord);
-                    if (members[i]->x_nsend[side]) CHK(sparkl_hip_halo_pack(members[i], side, members[i]->x_send[side].p));
-                }
+            for (int i = 0; i < G.n; ++i) {
+                SparklPipeline* p = members[i];
+                for (int side = 0; side < 2; ++side) { bs[i][side] = p->x_nsend[side] * sizeof(HaloRecord); br[i][side] = p->x_nrecv[side] * sizeof(HaloRecord); }
+                const int n0 = (int)p->x_nsend[0], n1 = (int)p->x_nsend[1];
+                if (n0 + n1 == 0 || p->num_pblocks == 0) continue;
+                HIPCHK(hipSetDevice(p->device));
+                HaloSides hs{};
+                for (int side = 0; side < 2; ++side) { hs.list[side] = p->halo_list[side].p; hs.n[side] = (int)p->x_nsend[side]; hs.out[side] = (HaloRecord*)p->x_send[side].p; }
+                size_t tok = 0;
+                CHK(clock_begin(p, SPAN_HALO, &tok));
+                hipLaunchKernelGGL(k_halo_pack2, dim3((n0 + n1 + 3) / 4), dim3(BLK_THREADS), 0, p->stream, grid_arrays(p), p->blk_keys.p, hs, p->slab_axis, p->d_ctl, p->pending.parity);
+                CHK(clock_end(p, tok));
+            }
             {
                 size_t tok = 0;
                 CHK(clock_begin(members[0], SPAN_HALO, &tok));
                 CHK(group_exchange(G, &SparklPipeline::x_send, &SparklPipeline::x_recv, (const uint64_t(*)[2])bs.data(), (const uint64_t(*)[2])br.data()));
                 CHK(clock_end(members[0], tok));
             }
-            for (int i = 0; i < G.n; ++i)
-                for (int side = 0; side < 2; ++side)
-                    if (members[i]->x_nrecv[side]) CHK(sparkl_hip_halo_merge(members[i], side, members[i]->x_recv[side].p, members[i]->x_nrecv[side]));
+            for (int i = 0; i < G.n; ++i) {
+                SparklPipeline* p = members[i];
+                const int n0 = (int)p->x_nrecv[0], n1 = (int)p->x_nrecv[1];
+                if (n0 + n1 == 0 || p->num_blocks == 0) continue;
+                HIPCHK(hipSetDevice(p->device));
+                HaloSides hs{};
+                for (int side = 0; side < 2; ++side) { hs.in[side] = (const HaloRecord*)p->x_recv[side].p; hs.nin[side] = (int)p->x_nrecv[side]; }
+                HashTable H{p->hash_keys.p, p->hash_vals.p, p->hash_mask};
+                size_t tok = 0;
+                CHK(clock_begin(p, SPAN_HALO, &tok));
+                hipLaunchKernelGGL(k_halo_merge2, dim3((n0 + n1 + 3) / 4), dim3(BLK_THREADS), 0, p->stream, hs, p->slab_axis, H, p->halo_in.p, p->d_ctl, p->pending.parity);
+                CHK(clock_end(p, tok));
+            }
             for (int i = 0; i < G.n; ++i) CHK(substep_finish_impl(members[i], j + 1 < batch, true));
             HIPCHK(hipGetLastError());
         }
@@ -2209,10 +2271,12 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
             ran = i == 0 ? r : std::min(ran, r);
             needs[i] = (r < done + batch || members[i]->h_ctl->abort_flag[0] || members[i]->h_ctl->abort_flag[1]) ? 1 : 0;
         }
-        CHK(group_max(G, needs.data(), &need));
+        std::vector<long long> veto(G.n, balance_veto(G));
+        long long no_balance = 0;
+        CHK(group_max(G, needs.data(), &need, veto.data(), &no_balance));
         done = ran;
         if (need) {
-            CHK(group_rebin(G));
+            CHK(group_rebin(G, no_balance == 0));
             if (++guard > (int)nsubsteps * 2 + 16) return set_error(SPARKL_ERR_INTERNAL, "re-bin loop did not make progress");
         }
     }

@@ -166,19 +166,34 @@ def fluid_dam(nx, ny, nz, h=0.8, r=0.1, jitter=True, name=None):
                  _domain_bits_for(max_cell))
 
 
-def cube_through_sand(nx, ny, nz, cube_n=25, h=0.2, jitter=True, name=None):
-    """Config 5: sand bed + kinematic cube moving at (10,0,0) (examples3d/cube_through_sand3.rs:40-81)."""
-    sc = sand_column(nx, ny, nz, h=h, jitter=jitter)
+def cube_through_sand(nx, ny, nz, cube_n=25, h=0.2, jitter=True, name=None, x_slab=(0, 1)):
+    """Config 5: sand bed + kinematic cube moving at (10,0,0) (examples3d/cube_through_sand3.rs:40-81).
+
+    x_slab=(k, K): only the k-th of K x-slabs of a bed K*nx particles long (multi-GPU); the cube starts over slab 0 and belongs
+    to it.  `Scene.id_offset` is then the global id of the slab's first particle (bed slabs in order, the cube after slab 0)."""
+    k, K = x_slab
+    sc = sand_column(nx, ny, nz, h=h, jitter=jitter, x_slab=x_slab)
     r = h / 4.0
     kin_model = sc.models.insert(ParticleModel.new(CorotatedLinearElasticity(1.0e7, 0.2)))
-    top = sc.particles.position["point"][:, 1].max()
-    origin = [4 * h + r, top + 2 * h, 4 * h + r + (nz // 2 - cube_n // 2) * 2 * r]
-    kin = new_particles(kin_model, cube_positions(origin, cube_n, cube_n, cube_n, r, jitter, rng_offset=nx * ny * nz), r, 2700.0)
-    kin.status["kinematic_vel_enabled"] = 1
-    kin.status["kinematic_vel"] = np.array([10.0, 0.0, 0.0], dtype=f32)
-    sc.particles = ParticleComponents.concatenate([sc.particles, kin])
-    sc.name = name or f"cube_through_sand_{nx}x{ny}x{nz}"
-    max_cell = int(np.ceil(sc.particles.position["point"].max() / h)) + 2
+    n_bed = nx * ny * nz
+    nc = cube_n ** 3
+    if K == 1:
+        top = sc.particles.position["point"][:, 1].max()
+    else:   # the same on every rank: the lattice top plus the largest jitter
+        top = f32(4 * h + r) + f32(ny - 1) * f32(2 * r) + f32(0.25 * 2 * r)
+    if k == 0:
+        origin = [4 * h + r, top + 2 * h, 4 * h + r + (nz // 2 - cube_n // 2) * 2 * r]
+        kin = new_particles(kin_model, cube_positions(origin, cube_n, cube_n, cube_n, r, jitter, rng_offset=nx * ny * nz), r, 2700.0)
+        kin.status["kinematic_vel_enabled"] = 1
+        kin.status["kinematic_vel"] = np.array([10.0, 0.0, 0.0], dtype=f32)
+        sc.particles = ParticleComponents.concatenate([sc.particles, kin])
+    sc.id_offset = k * n_bed + (nc if k > 0 else 0)
+    sc.total_particles = K * n_bed + nc
+    sc.name = name or f"cube_through_sand_{K * nx}x{ny}x{nz}"
+    if K == 1:
+        max_cell = int(np.ceil(sc.particles.position["point"].max() / h)) + 2
+    else:
+        max_cell = int(np.ceil(max(float(sc.particles.position["point"].max()), float(top) + 2 * h + cube_n * 2 * r, 4 * h + K * nx * 2 * r) / h)) + 2
     sc.domain_log2_bytes = _domain_bits_for(max_cell)
     return sc
 

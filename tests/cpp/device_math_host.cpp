@@ -46,7 +46,7 @@ void devmath_dp_update(const float* mp, float phase, float eh, const float* E_in
     for (int i = 0; i < 6; ++i) tau6[i] = T.valid ? T.t[i] : 0.f;
     M3 F = E;
     F.m[0] += 1.f; F.m[4] += 1.f; F.m[8] += 1.f;
-    *psi = model_pos_energy(mo, phase, eh, F, E, s, sv_valid);
+    *psi = model_pos_energy(mo, phase, eh, F, E, s, sv_valid, det_minus_one(E));
     *flags = (sv_valid ? 1 : 0) | (T.valid ? 2 : 0);
 }
 // phase == 1 corotated Kirchhoff stress of F = I + E (column-major 3x3 out) and the positive energy without a return map
@@ -59,7 +59,7 @@ void devmath_corotated(const float* mp, float eh, const float* E_in, float* tau9
     M3 F = E;
     F.m[0] += 1.f; F.m[4] += 1.f; F.m[8] += 1.f;
     const float s[3] = {0.f, 0.f, 0.f};
-    *psi = model_pos_energy(mo, 1.f, eh, F, E, s, false);
+    *psi = model_pos_energy(mo, 1.f, eh, F, E, s, false, det_minus_one(E));
 }
 void devmath_sym_eigvals(const float* a6, float* e3) { sym_eigvals(a6, e3); }
 float devmath_series_max(void) { return SPK_SERIES_MAX; }
