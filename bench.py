@@ -40,7 +40,9 @@ VOLUME_NODE_BYTES = {"p2g_mass": 4, "grid_update_mass": 8}
 # the parity gate of tests/parity.py (TOLERANCE_STATEMENT), stated beside every number this file prints
 PARITY_TOLERANCE = ("arbiter = the reference's algorithm evaluated in f64 (oracle/): eps_x (in h) and eps_v (relative to max |v|) of the HIP path "
                     "vs that trajectory <= 1e-4; vs the reference's own f32 arithmetic (f32 oracle): eps_x <= 1e-4 and "
-                    "eps_v <= eps_v(f32 oracle vs f64 oracle) + 1e-4 -- the f32 oracle itself sits 1e-4..6e-4 from the f64 trajectory on stiff sand")
+                    "eps_v <= eps_v(f32 oracle vs f64 oracle) + 1e-4 -- the f32 oracle itself sits 1e-4..6e-4 from the f64 trajectory on stiff sand; "
+                    "full-size cases: eps_x bound + substeps * ulp_f32(max |x|) / 2h (f32 position storage), 2 M-particle fluid: eps_v vs the f32 oracle "
+                    "(the f32 reference is 4.6e-3 from f64 there)")
 KERNEL_NAMES = {"p2g": "k_p2g_pair", "g2p": "k_g2p", "grid_update": "k_grid_update", "g2p2g": "k_g2p2g", "p2g_mass": "k_p2g_mass",
                 "grid_update_mass": "k_grid_update<mass>", "g2p_volume": "k_g2p_volume"}
 

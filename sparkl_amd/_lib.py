@@ -32,7 +32,7 @@ SYMBOLS = [
 def build(force=False, extra=""):
     """hipcc --offload-arch=gfx950 build of the library (cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("sparkl_hip.hip", "kernels.h", "device_math.h", "probes.h")] + [os.path.join(_HERE, "..", "include", "sparkl_hip.h")]
+    srcs = [os.path.join(src_dir, f) for f in ("sparkl_hip.hip", "kernels.h", "device_math.h", "probes.h", "probe_hooks.h")] + [os.path.join(_HERE, "..", "include", "sparkl_hip.h")]
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
         cmd = ["make", "-C", src_dir, "-s"] + (["-B"] if force else []) + ([f"EXTRA={extra}"] if extra else [])
@@ -48,7 +48,7 @@ def lib():
                                "(hipcc --offload-arch=gfx950). sparkl_amd has no CPU fallback.")
         L = C.CDLL(LIB_PATH)
         for s in SYMBOLS:
-            if not os.environ.get("SPARKL_HIP_LIB_AB"):   # A/B runs against libraries of older revisions (tools/tools_ab3.sh)
+            if not os.environ.get("SPARKL_HIP_LIB_AB"):   # A/B runs against libraries of older revisions (tools/build_rev.sh)
                 getattr(L, s)  # AttributeError if the library does not export it
         L.sparkl_hip_last_error_string.restype = C.c_char_p
         L.sparkl_hip_version.restype = C.c_char_p

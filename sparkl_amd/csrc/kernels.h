@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_math.h"
+#include "probe_hooks.h"
 
 namespace spk {
 
@@ -263,16 +264,10 @@ SPK_DEV Scatter p2g_prepare(const DevModel& mo, uint32_t flags, const float px[3
     sc.base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
     sc.shell = ((lc[0] < 1) | (lc[0] > 4) | (lc[1] < 1) | (lc[1] > 4) | (lc[2] < 1) | (lc[2] > 4)) ? 1 : 0;
     M3 tau = m3_zero();
-#ifdef SPK_EXP_NO_STRESS
-    if (mass == 123.456f) {
-#else
     if (!(flags & FLAG_FAILED)) {
-#endif
         if (mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR) {
-#ifndef SPK_EXP_NO_SVD_STRESS
             if (T != nullptr && T->valid && phase == 1.f) tau = sym_to_m3(*T);
             else
-#endif
                 tau = phase == 1.f ? corotated_kirchhoff_fe(mo, eh, Fe) : corotated_kirchhoff(mo, phase, eh, F);
         } else if (mo.ctag == SPARKL_CONSTITUTIVE_NEO_HOOKEAN) tau = neo_hookean_kirchhoff(mo, phase, eh, F);
         else if (mo.ctag == SPARKL_CONSTITUTIVE_EOS_MONAGHAN_SPH) tau = monaghan_kirchhoff(mo, mass, vol0, F.m[0], fluid_jp, C);
@@ -350,28 +345,16 @@ SPK_DEV int p2g_scatter(double (*tile)[ACC_N], const Scatter& sc, bool live, int
                     // v_fmac (+ s_nop) for the builtin form, so this is hand-written; the four independent chains are
                     // interleaved so that a DPP read of c_k is >= 3 VALU ops after its write (DPP needs 2 wait states),
                     // and the leading s_nop covers the compiler's last write.
-#ifdef SPK_EXP_NO_DPP
-                    if (false) {
-#else
                     if (REDUCE_STEPS == 2) {
-#endif
                         asm volatile("s_nop 1\n" SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2));
-#ifdef SPK_EXP_NO_DPP
-                    } else if (false) {
-#else
                     } else if (REDUCE_STEPS == 3) {
-#endif
                         asm volatile("s_nop 1\n" SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") SPK_FMAC_DPP("4", "%6")
                                      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4));
                     } else if (REDUCE_STEPS == 4) {
                         asm volatile("s_nop 1\n" SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") SPK_FMAC_DPP("4", "%6") SPK_FMAC_DPP("8", "%7")
                                      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4), "v"(f8));
                     }
-#ifdef SPK_EXP_NO_ATOMICS
-                    if (live && head && c0 == 123.456f) {
-#else
                     if (live && head) {
-#endif
                         const int n = acc_slot(sc.base + sx + TILE_W * sy + TILE_W * TILE_W * sz);
                         atomicAdd(&tile[0][n], (double)c0);
                         atomicAdd(&tile[1][n], (double)c1);
@@ -1338,11 +1321,7 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
         o.store_aux = alpha != alpha0;
         o.alpha = alpha;
     }
-#ifdef SPK_EXP_NO_PLASTICITY
-    if (dp_e && Jp == 123.456f) {
-#else
     if (dp_e) {
-#endif
         SPK_MARK("dp_update");
         dp_update_e<WANT_STRESS>(mo, phase, eh, E, Jp, q, lvg, sv, sv_valid, o.T);   // sv: sigma' - 1
         SPK_MARK("post_dp");
@@ -1498,11 +1477,6 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     __shared__ int s_runs[BLK_THREADS / 64][64];   // run list of each wave (run-task scatter)
     __shared__ float s_A[BLK_THREADS / 64][9][64]; // affine part of the scatter descriptors, per wave
     __shared__ DevModel s_models[LDS_MODELS ? MAX_LDS_MODELS : 1];
-#ifdef SPK_EXP_LDS_PAD   // occupancy experiment: fewer resident workgroups per CU
-    __shared__ float lds_pad[SPK_EXP_LDS_PAD / 4];
-    if (S.h < 0.f) lds_pad[tid] = 1.f;
-    if (S.h < -1.f) tile[0][0] = lds_pad[tid + 1];
-#endif
     const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int b = org.w, pfirst = rng.x, pcount = rng.y;
@@ -1510,13 +1484,11 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     // Software pipeline: the five float4 of the next batch are in flight while this batch computes.  The first batch is requested
     // before anything else that touches memory (abort flag, model table, velocity tile): every vector load the wave waits for
     // also waits for all older ones, so whatever is issued first pays the HBM latency for the rest.
-#ifndef SPK_EXP_NO_PREFETCH
     float4 n0, n1, n2, nd, nk;
     {
         const int i0 = pfirst + min(tid, pcount - 1);
         n0 = P.q[0][i0]; n1 = P.q[1][i0]; n2 = P.q[2][i0]; nd = P.d[i0]; nk = P.k[i0];
     }
-#endif
     if (ctl->abort_flag[S.parity]) {   // sticky abort: keep every later substep a no-op until the host re-bins
         if (blockIdx.x == 0 && tid == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
         return;
@@ -1540,15 +1512,11 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
         const int li = it * BLK_THREADS + tid;
         const bool active = li < pcount;
         const int i = pfirst + (active ? li : 0);
-#ifdef SPK_EXP_NO_PREFETCH
-        const float4 q0 = P.q[0][i], q1 = P.q[1][i], q2 = P.q[2][i], dd = P.d[i], kk = P.k[i];
-#else
         const float4 q0 = n0, q1 = n1, q2 = n2, dd = nd, kk = nk;
         if (it + 1 < niter) {
             const int inx = pfirst + min(li + BLK_THREADS, pcount - 1);
             n0 = P.q[0][inx]; n1 = P.q[1][inx]; n2 = P.q[2][inx]; nd = P.d[inx]; nk = P.k[inx];
         }
-#endif
         const uint32_t flags = __float_as_uint(kk.w);
         bool live = active && !(flags & FLAG_INVALID);
         Scatter sc;
@@ -1569,25 +1537,7 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
             SPK_MARK("p2g_prepare");
             if (live) { sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.Fe, kk.x, kk.y, o.eh, o.phase, o.Jp, org, h, inv_h, S.inv_d, S.dt_next, &o.T, o.rnew); shell_used |= sc.shell != 0; }
             SPK_MARK("scatter");
-#ifdef SPK_EXP_DUMMY_LDS    // sensitivity probe: N extra LDS reads (ds_read_b32, one wave-wide 256 B access each) per particle batch
-            {
-                volatile float* vp = &s_A[tid >> 6][0][0];
-                float acc = 0.f;
-#pragma unroll
-                for (int k = 0; k < SPK_EXP_DUMMY_LDS; ++k) acc += vp[((tid + 7 * k) & 63) + 64 * (k % 9)];
-                if (acc == 123.456f) sc.val_m += 1.f;
-            }
-#endif
-#ifdef SPK_EXP_DUMMY_VALU   // sensitivity probe: N extra dependent-free VALU instructions per particle batch
-            {
-                float d0 = o.px[0], d1 = o.px[1], d2 = o.px[2], d3 = o.vel[0];
-#pragma unroll
-                for (int k = 0; k < SPK_EXP_DUMMY_VALU / 4; ++k) {
-                    asm volatile("v_fmac_f32 %0, %0, %1\n v_fmac_f32 %1, %1, %2\n v_fmac_f32 %2, %2, %3\n v_fmac_f32 %3, %3, %0" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
-                }
-                if (d0 + d1 + d2 + d3 == 123.456f) sc.val_m += 1.f;
-            }
-#endif
+            probe_extra_work(s_A[tid >> 6], tid, o.px, o.vel, sc);   // probe_hooks.h: nothing unless an analysis build asks for it
         }
         // (a hybrid -- run tasks for regular waves, DPP for ragged ones -- was measured: the two paths in one kernel spill, +15 %)
         if (REDUCE_STEPS < 0) wave_heads += p2g_scatter_runs(tile, sc, live, tid, s_runs[tid >> 6], s_A[tid >> 6]);

@@ -9,7 +9,7 @@
 namespace spk {
 
 constexpr int RS_BINS = 65;
-enum { RS_NRUNS = 0, RS_MAXLEN = 1, RS_DISTINCT = 2, RS_CHUNKS4 = 3, RS_ROUNDS = 4, RS_ITERS = 5, RS_PCOUNT64 = 6, RS_LIVE = 7, RS_ROWS = 8, RS_LAYERS = 9, RS_HISTS = 10 };
+enum { RS_NRUNS = 0, RS_MAXLEN = 1, RS_DISTINCT = 2, RS_CHUNKS4 = 3, RS_ROUNDS = 4, RS_ITERS = 5, RS_PCOUNT64 = 6, RS_LIVE = 7, RS_ROWS = 8, RS_LAYERS = 9, RS_STRAIN = 10, RS_HISTS = 11 };
 
 __global__ __launch_bounds__(BLK_THREADS) void k_run_stats(ParticleArrays P, GridArrays G, float h, unsigned long long* out) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -71,6 +71,18 @@ __global__ __launch_bounds__(BLK_THREADS) void k_run_stats(ParticleArrays P, Gri
             iters += max(wave_max_i32(cnt), 1);
         }
         const int nlive = (int)__popcll(__ballot(live));
+        // wave maximum of |F^T F - I|_F (what selects the series path of the return map): bin k = first threshold of
+        // {1e-3, 3e-3, 1e-2, 3e-2, 1e-1, 3e-1, inf} above it
+        int sbin = 0;
+        {
+            const float4 q1 = P.q[1][i], q2 = P.q[2][i];
+            const M3 E = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
+            float S6[6];
+            strain_metric(E, S6);
+            float f = live ? sqrtf(sym_frob2(S6)) : 0.f;
+            for (int o = 32; o > 0; o >>= 1) f = fmaxf(f, __shfl_xor(f, o));
+            sbin = f < 1e-3f ? 0 : f < 3e-3f ? 1 : f < 1e-2f ? 2 : f < 3e-2f ? 3 : f < 1e-1f ? 4 : f < 3e-1f ? 5 : 6;
+        }
         if (lane == 0) {
             atomicAdd(&out[RS_NRUNS * RS_BINS + nruns], 1ull);
             atomicAdd(&out[RS_MAXLEN * RS_BINS + maxlen], 1ull);
@@ -81,6 +93,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_run_stats(ParticleArrays P, Gri
             atomicAdd(&out[RS_LIVE * RS_BINS + nlive], 1ull);
             atomicAdd(&out[RS_ROWS * RS_BINS + rows], 1ull);
             atomicAdd(&out[RS_LAYERS * RS_BINS + layers], 1ull);
+            atomicAdd(&out[RS_STRAIN * RS_BINS + sbin], 1ull);
         }
     }
 }

@@ -114,6 +114,13 @@ struct SparklPipeline {
     bool pending_clock_saved = false;
     bool tiles_ready = false;      // the previous substep_finish_fused already scattered this substep's tiles
     bool halo_store_mode = false;  // inside sparkl_hip_group_substeps: halo records are stored, not added (no per-substep memset)
+    // Tile carry-over between fixed-dt batches and calls: the LAST substep of a fused batch also runs k_g2p2g (complete state stored), so
+    // the tiles of substep `carry_index` for step length `carry_dt` are already scattered and the next batch skips its standalone
+    // P2G + the plain G2P it would have ended with (0.35 + 0.34 -> 0.53 ms per batch boundary at 10M).  Anything that touches the
+    // particles, the binning or the tiles in between clears it.  SPARKL_HIP_CARRY=0: off.
+    bool carry_on = true, carry_valid = false;
+    float carry_dt = 0.f;
+    uint32_t carry_index = 0;
 
     // models / colliders
     DevBuf<DevModel> d_models;
@@ -309,6 +316,7 @@ static int maybe_reorder(SparklPipeline* p, int parity) {
 
 static int resort(SparklPipeline* p) {
     hipStream_t st = p->stream;
+    p->carry_valid = false;   // the tiles belong to the old binning
     const int n = (int)p->n;
     size_t tok = 0;
     CHK(clock_begin(p, SPAN_SORT, &tok));
@@ -613,7 +621,10 @@ static int enqueue_fused_batch(SparklPipeline* p, const SparklSolverParams* sp, 
     const ParticleArrays P = p->cur.arrays();
     const bool was_on = p->clock_on;
     size_t tk = 0;
-    {
+    const bool carry_in = p->carry_on && p->carry_valid && p->carry_dt == dt && p->carry_index == p->substep_index;
+    const bool carry_out = p->carry_on && !p->rare_models && !sp->enable_boundary_particle_projection;
+    p->carry_valid = false;
+    if (!carry_in) {
         const StepParams S = make_params(p, sp, g, dt);
         if (was_on && (p->substep_index % p->clock_stride) != 0) p->clock_on = false;
         CHK(clock_begin(p, SPAN_P2G, &tk));
@@ -636,6 +647,11 @@ static int enqueue_fused_batch(SparklPipeline* p, const SparklSolverParams* sp, 
             CHK(clock_begin(p, SPAN_FUSED, &tk));
             launch_g2p2g(p, P, G, Sf, st);
             CHK(clock_end(p, tk));
+        } else if (carry_out) {
+            // the batch ends with the fused kernel too: complete particle state (C included) + the tiles of the next substep
+            CHK(clock_begin(p, SPAN_FUSED, &tk));
+            launch_g2p2g(p, P, G, S, st);
+            CHK(clock_end(p, tk));
         } else {
             CHK(clock_begin(p, SPAN_G2P, &tk));
             launch_g2p(p, P, G, S, st);
@@ -644,6 +660,7 @@ static int enqueue_fused_batch(SparklPipeline* p, const SparklSolverParams* sp, 
         p->clock_on = was_on;
         p->substep_index++;
     }
+    if (carry_out) { p->carry_valid = true; p->carry_dt = dt; p->carry_index = p->substep_index; }
     return SPARKL_OK;
 }
 
@@ -736,6 +753,7 @@ int sparkl_hip_pipeline_create(const SparklPipelineDesc* desc, SparklPipeline** 
     SparklPipeline* p = new SparklPipeline;
     p->fuse_fixed_dt = getenv("SPARKL_HIP_NO_FUSE") == nullptr;
     p->defer_c = !(getenv("SPARKL_HIP_DEFER_C") && !strcmp(getenv("SPARKL_HIP_DEFER_C"), "0"));
+    if (const char* e = getenv("SPARKL_HIP_CARRY")) p->carry_on = atoi(e) != 0;
     p->lookahead = !(getenv("SPARKL_HIP_LOOKAHEAD") && !strcmp(getenv("SPARKL_HIP_LOOKAHEAD"), "0"));
     p->lookahead_force = getenv("SPARKL_HIP_LOOKAHEAD") && !strcmp(getenv("SPARKL_HIP_LOOKAHEAD"), "force");
     p->device = desc->device_id;
@@ -813,6 +831,7 @@ int sparkl_hip_pipeline_sync(SparklPipeline* p) {
 
 // ------------------------------------------------------------------------------ models / colliders
 int sparkl_hip_models_set(SparklPipeline* p, uint32_t n, const SparklParticleModel* models) {
+    if (p) p->carry_valid = false;   // tiles scattered with the old model table
     if (!p || (n && !models)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
     HIPCHK(hipSetDevice(p->device));
     std::vector<DevModel> dm(n);
@@ -1381,8 +1400,8 @@ int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* pa
                     base_done, p->h_ctl->abort_flag[0], p->h_ctl->abort_flag[1], p->h_ctl->num_invalid, (unsigned long long)p->n, p->num_pblocks, p->num_blocks, p->substep_index & 1u);
         const uint32_t now_done = p->num_pblocks ? (p->h_ctl->steps_done - base_done) : done + batch;
         const bool aborted = now_done < done + batch;
-        // cut short behind a fused launch that deferred C.m[1..8]: the last substep of a batch that runs to its end is a
-        // plain k_g2p, which stores everything
+        // cut short behind a fused launch that deferred C.m[1..8]: the last substep of a batch that runs to its end stores
+        // everything (plain k_g2p, or k_g2p2g without the deferral when the tiles are carried over)
         if (fuse && aborted && now_done > done && p->defer_c && !p->rare_models && !params->enable_boundary_particle_projection) p->c_stale = true;
         done = now_done;
         if (aborted || p->h_ctl->abort_flag[0] || p->h_ctl->abort_flag[1]) {

@@ -6,7 +6,9 @@ the scene's largest coordinate (tests/parity.py::position_storage_allowance: 3.2
 oracle itself is 3.9e-4 from the f64 trajectory there); velocity bound: the plain 1e-4.
   configs[1]  1 M neo-Hookean cube       x 100 substeps
   configs[2] 10 M Drucker-Prager column  x  10 substeps
-  configs[3]  2 M-particle slice of the 20 M fluid dam (64 ppc, volume recompute sweep) x 10 substeps"""
+  configs[3]  2 M-particle slice of the 20 M fluid dam (64 ppc, volume recompute sweep) x 100 substeps (after 10 the dam has
+              barely started to move: max |v| = 0.02 m/s, and eps_v -- relative to it -- only measures the f32 noise of the stiff
+              equation of state, 3.5e-4 for the HIP path and 4.2e-4 for the f32 oracle alike)"""
 import json
 import os
 import time
@@ -38,7 +40,7 @@ def _oracle_run(sc, nsub, f64):
     return out, dt
 
 
-def _case(name, sc, nsub):
+def _case(name, sc, nsub, arbiter="f64"):
     from sparkl_amd.pipeline import MpmPipeline
     with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
         p.load_scene(sc)
@@ -49,7 +51,7 @@ def _case(name, sc, nsub):
     assert all(int(chk[k]) == 0 for k in VIOLATIONS), chk
     r32, t32 = _oracle_run(sc, nsub, False)
     r64, t64 = _oracle_run(sc, nsub, True)
-    rep, bad = parity_verdict(got, r32, r64, sc.cell_width, x_storage_steps=nsub)
+    rep, bad = parity_verdict(got, r32, r64, sc.cell_width, x_storage_steps=nsub, arbiter=arbiter)
     rec = {"test": name, "particles": len(sc.particles), "substeps": nsub, "particle_blocks": npb, "oracle_seconds": [t32, t64], "threads": _threads(), **rep}
     os.makedirs("gpurun_out", exist_ok=True)
     with open(os.path.join("gpurun_out", "parity.jsonl"), "a") as f:
@@ -71,8 +73,10 @@ def test_config3_drucker_prager_10M_10_substeps_vs_oracle():
     _case("full_size_sand10m_k10", sc, 10)
 
 
-def test_config4_fluid_2M_slice_10_substeps_vs_oracle():
+def test_config4_fluid_2M_slice_100_substeps_vs_oracle():
     """160 x 112 x 112 = 2.0 M particles of the dam (64 per cell): mass-only sweep, volume gather, hash of a 64 ppc cloud."""
     sc = scenes.fluid_dam(160, 112, 112, name="config4_fluid_slice")
     assert sc.params.force_fluids_volume_recomputation and len(sc.particles) == 160 * 112 * 112
-    _case("full_size_fluid2m_k10", sc, 10)
+    # the f32 reference itself is 4.6e-3 from its f64 trajectory here (pressure noise of the stiff equation of state): held to the
+    # f32 oracle, see parity_verdict(arbiter="either")
+    _case("full_size_fluid2m_k100", sc, 100, arbiter="either")

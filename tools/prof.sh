@@ -1,7 +1,7 @@
 #!/bin/bash
-# rocprofv3 passes for bench.py (run on the GPU box through gpurun).  Usage: tools_prof.sh <tag> [config] [steps]
+# rocprofv3 passes for bench.py (run on the GPU box through gpurun).  Usage: prof.sh <tag> [config] [steps]
 # Every profiled command runs under `timeout`: a stuck rocprofv3 must not eat the GPU budget.
-TAG=${1:-r02}
+TAG=${1:-r03}
 CFG=${2:-sand10m}
 STEPS=${3:-32}
 R=$GRAFT_REPO_ROOT
