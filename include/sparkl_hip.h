@@ -335,8 +335,8 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
  * sparkl_hip_pipeline_step (the latter runs its psi_mass / psi_momentum sweep only while a ParticleFracture
  * component is uploaded -- sparkl_hip_particles_set_fracture -- and turns the fused G2P->P2G schedule off);
  * SPARKL_DAMAGE_CDMPM / SPARKL_DAMAGE_EIGENEROSION return SPARKL_ERR_UNSUPPORTED everywhere, and the
- * split-phase / slab entry points (sparkl_hip_substep_begin, sparkl_hip_group_substeps, sparkl_hip_group_step)
- * accept SPARKL_DAMAGE_NONE only.  Substeps are enqueued in batches; the host reads the control block
+ * sparkl_hip_group_substeps accepts both as well (the psi planes and, with force_fluids_volume_recomputation, the mass planes of
+ * the cuts travel in extra halo rounds); the split-phase entry points (sparkl_hip_substep_begin ...) accept SPARKL_DAMAGE_NONE only.  Substeps are enqueued in batches; the host reads the control block
  * (72 bytes) back once per batch (a stream sync) to learn whether a re-bin is needed, so the call returns
  * when the last batch has been read. */
 int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* params,

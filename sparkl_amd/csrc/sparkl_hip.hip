@@ -1245,7 +1245,9 @@ int sparkl_hip_particles_read_sorted_ids(SparklPipeline* p, uint32_t* out, uint6
 int sparkl_hip_particles_set_fracture(SparklPipeline* p, const SparklParticleFracture* fracture, uint64_t n) {
     if (!p || (n && !fracture)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
     if (n != p->n) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "n (%llu) != particle count (%llu)", (unsigned long long)n, (unsigned long long)p->n);
-    if (p->slab_on) return set_error(SPARKL_ERR_UNSUPPORTED, "ParticleFracture on a slab pipeline");
+    // a slab numbers its particles id_offset .. id_offset + n in upload order; once a collective re-bin has migrated particles the
+    // local set is no longer that range (migration records carry the component along: k_pack_particles)
+    if (p->slab_on && p->group_rebins > 0) return set_error(SPARKL_ERR_UNSUPPORTED, "ParticleFracture of a slab pipeline must be set before the first collective re-bin");
     HIPCHK(hipSetDevice(p->device));
     if (n == 0) return SPARKL_OK;
     static_assert(sizeof(SparklParticleFracture) == 8, "");
@@ -1762,9 +1764,10 @@ int sparkl_hip_substep_status(SparklPipeline* p, uint32_t* steps_done, uint32_t*
 int sparkl_hip_substep_begin(SparklPipeline* p, const SparklSolverParams* params, const float gravity[3], float dt) {
     if (!p || !params || !gravity) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
     if (p->in_substep) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "substep_begin called twice");
-    if (params->damage_model != SPARKL_DAMAGE_NONE) return unsupported_damage_model(params);   // slabs: the psi planes do not cross cuts
-    if (params->force_fluids_volume_recomputation && p->any_fluid && p->slab_on && (p->slab_lo != INT32_MIN || p->slab_hi != INT32_MAX))
-        return set_error(SPARKL_ERR_UNSUPPORTED, "fluid volume recomputation across slab cuts is not implemented");
+    // split-phase callers move the halo themselves and have no psi round; the group loop (halo_store_mode) runs one
+    if (params->damage_model != SPARKL_DAMAGE_NONE && !(p->halo_store_mode && damage_supported(params))) return unsupported_damage_model(params);
+    if (params->force_fluids_volume_recomputation && p->any_fluid && p->slab_on && (p->slab_lo != INT32_MIN || p->slab_hi != INT32_MAX) && !p->halo_store_mode)
+        return set_error(SPARKL_ERR_UNSUPPORTED, "fluid volume recomputation across slab cuts needs the mass planes exchanged: use sparkl_hip_group_substeps");
     HIPCHK(hipSetDevice(p->device));
     if (!p->sorted) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "particles are not binned: call sparkl_hip_rebin (collectively) first");
     p->pending = make_params(p, params, gravity, dt);
@@ -1779,7 +1782,8 @@ int sparkl_hip_substep_begin(SparklPipeline* p, const SparklSolverParams* params
     // loop stores its records instead (k_halo_merge2) and relies on the zero fill of the re-bin.
     if (G.halo_in && !p->halo_store_mode) HIPCHK(hipMemsetAsync(p->halo_in.p, 0, (size_t)p->num_blocks * 64 * sizeof(float4), st));
     if (p->tiles_ready) { p->tiles_ready = false; return SPARKL_OK; }   // scattered by the fused kernel of the previous substep
-    if (params->force_fluids_volume_recomputation && p->any_fluid) CHK(enqueue_fluid_volumes(p, p->pending));
+    // (the slab-group loop runs the volume sweep itself, with the mass planes of the cuts exchanged: halo_store_mode)
+    if (params->force_fluids_volume_recomputation && p->any_fluid && !p->halo_store_mode) CHK(enqueue_fluid_volumes(p, p->pending));
     size_t t0 = 0;
     CHK(clock_begin(p, SPAN_P2G, &t0));
     launch_p2g(p, p->cur.arrays(), G, p->pending, st);
@@ -1817,12 +1821,14 @@ int sparkl_hip_halo_merge(SparklPipeline* p, int side, const void* dev_in, uint6
     CHK(clock_end(p, tok));
     return SPARKL_OK;
 }
-static int substep_finish_impl(SparklPipeline* p, bool fuse_next, bool defer_c = false) {
+// `part`: 1 = the grid update only (the substep stays open: the slab-group loop runs the psi sweep with its own halo round behind
+// it), 2 = the particle update only, 3 = both
+static int substep_finish_impl(SparklPipeline* p, bool fuse_next, bool defer_c = false, int part = 3) {
     if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
     if (!p->in_substep) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "substep_finish without substep_begin");
-    p->in_substep = false;
-    p->tiles_ready = false;
+    if (part & 2) { p->in_substep = false; p->tiles_ready = false; }
     if (p->num_pblocks == 0) {
+        if (!(part & 2)) return SPARKL_OK;
         hipLaunchKernelGGL(k_bump_steps, dim3(1), dim3(1), 0, p->stream, p->d_ctl, p->pending.parity);
         p->clock_on = p->pending_clock_saved;
         p->substep_index++;
@@ -1831,10 +1837,13 @@ static int substep_finish_impl(SparklPipeline* p, bool fuse_next, bool defer_c =
     hipStream_t st = p->stream;
     const GridArrays G = grid_arrays(p);
     size_t t1 = 0, t2 = 0;
-    CHK(maybe_reorder(p, p->pending.parity));
-    CHK(clock_begin(p, SPAN_GRID, &t1));
-    launch_grid_update(p, G, p->pending, st);
-    CHK(clock_end(p, t1));
+    if (part & 1) {
+        CHK(maybe_reorder(p, p->pending.parity));
+        CHK(clock_begin(p, SPAN_GRID, &t1));
+        launch_grid_update(p, G, p->pending, st);
+        CHK(clock_end(p, t1));
+    }
+    if (!(part & 2)) return SPARKL_OK;
     if (fuse_next && p->fuse_fixed_dt) {
         // G2P of this substep + P2G of the next one (same dt) in one kernel; the next substep_begin is then free
         // defer_c: only from sparkl_hip_group_substeps, which owns the batch and rebuilds C if it is cut (the public
@@ -1934,6 +1943,17 @@ static void comm_destroy(SparklPipeline* p) {
     p->comm = nullptr;
 }
 
+
+// every member of a slab group carries the ParticleFracture stream under DamageModel::ModifiedEigenerosion (immigrants bring theirs)
+static int ensure_fracture(SparklPipeline* p) {
+    if (p->cur.has_frac) return SPARKL_OK;
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    p->cur.has_frac = true;
+    CHK(p->cur.frac.reserve(std::max<size_t>(p->cur.q[0].cap, 1)));
+    if (p->n) hipLaunchKernelGGL(k_fracture, dim3(grid_for(p->n, 256)), dim3(256), 0, p->stream, p->cur.arrays(), (float2*)nullptr, 0, (int)p->n, 0ll, 2);
+    return SPARKL_OK;
+}
 
 namespace {
 struct Group {
@@ -2192,9 +2212,12 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
             if (members[i]->device != members[0]->device || members[i]->stream != members[0]->stream)
                 return set_error(SPARKL_ERR_INVALID_ARGUMENT, "members without a communicator must share one device and one stream");
         }
-    if (params->damage_model != SPARKL_DAMAGE_NONE) return unsupported_damage_model(params);
-    if (params->force_fluids_volume_recomputation) for (int i = 0; i < G.n; ++i) if (members[i]->any_fluid)
-        return set_error(SPARKL_ERR_UNSUPPORTED, "fluid volume recomputation across slab cuts is not implemented");
+    if (!damage_supported(params)) return unsupported_damage_model(params);
+    // Collective by construction: decided by the solver parameters alone, never by what a rank happens to hold (a slab without fluid
+    // or without the ParticleFracture component still takes part in the extra halo rounds, with zeros).
+    const bool fluid_sweep = params->force_fluids_volume_recomputation != 0;
+    const bool psi_sweep = params->damage_model == SPARKL_DAMAGE_MODIFIED_EIGENEROSION;
+    if (psi_sweep) for (int i = 0; i < G.n; ++i) CHK(ensure_fracture(members[i]));
     for (int i = 0; i < G.n; ++i) { HIPCHK(hipSetDevice(members[i]->device)); CHK(x_staging(members[i])); }
     bool need_rebin = false;
     for (int i = 0; i < G.n; ++i) need_rebin |= !members[i]->sorted || members[i]->group_rebins == 0;
@@ -2239,40 +2262,95 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
                     }
             }
             // 2. scatter (nothing when the previous fused kernel already did), pack the shared planes of both cuts, swap, store
+            // One halo round: every member packs its partial sums of the shared node planes (from the mass / momentum tiles, or from
+            // the psi tiles), the records travel to both neighbours and are stored into halo_in, which the next node kernel adds.
+            auto halo_round = [&](bool psi) -> int {
+                for (int i = 0; i < G.n; ++i) {
+                    SparklPipeline* p = members[i];
+                    for (int side = 0; side < 2; ++side) { bs[i][side] = p->x_nsend[side] * sizeof(HaloRecord); br[i][side] = p->x_nrecv[side] * sizeof(HaloRecord); }
+                    const int n0 = (int)p->x_nsend[0], n1 = (int)p->x_nsend[1];
+                    if (n0 + n1 == 0 || p->num_pblocks == 0) continue;
+                    HIPCHK(hipSetDevice(p->device));
+                    HaloSides hs{};
+                    for (int side = 0; side < 2; ++side) { hs.list[side] = p->halo_list[side].p; hs.n[side] = (int)p->x_nsend[side]; hs.out[side] = (HaloRecord*)p->x_send[side].p; }
+                    size_t tok = 0;
+                    CHK(clock_begin(p, SPAN_HALO, &tok));
+                    hipLaunchKernelGGL(k_halo_pack2, dim3((n0 + n1 + 3) / 4), dim3(BLK_THREADS), 0, p->stream, grid_arrays(p), p->blk_keys.p, hs, p->slab_axis, p->d_ctl, p->pending.parity,
+                                       psi ? (const float2*)p->psi_tiles.p : (const float2*)nullptr);
+                    CHK(clock_end(p, tok));
+                }
+                {
+                    size_t tok = 0;
+                    CHK(clock_begin(members[0], SPAN_HALO, &tok));
+                    CHK(group_exchange(G, &SparklPipeline::x_send, &SparklPipeline::x_recv, (const uint64_t(*)[2])bs.data(), (const uint64_t(*)[2])br.data()));
+                    CHK(clock_end(members[0], tok));
+                }
+                for (int i = 0; i < G.n; ++i) {
+                    SparklPipeline* p = members[i];
+                    const int n0 = (int)p->x_nrecv[0], n1 = (int)p->x_nrecv[1];
+                    if (n0 + n1 == 0 || p->num_blocks == 0) continue;
+                    HIPCHK(hipSetDevice(p->device));
+                    HaloSides hs{};
+                    for (int side = 0; side < 2; ++side) { hs.in[side] = (const HaloRecord*)p->x_recv[side].p; hs.nin[side] = (int)p->x_nrecv[side]; }
+                    HashTable H{p->hash_keys.p, p->hash_vals.p, p->hash_mask};
+                    size_t tok = 0;
+                    CHK(clock_begin(p, SPAN_HALO, &tok));
+                    hipLaunchKernelGGL(k_halo_merge2, dim3((n0 + n1 + 3) / 4), dim3(BLK_THREADS), 0, p->stream, hs, p->slab_axis, H, p->halo_in.p, p->d_ctl, p->pending.parity);
+                    CHK(clock_end(p, tok));
+                }
+                return SPARKL_OK;
+            };
+            if (fluid_sweep) {
+                // fluids_volume.rs:9-115 across the cuts: mass-only scatter, the mass planes of the cuts swapped like the momentum planes
+                // (the records carry the mass alone), merge, volume gather -- then the substep proper.  Unfused order.
+                for (int i = 0; i < G.n; ++i) {
+                    SparklPipeline* p = members[i];
+                    HIPCHK(hipSetDevice(p->device));
+                    p->pending = make_params(p, params, gravity, dt);
+                    if (p->num_pblocks) hipLaunchKernelGGL(k_p2g_mass, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, p->stream, p->cur.arrays(), grid_arrays(p), p->d_ctl, p->pending);
+                }
+                CHK(halo_round(false));
+                for (int i = 0; i < G.n; ++i) {
+                    SparklPipeline* p = members[i];
+                    if (!p->num_pblocks) continue;
+                    HIPCHK(hipSetDevice(p->device));
+                    GridArrays Gm = grid_arrays(p);
+                    Gm.node_mom = nullptr;
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<true>), dim3((p->num_blocks + 3) / 4), dim3(BLK_THREADS), 0, p->stream, Gm, p->d_cuboids.p, p->d_heightfields.p,
+                                       p->d_trimeshes.p, p->d_ctl, p->pending);
+                    hipLaunchKernelGGL(k_g2p_volume, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, p->stream, p->cur.arrays(), Gm, p->d_models.p, p->d_ctl, p->pending);
+                }
+            }
             for (int i = 0; i < G.n; ++i) CHK(sparkl_hip_substep_begin(members[i], params, gravity, dt));
-            for (int i = 0; i < G.n; ++i) {
-                SparklPipeline* p = members[i];
-                for (int side = 0; side < 2; ++side) { bs[i][side] = p->x_nsend[side] * sizeof(HaloRecord); br[i][side] = p->x_nrecv[side] * sizeof(HaloRecord); }
-                const int n0 = (int)p->x_nsend[0], n1 = (int)p->x_nsend[1];
-                if (n0 + n1 == 0 || p->num_pblocks == 0) continue;
-                HIPCHK(hipSetDevice(p->device));
-                HaloSides hs{};
-                for (int side = 0; side < 2; ++side) { hs.list[side] = p->halo_list[side].p; hs.n[side] = (int)p->x_nsend[side]; hs.out[side] = (HaloRecord*)p->x_send[side].p; }
-                size_t tok = 0;
-                CHK(clock_begin(p, SPAN_HALO, &tok));
-                hipLaunchKernelGGL(k_halo_pack2, dim3((n0 + n1 + 3) / 4), dim3(BLK_THREADS), 0, p->stream, grid_arrays(p), p->blk_keys.p, hs, p->slab_axis, p->d_ctl, p->pending.parity);
-                CHK(clock_end(p, tok));
+            CHK(halo_round(false));
+            const bool fuse_next = j + 1 < batch && !fluid_sweep && !psi_sweep;
+            if (psi_sweep) {
+                // DamageModel::ModifiedEigenerosion across the cuts: the psi_mass / psi_momentum planes travel like the momentum planes,
+                // between the grid update and the crack test (grid_to_particle.rs:57-77)
+                for (int i = 0; i < G.n; ++i) CHK(substep_finish_impl(members[i], false, false, 1));
+                for (int i = 0; i < G.n; ++i) {
+                    SparklPipeline* p = members[i];
+                    if (!p->num_pblocks) continue;
+                    HIPCHK(hipSetDevice(p->device));
+                    CHK(p->psi_tiles.reserve((size_t)p->num_pblocks * TILE_N));
+                    CHK(p->node_psi.reserve((size_t)p->num_blocks * 64));
+                    if (p->cur.has_frac) hipLaunchKernelGGL(k_p2g_psi, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, p->stream, p->cur.arrays(), grid_arrays(p), p->d_ctl, p->pending, p->psi_tiles.p);
+                    else HIPCHK(hipMemsetAsync(p->psi_tiles.p, 0, (size_t)p->num_pblocks * TILE_N * sizeof(float2), p->stream));   // no component here: zeros to the neighbours
+                }
+                CHK(halo_round(true));
+                for (int i = 0; i < G.n; ++i) {
+                    SparklPipeline* p = members[i];
+                    if (!p->num_pblocks) continue;
+                    HIPCHK(hipSetDevice(p->device));
+                    const GridArrays Gp = grid_arrays(p);
+                    hipLaunchKernelGGL(k_grid_psi, dim3((p->num_blocks + 3) / 4), dim3(BLK_THREADS), 0, p->stream, Gp, p->psi_tiles.p, p->node_psi.p, p->d_ctl, p->pending.parity,
+                                       (const float4*)p->halo_in.p);
+                    if (p->cur.has_frac) hipLaunchKernelGGL(k_g2p_psi, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, p->stream, p->cur.arrays(), Gp, p->node_psi.p, p->d_ctl, p->pending);
+                }
+                for (int i = 0; i < G.n; ++i) CHK(substep_finish_impl(members[i], false, false, 2));
+            } else {
+                for (int i = 0; i < G.n; ++i) CHK(substep_finish_impl(members[i], fuse_next, true));
             }
-            {
-                size_t tok = 0;
-                CHK(clock_begin(members[0], SPAN_HALO, &tok));
-                CHK(group_exchange(G, &SparklPipeline::x_send, &SparklPipeline::x_recv, (const uint64_t(*)[2])bs.data(), (const uint64_t(*)[2])br.data()));
-                CHK(clock_end(members[0], tok));
-            }
-            for (int i = 0; i < G.n; ++i) {
-                SparklPipeline* p = members[i];
-                const int n0 = (int)p->x_nrecv[0], n1 = (int)p->x_nrecv[1];
-                if (n0 + n1 == 0 || p->num_blocks == 0) continue;
-                HIPCHK(hipSetDevice(p->device));
-                HaloSides hs{};
-                for (int side = 0; side < 2; ++side) { hs.in[side] = (const HaloRecord*)p->x_recv[side].p; hs.nin[side] = (int)p->x_nrecv[side]; }
-                HashTable H{p->hash_keys.p, p->hash_vals.p, p->hash_mask};
-                size_t tok = 0;
-                CHK(clock_begin(p, SPAN_HALO, &tok));
-                hipLaunchKernelGGL(k_halo_merge2, dim3((n0 + n1 + 3) / 4), dim3(BLK_THREADS), 0, p->stream, hs, p->slab_axis, H, p->halo_in.p, p->d_ctl, p->pending.parity);
-                CHK(clock_end(p, tok));
-            }
-            for (int i = 0; i < G.n; ++i) CHK(substep_finish_impl(members[i], j + 1 < batch, true));
             HIPCHK(hipGetLastError());
         }
         // one host read per batch; the flag is global, so every member ran the same substeps
@@ -2285,7 +2363,8 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
             if (members[i]->clock_on) CHK(clock_collect(members[i]));
             const uint32_t r = members[i]->h_ctl->steps_done - base[i];
             // cut short behind a fused launch that deferred C.m[1..8] (the last substep of a whole batch is a plain k_g2p)
-            if (r > done && r < done + batch && members[i]->fuse_fixed_dt && members[i]->defer_c && !members[i]->rare_models && !params->enable_boundary_particle_projection)
+            if (r > done && r < done + batch && !fluid_sweep && !psi_sweep && members[i]->fuse_fixed_dt && members[i]->defer_c && !members[i]->rare_models &&
+                !params->enable_boundary_particle_projection)
                 members[i]->c_stale = true;
             ran = i == 0 ? r : std::min(ran, r);
             needs[i] = (r < done + batch || members[i]->h_ctl->abort_flag[0] || members[i]->h_ctl->abort_flag[1]) ? 1 : 0;
@@ -2316,6 +2395,9 @@ int sparkl_hip_group_step(SparklPipeline** members, uint32_t n_members, const Sp
         if (!members[i]) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null member");
         rccl = rccl && members[i]->comm != nullptr;
     }
+    // mls_solver.rs:46-48 recomputes the fluid volumes BEFORE the dt estimate of every substep; the bound exported below is taken
+    // before the sweep that sparkl_hip_group_substeps runs: not the reference's sequence, so refused rather than approximated
+    if (params->force_fluids_volume_recomputation) return set_error(SPARKL_ERR_UNSUPPORTED, "adaptive group step with force_fluids_volume_recomputation: use sparkl_hip_group_substeps");
     const float min_dt = params->dt / (float)params->max_num_substeps;
     float remaining = params->dt;
     uint32_t nsub = 0;

@@ -340,6 +340,112 @@ def test_group_rebalancing_moves_the_cut_and_changes_nothing(tmp_path):
     assert ex < 2e-5 and ev < 2e-4, (ex, ev)
 
 
+def _two_slabs(sc, fracture=None):
+    """The scene cut into two x-slabs of one device (balanced on the block histogram): pipelines, per-slab caller indices."""
+    from sparkl_amd.pipeline import MpmPipeline
+    cuts, all_gids = _ownership(sc, 2)
+    stream = torch.cuda.Stream()
+    pipes = []
+    for r in range(2):
+        comps = ParticleComponents(0)
+        for k in ParticleComponents.__slots__:
+            setattr(comps, k, np.ascontiguousarray(getattr(sc.particles, k)[all_gids[r]]))
+        pipe = MpmPipeline(sc.cell_width, device_id=0, domain_log2_bytes=sc.domain_log2_bytes, stream=stream.cuda_stream)
+        pipe.set_slab(0, cuts[r], cuts[r + 1], id_offset=int(sum(len(g) for g in all_gids[:r])))
+        pipe.set_models(sc.models)
+        pipe.set_colliders(sc.colliders)
+        pipe.upload_particles(comps)
+        if fracture is not None:
+            pipe.set_fracture(fracture[all_gids[r]])
+        pipes.append(pipe)
+    return pipes, all_gids
+
+
+def _gather(pipes, all_gids, n):
+    id_to_caller = np.concatenate(all_gids)
+    parts = [(p.read_particles(), id_to_caller[p.read_sorted_particle_ids()]) for p in pipes]
+    caller = np.concatenate([c for _, c in parts])
+    assert np.array_equal(np.sort(caller), np.arange(n)), "particles lost or duplicated across slabs"
+    inv = np.argsort(caller)
+    got = ParticleComponents(n)
+    for k in ("position", "velocity", "volume", "status", "velocity_gradient", "phase", "data"):
+        setattr(got, k, np.concatenate([getattr(c, k) for c, _ in parts])[inv])
+    return got
+
+
+def _oracles(sc, nsteps, dt, fracture=None):
+    from oracle import Oracle
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    refs = []
+    for f64 in (False, True):
+        o = Oracle(sc.cell_width, f64=f64, domain_log2_bytes=sc.domain_log2_bytes, threads=threads)
+        o.load_scene(sc)
+        if fracture is not None:
+            o.set_fracture(np.stack([fracture["crack_propagation_factor"], fracture["crack_threshold"]], 1))
+        for _ in range(nsteps):
+            o.substep_fixed(sc.params, sc.gravity, dt)
+        refs.append(o.get_particles())
+        o.close()
+    return refs
+
+
+def test_group_substeps_fluid_volume_sweep_across_the_cut():
+    """force_fluids_volume_recomputation across a slab cut (fluids_volume.rs:9-115): the mass planes of the cut travel in their own halo
+    round before the volume gather.  A fluid dam on two slabs against the oracle (and the cut runs through the fluid: both slabs
+    hold particles whose volume depends on the other slab's masses)."""
+    from sparkl_amd.pipeline import MpmPipeline
+    from tests.parity import parity_verdict
+    sc = scenes.fluid_dam(48, 24, 24)
+    assert sc.params.force_fluids_volume_recomputation
+    dt, nsteps = sc.fixed_dt, 100
+    pipes, all_gids = _two_slabs(sc)
+    assert min(len(g) for g in all_gids) > len(sc.particles) // 4
+    MpmPipeline.group_substeps(pipes, sc.params, sc.gravity, dt, nsteps)
+    got = _gather(pipes, all_gids, len(sc.particles))
+    for p in pipes:
+        p.close()
+    r32, r64 = _oracles(sc, nsteps, dt)
+    # the f32 arithmetic of the stiff equation of state sits 2.5e-4 from its f64 trajectory on this 4.8 m deep dam, the reference's
+    # own included (tests/parity.py, arbiter="either"): held to the f32 oracle (8e-6), bounded against the f64 one
+    rep, bad = parity_verdict(got, r32, r64, sc.cell_width, arbiter="either")
+    print("fluid dam on two slabs vs oracle:", rep["vs_f64"], rep["vs_f32"], rep["oracle_f32_vs_f64"])
+    assert rep["vs_f32"]["eps_v"] < 3e-5 and rep["vs_f32"]["eps_x"] < 3e-5, rep["vs_f32"]
+    assert not bad, (bad, rep)
+    # the volumes were really recomputed from both sides' masses: F00 of the particles next to the cut matches too
+    dF = np.abs(got.volume["deformation_gradient"][:, 0].astype(np.float64) - r64.volume["deformation_gradient"][:, 0]).max()
+    assert dF < 2e-5, dF
+
+
+def test_group_substeps_modified_eigenerosion_across_the_cut():
+    """DamageModel::ModifiedEigenerosion on two slabs: the psi_mass / psi_momentum planes of the cut are exchanged between the grid update
+    and the crack test.  The block of test_modified_eigenerosion_parity torn apart, crack front against the oracle."""
+    from sparkl_amd import abi
+    from sparkl_amd.models import CorotatedLinearElasticity
+    from sparkl_amd.pipeline import MpmPipeline
+    from tests.parity import parity_verdict
+    sc = scenes.block_on_floor(16, CorotatedLinearElasticity(1.0e6, 0.3), expand=6.0, v0=(0.0, 0.0, 0.0), gravity=(0.0, 0.0, 0.0), name="eigenerosion")
+    dt, n = sc.fixed_dt, len(sc.particles)
+    probe = _oracles(sc, 60, dt)[0]
+    frac = np.zeros(n, dtype=abi.FRACTURE_DTYPE)
+    frac["crack_propagation_factor"] = 1.0
+    frac["crack_propagation_factor"][::7] = 0.0
+    frac["crack_threshold"] = np.float32(sc.cell_width * np.percentile(probe.phase["psi_pos"], 70))
+    sc.params.damage_model = abi.DAMAGE_MODIFIED_EIGENEROSION
+    pipes, all_gids = _two_slabs(sc, fracture=frac)
+    MpmPipeline.group_substeps(pipes, sc.params, sc.gravity, dt, 100)
+    got = _gather(pipes, all_gids, n)
+    for p in pipes:
+        p.close()
+    r32, r64 = _oracles(sc, 100, dt, fracture=frac)
+    cracked = int((r32.phase["phase"] == 0.0).sum())
+    mismatch = int((got.phase["phase"] != r32.phase["phase"]).sum())
+    rep, bad = parity_verdict(got, r32, r64, sc.cell_width)
+    print("eigenerosion on two slabs vs oracle:", rep["vs_f64"], "cracked", cracked, "phase mismatch", mismatch)
+    assert n // 20 < cracked < n - n // 20, "the crack front must pass through part of the block"
+    assert mismatch <= max(2, cracked // 100), (mismatch, cracked)
+    assert not bad, (bad, rep)
+
+
 def test_group_step_adaptive_two_slabs_in_the_library():
     """sparkl_hip_group_step (`MpmPipeline::step` across slabs, dt bound = MIN over the members) against
     sparkl_hip_pipeline_step on the un-decomposed set: same substep count, same simulated time, same particles."""
