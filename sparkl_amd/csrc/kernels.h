@@ -100,6 +100,12 @@ struct GridArrays {
     float4* node_mom;          // [B][64]  (px, py, pz, -) debug capture or NULL
     const float4* halo_in;     // [B][64]  (mass, px, py, pz) received from neighbour slabs, or NULL
     int halo_axis, halo_lo, halo_hi;   // slab cuts (block planes): only the node blocks of planes lo - 1, lo, hi - 1, hi receive
+    // Launch over a subset (slab groups overlap the halo exchange with the interior blocks: the cut-adjacent particle / node blocks run
+    // on a second stream behind the exchange).  NULL = every block.  `primary`: this launch does the once-per-substep bookkeeping
+    // (steps_done, disorder policy); exactly one launch of a kernel per substep has it.
+    const int* pb_list; int pb_count;
+    const int* nb_list; int nb_count;
+    int primary;
     uint32_t* dt_partial;      // [gridDim] per-workgroup minimum of the dt bound (float bits), reduced by k_dt_reduce
     const DevCuboid* cuboids;  // the collider arrays, for enable_boundary_particle_projection (G2P tail)
     const DevHeightField* heightfields;
@@ -165,6 +171,12 @@ struct DevTriMesh {
     int oriented, flip_interior;
 };
 
+SPK_DEV int xcd_remap(int bid, int n);
+// particle block of this workgroup: the whole list or the launch's subset
+SPK_DEV int launch_pblock(const GridArrays& G) {
+    if (G.pb_list) return G.pb_list[xcd_remap(blockIdx.x, G.pb_count)];
+    return xcd_remap(blockIdx.x, G.num_pblocks);
+}
 // Observed placement is workgroup b -> XCD b % 8: give each XCD a contiguous run of Morton-ordered
 // blocks so neighbouring tiles / node blocks share an L2.  Speed only, never correctness.
 SPK_DEV int xcd_remap(int bid, int n) {
@@ -964,9 +976,10 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
     // The abort flag is read first but only consulted behind the first table loads: the topology arrays stay valid (stale) after an
     // abort, and the dependent-load chain stays at  blk_tnbr -> tile_mode -> tile  (3 hops; it used to be 5).
     const int aborted = ctl->abort_flag[S.parity];
-    const int nb_total = G.num_blocks;
-    const int b = xcd_remap(blockIdx.x, (nb_total + 3) / 4) * 4 + (threadIdx.x >> 6);
-    if (b >= nb_total) return;
+    const int nb_total = G.nb_list ? G.nb_count : G.num_blocks;
+    const int bi = xcd_remap(blockIdx.x, (nb_total + 3) / 4) * 4 + (threadIdx.x >> 6);
+    if (bi >= nb_total) return;
+    const int b = G.nb_list ? G.nb_list[bi] : bi;
     const int lane = threadIdx.x & 63;
     const int cx = lane & 3, cy = (lane >> 2) & 3, cz = lane >> 4;
     const int dx0 = cx <= 2 ? -1 : 0, dy0 = cy <= 2 ? -1 : 0, dz0 = cz <= 2 ? -1 : 0;
@@ -1416,7 +1429,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
         return;
     }
     __shared__ VelTile vt;
-    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    const int pb = launch_pblock(G);
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int b = org.w, pfirst = rng.x, pcount = rng.y;
     // first batch of particle data goes in flight before the tile is staged
@@ -1429,7 +1442,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
     }
     load_vel_tile(vt, G, b, tid);
     if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
-    if (blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
+    if (G.primary && blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
     __syncthreads();
     const float inv_h = 1.0f / S.h;
     bool want_sort = false;
@@ -1481,7 +1494,7 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     __shared__ int s_runs[BLK_THREADS / 64][64];   // run list of each wave (run-task scatter)
     __shared__ float s_A[BLK_THREADS / 64][9][64]; // affine part of the scatter descriptors, per wave
     __shared__ DevModel s_models[LDS_MODELS ? MAX_LDS_MODELS : 1];
-    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    const int pb = launch_pblock(G);
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int b = org.w, pfirst = rng.x, pcount = rng.y;
     const int niter = (pcount + BLK_THREADS - 1) / BLK_THREADS;
@@ -1499,13 +1512,13 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     }
     if (tid == 0) s_heads = 0;
     // this launch scatters for substep s + 1: its heads go to [(parity + 1) & 1], the previous scatter's are at [parity]
-    if (blockIdx.x == 0 && tid == 0) disorder_policy(ctl, S.parity, S.parity);
+    if (G.primary && blockIdx.x == 0 && tid == 0) disorder_policy(ctl, S.parity, S.parity);
     for (int n = tid; n < ACC_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
     // the particle loads above are already in flight: the L2 round trips of the model table and the velocity tile overlap
     // with their HBM latency instead of preceding it
     if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
     load_vel_tile(vt, G, b, tid);
-    if (blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
+    if (G.primary && blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
     __syncthreads();
     const float h = S.h, inv_h = 1.0f / S.h;
     bool want_sort = false, shell_used = false;
@@ -2475,6 +2488,22 @@ __global__ void k_halo_list(const int4* __restrict__ blk_origin, const int* __re
     const int bs = (axis == 0 ? o.x : (axis == 1 ? o.y : o.z)) >> 2;
     if (bs == cut) list[atomicAdd(count, 1)] = b << 1;
     else if (bs == cut - 1 && blk_nbr[b * 27 + nbr_slot(axis, +1)] < 0) list[atomicAdd(count, 1)] = (b << 1) | 1;
+}
+// flags for the interior / cut-adjacent split of a slab (see GridArrays::pb_list): a particle block whose G2P reads a node plane that
+// receives halo (home plane within two of a cut) and a node block that receives halo itself (planes lo - 1, lo, hi - 1, hi)
+__global__ void k_split_flags(const int4* __restrict__ pb_info, int npb, const int4* __restrict__ blk_origin, int nb, int axis, int lo, int hi, unsigned char* pb_flag,
+                              unsigned char* nb_flag) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < npb) {
+        const int4 o = pb_info[2 * j];
+        const long long pl = (axis == 0 ? o.x : (axis == 1 ? o.y : o.z)) >> 2;
+        pb_flag[j] = (pl < (long long)lo + 2 || pl >= (long long)hi - 2) ? 1 : 0;
+    }
+    if (j < nb) {
+        const int4 o = blk_origin[j];
+        const long long pl = (axis == 0 ? o.x : (axis == 1 ? o.y : o.z)) >> 2;
+        nb_flag[j] = (pl == lo || pl == hi || pl + 1 == lo || pl + 1 == hi) ? 1 : 0;
+    }
 }
 // this slab's partial (mass, momentum) of node (cx, cy, cz) of block b, gathered from its own tiles
 SPK_DEV float4 halo_node_sum(const GridArrays& G, int b, int cx, int cy, int cz) {

@@ -114,6 +114,17 @@ struct SparklPipeline {
     bool pending_clock_saved = false;
     bool tiles_ready = false;      // the previous substep_finish_fused already scattered this substep's tiles
     bool halo_store_mode = false;  // inside sparkl_hip_group_substeps: halo records are stored, not added (no per-substep memset)
+    // interior / cut-adjacent split of a slab (built by the re-bin): split_pb = [cut-adjacent particle blocks in Morton order | interior
+    // ones], split_nb likewise for node blocks; the slab-group loop runs the cut-adjacent part on `halo_stream` behind the exchange
+    DevBuf<int> split_pb, split_nb;
+    DevBuf<unsigned char> split_flags;
+    int pb_bnd = 0, nb_bnd = 0;
+    // Halo / compute overlap of the slab-group loop: -1 = automatic (on between RCCL ranks, where the exchange has a network latency to
+    // hide; off for the members of one process on one device, where the cross-stream events cost more than they hide: 2 slabs of 10 M
+    // on one MI355X 1.19 ms per substep in line, 1.23 overlapped), 0 / 1 = SPARKL_HIP_OVERLAP forces it
+    int overlap_mode = -1;
+    hipStream_t halo_stream = nullptr;
+    hipEvent_t ev_main = nullptr, ev_halo = nullptr, ev_flag = nullptr, ev_grid = nullptr, ev_xfer = nullptr;
     // Tile carry-over between fixed-dt batches and calls: the LAST substep of a fused batch also runs k_g2p2g (complete state stored), so
     // the tiles of substep `carry_index` for step length `carry_dt` are already scattered and the next batch skips its standalone
     // P2G + the plain G2P it would have ended with (0.35 + 0.34 -> 0.53 ms per batch boundary at 10M).  Anything that touches the
@@ -211,8 +222,9 @@ struct SparklPipeline {
 static void comm_destroy(SparklPipeline* p);
 enum { SPAN_P2G = 0, SPAN_GRID = 1, SPAN_G2P = 2, SPAN_SORT = 3, SPAN_DT = 4, SPAN_HALO = 5, SPAN_FUSED = 6, SPAN_REORDER = 7, SPAN_P2G_MASS = 8, SPAN_GRID_MASS = 9, SPAN_G2P_VOLUME = 10 };
 
-static int clock_begin(SparklPipeline* p, int kind, size_t* tok) {
+static int clock_begin(SparklPipeline* p, int kind, size_t* tok, hipStream_t st = nullptr) {
     if (!p->clock_on) return SPARKL_OK;
+    if (!st) st = p->stream;
     if (p->ev_used + 2 > p->ev_pool.size()) {
         size_t old = p->ev_pool.size();
         p->ev_pool.resize(old + 256);
@@ -220,13 +232,13 @@ static int clock_begin(SparklPipeline* p, int kind, size_t* tok) {
     }
     *tok = p->spans.size();
     p->spans.push_back({p->ev_used, p->ev_used + 1, kind});
-    HIPCHK(hipEventRecord(p->ev_pool[p->ev_used], p->stream));
+    HIPCHK(hipEventRecord(p->ev_pool[p->ev_used], st));
     p->ev_used += 2;
     return SPARKL_OK;
 }
-static int clock_end(SparklPipeline* p, size_t tok) {
+static int clock_end(SparklPipeline* p, size_t tok, hipStream_t st = nullptr) {
     if (!p->clock_on) return SPARKL_OK;
-    HIPCHK(hipEventRecord(p->ev_pool[p->spans[tok].b], p->stream));
+    HIPCHK(hipEventRecord(p->ev_pool[p->spans[tok].b], st ? st : p->stream));
     return SPARKL_OK;
 }
 // requires the stream to be idle
@@ -285,6 +297,7 @@ static GridArrays grid_arrays(const SparklPipeline* p) {
     g.pblk = p->pblk.p; g.pb_info = p->pb_info.p; g.tile_mode = p->tile_mode.p; g.tiles = p->tiles.p; g.node_vel = p->node_vel.p; g.node_mom = p->capture_mom ? p->node_mom.p : nullptr;
     g.halo_in = (p->slab_on && p->num_blocks) ? p->halo_in.p : nullptr;
     g.halo_axis = p->slab_axis; g.halo_lo = p->slab_lo; g.halo_hi = p->slab_hi;
+    g.pb_list = nullptr; g.pb_count = 0; g.nb_list = nullptr; g.nb_count = 0; g.primary = 1;
     g.num_blocks = p->num_blocks; g.num_pblocks = p->num_pblocks;
     return g;
 }
@@ -330,7 +343,7 @@ static int resort(SparklPipeline* p) {
     if (n > 0) {
         CHK(p->keys_a.reserve(n)); CHK(p->keys_b.reserve(n)); CHK(p->idx_a.reserve(n)); CHK(p->idx_b.reserve(n));
         CHK(p->bkeys.reserve(n)); CHK(p->pb_keys.reserve(n)); CHK(p->pb_counts.reserve(n)); CHK(p->pb_first.reserve(n));
-        CHK(p->d_scalars.reserve(4));
+        CHK(p->d_scalars.reserve(8));
         p->alt.has_frac = p->cur.has_frac;
         CHK(p->alt.reserve(p->cur.q[0].cap));
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dead_dt_bits, 0x7f7fffff, 1, st));   // rebuilt from the particles that are outside the domain now
@@ -430,6 +443,22 @@ static int resort(SparklPipeline* p) {
                     HIPCHK(hipMemsetAsync(p->d_scalars.p + 2 + side, 0, sizeof(int), st));
                     hipLaunchKernelGGL(k_halo_list, dim3(grid_for(nb, 256)), dim3(256), 0, st, p->blk_origin.p, p->blk_nbr.p, nb, p->slab_axis, cut, p->halo_list[side].p, p->d_scalars.p + 2 + side);
                     HIPCHK(hipMemcpyAsync(&p->halo_count[side], p->d_scalars.p + 2 + side, sizeof(int), hipMemcpyDeviceToHost, st));
+                }
+                // interior / cut-adjacent split (stable: both parts keep the Morton order the XCD mapping relies on)
+                {
+                    const int m = std::max(nb, npb);
+                    CHK(p->split_flags.reserve((size_t)2 * m));
+                    CHK(p->split_pb.reserve(npb)); CHK(p->split_nb.reserve(nb));
+                    hipLaunchKernelGGL(k_split_flags, dim3(grid_for(m, 256)), dim3(256), 0, st, p->pb_info.p, npb, p->blk_origin.p, nb, p->slab_axis, p->slab_lo, p->slab_hi,
+                                       p->split_flags.p, p->split_flags.p + m);
+                    hipcub::CountingInputIterator<int> iota(0);
+                    size_t tb = 0;
+                    HIPCHK(hipcub::DevicePartition::Flagged(nullptr, tb, iota, p->split_flags.p, p->split_pb.p, p->d_scalars.p + 6, m, st));
+                    CHK(cub_reserve(p, tb));
+                    HIPCHK(hipcub::DevicePartition::Flagged(p->cub_temp.p, tb, iota, p->split_flags.p, p->split_pb.p, p->d_scalars.p + 6, npb, st));
+                    HIPCHK(hipcub::DevicePartition::Flagged(p->cub_temp.p, tb, iota, p->split_flags.p + m, p->split_nb.p, p->d_scalars.p + 7, nb, st));
+                    HIPCHK(hipMemcpyAsync(&p->pb_bnd, p->d_scalars.p + 6, sizeof(int), hipMemcpyDeviceToHost, st));
+                    HIPCHK(hipMemcpyAsync(&p->nb_bnd, p->d_scalars.p + 7, sizeof(int), hipMemcpyDeviceToHost, st));
                 }
                 HIPCHK(hipStreamSynchronize(st));
             }
@@ -754,6 +783,7 @@ int sparkl_hip_pipeline_create(const SparklPipelineDesc* desc, SparklPipeline** 
     p->fuse_fixed_dt = getenv("SPARKL_HIP_NO_FUSE") == nullptr;
     p->defer_c = !(getenv("SPARKL_HIP_DEFER_C") && !strcmp(getenv("SPARKL_HIP_DEFER_C"), "0"));
     if (const char* e = getenv("SPARKL_HIP_CARRY")) p->carry_on = atoi(e) != 0;
+    if (const char* e = getenv("SPARKL_HIP_OVERLAP")) p->overlap_mode = atoi(e) != 0 ? 1 : 0;
     p->lookahead = !(getenv("SPARKL_HIP_LOOKAHEAD") && !strcmp(getenv("SPARKL_HIP_LOOKAHEAD"), "0"));
     p->lookahead_force = getenv("SPARKL_HIP_LOOKAHEAD") && !strcmp(getenv("SPARKL_HIP_LOOKAHEAD"), "force");
     p->device = desc->device_id;
@@ -798,6 +828,8 @@ void sparkl_hip_pipeline_destroy(SparklPipeline* p) {
     if (p->rb_stream) { (void)hipStreamSynchronize(p->rb_stream); (void)hipStreamDestroy(p->rb_stream); (void)hipEventDestroy(p->rb_gathered); (void)hipEventDestroy(p->rb_done); }
     p->rb_staging.release();
     for (auto e : p->ev_pool) (void)hipEventDestroy(e);
+    if (p->halo_stream) { (void)hipStreamSynchronize(p->halo_stream); (void)hipStreamDestroy(p->halo_stream); }
+    for (hipEvent_t e : {p->ev_main, p->ev_halo, p->ev_flag, p->ev_grid, p->ev_xfer}) if (e) (void)hipEventDestroy(e);
     if (p->d_ctl) (void)hipFree(p->d_ctl);
     if (p->h_ctl) (void)hipHostFree(p->h_ctl);
     if (p->own_stream) (void)hipStreamDestroy(p->stream);
@@ -1970,6 +2002,10 @@ struct Group {
         return (j >= 0 && j < n) ? j : -2;
     }
     int peer_rank(int i, int side) const { return m[i]->comm_rank + (side == 0 ? -1 : 1); }
+    // stream the halo chain of member i runs on: its own when the exchange is serial, the halo stream when it overlaps the interior
+    // work (members of one process share ONE halo stream, like they share one main stream: ordering by enqueue order)
+    bool overlap = false;
+    hipStream_t xs(int i) const { return overlap ? (rccl ? m[i]->halo_stream : m[0]->halo_stream) : m[i]->stream; }
 };
 
 static int x_staging(SparklPipeline* p) {
@@ -2058,8 +2094,8 @@ static int group_exchange(const Group& G, BufPair send, BufPair recv, const uint
             for (int side = 0; side < 2; ++side) {
                 if (G.nbr(i, side) != -1) continue;
                 SparklPipeline* p = G.m[i];
-                if (nsend[i][side]) NCCLCHK(g_rccl.Send((p->*send)[side].p, nsend[i][side], ncclUint8, G.peer_rank(i, side), p->comm, p->stream));
-                if (nrecv[i][side]) NCCLCHK(g_rccl.Recv((p->*recv)[side].p, nrecv[i][side], ncclUint8, G.peer_rank(i, side), p->comm, p->stream));
+                if (nsend[i][side]) NCCLCHK(g_rccl.Send((p->*send)[side].p, nsend[i][side], ncclUint8, G.peer_rank(i, side), p->comm, G.xs(i)));
+                if (nrecv[i][side]) NCCLCHK(g_rccl.Recv((p->*recv)[side].p, nrecv[i][side], ncclUint8, G.peer_rank(i, side), p->comm, G.xs(i)));
             }
         NCCLCHK(g_rccl.GroupEnd());
         return SPARKL_OK;
@@ -2068,7 +2104,7 @@ static int group_exchange(const Group& G, BufPair send, BufPair recv, const uint
         for (int side = 0; side < 2; ++side) {
             const int j = G.nbr(i, side);
             if (j < 0 || !nsend[i][side]) continue;
-            HIPCHK(hipMemcpyAsync((G.m[j]->*recv)[1 - side].p, (G.m[i]->*send)[side].p, nsend[i][side], hipMemcpyDeviceToDevice, G.m[i]->stream));
+            HIPCHK(hipMemcpyAsync((G.m[j]->*recv)[1 - side].p, (G.m[i]->*send)[side].p, nsend[i][side], hipMemcpyDeviceToDevice, G.xs(i)));
         }
     return SPARKL_OK;
 }
@@ -2163,6 +2199,48 @@ static int group_rebin(const Group& G, bool balance) {
 }
 }  // namespace
 
+// halo stream and fork / join events of a member (created on first use)
+static int overlap_resources(SparklPipeline* p) {
+    HIPCHK(hipSetDevice(p->device));
+    if (!p->halo_stream) HIPCHK(hipStreamCreateWithFlags(&p->halo_stream, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&p->ev_main, &p->ev_halo, &p->ev_flag, &p->ev_grid, &p->ev_xfer}) if (!*e) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return SPARKL_OK;
+}
+// The node / particle kernels of one substep over a subset of the blocks (GridArrays::pb_list / nb_list), on stream `st`.
+// which = 0: grid update of the interior node blocks, 1: of the cut-adjacent ones; 2 / 3: the particle kernel likewise.
+static int launch_subset(SparklPipeline* p, int which, bool fuse_next, bool primary, hipStream_t st) {
+    GridArrays G = grid_arrays(p);
+    const bool bnd = which & 1;
+    StepParams S = p->pending;
+    if (which < 2) {
+        G.nb_list = bnd ? p->split_nb.p : p->split_nb.p + p->nb_bnd;
+        G.nb_count = bnd ? p->nb_bnd : p->num_blocks - p->nb_bnd;
+        if (G.nb_count == 0) return SPARKL_OK;
+        const dim3 grid((G.nb_count + 3) / 4), block(BLK_THREADS);
+        if (p->num_heightfields > 0 || p->num_trimeshes > 0)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, true>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, false>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);
+        return SPARKL_OK;
+    }
+    G.pb_list = bnd ? p->split_pb.p : p->split_pb.p + p->pb_bnd;
+    G.pb_count = bnd ? p->pb_bnd : p->num_pblocks - p->pb_bnd;
+    G.primary = primary ? 1 : 0;
+    if (G.pb_count == 0) return SPARKL_OK;
+    const ParticleArrays P = p->cur.arrays();
+    const dim3 grid(G.pb_count), block(BLK_THREADS);
+    if (fuse_next && p->fuse_fixed_dt) {
+        S.defer_c = (p->defer_c && !p->rare_models && !S.project_particles) ? 1 : 0;
+        if (S.defer_c) p->c_stale_S = p->pending;
+        if (p->rare_models || S.project_particles) SPK_LAUNCH_MODELS(k_g2p2g, -1, true);
+        else SPK_LAUNCH_MODELS(k_g2p2g, -1, false);
+    } else {
+        if (p->rare_models || S.project_particles) SPK_LAUNCH_MODELS(k_g2p, true);
+        else SPK_LAUNCH_MODELS(k_g2p, false);
+    }
+    return SPARKL_OK;
+}
+
 extern "C" {
 
 int sparkl_hip_comm_unique_id(void* out_128_bytes) {
@@ -2234,6 +2312,9 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
     } store_mode(G);
     std::vector<uint32_t> base(G.n);
     for (int i = 0; i < G.n; ++i) { HIPCHK(hipSetDevice(members[i]->device)); CHK(read_ctl(members[i])); base[i] = members[i]->h_ctl->steps_done; }
+    G.overlap = !fluid_sweep && !psi_sweep;
+    for (int i = 0; i < G.n; ++i) G.overlap = G.overlap && (members[i]->overlap_mode < 0 ? G.rccl && members[i]->comm_world > 1 : members[i]->overlap_mode == 1);
+    if (G.overlap) for (int i = 0; i < G.n; ++i) CHK(overlap_resources(members[i]));
     uint32_t done = 0;
     int guard = 0;
     std::vector<std::array<uint64_t, 2>> bs(G.n), br(G.n);
@@ -2242,11 +2323,17 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
         for (uint32_t j = 0; j < batch; ++j) {
             // 1. the re-bin request of the upcoming substep, MAX over every slab: all ranks skip the same substeps.  In place on the
             //    control blocks: one 4-byte all-reduce (RCCL) or one single-thread kernel (members of one process)
+            if (G.overlap)   // fork: the halo stream sees everything the main stream has done (the tiles of this substep among it)
+                for (int i = 0; i < G.n; ++i) {
+                    HIPCHK(hipSetDevice(members[i]->device));
+                    HIPCHK(hipEventRecord(members[i]->ev_main, members[i]->stream));
+                    HIPCHK(hipStreamWaitEvent(G.xs(i), members[i]->ev_main, 0));
+                }
             if (G.rccl) {
                 NCCLCHK(g_rccl.GroupStart());
                 for (int i = 0; i < G.n; ++i) {
                     uint32_t* flag = &members[i]->d_ctl->abort_flag[members[i]->substep_index & 1u];
-                    NCCLCHK(g_rccl.AllReduce(flag, flag, 1, ncclUint32, ncclMax, members[i]->comm, members[i]->stream));
+                    NCCLCHK(g_rccl.AllReduce(flag, flag, 1, ncclUint32, ncclMax, members[i]->comm, G.xs(i)));
                 }
                 NCCLCHK(g_rccl.GroupEnd());
             } else if (G.n > 1) {
@@ -2258,9 +2345,15 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
                         L.n = 0;
                         L.c[L.n++] = members[0]->d_ctl;
                         for (int i = i0; i < G.n && L.n < 16; ++i) L.c[L.n++] = members[i]->d_ctl;
-                        hipLaunchKernelGGL(k_flags_max, dim3(1), dim3(1), 0, members[0]->stream, L, parity);
+                        hipLaunchKernelGGL(k_flags_max, dim3(1), dim3(1), 0, G.xs(0), L, parity);
                     }
             }
+            if (G.overlap)   // every kernel of the substep reads the agreed flag: the main stream waits for it (and for nothing else)
+                for (int i = 0; i < G.n; ++i) {
+                    HIPCHK(hipSetDevice(members[i]->device));
+                    HIPCHK(hipEventRecord(members[i]->ev_flag, G.xs(i)));
+                    HIPCHK(hipStreamWaitEvent(members[i]->stream, members[i]->ev_flag, 0));
+                }
             // 2. scatter (nothing when the previous fused kernel already did), pack the shared planes of both cuts, swap, store
             // One halo round: every member packs its partial sums of the shared node planes (from the mass / momentum tiles, or from
             // the psi tiles), the records travel to both neighbours and are stored into halo_in, which the next node kernel adds.
@@ -2274,16 +2367,16 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
                     HaloSides hs{};
                     for (int side = 0; side < 2; ++side) { hs.list[side] = p->halo_list[side].p; hs.n[side] = (int)p->x_nsend[side]; hs.out[side] = (HaloRecord*)p->x_send[side].p; }
                     size_t tok = 0;
-                    CHK(clock_begin(p, SPAN_HALO, &tok));
-                    hipLaunchKernelGGL(k_halo_pack2, dim3((n0 + n1 + 3) / 4), dim3(BLK_THREADS), 0, p->stream, grid_arrays(p), p->blk_keys.p, hs, p->slab_axis, p->d_ctl, p->pending.parity,
+                    CHK(clock_begin(p, SPAN_HALO, &tok, G.xs(i)));
+                    hipLaunchKernelGGL(k_halo_pack2, dim3((n0 + n1 + 3) / 4), dim3(BLK_THREADS), 0, G.xs(i), grid_arrays(p), p->blk_keys.p, hs, p->slab_axis, p->d_ctl, p->pending.parity,
                                        psi ? (const float2*)p->psi_tiles.p : (const float2*)nullptr);
-                    CHK(clock_end(p, tok));
+                    CHK(clock_end(p, tok, G.xs(i)));
                 }
                 {
                     size_t tok = 0;
-                    CHK(clock_begin(members[0], SPAN_HALO, &tok));
+                    CHK(clock_begin(members[0], SPAN_HALO, &tok, G.xs(0)));
                     CHK(group_exchange(G, &SparklPipeline::x_send, &SparklPipeline::x_recv, (const uint64_t(*)[2])bs.data(), (const uint64_t(*)[2])br.data()));
-                    CHK(clock_end(members[0], tok));
+                    CHK(clock_end(members[0], tok, G.xs(0)));
                 }
                 for (int i = 0; i < G.n; ++i) {
                     SparklPipeline* p = members[i];
@@ -2294,9 +2387,9 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
                     for (int side = 0; side < 2; ++side) { hs.in[side] = (const HaloRecord*)p->x_recv[side].p; hs.nin[side] = (int)p->x_nrecv[side]; }
                     HashTable H{p->hash_keys.p, p->hash_vals.p, p->hash_mask};
                     size_t tok = 0;
-                    CHK(clock_begin(p, SPAN_HALO, &tok));
-                    hipLaunchKernelGGL(k_halo_merge2, dim3((n0 + n1 + 3) / 4), dim3(BLK_THREADS), 0, p->stream, hs, p->slab_axis, H, p->halo_in.p, p->d_ctl, p->pending.parity);
-                    CHK(clock_end(p, tok));
+                    CHK(clock_begin(p, SPAN_HALO, &tok, G.xs(i)));
+                    hipLaunchKernelGGL(k_halo_merge2, dim3((n0 + n1 + 3) / 4), dim3(BLK_THREADS), 0, G.xs(i), hs, p->slab_axis, H, p->halo_in.p, p->d_ctl, p->pending.parity);
+                    CHK(clock_end(p, tok, G.xs(i)));
                 }
                 return SPARKL_OK;
             };
@@ -2322,8 +2415,55 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
                 }
             }
             for (int i = 0; i < G.n; ++i) CHK(sparkl_hip_substep_begin(members[i], params, gravity, dt));
-            CHK(halo_round(false));
             const bool fuse_next = j + 1 < batch && !fluid_sweep && !psi_sweep;
+            if (G.overlap) {
+                // Halo / compute overlap (the reference runs its halo work on a second stream too: cuda_mpm_pipeline.rs:410-430).
+                //   main stream:  [P2G, reorder]  grid update of the interior node blocks ; particle kernel of the interior particle blocks
+                //   halo stream:  pack ; send / recv ; store ; grid update of the node planes that received ; particle kernel of the
+                //                 particle blocks within two block planes of a cut (the ones whose gather reads those planes)
+                // The cut-adjacent particle kernel also reads interior node planes (it waits for the interior grid update) and rewrites
+                // tiles the interior grid update reads (same wait); nothing on the main stream reads what the halo stream writes before
+                // the join at the end of the substep.
+                for (int i = 0; i < G.n; ++i) {
+                    SparklPipeline* p = members[i];
+                    HIPCHK(hipSetDevice(p->device));
+                    if (p->num_pblocks) CHK(maybe_reorder(p, p->pending.parity));
+                    HIPCHK(hipEventRecord(p->ev_xfer, p->stream));
+                    HIPCHK(hipStreamWaitEvent(G.xs(i), p->ev_xfer, 0));
+                }
+                CHK(halo_round(false));
+                for (int i = 0; i < G.n; ++i) {
+                    SparklPipeline* p = members[i];
+                    HIPCHK(hipSetDevice(p->device));
+                    if (p->num_pblocks == 0) { hipLaunchKernelGGL(k_bump_steps, dim3(1), dim3(1), 0, p->stream, p->d_ctl, p->pending.parity); continue; }
+                    const bool has_interior = p->num_pblocks > p->pb_bnd;
+                    size_t t1 = 0, t2 = 0;
+                    CHK(clock_begin(p, SPAN_GRID, &t1));
+                    CHK(launch_subset(p, 0, fuse_next, false, p->stream));
+                    CHK(clock_end(p, t1));
+                    HIPCHK(hipEventRecord(p->ev_grid, p->stream));
+                    CHK(clock_begin(p, fuse_next && p->fuse_fixed_dt ? SPAN_FUSED : SPAN_G2P, &t2));
+                    CHK(launch_subset(p, 2, fuse_next, has_interior, p->stream));
+                    CHK(clock_end(p, t2));
+                    CHK(launch_subset(p, 1, fuse_next, false, G.xs(i)));
+                    HIPCHK(hipStreamWaitEvent(G.xs(i), p->ev_grid, 0));
+                    CHK(launch_subset(p, 3, fuse_next, !has_interior, G.xs(i)));
+                }
+                for (int i = 0; i < G.n; ++i) {   // join
+                    SparklPipeline* p = members[i];
+                    HIPCHK(hipSetDevice(p->device));
+                    HIPCHK(hipEventRecord(p->ev_halo, G.xs(i)));
+                    HIPCHK(hipStreamWaitEvent(p->stream, p->ev_halo, 0));
+                    p->in_substep = false;
+                    p->tiles_ready = p->num_pblocks > 0 && fuse_next && p->fuse_fixed_dt;
+                    p->clock_on = p->pending_clock_saved;
+                    p->substep_index++;
+                    if (p->num_pblocks) p->clock.substeps++;
+                }
+                HIPCHK(hipGetLastError());
+                continue;
+            }
+            CHK(halo_round(false));
             if (psi_sweep) {
                 // DamageModel::ModifiedEigenerosion across the cuts: the psi_mass / psi_momentum planes travel like the momentum planes,
                 // between the grid update and the crack test (grid_to_particle.rs:57-77)

@@ -198,13 +198,16 @@ def test_cube_through_sand_two_slabs_match_oracle(tmp_path):
     assert not bad, (bad, rep)
 
 
-@pytest.mark.parametrize("kind,nsteps", [("spin", 40), ("cube", 100)])
-def test_group_substeps_two_slabs_in_the_library(kind, nsteps):
+@pytest.mark.parametrize("kind,nsteps,overlap", [("spin", 40, "0"), ("cube", 100, "0"), ("spin", 40, "1"), ("cube", 100, "1")])
+def test_group_substeps_two_slabs_in_the_library(kind, nsteps, overlap, monkeypatch):
     """sparkl_hip_group_substeps: the whole slab loop (re-bin agreement, halo swap, migration) inside the C ABI, no Python in
     the exchange.  Two slabs share one GPU and one stream (device-copy transport of the same loop that uses RCCL between ranks);
     the union must match the un-decomposed pipeline, and -- for the cube ploughing through sand -- the oracle."""
     from sparkl_amd.pipeline import MpmPipeline
     from tests.parity import parity_verdict
+    # SPARKL_HIP_OVERLAP (read when a pipeline is created): 1 forces the two-stream schedule the RCCL ranks use by default -- interior
+    # blocks on the main stream while the halo chain and the cut-adjacent blocks run on the halo stream --, 0 the in-line schedule
+    monkeypatch.setenv("SPARKL_HIP_OVERLAP", overlap)
     world = 2
     sc, dt = _scene(kind)
     cuts, all_gids = _ownership(sc, world)
@@ -412,8 +415,8 @@ def test_group_substeps_fluid_volume_sweep_across_the_cut():
     assert rep["vs_f32"]["eps_v"] < 3e-5 and rep["vs_f32"]["eps_x"] < 3e-5, rep["vs_f32"]
     assert not bad, (bad, rep)
     # the volumes were really recomputed from both sides' masses: F00 of the particles next to the cut matches too
-    dF = np.abs(got.volume["deformation_gradient"][:, 0].astype(np.float64) - r64.volume["deformation_gradient"][:, 0]).max()
-    assert dF < 2e-5, dF
+    dF = np.abs(got.volume["deformation_gradient"][:, 0].astype(np.float64) - r32.volume["deformation_gradient"][:, 0]).max()
+    assert dF < 1e-5, dF
 
 
 def test_group_substeps_modified_eigenerosion_across_the_cut():
