@@ -96,6 +96,9 @@ struct GridArrays {
     const int4* pb_info;       // [PB][2]: (origin.xyz, block index), (pfirst, pcount, -, -): one hop instead of three
     float4* tiles;             // [PB][512] (mass, px, py, pz); a core-only tile keeps its 6^3 inner nodes compactly in front
     int* tile_mode;            // [PB] 0: only the 6^3 core was written (no particle sits in the drift margin), 1: all 8^3
+    // [PB][2] run heads of the block's last fused scatter, and of its first one after the last re-bin / reorder of the block (0 = not
+    // taken yet): k_block_reorder only touches the blocks whose runs have fragmented (the static bulk of a collapse never does)
+    int2* pb_heads;
     float4* node_vel;          // [B][64]  (vx, vy, vz, mass)
     float4* node_mom;          // [B][64]  (px, py, pz, -) debug capture or NULL
     const float4* halo_in;     // [B][64]  (mass, px, py, pz) received from neighbour slabs, or NULL
@@ -1562,7 +1565,15 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     }
     if ((tid & 63) == 0) atomicAdd(&s_heads, wave_heads);
     tile_write(tile, G, pb, tid, shell_used);
-    if (tid == 0) atomicAdd(&ctl->heads[(S.parity + 1) & 1], (uint32_t)s_heads);
+    if (tid == 0) {
+        atomicAdd(&ctl->heads[(S.parity + 1) & 1], (uint32_t)s_heads);
+        if (REDUCE_STEPS < 0) {   // per-block record (run-task scatter only: the DPP variants count group heads, another measure)
+            int2 hd = G.pb_heads[pb];
+            hd.x = s_heads;
+            if (hd.y == 0) hd.y = max(s_heads, 1);
+            G.pb_heads[pb] = hd;
+        }
+    }
     if (__any(want_sort)) {
         if ((tid & 63) == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
     }
@@ -1612,6 +1623,11 @@ __global__ __launch_bounds__(BLK_THREADS) void k_block_reorder(ParticleArrays P,
     __shared__ int wave_sum[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    {   // a block whose run count has not grown by an eighth since it was last in order has nothing to gain (workgroup-uniform)
+        const int2 hd = G.pb_heads[pb];
+        if (hd.y > 0 && hd.x <= hd.y + (hd.y >> 3)) return;
+        if (tid == 0) G.pb_heads[pb] = make_int2(0, 0);   // re-armed: the next scatter records the new baseline
+    }
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int pfirst = rng.x, pcount = rng.y;
     const float inv_h = 1.0f / h;

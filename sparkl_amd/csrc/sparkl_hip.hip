@@ -167,6 +167,7 @@ struct SparklPipeline {
     int num_blocks = 0, num_pblocks = 0;
     DevBuf<int4> blk_origin;
     DevBuf<int> blk_pfirst, blk_pcount, blk_nbr, blk_tnbr, pblk, tile_mode;
+    DevBuf<int2> pb_heads;
     DevBuf<int4> pb_info;
     DevBuf<uint32_t> blk_keys;
     DevBuf<float4> tiles, node_vel, node_mom;
@@ -282,9 +283,12 @@ static int clock_collect(SparklPipeline* p) {
 
 static inline int grid_for(size_t n, int threads) { return (int)((n + threads - 1) / threads); }
 
-// Default reorder budget (see Ctl): an in-place block reorder costs about as much as this many excess run heads per
-// particle (~0.1 ns per excess head, ~0.6 ms per reorder at 10M: tools/long_run_probe.py, profiles/r01_reorder_policy.txt).
-static constexpr float DEFAULT_REORDER_HEADS_PER_PARTICLE = 0.6f;
+// Default reorder budget (see Ctl): the excess run heads per particle, summed over the substeps since the last reorder, that make
+// k_block_reorder act.  0.6 while every reorder moved every block (~0.6 ms at 10M, profiles/r01_reorder_policy.txt); since the
+// kernel skips the blocks whose runs have not fragmented (GridArrays::pb_heads) a pass costs what the flowing part of the scene
+// costs and 0.2 is the optimum of tools/debug/reorder_threshold.sh (late / deep phase of the 10M collapse: 0.683 / 0.815 ms per
+// substep at 0.6, 0.673 / 0.797 at 0.2, 0.676 / 0.799 at 0.1).
+static constexpr float DEFAULT_REORDER_HEADS_PER_PARTICLE = 0.2f;
 #ifndef SPK_REORDER_PERIOD
 #define SPK_REORDER_PERIOD 16
 #endif
@@ -294,7 +298,7 @@ static GridArrays grid_arrays(const SparklPipeline* p) {
     GridArrays g;
     g.blk_origin = p->blk_origin.p; g.blk_pfirst = p->blk_pfirst.p; g.blk_pcount = p->blk_pcount.p; g.blk_nbr = p->blk_nbr.p; g.blk_tnbr = p->blk_tnbr.p; g.dt_partial = p->dt_partial.p;
     g.cuboids = p->d_cuboids.p; g.heightfields = p->d_heightfields.p; g.trimeshes = p->d_trimeshes.p;
-    g.pblk = p->pblk.p; g.pb_info = p->pb_info.p; g.tile_mode = p->tile_mode.p; g.tiles = p->tiles.p; g.node_vel = p->node_vel.p; g.node_mom = p->capture_mom ? p->node_mom.p : nullptr;
+    g.pblk = p->pblk.p; g.pb_info = p->pb_info.p; g.tile_mode = p->tile_mode.p; g.pb_heads = p->pb_heads.p; g.tiles = p->tiles.p; g.node_vel = p->node_vel.p; g.node_mom = p->capture_mom ? p->node_mom.p : nullptr;
     g.halo_in = (p->slab_on && p->num_blocks) ? p->halo_in.p : nullptr;
     g.halo_axis = p->slab_axis; g.halo_lo = p->slab_lo; g.halo_hi = p->slab_hi;
     g.pb_list = nullptr; g.pb_count = 0; g.nb_list = nullptr; g.nb_count = 0; g.primary = 1;
@@ -418,6 +422,8 @@ static int resort(SparklPipeline* p) {
             HIPCHK(hipMemsetAsync(p->hash_keys.p, 0xFF, (size_t)hcap * sizeof(uint64_t), st));
             CHK(p->blk_origin.reserve(nb)); CHK(p->blk_pfirst.reserve(nb)); CHK(p->blk_pcount.reserve(nb));
             CHK(p->blk_nbr.reserve((size_t)nb * 27)); CHK(p->blk_tnbr.reserve((size_t)nb * 27)); CHK(p->pblk.reserve(npb)); CHK(p->pb_info.reserve((size_t)npb * 2)); CHK(p->tile_mode.reserve(npb));
+            CHK(p->pb_heads.reserve(npb));
+            HIPCHK(hipMemsetAsync(p->pb_heads.p, 0, (size_t)npb * sizeof(int2), st));   // new binning: every block is in order, baselines not taken yet
             CHK(p->tiles.reserve((size_t)npb * TILE_N)); CHK(p->node_vel.reserve((size_t)nb * 64));
             if (p->capture_mom) CHK(p->node_mom.reserve((size_t)nb * 64));
             HashTable H{p->hash_keys.p, p->hash_vals.p, p->hash_mask};
@@ -815,7 +821,7 @@ void sparkl_hip_pipeline_destroy(SparklPipeline* p) {
     for (float* d : p->d_heights) (void)hipFree(d);
     for (void* d : p->d_mesh_bufs) (void)hipFree(d);
     p->d_trimeshes.release();
-    p->blk_origin.release(); p->blk_pfirst.release(); p->blk_pcount.release(); p->blk_nbr.release(); p->blk_tnbr.release(); p->pblk.release(); p->pb_info.release(); p->tile_mode.release(); p->blk_keys.release();
+    p->blk_origin.release(); p->blk_pfirst.release(); p->blk_pcount.release(); p->blk_nbr.release(); p->blk_tnbr.release(); p->pblk.release(); p->pb_info.release(); p->tile_mode.release(); p->pb_heads.release(); p->blk_keys.release();
     p->tiles.release(); p->node_vel.release(); p->node_mom.release(); p->hash_keys.release(); p->hash_vals.release();
     p->keys_a.release(); p->keys_b.release(); p->pb_keys.release(); p->bkeys.release(); p->idx_a.release(); p->idx_b.release();
     p->pb_counts.release(); p->pb_first.release(); p->cand_a.release(); p->cand_b.release(); p->cub_temp.release(); p->d_scalars.release();
