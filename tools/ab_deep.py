@@ -1,4 +1,4 @@
-"""A/B of library variants in three phases of the 10M collapse on one box: python tools/ab_deep.py name=lib.so ...  (empty lib = working tree).
+"""A/B of library variants in three phases of the 10M collapse on one box: python tools/ab_deep.py name=lib.so ...  (empty lib = working tree; name=lib.so,ENV=VAL sets environment variables for that variant).
 Each variant runs the column once: 64 timed substeps from substep 100, 640 and 2000 (kernel spans from the library clock)."""
 import os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,8 +23,12 @@ print(" | ".join(out))
 ''' % root
 for rep in range(2):
     for spec in sys.argv[1:]:
-        name, lib = spec.split("=", 1)
+        name, rest = spec.split("=", 1)
+        lib, *kvs = rest.split(",")
         env = dict(os.environ)
         if lib: env["SPARKL_HIP_LIB"] = os.path.join(root, lib)
+        for kv in kvs:
+            k, v = kv.split("=")
+            env[k] = v
         r = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True)
         print(f"{name:10s}", (r.stdout.strip().splitlines() or ["FAILED " + r.stderr[-300:]])[-1], flush=True)
