@@ -536,7 +536,15 @@ SPK_DEV M3 sym_to_m3(const SymStress& s) { return M3{{s.t[0], s.t[3], s.t[4], s.
 //   2 mu (F - R) F^T + lambda (J - 1) J I  =  2 mu F M F^T + lambda (J - 1) J I,   M = V diag((sigma - 1)/sigma) V^T = I - exp(-eps)
 // (elasticity_corotated_linear.rs:31-78; R = U V^T, U = F V Sigma^-1).  The caller hands M over as (xx, yy, zz, xy, xz, yz):
 // first order of eps as a matrix, remainder -expm1_rem(-e_k) in the eigenbasis.  J - 1 = det(I + E) - 1 without cancellation.
-SPK_DEV SymStress corotated_tau_e(const DevModel& mo, float hardening, const M3& E, const float m6[6]) {
+// `park` (fused kernel): the six components go straight to the LDS, element k of this lane at park[64 k], as each is formed -- this is
+// where the kernel's register pressure peaks (E, M, A = F M and everything the particle update still holds), and the components are not
+// needed again before the scatter ~2 000 instructions later: kept in registers they were spilled to scratch (kernels.h, lds_fp).
+#ifdef SPK_HOST_BUILD_NO_AS
+typedef volatile float* lds_fp;
+#else
+typedef volatile __attribute__((address_space(3))) float* lds_fp;
+#endif
+SPK_DEV SymStress corotated_tau_e(const DevModel& mo, float hardening, const M3& E, const float m6[6], lds_fp park = nullptr) {
     const M3 M = sym6_to_m3(m6);
     M3 A = m3_mul(E, M);                 // A = F M = M + E M
 #pragma unroll
@@ -550,9 +558,10 @@ SPK_DEV SymStress corotated_tau_e(const DevModel& mo, float hardening, const M3&
     for (int k = 0; k < 6; ++k) {
         const int a = ii[k], b = jj[k];
         // (A F^T)_ab = A_ab + sum_c A_ac E_bc
-        S.t[k] = k2 * (A.m[a + 3 * b] + (A.m[a] * E.m[b] + A.m[a + 3] * E.m[b + 3] + A.m[a + 6] * E.m[b + 6]));
+        const float t = k2 * (A.m[a + 3 * b] + (A.m[a] * E.m[b] + A.m[a + 3] * E.m[b + 3] + A.m[a + 6] * E.m[b + 6])) + (k < 3 ? sph : 0.f);
+        if (park != nullptr) { park[64 * k] = t; S.t[k] = 0.f; }
+        else S.t[k] = t;
     }
-    S.t[0] += sph; S.t[1] += sph; S.t[2] += sph;
     S.jm1 = jm1;
     S.valid = true;
     return S;
@@ -593,7 +602,7 @@ SPK_DEV M3 corotated_kirchhoff_e(const DevModel& mo, float hardening, const M3& 
 // exp(K) - I = expm1(c) I + e^c (D + D^2/2 + D^3/6).
 template <bool WANT_STRESS>
 SPK_DEV void dp_update_series(const DevModel& mo, float phase, float eh, const float S[6], M3& E, float& Jp, float& q, float& lvg, float sm1[3], bool& sv_valid,
-                              SymStress& T) {
+                              SymStress& T, lds_fp park = nullptr) {
     float eps[6];
     SPK_MARK("dp_series_log");
     hencky_series(S, eps);
@@ -656,12 +665,13 @@ SPK_DEV void dp_update_series(const DevModel& mo, float phase, float eh, const f
     if (WANT_STRESS && mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR && phase == 1.f) {
         float m6[6];
         one_minus_exp_neg_series(eps, m6);
-        T = corotated_tau_e(mo, eh, E, m6);
+        T = corotated_tau_e(mo, eh, E, m6, park);
     }
 }
 
 template <bool WANT_STRESS>
-SPK_DEV void dp_update_e(const DevModel& mo, float phase, float eh, M3& E, float& Jp, float& q, float& lvg, float sm1[3], bool& sv_valid, SymStress& T) {
+SPK_DEV void dp_update_e(const DevModel& mo, float phase, float eh, M3& E, float& Jp, float& q, float& lvg, float sm1[3], bool& sv_valid, SymStress& T,
+                         lds_fp park = nullptr) {
     sv_valid = false;
     T.valid = false;
     if (mo.only_active_when_failed && phase != 0.f) return;
@@ -669,7 +679,7 @@ SPK_DEV void dp_update_e(const DevModel& mo, float phase, float eh, M3& E, float
     float lin[6], e[3], dv[3];
     strain_metric(E, lin);
     if (SPK_SERIES_MAX > 0.f && __all(series_ok(lin, lvg))) {   // wave-uniform
-        dp_update_series<WANT_STRESS>(mo, phase, eh, lin, E, Jp, q, lvg, sm1, sv_valid, T);
+        dp_update_series<WANT_STRESS>(mo, phase, eh, lin, E, Jp, q, lvg, sm1, sv_valid, T, park);
         return;
     }
     const Eig3 d = log_stretch_s(lin, e, dv);
@@ -741,7 +751,7 @@ SPK_DEV void dp_update_e(const DevModel& mo, float phase, float eh, M3& E, float
         sym_compose(d.v, mr, m6);
 #pragma unroll
         for (int i = 0; i < 6; ++i) m6[i] += lin[i];
-        T = corotated_tau_e(mo, eh, E, m6);
+        T = corotated_tau_e(mo, eh, E, m6, park);
     }
 }
 

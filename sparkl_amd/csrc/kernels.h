@@ -1289,7 +1289,7 @@ SPK_DEV void apic_gather(const VelTile& vt, const float px[3], const int4& org, 
 template <bool RARE, bool WANT_STRESS = false>
 SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevModel& mo, uint32_t flags, const float4& q0, const float4& q1, const float4& q2, const float4& dd,
                             const float4& kk, const float4* kinvel_i, const float4* aux_i, float phase, const int4& org, const StepParams& S, float inv_h,
-                            unsigned* num_invalid) {
+                            unsigned* num_invalid, lds_fp park = nullptr) {
     Advected o;
     const float h = S.h, dt = S.dt;
     float px[3] = {q0.x, q0.y, q0.z};
@@ -1343,7 +1343,7 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
     }
     if (dp_e) {
         SPK_MARK("dp_update");
-        dp_update_e<WANT_STRESS>(mo, phase, eh, E, Jp, q, lvg, sv, sv_valid, o.T);   // sv: sigma' - 1
+        dp_update_e<WANT_STRESS>(mo, phase, eh, E, Jp, q, lvg, sv, sv_valid, o.T, park);   // sv: sigma' - 1; the stress goes to `park` (device_math.h, lds_fp)
         SPK_MARK("post_dp");
         F = E;
         F.m[0] += 1.f; F.m[4] += 1.f; F.m[8] += 1.f;
@@ -1544,7 +1544,9 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
         if (live) {
             const DevModel& mo = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
             const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
-            const Advected o = g2p_update<RARE, true>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
+            const lds_fp park = (lds_fp)(&s_A[tid >> 6][0][tid & 63]);
+            const Advected o = g2p_update<RARE, true>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid, park);
+            const bool t_valid = o.T.valid;   // the six components themselves sit in the LDS (see g2p_update's `park`)
             SPK_MARK("store");
             g2p_store(P, i, o, S.defer_c);
             want_sort |= !o.in_tile && !(o.flags & FLAG_INVALID);   // a particle that left the DOMAIN is dead (skipped from now on): no re-bin for it
@@ -1555,7 +1557,14 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
                 dt_bound = fminf(dt_bound, bnd);
             }
             SPK_MARK("p2g_prepare");
-            if (live) { sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.Fe, kk.x, kk.y, o.eh, o.phase, o.Jp, org, h, inv_h, S.inv_d, S.dt_next, &o.T, o.rnew); shell_used |= sc.shell != 0; }
+            if (live) {
+                SymStress T2;
+                T2.valid = t_valid; T2.jm1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) T2.t[k] = t_valid ? park[64 * k] : 0.f;
+                sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.Fe, kk.x, kk.y, o.eh, o.phase, o.Jp, org, h, inv_h, S.inv_d, S.dt_next, &T2, o.rnew);
+                shell_used |= sc.shell != 0;
+            }
             SPK_MARK("scatter");
             probe_extra_work(s_A[tid >> 6], tid, o.px, o.vel, sc);   // probe_hooks.h: nothing unless an analysis build asks for it
         }

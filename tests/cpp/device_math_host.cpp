@@ -13,6 +13,7 @@
 #define __any(x) (x)
 #define __all(x) (x)
 #define __device__
+#define SPK_HOST_BUILD_NO_AS 1
 #define __forceinline__ inline
 #include "../../sparkl_amd/csrc/device_math.h"
 
