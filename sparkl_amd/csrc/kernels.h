@@ -1626,7 +1626,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_regather_c(ParticleArrays P, Gr
 // thread held in registers between the read and the write.  Restores the same-cell lane runs the scatter's pre-reduction
 // needs (see Ctl) for one pass over the particle data (~0.6 ms at 10M) instead of a full re-bin with its host round trip.
 // Launched blindly every few substeps; does nothing unless the policy asked for it.
-__global__ __launch_bounds__(BLK_THREADS) void k_block_reorder(ParticleArrays P, GridArrays G, const Ctl* __restrict__ ctl, float h, int parity) {
+__global__ __launch_bounds__(BLK_THREADS, 4) void k_block_reorder(ParticleArrays P, GridArrays G, const Ctl* __restrict__ ctl, float h, int parity) {
     if (ctl->abort_flag[parity] || !ctl->reorder_request) return;
     __shared__ int hist[8][TILE_N];   // [slot-order segment = iteration * 4 + wave][cell]: count, then start offset
     __shared__ int wave_sum[4];
@@ -1645,18 +1645,16 @@ __global__ __launch_bounds__(BLK_THREADS) void k_block_reorder(ParticleArrays P,
         const int cnt = min(2 * BLK_THREADS, pcount - c0);
         for (int n = tid; n < 8 * TILE_N; n += BLK_THREADS) (&hist[0][0])[n] = 0;
         __syncthreads();
-        float4 r[2][10], fr[2];
-        int key[2], rank[2];
+        float4 r0[2];
+        int key[2], rank[2], src[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int li = k * BLK_THREADS + tid;
             const bool valid = li < cnt;
             const int i = pfirst + c0 + (valid ? li : 0);
-#pragma unroll
-            for (int a = 0; a < 6; ++a) r[k][a] = P.q[a][i];
-            r[k][6] = P.d[i]; r[k][7] = P.k[i]; r[k][8] = P.kinvel[i]; r[k][9] = P.aux[i];
-            if (P.frac) fr[k] = P.frac[i];
-            const float px[3] = {r[k][0].x, r[k][0].y, r[k][0].z};
+            src[k] = i;
+            r0[k] = P.q[0][i];
+            const float px[3] = {r0[k].x, r0[k].y, r0[k].z};
             int kk = 0;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
@@ -1690,17 +1688,32 @@ __global__ __launch_bounds__(BLK_THREADS) void k_block_reorder(ParticleArrays P,
             hist[w][2 * tid] = start0; hist[w][2 * tid + 1] = start1;
             start0 += a0; start1 += a1;
         }
-        __syncthreads();   // also: every read of this chunk has completed (workgroup fence) before the first write
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int li = k * BLK_THREADS + tid;
-            if (li < cnt) {
-                const int dst = pfirst + c0 + hist[4 * k + wv][key[k]] + rank[k];
-#pragma unroll
-                for (int a = 0; a < 6; ++a) P.q[a][dst] = r[k][a];
-                P.d[dst] = r[k][6]; P.k[dst] = r[k][7]; P.kinvel[dst] = r[k][8]; P.aux[dst] = r[k][9];
-                if (P.frac) P.frac[dst] = fr[k];
-            }
+        __syncthreads();
+        const bool ok0 = tid < cnt, ok1 = BLK_THREADS + tid < cnt;
+        const int s0 = src[0], s1 = src[1];
+        const int d0 = pfirst + c0 + hist[wv][key[0]] + rank[0], d1 = pfirst + c0 + hist[4 + wv][key[1]] + rank[1];
+        // The streams move in three groups (five float4 per particle in flight at a time: 40 registers; all ten at once spilled 80 B per
+        // lane to scratch, a quarter more traffic than the move itself).  Per group: every read of the chunk completes (workgroup
+        // barrier) before the first write -- the move is in place.
+        {   // Q0 (already here) .. Q4
+            const float4 a1 = P.q[1][s0], a2 = P.q[2][s0], a3 = P.q[3][s0], a4 = P.q[4][s0];
+            const float4 b1 = P.q[1][s1], b2 = P.q[2][s1], b3 = P.q[3][s1], b4 = P.q[4][s1];
+            __syncthreads();
+            if (ok0) { P.q[0][d0] = r0[0]; P.q[1][d0] = a1; P.q[2][d0] = a2; P.q[3][d0] = a3; P.q[4][d0] = a4; }
+            if (ok1) { P.q[0][d1] = r0[1]; P.q[1][d1] = b1; P.q[2][d1] = b2; P.q[3][d1] = b3; P.q[4][d1] = b4; }
+        }
+        {   // Q5, D, K, kinvel, aux
+            const float4 a1 = P.q[5][s0], a2 = P.d[s0], a3 = P.k[s0], a4 = P.kinvel[s0], a5 = P.aux[s0];
+            const float4 b1 = P.q[5][s1], b2 = P.d[s1], b3 = P.k[s1], b4 = P.kinvel[s1], b5 = P.aux[s1];
+            __syncthreads();
+            if (ok0) { P.q[5][d0] = a1; P.d[d0] = a2; P.k[d0] = a3; P.kinvel[d0] = a4; P.aux[d0] = a5; }
+            if (ok1) { P.q[5][d1] = b1; P.d[d1] = b2; P.k[d1] = b3; P.kinvel[d1] = b4; P.aux[d1] = b5; }
+        }
+        if (P.frac) {   // kernel-uniform
+            const float4 a1 = P.frac[s0], b1 = P.frac[s1];
+            __syncthreads();
+            if (ok0) P.frac[d0] = a1;
+            if (ok1) P.frac[d1] = b1;
         }
         __syncthreads();
     }
