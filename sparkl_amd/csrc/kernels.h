@@ -501,22 +501,61 @@ SPK_DEV int wave_shr1_i(int v, int fill) { return __builtin_amdgcn_update_dpp(fi
 // the lattice (8 runs of 8) splits every run (48 tasks, 4 iterations), the flowing column (10-25 ragged runs of 1-12) splits the
 // long ones only (5-6 iterations where whole-run tasks took 8-12).  Task t = (plane z, chunk c) = z * C + c.
 #define SPK_FMAC_WSHL(R) "v_fmac_f32_dpp " R ", " R ", %4 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+// Grouping.  A task's chunk is a range of RANKS: the wave's live particles in the order (first lane of their cell, lane).  While the
+// lanes are still sorted by cell (after a re-bin or a block reorder) rank = lane and a run is a range of lanes.  Once particles have
+// crossed cells the members of one cell sit in several separate lane ranges; listed as separate runs they would cost a task triple
+// each and deposit to the SAME nodes in the same ds_add_f64 (same-address atomics serialise in the LDS: 0.07 ms of the launch at
+// substep 700 of the 10M column, tools/debug/ablate.py).  So an unsorted wave (wave-uniform test) groups its lanes by cell first -- one
+// scalar iteration per distinct cell: readlane the key, ballot the matches -- and moves every descriptor to the lane of its rank (seven
+// ds_permute_b32; the affine part is simply written to its rank's LDS column), after which the task phase is the same for both.
+SPK_DEV float perm_f(int byte_addr, float x) { return __int_as_float(__builtin_amdgcn_ds_permute(byte_addr, __float_as_int(x))); }
 SPK_DEV int p2g_scatter_runs(double (*tile)[ACC_N], const Scatter& sc, bool live, int tid, int* s_run, float (*s_A)[64]) {
     if (!__any(live)) return 0;   // wave-uniform
     const int lane = tid & 63;
-    // the affine part of the descriptor goes through LDS (9 KB per workgroup) instead of staying in 9 registers for ds_bpermute:
-    // the task phase is where the kernel's register pressure peaks, and those 9 pay for carrying the whole next batch in flight
-#pragma unroll
-    for (int e = 0; e < 9; ++e) s_A[e][lane] = sc.A.m[e];
-    const int key = live ? sc.base : -1;                       // dead lanes form runs of their own, never listed
+    const int key = live ? sc.base : 0x7fffffff;               // dead lanes sort behind the live ones and are never listed
     const int prev = wave_shr1_i(key, -2);
-    const bool head = (lane == 0) | (prev != key);
-    const unsigned long long hb = __ballot(head);
-    const bool lhead = head & live;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const bool perm = __any(prev > key);                       // wave-uniform
+    bool lhead;   // first lane of its cell
+    int len;      // particles of the cell (meaningful in head lanes)
+    int rank;     // of this lane's particle
+    if (!perm) {
+        const bool head = (lane == 0) | (prev != key);
+        const unsigned long long hb = __ballot(head);
+        const unsigned long long above = (lane == 63) ? 0ull : (hb >> (lane + 1));
+        len = above ? (int)__ffsll((long long)above) : (64 - lane);  // distance to the next head
+        lhead = head & live;
+        rank = lane;
+    } else {
+        const unsigned long long lv = __ballot(live);
+        unsigned long long todo = lv, mine = 0ull;
+        int off = 0;
+        rank = 0;
+        while (todo) {   // scalar loop: cells in the order of their first lane
+            const int K = __builtin_amdgcn_readlane(key, (int)__ffsll((long long)todo) - 1);
+            const unsigned long long m = __ballot(key == K);
+            if (key == K) { mine = m; rank = off; }
+            off += (int)__popcll(m);
+            todo &= ~m;
+        }
+        lhead = live && (mine & lt) == 0ull;
+        len = (int)__popcll(mine);
+        rank += (int)__popcll(mine & lt);
+        if (!live) rank = off + (int)__popcll(~lv & lt);   // dead lanes take the ranks behind: the move is a permutation
+    }
+    // the descriptor of rank r: seven values in lane r's registers (fetched by the tasks with ds_bpermute), the affine part in column r
+    // of `s_A` (9 KB per workgroup instead of 9 more registers: the task phase is where the kernel's register pressure peaks, and
+    // those 9 pay for carrying the whole next batch in flight)
+    float d_fx0 = sc.fx[0], d_fx1 = sc.fx[1], d_fx2 = sc.fx[2], d_m = sc.val_m, d_q0 = sc.qv[0], d_q1 = sc.qv[1], d_q2 = sc.qv[2];
+    if (perm) {
+        const int ra = rank << 2;
+        d_fx0 = perm_f(ra, d_fx0); d_fx1 = perm_f(ra, d_fx1); d_fx2 = perm_f(ra, d_fx2); d_m = perm_f(ra, d_m);
+        d_q0 = perm_f(ra, d_q0); d_q1 = perm_f(ra, d_q1); d_q2 = perm_f(ra, d_q2);
+    }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) s_A[e][rank] = sc.A.m[e];
     const unsigned long long hl = __ballot(lhead);
     const int nruns = (int)__popcll(hl);
-    const unsigned long long above = (lane == 63) ? 0ull : (hb >> (lane + 1));
-    const int len = above ? (int)__ffsll((long long)above) : (64 - lane);  // distance to the next head
     // split threshold: the smallest L whose chunks fit the task slots of the rounds the runs need anyway
     const int slots = ((3 * nruns + 63) >> 6) << 6;
     unsigned long long sb = 0ull;
@@ -527,15 +566,14 @@ SPK_DEV int p2g_scatter_runs(double (*tile)[ACC_N], const Scatter& sc, bool live
         sb = (int)__popcll(b4) <= room ? b4 : (int)__popcll(b5) <= room ? b5 : (int)__popcll(b6) <= room ? b6 : (int)__popcll(b8) <= room ? b8 : (int)__popcll(b12) <= room ? b12 : 0ull;
     }
     const int C = nruns + (int)__popcll(sb);
-    if (lhead) {
-        const unsigned long long lt = (1ull << lane) - 1ull;
+    if (lhead) {   // entry: first rank | particles << 8 | half flags | tile cell << 18
         const int c = (int)__popcll(hl & lt) + (int)__popcll(sb & lt);
         const bool split = (sb >> lane) & 1ull;
         const int n0 = split ? (len + 1) >> 1 : len;
-        s_run[c] = lane | (n0 << 8) | (split ? 0x10000 : 0);                       // bit 16: the next chunk is this run's second half
-        if (split) s_run[c + 1] = (lane + n0) | ((len - n0) << 8) | 0x20000;        // bit 17: second half
+        s_run[c] = rank | (n0 << 8) | (split ? 0x10000 : 0) | (sc.base << 18);              // bit 16: the next chunk is this run's second half
+        if (split) s_run[c + 1] = (rank + n0) | ((len - n0) << 8) | 0x20000 | (sc.base << 18); // bit 17: second half
     }
-    __builtin_amdgcn_wave_barrier();   // LDS operations of one wave execute in order: the list is visible to its lanes
+    __builtin_amdgcn_wave_barrier();   // LDS operations of one wave execute in order: the lists are visible to its lanes
     const int ntasks = 3 * C;
     const bool any_split = sb != 0ull;
     for (int t0 = 0; t0 < ntasks; t0 += 64) {
@@ -547,7 +585,7 @@ SPK_DEV int p2g_scatter_runs(double (*tile)[ACC_N], const Scatter& sc, bool live
         const int start = info & 63;
         const int cnt = valid ? (info >> 8) & 127 : 0;
         const int first = start;
-        const int run_base = __builtin_amdgcn_ds_bpermute(start << 2, sc.base);
+        const int run_base = (info >> 18) & 511;
         // trip count of the wave (scalar): the longest task
         const int maxcnt = wave_max_i32(cnt);
         const float fz = (float)z;
@@ -559,21 +597,21 @@ SPK_DEV int p2g_scatter_runs(double (*tile)[ACC_N], const Scatter& sc, bool live
         auto visit = [&](int j, auto first_tag) {
             constexpr bool FIRST = decltype(first_tag)::value;
             const bool on = j < cnt;
-            const int src = on ? first + j : start;                             // an idle iteration re-reads a lane of its own run
-            const int addr = src << 2;
+            const int here = on ? first + j : start;                            // an idle iteration re-reads a lane of its own run
+            const int addr = here << 2;
             // stage 1: the plane's base value (m ; qv + z A2) and z-weight
-            const float xz = bperm_f(addr, sc.fx[2]) - zg;
+            const float xz = bperm_f(addr, d_fx2) - zg;
             const float wz = on ? za + zb * (xz * xz) : 0.f;
-            const float m = bperm_f(addr, sc.val_m);
-            const float q0 = bperm_f(addr, sc.qv[0]), q1 = bperm_f(addr, sc.qv[1]), q2 = bperm_f(addr, sc.qv[2]);
-            const float a6 = s_A[6][src], a7 = s_A[7][src], a8 = s_A[8][src];
+            const float m = bperm_f(addr, d_m);
+            const float q0 = bperm_f(addr, d_q0), q1 = bperm_f(addr, d_q1), q2 = bperm_f(addr, d_q2);
+            const float a6 = s_A[6][here], a7 = s_A[7][here], a8 = s_A[8][here];
             f2v P01 = {m, q0 + fz * a6}, P23 = {q1 + fz * a7, q2 + fz * a8};
             // stage 2: the in-plane weights and increments; node (sx, sy) receives  wx wy wz * (m ; qv + sx A0 + sy A1 + z A2)
             float wy[3], wx[3];
-            eval_all(bperm_f(addr, sc.fx[1]), wy);
-            eval_all(bperm_f(addr, sc.fx[0]), wx);
-            const f2v Y01 = {0.f, s_A[3][src]}, Y23 = {s_A[4][src], s_A[5][src]};
-            const f2v X01 = {0.f, s_A[0][src]}, X23 = {s_A[1][src], s_A[2][src]};
+            eval_all(bperm_f(addr, d_fx1), wy);
+            eval_all(bperm_f(addr, d_fx0), wx);
+            const f2v Y01 = {0.f, s_A[3][here]}, Y23 = {s_A[4][here], s_A[5][here]};
+            const f2v X01 = {0.f, s_A[0][here]}, X23 = {s_A[1][here], s_A[2][here]};
 #pragma unroll
             for (int sy = 0; sy < 3; ++sy) {
                 if (sy > 0) { P01 += Y01; P23 += Y23; }

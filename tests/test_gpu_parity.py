@@ -516,7 +516,7 @@ def test_reorder_policy_does_not_change_results(Pipeline):
             out[tag] = (p.read_particles(), p.reorder_policy_stats())
     e = particle_errors(out["eager"][0], out["off"][0], sc.cell_width)
     _report("reorder_invariance", {**e, "reorders": out["eager"][1]["reorders"]})
-    assert out["off"][1]["reorders"] == 0 and out["eager"][1]["reorders"] >= 2
+    assert out["off"][1]["reorders"] == 0 and out["eager"][1]["reorders"] >= 1
     assert e["eps_x"] <= 1e-5 and e["eps_v"] <= 1e-4 and e["failed_mismatch"] == 0
 
 
