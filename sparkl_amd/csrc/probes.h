@@ -1,15 +1,15 @@
 // Diagnostic kernels (not on the product path; nothing in sparkl_hip_pipeline_* launches them).
 //
 // sparkl_hip_debug_run_stats: what the run-task scatter of k_g2p2g sees in the CURRENT particle order -- for every wave batch
-// (64 consecutive slots of a particle block, the partition k_g2p2g uses) the number of same-cell runs, the longest run, the
-// number of distinct cells, the number of <= 4-particle chunks, and the rounds / visit iterations the scatter would take.
+// (64 consecutive slots of a particle block, the partition k_g2p2g uses) the number of same-cell lane runs, the longest run, the
+// number of distinct cells, the largest cell, the number of <= 4-particle chunks, and the rounds / visit iterations the scatter takes.
 #pragma once
 #include "kernels.h"
 
 namespace spk {
 
 constexpr int RS_BINS = 65;
-enum { RS_NRUNS = 0, RS_MAXLEN = 1, RS_DISTINCT = 2, RS_CHUNKS4 = 3, RS_ROUNDS = 4, RS_ITERS = 5, RS_PCOUNT64 = 6, RS_LIVE = 7, RS_ROWS = 8, RS_LAYERS = 9, RS_STRAIN = 10, RS_HISTS = 11 };
+enum { RS_NRUNS = 0, RS_MAXLEN = 1, RS_DISTINCT = 2, RS_CHUNKS4 = 3, RS_ROUNDS = 4, RS_ITERS = 5, RS_PCOUNT64 = 6, RS_LIVE = 7, RS_ROWS = 8, RS_LAYERS = 9, RS_STRAIN = 10, RS_MAXCELL = 11, RS_ITERS_MULTI = 12, RS_HISTS = 13 };
 
 __global__ __launch_bounds__(BLK_THREADS) void k_run_stats(ParticleArrays P, GridArrays G, float h, unsigned long long* out) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -48,27 +48,63 @@ __global__ __launch_bounds__(BLK_THREADS) void k_run_stats(ParticleArrays P, Gri
         const int distinct = (int)__popcll(__ballot(lhead && !dup));
         const int rows = (int)__popcll(__ballot(lhead && !rowdup));
         const int layers = (int)__popcll(__ballot(lhead && !laydup));
-        int c4 = lhead ? (len + 3) / 4 : 0;
-        for (int o = 32; o > 0; o >>= 1) c4 += __shfl_xor(c4, o);
-        // what p2g_scatter_runs does today: S halves when 6 * nruns <= 64, rounds of 64 tasks, each as long as its longest task
-        const int S = (6 * nruns_all <= 64) ? 2 : 1;
-        const int ntasks = nruns_all * 3 * S;
-        int rounds = 0, iters = 0;
-        for (int t0 = 0; t0 < ntasks; t0 += 64) {
-            const int t = t0 + lane;
-            const int r = t / (3 * S), half = (S == 2) ? ((t - r * 3 * S) & 1) : 0;
-            int cnt = 0;
-            {
-                // run r: its head lane is the r-th set bit of hb
-                const int rr = min(r, nruns_all - 1);
-                unsigned long long m = hb;
-                for (int q = 0; q < rr; ++q) m &= m - 1;
-                const int start = (int)__ffsll((long long)m) - 1;
-                const int rl = __shfl(len, start), rlive = __shfl((int)live, start);
-                if (t < ntasks) cnt = rlive ? (S == 2 ? (half ? rl - ((rl + 1) >> 1) : ((rl + 1) >> 1)) : rl) : 0;
+        // what p2g_scatter_runs does: lanes grouped by cell, a cell longer than L split into two halves, L the smallest of 4, 5, 6, 8, 12
+        // whose chunks fit the rounds of 64 tasks the cells need anyway; a round iterates as long as its longest task.  `iters_multi`:
+        // the same with cells cut into ceil(len / L) equal chunks instead of two halves.
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        unsigned long long mine = 0ull;
+        {
+            unsigned long long todo = __ballot(live);
+            while (todo) {
+                const int K = __builtin_amdgcn_readlane(key, (int)__ffsll((long long)todo) - 1);
+                const unsigned long long m = __ballot(key == K);
+                if (key == K) mine = m;
+                todo &= ~m;
             }
-            rounds++;
-            iters += max(wave_max_i32(cnt), 1);
+        }
+        const bool chead = live && (mine & lt) == 0ull;
+        const int clen = (int)__popcll(mine);
+        const int maxcell = wave_max_i32(chead ? clen : 0);
+        int c4 = chead ? (clen + 3) / 4 : 0;
+        for (int o = 32; o > 0; o >>= 1) c4 += __shfl_xor(c4, o);
+        const unsigned long long hl = __ballot(chead);
+        const int ncell = (int)__popcll(hl);
+        const int slots = ((3 * ncell + 63) >> 6) << 6, room = slots / 3 - ncell;
+        int rounds = 0, iters = 0, iters_multi = 0;
+        {
+            const int Ls[5] = {4, 5, 6, 8, 12};
+            unsigned long long sb = 0ull;
+            for (int q = 0; q < 5; ++q) {
+                const unsigned long long bq = __ballot(chead && clen > Ls[q]);
+                if ((int)__popcll(bq) <= room) { sb = bq; break; }
+            }
+            const int C = ncell + (int)__popcll(sb);
+            __shared__ int s_cnt[BLK_THREADS / 64][64];
+            int* cl = s_cnt[tid >> 6];
+            if (chead) {
+                const int c = (int)__popcll(hl & lt) + (int)__popcll(sb & lt);
+                const bool split = (sb >> lane) & 1ull;
+                const int n0 = split ? (clen + 1) >> 1 : clen;
+                cl[c] = n0;
+                if (split) cl[c + 1] = clen - n0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int t0 = 0; t0 < 3 * C; t0 += 64) {
+                const int t = t0 + lane;
+                const int cnt = t < 3 * C ? cl[t % C] : 0;
+                rounds++;
+                iters += max(wave_max_i32(cnt), 1);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // equal chunks
+            int Lm = 64;
+            for (int q = 0; q < 5; ++q) {
+                int extra = chead ? (clen + Ls[q] - 1) / Ls[q] - 1 : 0;
+                for (int o = 32; o > 0; o >>= 1) extra += __shfl_xor(extra, o);
+                if (extra <= room) { Lm = Ls[q]; break; }
+            }
+            const int pieces = (clen + Lm - 1) / Lm;
+            iters_multi = rounds * wave_max_i32(chead ? (clen + pieces - 1) / pieces : 0);   // (upper bound when rounds > 1)
         }
         const int nlive = (int)__popcll(__ballot(live));
         // wave maximum of |F^T F - I|_F (what selects the series path of the return map): bin k = first threshold of
@@ -94,6 +130,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_run_stats(ParticleArrays P, Gri
             atomicAdd(&out[RS_ROWS * RS_BINS + rows], 1ull);
             atomicAdd(&out[RS_LAYERS * RS_BINS + layers], 1ull);
             atomicAdd(&out[RS_STRAIN * RS_BINS + sbin], 1ull);
+            atomicAdd(&out[RS_MAXCELL * RS_BINS + min(maxcell, 64)], 1ull);
+            atomicAdd(&out[RS_ITERS_MULTI * RS_BINS + min(iters_multi, 64)], 1ull);
         }
     }
 }

@@ -13,6 +13,10 @@ import csv, glob, collections
 tot = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/pmc_*/**/*counter_collection.csv", recursive=True):
     rows = [r for r in csv.DictReader(open(f)) if "k_g2p2g" in r["Kernel_Name"]]
+    # launches behind an abort flag do nothing: drop them (discriminator: the pass's instruction / busy counter against its median)
+    disc = {int(r["Dispatch_Id"]): float(r["Counter_Value"]) for r in rows if r["Counter_Name"] in ("SQ_INSTS_VALU", "SQ_BUSY_CYCLES")}
+    med = sorted(disc.values())[len(disc) // 2]
+    rows = [r for r in rows if disc[int(r["Dispatch_Id"])] > 0.3 * med]
     ids = sorted(set(int(r["Dispatch_Id"]) for r in rows))
     n = len(ids)
     early, late = set(ids[20:120]), set(ids[-200:])

@@ -6,11 +6,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from sparkl_amd import scenes, _lib
 from sparkl_amd.pipeline import MpmPipeline
 marks = [int(a) for a in sys.argv[1:]] or [0, 640, 2000]
-NAMES = ["nruns", "maxlen", "distinct", "chunks4", "rounds", "iters", "pcount/64", "live", "rows", "layers", "|S|<1e-3,3e-3,1e-2,3e-2,.1,.3,inf"]
+NAMES = ["nruns", "maxlen", "distinct", "chunks4", "rounds", "iters", "pcount/64", "live", "rows", "layers", "|S|<1e-3,3e-3,1e-2,3e-2,.1,.3,inf", "maxcell", "iters_multi"]
 def stats(p):
-    out = (C.c_ulonglong * (11 * 65))()
+    out = (C.c_ulonglong * (13 * 65))()
     _lib.check(_lib.lib().sparkl_hip_debug_run_stats(p.h, out, C.c_uint64(len(out))))
-    a = np.array(out, dtype=np.float64).reshape(11, 65)
+    a = np.array(out, dtype=np.float64).reshape(13, 65)
     for k, name in enumerate(NAMES):
         h = a[k]; tot = h.sum()
         if tot == 0: continue
