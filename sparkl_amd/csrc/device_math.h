@@ -459,8 +459,15 @@ SPK_DEV Eig3 log_stretch(const M3& E, float S[6], float e[3], float re[3]) {
 // the strain is kept (truncation: |S|^4 / 5 and |e|^3 / 24 relative, < 2e-7 at the switch-over); two Jacobi sweeps with their
 // eigenvector accumulation (2 x 128 instructions, 18 transcendentals) and two eigenbasis compositions become seven symmetric
 // products of 18 FMAs.  Only the positive-energy bookkeeping needs eigenVALUES (sum of max(sigma_k - 1, 0)^2): closed form below.
+// Second tier, SPK_SERIES_MAX <= |S| < SPK_SERIES_MAX2 (the flowing sand: a third of the waves of the 10M column 2 000 substeps in):
+// the logarithm to S^7 -- one more product, Paterson-Stockmeyer: (S/2 - S^2/4 + S^3/6) + S^4 (-1/8 + S/10 - S^2/12 + S^3/14) -- next
+// term |S|^7 / 8 relative, 1.3e-8 at 0.1; the exponentials are quartic on both tiers (x^2 (x/6 + x^2/24): the same two products as the
+// cubic), next term |x|^4 / 120 relative with |x| <= |S| / 2: 5e-8.
 #ifndef SPK_SERIES_MAX
 #define SPK_SERIES_MAX 0.03f
+#endif
+#ifndef SPK_SERIES_MAX2
+#define SPK_SERIES_MAX2 0.1f
 #endif
 // a * b for two commuting symmetric matrices (the product is symmetric), (xx, yy, zz, xy, xz, yz)
 SPK_DEV void sym_mul(const float a[6], const float b[6], float o[6]) {
@@ -496,28 +503,40 @@ SPK_DEV void sym_eigvals(const float a[6], float e[3]) {
     e[1] = q + sg * (-c + 2.f * sn);
     e[2] = q + sg * (-c - 2.f * sn);
 }
-// eps = ln(I + S) / 2 by its series (quartic: the next term is |S|^4 / 5 of the first)
-SPK_DEV void hencky_series(const float S[6], float eps[6]) {
+// eps = ln(I + S) / 2 by its series: quartic (the next term is |S|^4 / 5 of the first), or to S^7 (`hi`, wave-uniform)
+SPK_DEV void hencky_series(const float S[6], float eps[6], bool hi = false) {
     float P2[6], P3[6], P4[6];
     sym_mul(S, S, P2);
     sym_mul(S, P2, P3);
     sym_mul(P2, P2, P4);
+    if (hi) {
+        float B[6], T[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) B[i] = 0.1f * S[i] + ((-1.f / 12.f) * P2[i] + (1.f / 14.f) * P3[i]);
+        sym_mul(P4, B, T);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) eps[i] = 0.5f * S[i] + (-0.25f * P2[i] + ((1.f / 6.f) * P3[i] + (T[i] - 0.125f * P4[i])));
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 6; ++i) eps[i] = 0.5f * S[i] + (-0.25f * P2[i] + ((1.f / 6.f) * P3[i] - 0.125f * P4[i]));
 }
-// x - x^2/2 + x^3/6 = I - exp(-x) to |x|^3 / 24 relative
+// x - x^2/2 + x^3/6 - x^4/24 = I - exp(-x) to |x|^4 / 120 relative
 SPK_DEV void one_minus_exp_neg_series(const float x[6], float m[6]) {
-    float X2[6], X3[6];
+    float X2[6], Q[6], T[6];
     sym_mul(x, x, X2);
-    sym_mul(x, X2, X3);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) m[i] = x[i] + (-0.5f * X2[i] + (1.f / 6.f) * X3[i]);
+    for (int i = 0; i < 6; ++i) Q[i] = (1.f / 6.f) * x[i] - (1.f / 24.f) * X2[i];
+    sym_mul(X2, Q, T);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) m[i] = x[i] + (T[i] - 0.5f * X2[i]);
 }
 // squared Frobenius norm: bounds every eigenvalue of the symmetric matrix
 SPK_DEV float sym_frob2(const float S[6]) {
     return (S[0] * S[0] + S[1] * S[1] + S[2] * S[2]) + 2.f * (S[3] * S[3] + S[4] * S[4] + S[5] * S[5]);
 }
 SPK_DEV bool series_ok(const float S[6], float extra = 0.f) { return fmaxf(sym_frob2(S), extra * extra) < SPK_SERIES_MAX * SPK_SERIES_MAX; }
+SPK_DEV bool series2_ok(const float S[6], float extra = 0.f) { return fmaxf(sym_frob2(S), extra * extra) < SPK_SERIES_MAX2 * SPK_SERIES_MAX2; }
 
 // Corotated Kirchhoff stress (phase == 1) of the particle's final F = U diag(sigma') V^T, formed by the return map itself from
 // the decomposition it holds (the fused kernel scatters it one substep later; see corotated_tau_e).  Symmetric:
@@ -571,14 +590,16 @@ SPK_DEV SymStress corotated_tau_e(const DevModel& mo, float hardening, const M3&
 SPK_DEV M3 corotated_kirchhoff_fe(const DevModel& mo, float hardening, const M3& E) {
     float S[6], e[3], re[3], g[3], m6[6];
     strain_metric(E, S);
-    if (SPK_SERIES_MAX > 0.f && __all(series_ok(S))) {   // wave-uniform; series path: M = I - (I + S)^(-1/2)
-        float P2[6], P3[6], P4[6], P5[6];
+    if (SPK_SERIES_MAX > 0.f && __all(series2_ok(S))) {   // wave-uniform; series path: M = I - (I + S)^(-1/2) to S^7 (next term 0.39 |S|^7 relative)
+        float P2[6], P3[6], P4[6], B[6], T[6];
         sym_mul(S, S, P2);
         sym_mul(S, P2, P3);
         sym_mul(P2, P2, P4);
-        sym_mul(P2, P3, P5);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) m6[k] = 0.5f * S[k] + (-0.375f * P2[k] + (0.3125f * P3[k] + (-0.2734375f * P4[k] + 0.24609375f * P5[k])));
+        for (int k = 0; k < 6; ++k) B[k] = 0.24609375f * S[k] + (-0.2255859375f * P2[k] + 0.20947265625f * P3[k]);   // 63/256, 231/1024, 429/2048
+        sym_mul(P4, B, T);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) m6[k] = 0.5f * S[k] + (-0.375f * P2[k] + (0.3125f * P3[k] + (T[k] - 0.2734375f * P4[k])));
         return sym_to_m3(corotated_tau_e(mo, hardening, E, m6));
     }
     const Eig3 d = log_stretch_s(S, e, re);
@@ -602,10 +623,10 @@ SPK_DEV M3 corotated_kirchhoff_e(const DevModel& mo, float hardening, const M3& 
 // exp(K) - I = expm1(c) I + e^c (D + D^2/2 + D^3/6).
 template <bool WANT_STRESS>
 SPK_DEV void dp_update_series(const DevModel& mo, float phase, float eh, const float S[6], M3& E, float& Jp, float& q, float& lvg, float sm1[3], bool& sv_valid,
-                              SymStress& T, lds_fp park = nullptr) {
+                              SymStress& T, lds_fp park = nullptr, bool hi = false) {
     float eps[6];
     SPK_MARK("dp_series_log");
-    hencky_series(S, eps);
+    hencky_series(S, eps, hi);
     SPK_MARK("dp_alpha");
     const float alpha = dp_alpha(mo, q);
     SPK_MARK("dp_cases");
@@ -637,15 +658,17 @@ SPK_DEV void dp_update_series(const DevModel& mo, float phase, float eh, const f
         Jp *= (1.f + pm1) * fast_rcp(1.f + nm1);
         lvg += so - lnew;
         q += dq;
-        float D[6], D2[6], D3[6], G6[6];
+        float D[6], D2[6], Q[6], D34[6], G6[6];
         SPK_MARK("dp_exp");
 #pragma unroll
         for (int i = 0; i < 6; ++i) D[i] = g * dev[i];
         sym_mul(D, D, D2);
-        sym_mul(D, D2, D3);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Q[i] = (1.f / 6.f) * D[i] + (1.f / 24.f) * D2[i];
+        sym_mul(D2, Q, D34);           // D^3/6 + D^4/24
         const float xc = expm1_small(c), ec = 1.f + xc;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) G6[i] = ec * (D[i] + (0.5f * D2[i] + (1.f / 6.f) * D3[i]));
+        for (int i = 0; i < 6; ++i) G6[i] = ec * (D[i] + (0.5f * D2[i] + D34[i]));
         G6[0] += xc; G6[1] += xc; G6[2] += xc;
         const M3 G = sym6_to_m3(G6);
         const M3 EG = m3_mul(E, G);
@@ -678,8 +701,8 @@ SPK_DEV void dp_update_e(const DevModel& mo, float phase, float eh, M3& E, float
     // eps = lin + V diag(dv) V^T throughout: `lin` the first-order matrix, `dv` the remainders in the eigenbasis, e_k its eigenvalues
     float lin[6], e[3], dv[3];
     strain_metric(E, lin);
-    if (SPK_SERIES_MAX > 0.f && __all(series_ok(lin, lvg))) {   // wave-uniform
-        dp_update_series<WANT_STRESS>(mo, phase, eh, lin, E, Jp, q, lvg, sm1, sv_valid, T, park);
+    if (SPK_SERIES_MAX > 0.f && __all(series2_ok(lin, lvg))) {   // wave-uniform, and so is the tier
+        dp_update_series<WANT_STRESS>(mo, phase, eh, lin, E, Jp, q, lvg, sm1, sv_valid, T, park, !__all(series_ok(lin, lvg)));
         return;
     }
     const Eig3 d = log_stretch_s(lin, e, dv);
@@ -887,9 +910,9 @@ SPK_DEV float model_pos_energy(const DevModel& mo, float phase, float eh, const 
         else {
             float S6[6], eps[3], re[3];
             strain_metric(E, S6);
-            if (SPK_SERIES_MAX > 0.f && __all(series_ok(S6))) {   // wave-uniform; series path
+            if (SPK_SERIES_MAX > 0.f && __all(series2_ok(S6))) {   // wave-uniform; series path
                 float eps6[6];
-                hencky_series(S6, eps6);
+                hencky_series(S6, eps6, !__all(series_ok(S6)));
                 sym_eigvals(eps6, eps);
             } else {
                 (void)log_stretch_s(S6, eps, re);

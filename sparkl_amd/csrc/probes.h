@@ -36,7 +36,6 @@ __global__ __launch_bounds__(BLK_THREADS) void k_run_stats(ParticleArrays P, Gri
         const unsigned long long above = (lane == 63) ? 0ull : (hb >> (lane + 1));
         const int len = above ? (int)__ffsll((long long)above) : (64 - lane);
         const bool lhead = head && live;
-        const int nruns_all = (int)__popcll(hb);
         const int nruns = (int)__popcll(__ballot(lhead));
         const int maxlen = wave_max_i32(lhead ? len : 0);
         bool dup = false, rowdup = false, laydup = false;

@@ -64,4 +64,5 @@ void devmath_corotated(const float* mp, float eh, const float* E_in, float* tau9
 }
 void devmath_sym_eigvals(const float* a6, float* e3) { sym_eigvals(a6, e3); }
 float devmath_series_max(void) { return SPK_SERIES_MAX; }
+float devmath_series_max2(void) { return SPK_SERIES_MAX2; }
 }

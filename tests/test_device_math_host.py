@@ -2,7 +2,7 @@
 C++ (tests/cpp/device_math_host.cpp maps the gfx950 builtins to libm) and held against the f64 oracle on random trial states.
 
 Two builds: the default one, whose Drucker-Prager return map / corotated stress take the series path (polynomials in
-S = F^T F - I, no eigenvectors) while |S| < SPK_SERIES_MAX, and -DSPK_SERIES_MAX=0.f, which always takes the eigenbasis path
+S = F^T F - I, no eigenvectors; two tiers) while |S| < SPK_SERIES_MAX2, and -DSPK_SERIES_MAX=0.f, which always takes the eigenbasis path
 (cyclic Jacobi).  Both must reproduce plasticity_drucker_prager.rs:36-104 / elasticity_corotated_linear.rs:31-118 as the oracle
 restates them, to a few 1e-7 of the TRIAL strain (the strain-form bound of DESIGN.md section 5); the series path must also hand over
 to the eigenbasis path without a step at the switch-over."""
@@ -39,6 +39,7 @@ def libs():
     L = {"series": _build("series", []), "jacobi": _build("jacobi", ["-DSPK_SERIES_MAX=0.f"])}
     for l in L.values():
         l.devmath_series_max.restype = C.c_float
+        l.devmath_series_max2.restype = C.c_float
     assert L["series"].devmath_series_max() > 0.0 and L["jacobi"].devmath_series_max() == 0.0
     return L
 
@@ -111,9 +112,11 @@ def test_drucker_prager_return_map_matches_the_f64_oracle(libs, scale):
         assert (worst["series"][:3] <= worst["jacobi"][:3] + 5e-7).all(), worst
 
 
-def test_series_path_hands_over_without_a_step(libs):
-    """Across the switch-over (|S|_F = SPK_SERIES_MAX) both builds agree to the truncation bound of the series (< 1e-6 of the strain)."""
-    thr = libs["series"].devmath_series_max()
+@pytest.mark.parametrize("which", ["devmath_series_max", "devmath_series_max2"])
+def test_series_path_hands_over_without_a_step(libs, which):
+    """Across each switch-over (|S|_F = SPK_SERIES_MAX: quartic -> S^7 logarithm; SPK_SERIES_MAX2: series -> eigenbasis) the series build
+    agrees with the eigenbasis build to the truncation bound of the series (< 1e-6 of the strain)."""
+    thr = getattr(libs["series"], which)()
     rng = np.random.default_rng(3)
     worst = 0.0
     for trial in range(200):

@@ -11,7 +11,6 @@ def rep(a, b):
     global k
     assert k.count(a) == 1, a
     k = k.replace(a, b)
-rep("constexpr int ACC_N = 576;", "constexpr int ACC_N = 576;\n__device__ int spk_ablate = 0;")
 rep("        const int maxcnt = wave_max_i32(cnt);", "        const int abl = spk_ablate;\n        const int maxcnt = (abl & 4) ? 1 : wave_max_i32(cnt);")
 rep("        if (deposit) {\n            const int p = (run_base >> 6) + z;\n            const int n0 = run_base + TILE_W * TILE_W * z + 8 * p - 4 * (p & 1);      // acc_slot of the plane's (0, 0) node",
     "        if (deposit && !(abl & 1)) {\n            const int p = (run_base >> 6) + z;\n            int n0 = run_base + TILE_W * TILE_W * z + 8 * p - 4 * (p & 1);\n            const int sxm = (abl & 2) ? 0 : 1, sym = (abl & 2) ? 0 : TILE_W; if (abl & 2) n0 = lane * 9;")
@@ -23,6 +22,13 @@ rep("            const float z0 = vt.z[row], z1 = vt.z[row + 1], z2 = vt.z[row +
 rep("        if (REDUCE_STEPS < 0) wave_heads += p2g_scatter_runs(tile, sc, live, tid, s_runs[tid >> 6], s_A[tid >> 6]);",
     "        if (REDUCE_STEPS < 0) { if (!(spk_ablate & 16)) wave_heads += p2g_scatter_runs(tile, sc, live, tid, s_runs[tid >> 6], s_A[tid >> 6]); }")
 open("kernels.h", "w").write(k)
+d = open("device_math.h").read()
+assert d.count("namespace spk {") == 1
+d = d.replace("namespace spk {", "namespace spk {\n__device__ int spk_ablate = 0;", 1)
+n = d.count("__all(series_ok(")
+assert n >= 2
+d = d.replace("__all(series_ok(lin, lvg))", "(__all(series_ok(lin, lvg)) || (spk_ablate & 64))").replace("__all(series_ok(S))", "(__all(series_ok(S)) || (spk_ablate & 64))").replace("__all(series_ok(S6))", "(__all(series_ok(S6)) || (spk_ablate & 64))")
+open("device_math.h", "w").write(d)
 s = open("sparkl_hip.hip").read()
 s += '\nextern "C" int sparkl_hip_debug_set_ablate(int mode) { return hipMemcpyToSymbol(HIP_SYMBOL(spk::spk_ablate), &mode, sizeof(int)) == hipSuccess ? 0 : -1; }\n'
 open("sparkl_hip.hip", "w").write(s)
