@@ -95,7 +95,7 @@ struct GridArrays {
     const int* pblk;           // [PB] block index of each tile owner
     const int4* pb_info;       // [PB][2]: (origin.xyz, block index), (pfirst, pcount, -, -): one hop instead of three
     float4* tiles;             // [PB][512] (mass, px, py, pz); a core-only tile keeps its 6^3 inner nodes compactly in front
-    int* tile_mode;            // [PB] 0: only the 6^3 core was written (no particle sits in the drift margin), 1: all 8^3
+    int* tile_mode;            // [PB] which margin planes the tile stores beside its 6^3 core (6 bits, see tile_write): 0 = core only, 63 = all 8^3
     // [PB][2] run heads of the block's last fused scatter, and of its first one after the last re-bin / reorder of the block (0 = not
     // taken yet): k_block_reorder only touches the blocks whose runs have fragmented (the static bulk of a collapse never does)
     int2* pb_heads;
@@ -254,7 +254,7 @@ struct Scatter {
     float qv[3];   // affine * d0 + m v
     M3 A;          // affine * h
     int base;      // tile index of the associated cell (also the cell key of the lane)
-    int shell;     // the particle sits in the one-cell drift margin: its support leaves the 6^3 core of the tile
+    int shell;     // faces of the one-cell drift margin the particle's support reaches: bit 2a = low side of axis a (tile coordinate 0), 2a + 1 = high (7)
 };
 
 // particle_to_grid.rs:42-59: stress, affine, weights.  `org` = cell origin of the home block.
@@ -277,7 +277,7 @@ SPK_DEV Scatter p2g_prepare(const DevModel& mo, uint32_t flags, const float px[3
         lc[a] = (int)r - 1 - orgv[a] + 1;  // tile coordinate of the associated cell, in [0, 5]
     }
     sc.base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
-    sc.shell = ((lc[0] < 1) | (lc[0] > 4) | (lc[1] < 1) | (lc[1] > 4) | (lc[2] < 1) | (lc[2] > 4)) ? 1 : 0;
+    sc.shell = (lc[0] < 1 ? 1 : 0) | (lc[0] > 4 ? 2 : 0) | (lc[1] < 1 ? 4 : 0) | (lc[1] > 4 ? 8 : 0) | (lc[2] < 1 ? 16 : 0) | (lc[2] > 4 ? 32 : 0);
     M3 tau = m3_zero();
     if (!(flags & FLAG_FAILED)) {
         if (mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR) {
@@ -661,26 +661,62 @@ SPK_DEV int p2g_scatter_runs(double (*tile)[ACC_N], const Scatter& sc, bool live
     return nruns;
 }
 
-// Tile write-out (ends with the workgroup barrier the caller needs anyway).  Most blocks have no particle in the drift
-// margin, so only the 6^3 core (216 of 512 nodes) goes to HBM: -58 % tile traffic here and in the grid update.
-SPK_DEV void tile_write(double (*tile)[ACC_N], const GridArrays& G, int pb, int tid, bool shell_used) {
-    const int full = __syncthreads_or(shell_used ? 1 : 0);
+// Tile write-out.  Only the box of the 8^3 tile that holds support nodes goes to HBM, compactly: the 6^3 core plus, per axis and side,
+// the margin plane a particle's support reaches (`tile_mode`: the OR of Scatter::shell over the block).  The lattice at rest writes
+// 216 of 512 nodes (-58 % tile traffic here and in the grid update); the flowing column, whose blocks nearly all hold a particle that
+// has sunk into the margin below, mostly 6 x 7 x 6 or 7 x 7 x 6 instead of all 512.
+struct TileBox {
+    int lx, ly, lz, wx, wy, wz;
+};
+SPK_DEV TileBox tile_box(int mode) {
+    TileBox t;
+    t.lx = 1 - (mode & 1); t.ly = 1 - ((mode >> 2) & 1); t.lz = 1 - ((mode >> 4) & 1);
+    t.wx = 6 + (mode & 1) + ((mode >> 1) & 1); t.wy = 6 + ((mode >> 2) & 1) + ((mode >> 3) & 1); t.wz = 6 + ((mode >> 4) & 1) + ((mode >> 5) & 1);
+    return t;
+}
+// index of tile coordinate (tx, ty, tz) in [0, 8)^3 inside a tile stored with `mode`, or -1 where nothing was stored (zero)
+SPK_DEV int tile_box_index(int mode, int tx, int ty, int tz) {
+    const TileBox t = tile_box(mode);
+    const int x = tx - t.lx, y = ty - t.ly, z = tz - t.lz;
+    if ((unsigned)x >= (unsigned)t.wx || (unsigned)y >= (unsigned)t.wy || (unsigned)z >= (unsigned)t.wz) return -1;
+    return x + t.wx * (y + t.wy * z);
+}
+constexpr int TILE_MODE_FULL = 63;
+// OR over the wave as a scalar (DPP inside the 16-lane rows, the four row results through readlane); every lane must call it.  The
+// margin faces a block uses are kept this way, wave-uniform in one SGPR, rather than per lane: a VGPR more across the particle loop
+// of k_g2p2g is a spill.
+SPK_DEV int wave_or_i32(int v) {
+    v |= __builtin_amdgcn_update_dpp(v, v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
+    v |= __builtin_amdgcn_update_dpp(v, v, 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false);
+    v |= __builtin_amdgcn_update_dpp(v, v, 0x141 /* row_half_mirror */, 0xF, 0xF, false);
+    v |= __builtin_amdgcn_update_dpp(v, v, 0x140 /* row_mirror */, 0xF, 0xF, false);
+    return __builtin_amdgcn_readlane(v, 0) | __builtin_amdgcn_readlane(v, 16) | __builtin_amdgcn_readlane(v, 32) | __builtin_amdgcn_readlane(v, 48);
+}
+SPK_DEV void tile_write(double (*tile)[ACC_N], const GridArrays& G, int pb, int tid, int shell_bits /* wave-uniform */) {
+    __shared__ int s_mode[BLK_THREADS / 64];
+    if ((tid & 63) == 0) s_mode[tid >> 6] = shell_bits;   // wave-uniform (wave_or_i32 by the caller)
+    __syncthreads();   // also: every deposit of the workgroup has landed
+    int mode = 0;
+#pragma unroll
+    for (int i = 0; i < BLK_THREADS / 64; ++i) mode |= s_mode[i];
+    const TileBox t = tile_box(mode);
     float4* out = G.tiles + (size_t)pb * TILE_N;
-    if (full) {
-        for (int l = tid; l < TILE_N; l += BLK_THREADS) { const int n = acc_slot(l); out[l] = make_float4((float)tile[0][n], (float)tile[1][n], (float)tile[2][n], (float)tile[3][n]); }
-    } else if (tid < 216) {
-        const int x = tid % 6, y = (tid / 6) % 6, z = tid / 36;
-        const int n = acc_slot((x + 1) + TILE_W * (y + 1) + TILE_W * TILE_W * (z + 1));
-        out[tid] = make_float4((float)tile[0][n], (float)tile[1][n], (float)tile[2][n], (float)tile[3][n]);
+    const int n = t.wx * t.wy * t.wz;
+    const float iwx = 1.f / (float)t.wx, iwy = 1.f / (float)t.wy;
+    for (int l = tid; l < n; l += BLK_THREADS) {
+        const int r = (int)(((float)l + 0.5f) * iwx);          // l / wx, exact for l < 2^20
+        const int z = (int)(((float)r + 0.5f) * iwy);
+        const int x = l - r * t.wx, y = r - z * t.wy;
+        const int s = acc_slot((x + t.lx) + TILE_W * (y + t.ly) + TILE_W * TILE_W * (z + t.lz));
+        out[l] = make_float4((float)tile[0][s], (float)tile[1][s], (float)tile[2][s], (float)tile[3][s]);
     }
-    if (tid == 0) G.tile_mode[pb] = full;
+    if (tid == 0) G.tile_mode[pb] = mode;
 }
 // (mass, momentum) partial of tile `t` at tile coordinate (tx, ty, tz) in [0, 8)^3
 SPK_DEV float4 tile_read(const GridArrays& G, int t, int tx, int ty, int tz) {
-    if (G.tile_mode[t]) return G.tiles[(size_t)t * TILE_N + tx + TILE_W * ty + TILE_W * TILE_W * tz];
-    const bool shell = (tx == 0) | (tx == 7) | (ty == 0) | (ty == 7) | (tz == 0) | (tz == 7);
-    if (shell) return make_float4(0.f, 0.f, 0.f, 0.f);
-    return G.tiles[(size_t)t * TILE_N + (tx - 1) + 6 * (ty - 1) + 36 * (tz - 1)];
+    const int i = tile_box_index(G.tile_mode[t], tx, ty, tz);
+    if (i < 0) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return G.tiles[(size_t)t * TILE_N + i];
 }
 
 // One thread per launch: account for the heads of the previous scatter (index `prev`), arm the counter, maybe abort.
@@ -729,7 +765,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
     }
     __syncthreads();
 
-    bool shell_used = false;
+    int shell_used = 0;
     int wave_heads = 0;
     for (int it = 0; it < niter; ++it) {
         const int li = it * BLK_THREADS + tid;
@@ -752,8 +788,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
             const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
             const float jp = mo.is_fluid ? P.d[i].z : 1.f;
             sc = p2g_prepare(mo, flags, px, v, C, F, kk.x, kk.y, kk.z, phase, jp, org, h, inv_h, S.inv_d, S.dt);
-            shell_used |= sc.shell != 0;
         }
+        shell_used |= wave_or_i32(sc.shell);
         wave_heads += p2g_scatter<REDUCE_STEPS>(tile, sc, live, tid);
     }
     if ((tid & 63) == 0) atomicAdd(&s_heads, wave_heads);
@@ -779,7 +815,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_pair(ParticleArrays P, Grid
     const int pfirst = rng.x, pcount = rng.y;
     const float h = S.h, inv_h = 1.0f / S.h;
     __syncthreads();
-    bool shell_used = false;
+    int shell_used = 0;
     int wave_heads = 0;
     for (int base = 0; base < pcount; base += 2 * BLK_THREADS) {
         Scatter sc[2];
@@ -801,9 +837,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_pair(ParticleArrays P, Grid
                 const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
                 const float jp = mo.is_fluid ? P.d[i].z : 1.f;
                 sc[k] = p2g_prepare(mo, flags, px, v, C, F, kk.x, kk.y, kk.z, phase, jp, org, h, inv_h, S.inv_d, S.dt);
-                shell_used |= sc[k].shell != 0;
             }
         }
+        shell_used |= wave_or_i32(sc[0].shell | sc[1].shell);
         wave_heads += p2g_scatter_pair<REDUCE_STEPS>(tile, sc[0], sc[1], live[0], live[1], tid);
     }
     if ((tid & 63) == 0) atomicAdd(&s_heads, wave_heads);
@@ -1024,16 +1060,11 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
     const int lane = threadIdx.x & 63;
     const int cx = lane & 3, cy = (lane >> 2) & 3, cz = lane >> 4;
     const int dx0 = cx <= 2 ? -1 : 0, dy0 = cy <= 2 ? -1 : 0, dz0 = cz <= 2 ? -1 : 0;
-    int tl[8], off_full[8], off_core[8];
-    bool shell[8];
+    int tl[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int dx = dx0 + (i & 1), dy = dy0 + ((i >> 1) & 1), dz = dz0 + (i >> 2);
         tl[i] = G.blk_tnbr[b * 27 + (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1)];
-        const int tx = cx - 4 * dx + 1, ty = cy - 4 * dy + 1, tz = cz - 4 * dz + 1;
-        off_full[i] = tx + TILE_W * ty + TILE_W * TILE_W * tz;
-        off_core[i] = (tx - 1) + 6 * (ty - 1) + 36 * (tz - 1);
-        shell[i] = (tx == 0) | (tx == 7) | (ty == 0) | (ty == 7) | (tz == 0) | (tz == 7);
     }
     // the flag (a scalar load issued first) has arrived long before the eight table entries: an aborted launch leaves here, 34 -> ~8 us
     // at 10M particles (a batch cut by a re-bin request leaves up to 127 of them behind)
@@ -1044,9 +1075,10 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
     float m = 0.f, px = 0.f, py = 0.f, pz = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const bool use = (tl[i] >= 0) & ((mode[i] != 0) | !shell[i]);
-        if (use) {
-            const float4 v = G.tiles[(size_t)tl[i] * TILE_N + (mode[i] ? off_full[i] : off_core[i])];
+        const int dx = dx0 + (i & 1), dy = dy0 + ((i >> 1) & 1), dz = dz0 + (i >> 2);
+        const int off = tile_box_index(mode[i], cx - 4 * dx + 1, cy - 4 * dy + 1, cz - 4 * dz + 1);   // -1: outside what the tile stored
+        if ((tl[i] >= 0) & (off >= 0)) {
+            const float4 v = G.tiles[(size_t)tl[i] * TILE_N + off];
             m += v.x; px += v.y; py += v.z; pz += v.w;
         }
     }
@@ -1562,7 +1594,8 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     if (G.primary && blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
     __syncthreads();
     const float h = S.h, inv_h = 1.0f / S.h;
-    bool want_sort = false, shell_used = false;
+    bool want_sort = false;
+    int shell_used = 0;
     int wave_heads = 0;
     float dt_bound = 3.402823466e+38f;
     bool dt_nan = false;
@@ -1601,11 +1634,11 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
 #pragma unroll
                 for (int k = 0; k < 6; ++k) T2.t[k] = t_valid ? park[64 * k] : 0.f;
                 sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.Fe, kk.x, kk.y, o.eh, o.phase, o.Jp, org, h, inv_h, S.inv_d, S.dt_next, &T2, o.rnew);
-                shell_used |= sc.shell != 0;
             }
             SPK_MARK("scatter");
             probe_extra_work(s_A[tid >> 6], tid, o.px, o.vel, sc);   // probe_hooks.h: nothing unless an analysis build asks for it
         }
+        shell_used |= wave_or_i32(sc.shell);
         // (a hybrid -- run tasks for regular waves, DPP for ragged ones -- was measured: the two paths in one kernel spill, +15 %)
         if (REDUCE_STEPS < 0) wave_heads += p2g_scatter_runs(tile, sc, live, tid, s_runs[tid >> 6], s_A[tid >> 6]);
         else wave_heads += p2g_scatter<(REDUCE_STEPS < 0 ? 0 : REDUCE_STEPS)>(tile, sc, live, tid);
@@ -1826,7 +1859,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_mass(ParticleArrays P, Grid
     __syncthreads();
     float4* out = G.tiles + (size_t)pb * TILE_N;
     for (int n = tid; n < TILE_N; n += BLK_THREADS) out[n] = make_float4((float)tile[n], 0.f, 0.f, 0.f);
-    if (tid == 0) G.tile_mode[pb] = 1;
+    if (tid == 0) G.tile_mode[pb] = TILE_MODE_FULL;
 }
 
 __global__ __launch_bounds__(BLK_THREADS) void k_g2p_volume(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models,
@@ -1996,7 +2029,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
     __syncthreads();
     float4* out = G.tiles + (size_t)pb * TILE_N;
     for (int n = tid; n < TILE_N; n += BLK_THREADS) out[n] = make_float4((float)mtile[n], 0.f, 0.f, 0.f);
-    if (tid == 0) G.tile_mode[pb] = 1;
+    if (tid == 0) G.tile_mode[pb] = TILE_MODE_FULL;
     if (__any(want_sort)) {
         if ((tid & 63) == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
     }
@@ -2032,7 +2065,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
     }
     const float h = S.h, inv_h = 1.0f / S.h;
     __syncthreads();
-    bool shell_used = false;
+    int shell_used = 0;
     int wave_heads = 0;
     for (int base = 0; base < pcount; base += 2 * BLK_THREADS) {
         Scatter sc[2];
@@ -2081,9 +2114,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
                 const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
                 const float jp = mo.is_fluid ? jp_stored : 1.f;
                 sc[k] = p2g_prepare(mo, flags, px, v, C, F, kk.x, kk.y, kk.z, phase, jp, org, h, inv_h, S.inv_d, S.dt);
-                shell_used |= sc[k].shell != 0;
             }
         }
+        shell_used |= wave_or_i32(sc[0].shell | sc[1].shell);
         wave_heads += p2g_scatter_pair<SPK_VOLP2G_STEPS>(tile, sc[0], sc[1], live[0], live[1], tid);
     }
     if ((tid & 63) == 0) atomicAdd(&s_heads, wave_heads);
