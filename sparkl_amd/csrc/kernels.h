@@ -95,7 +95,7 @@ struct GridArrays {
     const int* pblk;           // [PB] block index of each tile owner
     const int4* pb_info;       // [PB][2]: (origin.xyz, block index), (pfirst, pcount, -, -): one hop instead of three
     float4* tiles;             // [PB][512] (mass, px, py, pz); a core-only tile keeps its 6^3 inner nodes compactly in front
-    int* tile_mode;            // [PB] which margin planes the tile stores beside its 6^3 core (6 bits, see tile_write): 0 = core only, 63 = all 8^3
+    int* tile_mode;            // [PB] which margin planes the tile stores beside its 6^3 core (6 bits, see tile_write): 0 = core only, 63 = all 8^3; 64 = scalar mass tile
     // [PB][2] run heads of the block's last fused scatter, and of its first one after the last re-bin / reorder of the block (0 = not
     // taken yet): k_block_reorder only touches the blocks whose runs have fragmented (the static bulk of a collapse never does)
     int2* pb_heads;
@@ -682,6 +682,7 @@ SPK_DEV int tile_box_index(int mode, int tx, int ty, int tz) {
     return x + t.wx * (y + t.wy * z);
 }
 constexpr int TILE_MODE_FULL = 63;
+constexpr int TILE_MODE_MASS = 64;   // a fluid mass pass wrote the tile: all 8^3 nodes, one float each (2 KB instead of 8)
 // OR over the wave as a scalar (DPP inside the 16-lane rows, the four row results through readlane); every lane must call it.  The
 // margin faces a block uses are kept this way, wave-uniform in one SGPR, rather than per lane: a VGPR more across the particle loop
 // of k_g2p2g is a spill.
@@ -714,7 +715,9 @@ SPK_DEV void tile_write(double (*tile)[ACC_N], const GridArrays& G, int pb, int 
 }
 // (mass, momentum) partial of tile `t` at tile coordinate (tx, ty, tz) in [0, 8)^3
 SPK_DEV float4 tile_read(const GridArrays& G, int t, int tx, int ty, int tz) {
-    const int i = tile_box_index(G.tile_mode[t], tx, ty, tz);
+    const int mode = G.tile_mode[t];
+    if (mode == TILE_MODE_MASS) return make_float4(((const float*)(G.tiles + (size_t)t * TILE_N))[tx + TILE_W * ty + TILE_W * TILE_W * tz], 0.f, 0.f, 0.f);
+    const int i = tile_box_index(mode, tx, ty, tz);
     if (i < 0) return make_float4(0.f, 0.f, 0.f, 0.f);
     return G.tiles[(size_t)t * TILE_N + i];
 }
@@ -1076,7 +1079,12 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int dx = dx0 + (i & 1), dy = dy0 + ((i >> 1) & 1), dz = dz0 + (i >> 2);
-        const int off = tile_box_index(mode[i], cx - 4 * dx + 1, cy - 4 * dy + 1, cz - 4 * dz + 1);   // -1: outside what the tile stored
+        const int tx = cx - 4 * dx + 1, ty = cy - 4 * dy + 1, tz = cz - 4 * dz + 1;
+        if (MASS_ONLY) {   // every tile was written by a mass pass (TILE_MODE_MASS)
+            if (tl[i] >= 0) m += ((const float*)(G.tiles + (size_t)tl[i] * TILE_N))[tx + TILE_W * ty + TILE_W * TILE_W * tz];
+            continue;
+        }
+        const int off = tile_box_index(mode[i], tx, ty, tz);   // -1: outside what the tile stored
         if ((tl[i] >= 0) & (off >= 0)) {
             const float4 v = G.tiles[(size_t)tl[i] * TILE_N + off];
             m += v.x; px += v.y; py += v.z; pz += v.w;
@@ -1857,9 +1865,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_mass(ParticleArrays P, Grid
             }
     }
     __syncthreads();
-    float4* out = G.tiles + (size_t)pb * TILE_N;
-    for (int n = tid; n < TILE_N; n += BLK_THREADS) out[n] = make_float4((float)tile[n], 0.f, 0.f, 0.f);
-    if (tid == 0) G.tile_mode[pb] = TILE_MODE_FULL;
+    float* out = (float*)(G.tiles + (size_t)pb * TILE_N);   // mass tile: 8^3 scalars at the head of the block's slot
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) out[n] = (float)tile[n];
+    if (tid == 0) G.tile_mode[pb] = TILE_MODE_MASS;
 }
 
 __global__ __launch_bounds__(BLK_THREADS) void k_g2p_volume(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models,
@@ -2027,9 +2035,9 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
         mass_scatter(mtile, npx, kk.x, live, org, S.h, tid);
     }
     __syncthreads();
-    float4* out = G.tiles + (size_t)pb * TILE_N;
-    for (int n = tid; n < TILE_N; n += BLK_THREADS) out[n] = make_float4((float)mtile[n], 0.f, 0.f, 0.f);
-    if (tid == 0) G.tile_mode[pb] = TILE_MODE_FULL;
+    float* out = (float*)(G.tiles + (size_t)pb * TILE_N);   // mass tile: 8^3 scalars at the head of the block's slot
+    for (int n = tid; n < TILE_N; n += BLK_THREADS) out[n] = (float)mtile[n];
+    if (tid == 0) G.tile_mode[pb] = TILE_MODE_MASS;
     if (__any(want_sort)) {
         if ((tid & 63) == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
     }
