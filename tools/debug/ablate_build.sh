@@ -21,6 +21,9 @@ rep("            const unsigned long long u0 = vq[row], u1 = vq[row + 1], u2 = v
 rep("            const float z0 = vt.z[row], z1 = vt.z[row + 1], z2 = vt.z[row + 2];\n            const float wy = wgt[1][sy];", "            const float wy = wgt[1][sy];")
 rep("        if (REDUCE_STEPS < 0) wave_heads += p2g_scatter_runs(tile, sc, live, tid, s_runs[tid >> 6], s_A[tid >> 6]);",
     "        if (REDUCE_STEPS < 0) { if (!(spk_ablate & 16)) wave_heads += p2g_scatter_runs(tile, sc, live, tid, s_runs[tid >> 6], s_A[tid >> 6]); }")
+rep("    if (dp_e) {\n        SPK_MARK(\"dp_update\");", "    if (dp_e && (spk_ablate & 128)) { o.T.valid = true; o.T.jm1 = 0.f; sv_valid = true; sv[0] = sv[1] = sv[2] = 0.f; }\n    if (dp_e && !(spk_ablate & 128)) {\n        SPK_MARK(\"dp_update\");")
+rep("    psi = fmaxf(psi, model_pos_energy(mo, phase, eh, F, E, sv, sv_valid, jm1));", "    if (!(spk_ablate & 256)) psi = fmaxf(psi, model_pos_energy(mo, phase, eh, F, E, sv, sv_valid, jm1));")
+rep("    apic_gather(vt, px, org, S, inv_h, vel, C);\n    SPK_MARK(\"advect_F\");", "    if (spk_ablate & 512) { vel[0] = vel[1] = vel[2] = 0.f; C = m3_zero(); } else apic_gather(vt, px, org, S, inv_h, vel, C);\n    SPK_MARK(\"advect_F\");")
 open("kernels.h", "w").write(k)
 d = open("device_math.h").read()
 assert d.count("namespace spk {") == 1

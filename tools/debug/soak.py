@@ -10,6 +10,7 @@ sc = scenes.sand_column(200, 250, 200) if which == "sand" else (scenes.fluid_dam
 nchunks = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
     p.load_scene(sc)
+    if os.environ.get("REORDER_HEADS"): p.reorder_policy_set(float(os.environ["REORDER_HEADS"]) * len(sc.particles), 0.0)   # excess heads per particle; 0 = never
     p.clock_enable(True, stride=8)
     for chunk in range(nchunks):
         p.clock_read(reset=True)
