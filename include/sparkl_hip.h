@@ -345,12 +345,14 @@ int sparkl_hip_pipeline_sync(SparklPipeline* p);
 
 /* Re-order policy.  Particles keep their memory slots between re-bins, so lanes that shared a cell drift apart and the
  * scatter's lane pre-reduction degrades (k_g2p2g: 0.57 -> 1.0 ms over ~300 substeps of the collapsing 10M column).
- * Every scatter counts its run heads; the heads in excess of the count right after the last re-bin are summed over
- * the substeps since, and
- *   - past `reorder_limit` every particle block is re-sorted by current cell in place (device only, ~0.6 ms at 10M),
+ * Every scatter counts its heads (fused run-task scatter: the distinct cells of each wave -- it groups a wave's lanes by cell
+ * itself, so only the spread of a wave over cells costs; DPP scatters of the fluid sweep and the standalone P2G: lane-group
+ * heads); the heads in excess of the count right after the last re-bin are summed over the substeps since, and
+ *   - past `reorder_limit` the particle blocks whose own count has grown by an eighth are re-sorted by current cell in
+ *     place (device only; every block under the DPP scatters, ~0.6 ms at 10M),
  *   - past `rebin_limit` a full re-bin is requested through the same abort chain a margin violation uses.
- * Limits are in run heads (the cost of the remedy / the cost of one excess head).  0 = off, < 0 = built-in default
- * (reorder: scaled with the particle count; full re-bin: off).  Physical results do not depend on the policy beyond
+ * Limits are in heads (the cost of the remedy / the cost of one excess head).  0 = off, < 0 = built-in default
+ * (reorder: 0.2 heads per particle, 0.6 when a fluid model is present; full re-bin: off).  Physical results do not depend on the policy beyond
  * f32 summation order. */
 int sparkl_hip_reorder_policy_set(SparklPipeline* p, float reorder_limit, float rebin_limit);
 typedef struct {

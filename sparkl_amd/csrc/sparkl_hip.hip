@@ -287,8 +287,13 @@ static inline int grid_for(size_t n, int threads) { return (int)((n + threads - 
 // k_block_reorder act.  0.6 while every reorder moved every block (~0.6 ms at 10M, profiles/r01_reorder_policy.txt); since the
 // kernel skips the blocks whose runs have not fragmented (GridArrays::pb_heads) a pass costs what the flowing part of the scene
 // costs and 0.2 is the optimum of tools/debug/reorder_threshold.sh (late / deep phase of the 10M collapse: 0.683 / 0.815 ms per
-// substep at 0.6, 0.673 / 0.797 at 0.2, 0.676 / 0.799 at 0.1).
+// substep at 0.6, 0.673 / 0.797 at 0.2, 0.676 / 0.799 at 0.1).  Since the run-task scatter groups an unsorted wave's lanes by cell its
+// heads are the DISTINCT CELLS of a wave, which grow far slower, and the scan is flat from 0.05 to 2 (profiles/r03_kernel_experiments.txt
+// section 9).  Scenes with a fluid run the DPP scatters (k_vol_p2g, the mass scatter), whose heads are lane-group heads and whose
+// reorder moves every block: 0.6 there (20M dam in flow: 1.27 ms per substep at 0.2, 1.245 at 0.6 and at 2, 1.6 without the reorder:
+// profiles/r03b_soak.txt).
 static constexpr float DEFAULT_REORDER_HEADS_PER_PARTICLE = 0.2f;
+static constexpr float DEFAULT_REORDER_HEADS_PER_PARTICLE_FLUID = 0.6f;
 #ifndef SPK_REORDER_PERIOD
 #define SPK_REORDER_PERIOD 16
 #endif
@@ -311,7 +316,9 @@ static int cub_reserve(SparklPipeline* p, size_t bytes) { return p->cub_temp.res
 // --------------------------------------------------------------------------------- re-bin (resort)
 // Sort particles by (block Morton key, cell in block), move the data, rebuild the node-block list,
 // its hash and neighbour tables.  Host-orchestrated; runs only when a particle left its tile margin.
-static float effective_reorder_limit(const SparklPipeline* p) { return p->reorder_limit < 0.f ? DEFAULT_REORDER_HEADS_PER_PARTICLE * (float)p->n : p->reorder_limit; }
+static float effective_reorder_limit(const SparklPipeline* p) {
+    return p->reorder_limit < 0.f ? (p->any_fluid ? DEFAULT_REORDER_HEADS_PER_PARTICLE_FLUID : DEFAULT_REORDER_HEADS_PER_PARTICLE) * (float)p->n : p->reorder_limit;
+}
 static int upload_policy(SparklPipeline* p) {
     const float lim[2] = {effective_reorder_limit(p), p->rebin_limit < 0.f ? 0.f : p->rebin_limit};
     uint32_t bits[2];
@@ -947,6 +954,7 @@ int sparkl_hip_models_set(SparklPipeline* p, uint32_t n, const SparklParticleMod
         p->rare_models |= d.ptag > SPARKL_PLASTIC_DRUCKER_PRAGER || d.has_failure;
         p->all_plain_fluid &= d.is_fluid && d.ptag < 0 && !d.has_failure;
     }
+    if (p->d_ctl) CHK(upload_policy(p));   // the default reorder budget depends on whether a fluid is present
     return SPARKL_OK;
 }
 
