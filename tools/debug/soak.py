@@ -19,7 +19,7 @@ with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
         p.sync(); ms = 1e3 * (time.perf_counter() - t0) / 500
         k = p.clock_read()
         print(f"substeps {500 * chunk:4d}..{500 * chunk + 499}: {ms:.3f} ms per substep ({len(sc.particles) / ms / 1e6:.2f} G particle-substeps/s), re-bins {int(k.resorts)}, "
-              f"g2p2g {k.g2p2g_ms / max(k.g2p2g_launches, 1):.3f} gu {k.grid_update_ms / max(k.grid_update_launches, 1):.3f} sort {k.sort_ms:.1f} reorder {k.reorder_ms:.1f} ms, heads {p.reorder_policy_stats()['last_heads']}, "
+              f"g2p2g {k.g2p2g_ms / max(k.g2p2g_launches, 1):.3f} p2g {k.p2g_ms / max(k.p2g_launches, 1):.3f} g2p {k.g2p_ms / max(k.g2p_launches, 1):.3f} gu {k.grid_update_ms / max(k.grid_update_launches, 1):.3f} sort {k.sort_ms:.1f} reorder {k.reorder_ms:.1f} ms, heads {p.reorder_policy_stats()['last_heads']}, "
               f"blocks {p.num_particle_blocks()} / {p.num_active_blocks()}, reorders so far {p.reorder_policy_stats()['reorders']}, C rebuilt so far {p.step_stats()['c_regathers']}", flush=True)
     c = p.grid_check()
     part = p.read_particles()
