@@ -2197,7 +2197,12 @@ static int group_rebin(const Group& G, bool balance) {
                 if (n_out[i][side]) CHK(sparkl_hip_slab_emigrants_pack(p, side, p->x_mig_send[side].p));
             }
         }
-        CHK(group_exchange(G, &SparklPipeline::x_mig_send, &SparklPipeline::x_mig_recv, (const uint64_t(*)[2])b_out.data(), (const uint64_t(*)[2])b_in.data()));
+        {   // on the MAIN streams, whatever the substep schedule: the emigrants were packed there and the immigrants are unpacked there
+            // (with the overlapped schedule G.xs() is the halo stream, which nothing here has ordered behind the pack kernels)
+            Group Gm = G;
+            Gm.overlap = false;
+            CHK(group_exchange(Gm, &SparklPipeline::x_mig_send, &SparklPipeline::x_mig_recv, (const uint64_t(*)[2])b_out.data(), (const uint64_t(*)[2])b_in.data()));
+        }
         for (int i = 0; i < G.n; ++i)
             for (int side = 0; side < 2; ++side)
                 if (n_in[i][side]) CHK(sparkl_hip_slab_immigrants_add(G.m[i], G.m[i]->x_mig_recv[side].p, n_in[i][side]));
