@@ -2078,6 +2078,10 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
     for (int base = 0; base < pcount; base += 2 * BLK_THREADS) {
         Scatter sc[2];
         bool live[2];
+        // F00 of both particles is stored behind the pair: a store between the two particles' loads would pin the second particle's
+        // loads behind the first one's arithmetic (the compiler must assume they alias), i.e. two load latencies per batch instead of one
+        bool f00_store[2] = {false, false};
+        float4 q0_keep[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int li = base + 2 * tid + k;
@@ -2115,8 +2119,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
                                 new_mass += (wgt[0][sx] * wgt[1][sy] * wgt[2][sz]) * vm[vb + sx + TILE_W * sy + TILE_W * TILE_W * sz];
                     // F00 = (m / (M / h^3)) / V0 as one quotient (the reference divides three times: the same number to 1e-7)
                     q0.w = (kk.x * (h * h * h)) / (new_mass * kk.y) - 1.f;   // stored as F00 - 1
-                    P.q[0][i] = q0;
+                    f00_store[k] = true;
                 }
+                q0_keep[k] = q0;
                 const M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};   // F - I as stored
                 const M3 C = {{q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
                 const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
@@ -2124,6 +2129,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
                 sc[k] = p2g_prepare(mo, flags, px, v, C, F, kk.x, kk.y, kk.z, phase, jp, org, h, inv_h, S.inv_d, S.dt);
             }
         }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (f00_store[k]) P.q[0][pfirst + base + 2 * tid + k] = q0_keep[k];
         shell_used |= wave_or_i32(sc[0].shell | sc[1].shell);
         wave_heads += p2g_scatter_pair<SPK_VOLP2G_STEPS>(tile, sc[0], sc[1], live[0], live[1], tid);
     }
