@@ -2234,7 +2234,7 @@ static int overlap_resources(SparklPipeline* p) {
 }
 // The node / particle kernels of one substep over a subset of the blocks (GridArrays::pb_list / nb_list), on stream `st`.
 // which = 0: grid update of the interior node blocks, 1: of the cut-adjacent ones; 2 / 3: the particle kernel likewise.
-static int launch_subset(SparklPipeline* p, int which, bool fuse_next, bool primary, hipStream_t st) {
+static int launch_subset(SparklPipeline* p, int which, bool fuse_next, bool primary, hipStream_t st, bool defer = true) {
     GridArrays G = grid_arrays(p);
     const bool bnd = which & 1;
     StepParams S = p->pending;
@@ -2256,7 +2256,7 @@ static int launch_subset(SparklPipeline* p, int which, bool fuse_next, bool prim
     const ParticleArrays P = p->cur.arrays();
     const dim3 grid(G.pb_count), block(BLK_THREADS);
     if (fuse_next && p->fuse_fixed_dt) {
-        S.defer_c = (p->defer_c && !p->rare_models && !S.project_particles) ? 1 : 0;
+        S.defer_c = (defer && p->defer_c && !p->rare_models && !S.project_particles) ? 1 : 0;
         if (S.defer_c) p->c_stale_S = p->pending;
         if (p->rare_models || S.project_particles) SPK_LAUNCH_MODELS(k_g2p2g, -1, true);
         else SPK_LAUNCH_MODELS(k_g2p2g, -1, false);
@@ -2441,7 +2441,12 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
                 }
             }
             for (int i = 0; i < G.n; ++i) CHK(sparkl_hip_substep_begin(members[i], params, gravity, dt));
-            const bool fuse_next = j + 1 < batch && !fluid_sweep && !psi_sweep;
+            // the fused kernel also closes a batch that another one follows inside this call: the next batch then starts from its tiles
+            // instead of a standalone P2G (0.35 + 0.34 -> 0.5 ms per 16 substeps at 10M).  That launch stores C in full (`defer`): the host
+            // looks at the control block between batches and may re-bin there
+            const bool last_of_batch = j + 1 == batch;
+            const bool fuse_next = (!last_of_batch || done + batch < nsubsteps) && !fluid_sweep && !psi_sweep;
+            const bool defer = !last_of_batch;
             if (G.overlap) {
                 // Halo / compute overlap (the reference runs its halo work on a second stream too: cuda_mpm_pipeline.rs:410-430).
                 //   main stream:  [P2G, reorder]  grid update of the interior node blocks ; particle kernel of the interior particle blocks
@@ -2469,11 +2474,11 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
                     CHK(clock_end(p, t1));
                     HIPCHK(hipEventRecord(p->ev_grid, p->stream));
                     CHK(clock_begin(p, fuse_next && p->fuse_fixed_dt ? SPAN_FUSED : SPAN_G2P, &t2));
-                    CHK(launch_subset(p, 2, fuse_next, has_interior, p->stream));
+                    CHK(launch_subset(p, 2, fuse_next, has_interior, p->stream, defer));
                     CHK(clock_end(p, t2));
                     CHK(launch_subset(p, 1, fuse_next, false, G.xs(i)));
                     HIPCHK(hipStreamWaitEvent(G.xs(i), p->ev_grid, 0));
-                    CHK(launch_subset(p, 3, fuse_next, !has_interior, G.xs(i)));
+                    CHK(launch_subset(p, 3, fuse_next, !has_interior, G.xs(i), defer));
                 }
                 for (int i = 0; i < G.n; ++i) {   // join
                     SparklPipeline* p = members[i];
@@ -2515,7 +2520,7 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
                 }
                 for (int i = 0; i < G.n; ++i) CHK(substep_finish_impl(members[i], false, false, 2));
             } else {
-                for (int i = 0; i < G.n; ++i) CHK(substep_finish_impl(members[i], fuse_next, true));
+                for (int i = 0; i < G.n; ++i) CHK(substep_finish_impl(members[i], fuse_next, defer));
             }
             HIPCHK(hipGetLastError());
         }
@@ -2528,7 +2533,7 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
             CHK(read_ctl(members[i]));
             if (members[i]->clock_on) CHK(clock_collect(members[i]));
             const uint32_t r = members[i]->h_ctl->steps_done - base[i];
-            // cut short behind a fused launch that deferred C.m[1..8] (the last substep of a whole batch is a plain k_g2p)
+            // cut short behind a fused launch that deferred C.m[1..8] (the last launch of a whole batch stores C, fused or not)
             if (r > done && r < done + batch && !fluid_sweep && !psi_sweep && members[i]->fuse_fixed_dt && members[i]->defer_c && !members[i]->rare_models &&
                 !params->enable_boundary_particle_projection)
                 members[i]->c_stale = true;
