@@ -539,7 +539,13 @@ def main(args):
             out["kernel_clock_sampled_substeps"] = int(clock.sampled_substeps)
             out["resort"] = {"count": int(clock.resorts), "ms_total": clock.sort_ms}
             if mode == "slabs":
-                out["halo_ms_per_step"] = clock.halo_ms / max(int(clock.sampled_substeps), 1)
+                ns = max(int(clock.sampled_substeps), 1)
+                out["halo_ms_per_step"] = clock.halo_ms / ns
+                # what a substep of the slab loop costs beyond its particle / node kernels: wall clock per substep minus their spans per
+                # sampled substep (halo pack / exchange / store, flag all-reduce, event hops, the host's look at the control block per
+                # batch).  With the overlapped schedule the kernels of the two streams run side by side, so this is a lower bound there.
+                kernel_ms = (clock.p2g_ms + clock.grid_update_ms + clock.g2p_ms + clock.g2p2g_ms + clock.p2g_mass_ms + clock.grid_update_mass_ms + clock.g2p_volume_ms) / ns
+                out["slab_overhead_us"] = 1e3 * (out["ms_per_step"] - kernel_ms)
         if late is not None:
             out["late_collapse"] = late
             if late.get("roofline"):

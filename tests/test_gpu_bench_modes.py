@@ -36,6 +36,7 @@ def test_bench_two_ranks_cube80m_scene_is_one_fixed_job():
     assert cfg["particles_per_gpu"] == 64 * 29 * 54 + 27          # rank 0 owns the kinematic cube
     assert o["value"] == pytest.approx(cfg["particles_total"] * o["steps"] / (o["ms_per_step"] * 1e-3 * o["steps"]), rel=1e-6)
     assert o["halo_ms_per_step"] >= 0.0 and o["roofline"]["frac"] > 0.0
+    assert "slab_overhead_us" in o and abs(o["slab_overhead_us"]) < 1e3 * o["ms_per_step"]
     assert "cube80m strong scaling (not BASELINE.json's headline metric)" in o["metric"]
 
 
