@@ -31,8 +31,27 @@ d = d.replace("namespace spk {", "namespace spk {\n__device__ int spk_ablate = 0
 n = d.count("__all(series_ok(")
 assert n >= 2
 d = d.replace("__all(series_ok(lin, lvg))", "(__all(series_ok(lin, lvg)) || (spk_ablate & 64))").replace("__all(series_ok(S))", "(__all(series_ok(S)) || (spk_ablate & 64))").replace("__all(series_ok(S6))", "(__all(series_ok(S6)) || (spk_ablate & 64))")
+# counters of the return map's outcomes per wave (sparkl_hip_debug_map_counts): waves, all lanes tensile, any tensile, all inside, lanes moved
+d = d.replace("__device__ int spk_ablate = 0;", "__device__ int spk_ablate = 0;\n__device__ unsigned long long spk_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};", 1)
+x = "    if (moved) {\n        const float so = tre, sn = tre + 3.f * c;"
+assert d.count(x) == 1
+d = d.replace(x, """    {
+        const bool tens = dn2 == 0.f || tr > 0.f;
+        const unsigned long long bt = __ballot(tens), bm = __ballot(moved), ba = __ballot(true);
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {
+            atomicAdd(&spk_cnt[0], 1ull);
+            if (bt == ba) atomicAdd(&spk_cnt[1], 1ull);
+            if (bt) atomicAdd(&spk_cnt[2], 1ull);
+            if (!bm) atomicAdd(&spk_cnt[3], 1ull);
+            atomicAdd(&spk_cnt[4], (unsigned long long)__popcll(bm));
+            atomicAdd(&spk_cnt[5], (unsigned long long)__popcll(bt));
+            atomicAdd(&spk_cnt[6], (unsigned long long)__popcll(ba));
+        }
+    }
+""" + x)
 open("device_math.h", "w").write(d)
 s = open("sparkl_hip.hip").read()
+s += '\nextern "C" int sparkl_hip_debug_map_counts(unsigned long long* out, int reset) { unsigned long long z[8] = {0,0,0,0,0,0,0,0}; if (hipMemcpyFromSymbol(out, HIP_SYMBOL(spk::spk_cnt), sizeof(z)) != hipSuccess) return -1; if (reset) return hipMemcpyToSymbol(HIP_SYMBOL(spk::spk_cnt), z, sizeof(z)) == hipSuccess ? 0 : -1; return 0; }\n'
 s += '\nextern "C" int sparkl_hip_debug_set_ablate(int mode) { return hipMemcpyToSymbol(HIP_SYMBOL(spk::spk_ablate), &mode, sizeof(int)) == hipSuccess ? 0 : -1; }\n'
 open("sparkl_hip.hip", "w").write(s)
 EOF
