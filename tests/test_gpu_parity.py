@@ -110,6 +110,39 @@ def test_particle_state_parity_100_substeps(Pipeline, name, builder, dt):
             assert np.isfinite(got.position["point"]).all()
 
 
+def test_sheared_sand_crosses_every_return_map_path(Pipeline):
+    """Drucker-Prager sand with a shear rate that grows along x: within 60 substeps the column holds waves on the quartic series path
+    (|S| < 0.03), on its second tier (< 0.1) and on the eigenbasis path (>= 0.1) of the return map -- asserted from the library's
+    run statistics -- and the particles cross cells (grouped scatter, tile boxes).  Same gate as everywhere."""
+    import ctypes as C
+    from sparkl_amd import _lib
+    sc = scenes.sand_column(24, 16, 16)
+    pos = sc.particles.position["point"]
+    rel = (pos - pos.min(0)) / np.ptp(pos, axis=0)
+    amp = 60.0 * rel[:, 0]
+    v = sc.particles.velocity["vector"]
+    v[:, 0] = amp * (pos[:, 1] - pos[:, 1].min())
+    v[:, 1] = -0.3 * amp * (pos[:, 1] - pos[:, 1].min())
+    o32, o64 = _oracle(sc), _oracle(sc, f64=True)
+    seen = np.zeros(7)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        done = 0
+        for k in (20, 40, 60):
+            for _ in range(k - done):
+                o32.substep_fixed(sc.params, sc.gravity, sc.fixed_dt)
+                o64.substep_fixed(sc.params, sc.gravity, sc.fixed_dt)
+            p.substeps(sc.params, sc.gravity, sc.fixed_dt, k - done)
+            done = k
+            out = (C.c_ulonglong * (13 * 65))()
+            _lib.check(_lib.lib().sparkl_hip_debug_run_stats(p.h, out, C.c_uint64(len(out))))
+            seen += np.array(out, dtype=np.float64).reshape(13, 65)[10][:7]   # waves by max |F^T F - I|: < 1e-3, 3e-3, 1e-2, 3e-2, 0.1, 0.3, inf
+            rep, bad = parity_verdict(p.read_particles(), o32.get_particles(), o64.get_particles(), sc.cell_width)
+            _report(f"sheared_sand_k{k}", rep)
+            assert not bad, (k, bad, rep)
+    assert seen[:4].sum() > 0 and seen[4] > 0 and seen[5] > 0, seen
+
+
 def test_config1_sand3_50k_parity(Pipeline):
     """BASELINE configs[0] at its real size (sand3.rs:39-78: 25 k Drucker-Prager sand on a 25 k elastic block), 100 fixed
     substeps and one adaptive frame, against the oracle."""
