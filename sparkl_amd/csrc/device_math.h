@@ -23,6 +23,14 @@
 #else
 #define SPK_MARK(name) ((void)0)
 #endif
+// SPK_HOT(cond): nothing in the product build.  An analysis build (-DSPK_HOT_ONLY, tools/isa_sections.py --hot) turns it into
+// __builtin_assume(cond), which drops the cold side of the branch that follows: the static instruction count of such a build is the
+// count of the hot path of the 10M sand column (series return map, stress taken from the return map, nothing failed, phase == 1).
+#ifdef SPK_HOT_ONLY
+#define SPK_HOT(cond) __builtin_assume(cond)
+#else
+#define SPK_HOT(cond) ((void)0)
+#endif
 
 namespace spk {
 
@@ -181,6 +189,24 @@ struct DevModel {
     float max_principal_stress, max_shear_stress;
 };
 
+// Compile-time view of a model table whose every entry is a corotated-linear solid with Drucker-Prager plasticity, always active
+// (the sand of sand3 / cube_through_sand3 and of the 10M benchmark column): the tags are constants, so the kernels instantiated on it
+// carry no model dispatch; the parameters are still read per particle from the table.  Chosen by the host (models_set).
+struct DpSandModel {
+    static constexpr int ctag = SPARKL_CONSTITUTIVE_COROTATED_LINEAR;
+    static constexpr int ptag = SPARKL_PLASTIC_DRUCKER_PRAGER;
+    static constexpr int is_fluid = 0;
+    static constexpr int only_active_when_failed = 0;
+    static constexpr int has_failure = 0;
+    static constexpr float pressure0 = 0.f, viscosity = 0.f, max_neg_pressure = 0.f;
+    static constexpr int gamma = 0;
+    const int& split_stress_on_failure;
+    const float &cfl_coeff, &lambda, &mu, &h0, &h1, &h2, &h3, &p_lambda, &p_mu, &volume_correction, &p_k;
+    __device__ __host__ __forceinline__ explicit DpSandModel(const DevModel& m)
+        : split_stress_on_failure(m.split_stress_on_failure), cfl_coeff(m.cfl_coeff), lambda(m.lambda), mu(m.mu), h0(m.h0), h1(m.h1), h2(m.h2), h3(m.h3),
+          p_lambda(m.p_lambda), p_mu(m.p_mu), volume_correction(m.volume_correction), p_k(m.p_k) {}
+};
+
 SPK_DEV float powi_f(float x, int n) {
     float r = 1.f;
     for (int i = 0; i < n; ++i) r *= x;
@@ -189,8 +215,10 @@ SPK_DEV float powi_f(float x, int n) {
 
 // tau for the corotated model.  phase == 1 (every particle unless a damage model is active) only needs
 // the rotation R: U (S - I) V^T = F - R.
-SPK_DEV M3 corotated_kirchhoff_e(const DevModel& mo, float hardening, const M3& F);
-SPK_DEV M3 corotated_kirchhoff(const DevModel& mo, float phase, float hardening, const M3& F) {
+template <class MO>
+SPK_DEV M3 corotated_kirchhoff_e(const MO& mo, float hardening, const M3& F);
+template <class MO>
+SPK_DEV M3 corotated_kirchhoff(const MO& mo, float phase, float hardening, const M3& F) {
     const float j = m3_det(F);
     const float sph = mo.lambda * hardening * (j - 1.f) * j;
     M3 tau;
@@ -221,7 +249,8 @@ SPK_DEV M3 corotated_kirchhoff(const DevModel& mo, float phase, float hardening,
 
 SPK_DEV float nh_phase_coeff(float phase) { return (1.f - 0.001f) * phase * phase + 0.001f; }
 
-SPK_DEV M3 neo_hookean_kirchhoff(const DevModel& mo, float phase, float hardening, const M3& F) {
+template <class MO>
+SPK_DEV M3 neo_hookean_kirchhoff(const MO& mo, float phase, float hardening, const M3& F) {
     const float pc = nh_phase_coeff(phase);
     const float j = m3_det(F);
     const float k = 2.f / 3.f * mo.mu * hardening + mo.lambda * hardening;
@@ -244,18 +273,21 @@ SPK_DEV M3 neo_hookean_kirchhoff(const DevModel& mo, float phase, float hardenin
     return tau;
 }
 
-SPK_DEV float monaghan_pressure(const DevModel& mo, float mass, float volume0, float density_fluid) {
+template <class MO>
+SPK_DEV float monaghan_pressure(const MO& mo, float mass, float volume0, float density_fluid) {
     const float density0 = mass / volume0;
     return fmaxf(mo.pressure0 * (powi_f(density_fluid / density0, mo.gamma) - 1.f), -mo.max_neg_pressure);
 }
 // the same with the density ratio rho / rho0 = 1 / F00 given directly (the reference forms (m / V0) / F00 / (m / V0): the same
 // number to 1e-7, three divisions)
-SPK_DEV float monaghan_pressure_ratio(const DevModel& mo, float ratio) {
+template <class MO>
+SPK_DEV float monaghan_pressure_ratio(const MO& mo, float ratio) {
     return fmaxf(mo.pressure0 * (powi_f(ratio, mo.gamma) - 1.f), -mo.max_neg_pressure);
 }
 // NB: the reference glue passes plastic_deformation_gradient_det as `fluid_j`
 // (src/dynamics/models/eos_monaghan_sph.rs:12-20)
-SPK_DEV M3 monaghan_kirchhoff(const DevModel& mo, float mass, float volume0, float f00, float fluid_j, const M3& C) {
+template <class MO>
+SPK_DEV M3 monaghan_kirchhoff(const MO& mo, float mass, float volume0, float f00, float fluid_j, const M3& C) {
     const float p = -monaghan_pressure_ratio(mo, 1.0f / f00) * fluid_j;
     M3 tau = m3_zero();
     tau.m[0] = tau.m[4] = tau.m[8] = p;
@@ -280,7 +312,8 @@ SPK_DEV float sound_speed_bound(float alpha, float bulk, float shear, float dens
 }
 
 // model.constitutive_model.timestep_bound(particle, cell_width)
-SPK_DEV float model_timestep_bound(const DevModel& mo, float mass, float volume0, float eh, float f00, float vx, float vy, float vz, float h) {
+template <class MO>
+SPK_DEV float model_timestep_bound(const MO& mo, float mass, float volume0, float eh, float f00, float vx, float vy, float vz, float h) {
     const float vn2 = vx * vx + vy * vy + vz * vz;
     if (mo.ctag == SPARKL_CONSTITUTIVE_EOS_MONAGHAN_SPH) {
         const float j = f00, density0 = mass / volume0;
@@ -306,6 +339,7 @@ SPK_DEV float log_near_one(float sgm) {
 
 // sin(x) by its Taylor series to x^13 on |x| < 1.6 (friction angles), libm otherwise
 SPK_DEV float sin_small(float x) {
+    SPK_HOT(fabsf(x) < 1.6f);
     if (fabsf(x) < 1.6f) {
         const float x2 = x * x;
         return x * (1.f + x2 * (-1.f / 6.f + x2 * (1.f / 120.f + x2 * (-1.f / 5040.f + x2 * (1.f / 362880.f + x2 * (-1.f / 39916800.f + x2 * (1.f / 6227020800.f)))))));
@@ -313,7 +347,8 @@ SPK_DEV float sin_small(float x) {
     return sinf(x);
 }
 
-SPK_DEV float dp_alpha(const DevModel& mo, float q) {
+template <class MO>
+SPK_DEV float dp_alpha(const MO& mo, float q) {
     const float angle = mo.h0 + (mo.h1 * q - mo.h3) * __expf(-mo.h2 * q);
     const float s = sin_small(angle);
     return 0.81649658092772603f * (2.f * s) * fast_rcp(3.f - s);   // sqrt(2/3)
@@ -322,6 +357,7 @@ SPK_DEV float dp_alpha(const DevModel& mo, float q) {
 // e^x - 1 without the cancellation of expf(x) - 1 (plastic strains are ~1e-4: exp rounds 1 + x to ~1e-7 absolute, i.e. 1e-3
 // of the strain)
 SPK_DEV float expm1_small(float x) {
+    SPK_HOT(fabsf(x) < 0.1f);
     if (fabsf(x) < 0.1f) return x * (1.f + x * (0.5f + x * (1.f / 6.f + x * (1.f / 24.f + x * (1.f / 120.f + x * (1.f / 720.f))))));
     return __expf(x) - 1.f;
 }
@@ -336,6 +372,7 @@ SPK_DEV float expm1_small(float x) {
 // eigen-decomposition S = V diag(lam) V^T (sigma^2 - 1 = lam), ln sigma = log1p(lam) / 2 -- so that the strain keeps ~1e-7
 // RELATIVE precision.  U is never formed:  F' = U Sigma' V^T = F V diag(sigma'/sigma) V^T,  F - R = F V diag(1 - 1/sigma) V^T.
 SPK_DEV float log1p_small(float x) {   // ln(1 + x) = 2 atanh(x / (2 + x)); relative error ~1e-7 for |x| < 0.35
+    SPK_HOT(fabsf(x) < 0.35f);
     if (fabsf(x) < 0.35f) {
         const float z = x * fast_rcp(2.f + x), z2 = z * z;
         return 2.f * z * (1.f + z2 * (1.f / 3.f + z2 * (1.f / 5.f + z2 * (1.f / 7.f + z2 * (1.f / 9.f)))));
@@ -470,7 +507,8 @@ SPK_DEV Eig3 log_stretch(const M3& E, float S[6], float e[3], float re[3]) {
 #define SPK_SERIES_MAX2 0.1f
 #endif
 // a * b for two commuting symmetric matrices (the product is symmetric), (xx, yy, zz, xy, xz, yz)
-SPK_DEV void sym_mul(const float a[6], const float b[6], float o[6]) {
+template <class T>
+SPK_DEV void sym_mul(const T a[6], const T b[6], T o[6]) {
     o[0] = a[0] * b[0] + a[3] * b[3] + a[4] * b[4];
     o[1] = a[3] * b[3] + a[1] * b[1] + a[5] * b[5];
     o[2] = a[4] * b[4] + a[5] * b[5] + a[2] * b[2];
@@ -504,35 +542,38 @@ SPK_DEV void sym_eigvals(const float a[6], float e[3]) {
     e[2] = q + sg * (-c - 2.f * sn);
 }
 // eps = ln(I + S) / 2 by its series: quartic (the next term is |S|^4 / 5 of the first), or to S^7 (`hi`, wave-uniform)
-SPK_DEV void hencky_series(const float S[6], float eps[6], bool hi = false) {
-    float P2[6], P3[6], P4[6];
+template <class T>
+SPK_DEV void hencky_series(const T S[6], T eps[6], bool hi = false) {
+    T P2[6], P3[6], P4[6];
     sym_mul(S, S, P2);
     sym_mul(S, P2, P3);
     sym_mul(P2, P2, P4);
     if (hi) {
-        float B[6], T[6];
+        T B[6], U[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) B[i] = 0.1f * S[i] + ((-1.f / 12.f) * P2[i] + (1.f / 14.f) * P3[i]);
-        sym_mul(P4, B, T);
+        sym_mul(P4, B, U);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) eps[i] = 0.5f * S[i] + (-0.25f * P2[i] + ((1.f / 6.f) * P3[i] + (T[i] - 0.125f * P4[i])));
+        for (int i = 0; i < 6; ++i) eps[i] = 0.5f * S[i] + (-0.25f * P2[i] + ((1.f / 6.f) * P3[i] + (U[i] - 0.125f * P4[i])));
         return;
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) eps[i] = 0.5f * S[i] + (-0.25f * P2[i] + ((1.f / 6.f) * P3[i] - 0.125f * P4[i]));
 }
 // x - x^2/2 + x^3/6 - x^4/24 = I - exp(-x) to |x|^4 / 120 relative
-SPK_DEV void one_minus_exp_neg_series(const float x[6], float m[6]) {
-    float X2[6], Q[6], T[6];
+template <class T>
+SPK_DEV void one_minus_exp_neg_series(const T x[6], T m[6]) {
+    T X2[6], Q[6], U[6];
     sym_mul(x, x, X2);
 #pragma unroll
     for (int i = 0; i < 6; ++i) Q[i] = (1.f / 6.f) * x[i] - (1.f / 24.f) * X2[i];
-    sym_mul(X2, Q, T);
+    sym_mul(X2, Q, U);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) m[i] = x[i] + (T[i] - 0.5f * X2[i]);
+    for (int i = 0; i < 6; ++i) m[i] = x[i] + (U[i] - 0.5f * X2[i]);
 }
 // squared Frobenius norm: bounds every eigenvalue of the symmetric matrix
-SPK_DEV float sym_frob2(const float S[6]) {
+template <class T>
+SPK_DEV T sym_frob2(const T S[6]) {
     return (S[0] * S[0] + S[1] * S[1] + S[2] * S[2]) + 2.f * (S[3] * S[3] + S[4] * S[4] + S[5] * S[5]);
 }
 SPK_DEV bool series_ok(const float S[6], float extra = 0.f) { return fmaxf(sym_frob2(S), extra * extra) < SPK_SERIES_MAX * SPK_SERIES_MAX; }
@@ -563,7 +604,8 @@ typedef volatile float* lds_fp;
 #else
 typedef volatile __attribute__((address_space(3))) float* lds_fp;
 #endif
-SPK_DEV SymStress corotated_tau_e(const DevModel& mo, float hardening, const M3& E, const float m6[6], lds_fp park = nullptr) {
+template <class MO>
+SPK_DEV SymStress corotated_tau_e(const MO& mo, float hardening, const M3& E, const float m6[6], lds_fp park = nullptr) {
     const M3 M = sym6_to_m3(m6);
     M3 A = m3_mul(E, M);                 // A = F M = M + E M
 #pragma unroll
@@ -587,7 +629,8 @@ SPK_DEV SymStress corotated_tau_e(const DevModel& mo, float hardening, const M3&
 }
 
 // phase == 1 corotated stress of F = I + E
-SPK_DEV M3 corotated_kirchhoff_fe(const DevModel& mo, float hardening, const M3& E) {
+template <class MO>
+SPK_DEV M3 corotated_kirchhoff_fe(const MO& mo, float hardening, const M3& E) {
     float S[6], e[3], re[3], g[3], m6[6];
     strain_metric(E, S);
     if (SPK_SERIES_MAX > 0.f && __all(series2_ok(S))) {   // wave-uniform; series path: M = I - (I + S)^(-1/2) to S^7 (next term 0.39 |S|^7 relative)
@@ -610,7 +653,8 @@ SPK_DEV M3 corotated_kirchhoff_fe(const DevModel& mo, float hardening, const M3&
     for (int k = 0; k < 6; ++k) m6[k] += 0.5f * S[k];
     return sym_to_m3(corotated_tau_e(mo, hardening, E, m6));
 }
-SPK_DEV M3 corotated_kirchhoff_e(const DevModel& mo, float hardening, const M3& F) {
+template <class MO>
+SPK_DEV M3 corotated_kirchhoff_e(const MO& mo, float hardening, const M3& F) {
     M3 E = F;
     E.m[0] -= 1.f; E.m[4] -= 1.f; E.m[8] -= 1.f;
     return corotated_kirchhoff_fe(mo, hardening, E);
@@ -621,8 +665,8 @@ SPK_DEV M3 corotated_kirchhoff_e(const DevModel& mo, float hardening, const M3& 
 // The same return map on the series path (see "series path" above): `S` = F_trial^T F_trial - I with every entry, and the pending
 // log_vol_gain, below SPK_SERIES_MAX.  K = ln(Sigma' / Sigma) = c I + D with D = g dev(eps) traceless, so
 // exp(K) - I = expm1(c) I + e^c (D + D^2/2 + D^3/6).
-template <bool WANT_STRESS>
-SPK_DEV void dp_update_series(const DevModel& mo, float phase, float eh, const float S[6], M3& E, float& Jp, float& q, float& lvg, float sm1[3], bool& sv_valid,
+template <bool WANT_STRESS, class MO>
+SPK_DEV void dp_update_series(const MO& mo, float phase, float eh, const float S[6], M3& E, float& Jp, float& q, float& lvg, float sm1[3], bool& sv_valid,
                               SymStress& T, lds_fp park = nullptr, bool hi = false) {
     float eps[6];
     SPK_MARK("dp_series_log");
@@ -654,6 +698,7 @@ SPK_DEV void dp_update_series(const DevModel& mo, float phase, float eh, const f
         const float pm1 = expm1_small(so);
         float nm1 = expm1_small(sn), lnew = sn;
         const float diff = nm1 - pm1;
+        SPK_HOT(mo.volume_correction == 1.f);
         if (!(diff > 0.f) && mo.volume_correction != 1.f) { nm1 = pm1 + diff * mo.volume_correction; lnew = log1p_small(nm1); }
         Jp *= (1.f + pm1) * fast_rcp(1.f + nm1);
         lvg += so - lnew;
@@ -692,8 +737,8 @@ SPK_DEV void dp_update_series(const DevModel& mo, float phase, float eh, const f
     }
 }
 
-template <bool WANT_STRESS>
-SPK_DEV void dp_update_e(const DevModel& mo, float phase, float eh, M3& E, float& Jp, float& q, float& lvg, float sm1[3], bool& sv_valid, SymStress& T,
+template <bool WANT_STRESS, class MO>
+SPK_DEV void dp_update_e(const MO& mo, float phase, float eh, M3& E, float& Jp, float& q, float& lvg, float sm1[3], bool& sv_valid, SymStress& T,
                          lds_fp park = nullptr) {
     sv_valid = false;
     T.valid = false;
@@ -701,10 +746,12 @@ SPK_DEV void dp_update_e(const DevModel& mo, float phase, float eh, M3& E, float
     // eps = lin + V diag(dv) V^T throughout: `lin` the first-order matrix, `dv` the remainders in the eigenbasis, e_k its eigenvalues
     float lin[6], e[3], dv[3];
     strain_metric(E, lin);
+    SPK_HOT(__all(series2_ok(lin, lvg)));
     if (SPK_SERIES_MAX > 0.f && __all(series2_ok(lin, lvg))) {   // wave-uniform, and so is the tier
         dp_update_series<WANT_STRESS>(mo, phase, eh, lin, E, Jp, q, lvg, sm1, sv_valid, T, park, !__all(series_ok(lin, lvg)));
         return;
     }
+#ifndef SPK_HOT_ONLY   // (analysis build: the eigenbasis path compiled out, see SPK_HOT)
     const Eig3 d = log_stretch_s(lin, e, dv);
 #pragma unroll
     for (int i = 0; i < 6; ++i) lin[i] *= 0.5f;
@@ -776,6 +823,166 @@ SPK_DEV void dp_update_e(const DevModel& mo, float phase, float eh, M3& E, float
         for (int i = 0; i < 6; ++i) m6[i] += lin[i];
         T = corotated_tau_e(mo, eh, E, m6, park);
     }
+#endif
+}
+
+// ------------------------------------------------------------------------------ packed series path: two particles per lane
+// The series return map is ~600 straight-line scalar FMAs per particle, and the kernel that runs it is VALU-issue bound.  v_pk_fma_f32
+// retires two f32 per lane for about the cost of one, but packing INSIDE one particle's arithmetic does not pay (the pairs have to be
+// assembled and taken apart: measured, round 3).  So the wave folds itself in two for this section only: lane l < 32 takes the inputs of
+// lane l + 32 beside its own (ds_bpermute: LDS crossbar, no VALU), runs F update -> strain -> return map -> stress ONCE for both as
+// float2 arithmetic while lanes 32..63 sit out, and hands the second particle's results back (v_permlane32_swap_b32, one VALU each).
+// Same formulas as dp_update_series + corotated_tau_e above (plasticity_drucker_prager.rs:68-104, elasticity_corotated_linear.rs:31-78);
+// differences, all below the series' own truncation: the three outcomes (tensile / onto the cone / inside) are selects instead of
+// branches, e^x - 1 is one degree-7 polynomial (|x| < 0.2 here), and det F' - 1 = expm1(tr eps') comes from the return map's own
+// volume bookkeeping instead of the minors of E'.  Requires volume_correction == 1 (the reference's default) and phase == 1 for every
+// particle of the wave, and |S|, |lvg| below SPK_SERIES_MAX2 (else the wave takes the scalar path): the caller checks the first two.
+typedef int spk_i2 __attribute__((ext_vector_type(2)));
+SPK_DEV spk_f2 pk_rcp(spk_f2 x) { return spk_f2{fast_rcp(x.x), fast_rcp(x.y)}; }
+SPK_DEV spk_f2 pk_rsq(spk_f2 x) { return spk_f2{fast_rsq(x.x), fast_rsq(x.y)}; }
+SPK_DEV spk_f2 pk_sqrt(spk_f2 x) { return spk_f2{fast_sqrt(x.x), fast_sqrt(x.y)}; }
+SPK_DEV spk_f2 pk_max(spk_f2 a, spk_f2 b) { return spk_f2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+SPK_DEV spk_f2 pk_min(spk_f2 a, spk_f2 b) { return spk_f2{fminf(a.x, b.x), fminf(a.y, b.y)}; }
+SPK_DEV spk_f2 pk_abs(spk_f2 a) { return spk_f2{fabsf(a.x), fabsf(a.y)}; }
+SPK_DEV spk_f2 pk_sel(bool cx, bool cy, spk_f2 a, spk_f2 b) { return spk_f2{cx ? a.x : b.x, cy ? a.y : b.y}; }
+SPK_DEV spk_f2 pk_sel(bool cx, bool cy, spk_f2 a, float b) { return spk_f2{cx ? a.x : b, cy ? a.y : b}; }
+// e^x - 1 for |x| < 0.2 (next term x^7 / 40320 relative: 3e-10)
+SPK_DEV spk_f2 pk_expm1(spk_f2 x) {
+    spk_f2 p = x * (1.f / 5040.f) + (1.f / 720.f);
+    p = p * x + (1.f / 120.f);
+    p = p * x + (1.f / 24.f);
+    p = p * x + (1.f / 6.f);
+    p = p * x + 0.5f;
+    p = p * x + 1.f;
+    return p * x;
+}
+// sym_eigvals for two matrices at once
+SPK_DEV void pk_sym_eigvals(const spk_f2 a[6], spk_f2 e[3]) {
+    const spk_f2 q = (a[0] + a[1] + a[2]) * (1.f / 3.f);
+    const spk_f2 d0 = a[0] - q, d1 = a[1] - q, d2 = a[2] - q;
+    const spk_f2 p2r = (d0 * d0 + d1 * d1 + d2 * d2 + 2.f * (a[3] * a[3] + a[4] * a[4] + a[5] * a[5])) * (1.f / 6.f);
+    const bool zx = !(p2r.x > 1.0e-36f), zy = !(p2r.y > 1.0e-36f);
+    const spk_f2 p2 = pk_sel(zx, zy, spk_f2{1.f, 1.f}, p2r);
+    const spk_f2 ip = pk_rsq(p2), p = p2 * ip;
+    const spk_f2 det = d0 * (d1 * d2 - a[5] * a[5]) - a[3] * (a[3] * d2 - a[5] * a[4]) + a[4] * (a[3] * a[5] - d1 * a[4]);
+    const spk_f2 r = pk_min(pk_max(0.5f * det * (ip * ip * ip), spk_f2{-1.f, -1.f}), spk_f2{1.f, 1.f});
+    const spk_f2 ar = pk_abs(r);
+    spk_f2 c = 0.1339746f * ar + 0.8660254f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const spk_f2 c2 = c * c;
+        c -= ((4.f * c2 - 3.f) * c - ar) * pk_rcp(12.f * c2 - 3.f);
+    }
+    const spk_f2 sn = pk_sqrt(pk_max(1.f - c * c, spk_f2{0.f, 0.f})) * 0.8660254f;
+    const spk_f2 sg = pk_sel(r.x < 0.f, r.y < 0.f, -p, p);
+    e[0] = pk_sel(zx, zy, q, q + sg * (2.f * c));
+    e[1] = pk_sel(zx, zy, q, q + sg * (2.f * sn - c));
+    e[2] = pk_sel(zx, zy, q, q - sg * (c + 2.f * sn));
+}
+struct DpPair {
+    spk_f2 E[9];                       // in: E = F - I before the F update; out: E' (column-major)
+    spk_f2 C[9];                       // in: velocity gradient; the F update is E += dt C (I + E) (grid_to_particle.rs:91-95)
+    spk_f2 alpha, lvg, k2, lam, pk;    // in: dp_alpha(q), pending log_vol_gain, 2 mu eh, lambda eh, (3 lambda + 2 mu) / (2 mu) of the plastic model
+    spk_f2 dq, dlvg, jpf, nsq, jm1;    // out: q += dq, lvg += dlvg, Jp *= jpf; sum of max(sigma'_k - 1, 0)^2; det F' - 1
+};
+// Returns false (nothing written) when a particle of the wave is beyond the second series tier.  `active`: this lane holds a pair (lane < 32).
+// park_lo / park_hi: LDS columns of the two particles for the six stress components (element k at [64 k]).
+SPK_DEV bool dp_series_pair(DpPair& P, float dt, bool active, lds_fp park_lo, lds_fp park_hi) {
+    spk_f2 E[9];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const spk_f2 x = (P.C[i + 3 * j] + P.C[i] * P.E[3 * j]) + (P.C[i + 3] * P.E[3 * j + 1] + P.C[i + 6] * P.E[3 * j + 2]);
+            E[i + 3 * j] = P.E[i + 3 * j] + dt * x;
+        }
+    spk_f2 S[6];
+    {
+        const int ii[6] = {0, 1, 2, 0, 0, 1}, jj[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            const int a = ii[e], b = jj[e];
+            S[e] = (E[a + 3 * b] + E[b + 3 * a]) + (E[3 * a] * E[3 * b] + E[3 * a + 1] * E[3 * b + 1] + E[3 * a + 2] * E[3 * b + 2]);
+        }
+    }
+    const spk_f2 n2 = pk_max(sym_frob2(S), P.lvg * P.lvg);
+    const bool ok2 = !active || (n2.x < SPK_SERIES_MAX2 * SPK_SERIES_MAX2 && n2.y < SPK_SERIES_MAX2 * SPK_SERIES_MAX2);
+    if (!__all(ok2)) return false;
+    const bool ok1 = !active || (n2.x < SPK_SERIES_MAX * SPK_SERIES_MAX && n2.y < SPK_SERIES_MAX * SPK_SERIES_MAX);
+    spk_f2 eps[6];
+    hencky_series(S, eps, !__all(ok1));
+    const spk_f2 tre = eps[0] + eps[1] + eps[2], em = tre * (1.f / 3.f), tr = tre + P.lvg;
+    const spk_f2 dev[6] = {eps[0] - em, eps[1] - em, eps[2] - em, eps[3], eps[4], eps[5]};
+    const spk_f2 dn2 = (dev[0] * dev[0] + dev[1] * dev[1] + dev[2] * dev[2]) + 2.f * (dev[3] * dev[3] + dev[4] * dev[4] + dev[5] * dev[5]);
+    const bool tx = dn2.x == 0.f || tr.x > 0.f, ty = dn2.y == 0.f || tr.y > 0.f;          // tensile: sigma' = 1, K = -eps
+    const spk_f2 dn = pk_sqrt(dn2), gamma = dn + P.pk * tr * P.alpha;
+    const bool cx = !tx && gamma.x > 0.f, cy = !ty && gamma.y > 0.f;                      // onto the cone: K = (lvg / 3) I - (gamma / dn) dev(eps)
+    const spk_f2 zero = {0.f, 0.f};
+    const spk_f2 c = pk_sel(tx, ty, -em, pk_sel(cx, cy, P.lvg * (1.f / 3.f), zero));
+    const spk_f2 g = pk_sel(tx, ty, spk_f2{-1.f, -1.f}, pk_sel(cx, cy, -gamma * pk_rcp(dn), zero));
+    P.dq = pk_sel(tx, ty, pk_sqrt(dn2 + tr * tr * (1.f / 3.f)), pk_sel(cx, cy, gamma, zero));
+    const bool mx = tx || cx, my = ty || cy;
+    const spk_f2 sn = tre + 3.f * c;
+    const spk_f2 pm1 = pk_expm1(tre), nm1 = pk_expm1(sn);
+    P.jpf = pk_sel(mx, my, (1.f + pm1) * pk_rcp(1.f + nm1), 1.f);
+    P.dlvg = tre - sn;
+    P.jm1 = pk_sel(mx, my, nm1, pm1);
+    spk_f2 D[6], D2[6], Q[6], D34[6], G[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) D[i] = g * dev[i];
+    sym_mul(D, D, D2);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Q[i] = (1.f / 6.f) * D[i] + (1.f / 24.f) * D2[i];
+    sym_mul(D2, Q, D34);
+    const spk_f2 xc = pk_expm1(c), ec = 1.f + xc;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) G[i] = ec * (D[i] + (0.5f * D2[i] + D34[i]));
+    G[0] += xc; G[1] += xc; G[2] += xc;
+    {   // E' = E + G + E G
+        const int sidx[9] = {0, 3, 4, 3, 1, 5, 4, 5, 2};   // (i, j) -> index in (xx, yy, zz, xy, xz, yz)
+        spk_f2 En[9];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                En[i + 3 * j] = (E[i + 3 * j] + G[sidx[i + 3 * j]]) + (E[i] * G[sidx[3 * j]] + (E[i + 3] * G[sidx[1 + 3 * j]] + E[i + 6] * G[sidx[2 + 3 * j]]));
+#pragma unroll
+        for (int k = 0; k < 9; ++k) E[k] = En[k];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) eps[i] += D[i];
+    eps[0] += c; eps[1] += c; eps[2] += c;
+    {
+        spk_f2 ev[3];
+        pk_sym_eigvals(eps, ev);
+        spk_f2 nsq = zero;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const spk_f2 sp = pk_max(pk_expm1(ev[i]), zero); nsq += sp * sp; }
+        P.nsq = nsq;
+    }
+    spk_f2 M[6];
+    one_minus_exp_neg_series(eps, M);
+    {   // corotated_tau_e: tau = 2 mu F M F^T + lambda (J - 1) J I, F = I + E'
+        const int sidx[9] = {0, 3, 4, 3, 1, 5, 4, 5, 2};
+        spk_f2 A[9];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                A[i + 3 * j] = M[sidx[i + 3 * j]] + (E[i] * M[sidx[3 * j]] + (E[i + 3] * M[sidx[1 + 3 * j]] + E[i + 6] * M[sidx[2 + 3 * j]]));
+        const spk_f2 sph = P.lam * P.jm1 * (1.f + P.jm1);
+        const int ii[6] = {0, 1, 2, 0, 0, 1}, jj[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int a = ii[k], b = jj[k];
+            spk_f2 t = P.k2 * (A[a + 3 * b] + (A[a] * E[b] + (A[a + 3] * E[b + 3] + A[a + 6] * E[b + 6])));
+            if (k < 3) t += sph;
+            if (active) { park_lo[64 * k] = t.x; park_hi[64 * k] = t.y; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) P.E[k] = E[k];
+    return true;
 }
 
 // SnowPlasticity::update_particle (plasticity_snow.rs:26-48)
@@ -901,11 +1108,13 @@ SPK_DEV bool maximum_stress_failed(const DevModel& mo, const M3& t) {
 
 // constitutive_model.pos_energy(particle)
 // `jm1` = det(F) - 1 (det_minus_one(E)), which the caller holds anyway
-SPK_DEV float model_pos_energy(const DevModel& mo, float phase, float eh, const M3& F, const M3& E, const float sm1[3], bool sv_valid, float jm1) {
+template <class MO>
+SPK_DEV float model_pos_energy(const MO& mo, float phase, float eh, const M3& F, const M3& E, const float sm1[3], bool sv_valid, float jm1) {
     if (mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR) {
         // elasticity_corotated_linear.rs:105-118 on the small quantities: sigma_k - 1 (`sm1` when the return map already holds
         // them) and J - 1; E = F - I
         float s[3];
+        SPK_HOT(sv_valid);
         if (sv_valid) { s[0] = sm1[0]; s[1] = sm1[1]; s[2] = sm1[2]; }
         else {
             float S6[6], eps[3], re[3];

@@ -196,6 +196,7 @@ SPK_DEV int xcd_remap(int bid, int n) {
 SPK_DEV float round_cell(float x, float h, float inv_h) {
     const float t = x * inv_h;
     const float r = rintf(t);
+    SPK_HOT(!(fabsf(t - r) > 0.5f - 1.0e-6f * fmaxf(fabsf(t), 1.f)));
     if (fabsf(t - r) > 0.5f - 1.0e-6f * fmaxf(fabsf(t), 1.f)) return roundf(x / h);
     return r;
 }
@@ -221,6 +222,7 @@ SPK_DEV int dpp_shr1_i(int v, int fill) { return __builtin_amdgcn_update_dpp(fil
 // in the common path too.  rare_load keeps load and wait inside a wave-uniform branch that the common case skips.
 SPK_DEV float rare_load(bool cond, const float* p, float dflt) {
     float r = dflt;
+    SPK_HOT(!__any(cond));
     if (__any(cond)) {
         float t = dflt;
         if (cond) t = *p;
@@ -261,7 +263,8 @@ struct Scatter {
 // `T` (fused kernel only): the corotated stress the Drucker-Prager return map of this very thread formed from the decomposition
 // of F it held (corotated_tau_e) -- no second decomposition.
 // `Fe` = F - I, as the particle stores it.
-SPK_DEV Scatter p2g_prepare(const DevModel& mo, uint32_t flags, const float px[3], const float v[3], const M3& C, const M3& Fe, float mass, float vol0, float eh,
+template <class MO>
+SPK_DEV Scatter p2g_prepare(const MO& mo, uint32_t flags, const float px[3], const float v[3], const M3& C, const M3& Fe, float mass, float vol0, float eh,
                             float phase, float fluid_jp, const int4& org, float h, float inv_h, float inv_d, float dt, const SymStress* T = nullptr, const float* rcell = nullptr) {
     Scatter sc;
     M3 F = Fe;
@@ -279,6 +282,7 @@ SPK_DEV Scatter p2g_prepare(const DevModel& mo, uint32_t flags, const float px[3
     sc.base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
     sc.shell = (lc[0] < 1 ? 1 : 0) | (lc[0] > 4 ? 2 : 0) | (lc[1] < 1 ? 4 : 0) | (lc[1] > 4 ? 8 : 0) | (lc[2] < 1 ? 16 : 0) | (lc[2] > 4 ? 32 : 0);
     M3 tau = m3_zero();
+    SPK_HOT(!(flags & FLAG_FAILED) && T != nullptr && T->valid && phase == 1.f);
     if (!(flags & FLAG_FAILED)) {
         if (mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR) {
             if (T != nullptr && T->valid && phase == 1.f) tau = sym_to_m3(*T);
@@ -1173,7 +1177,8 @@ SPK_DEV float velocity_dt_bound(const float v[3], const M3& C, float h) {
     const float apic_v = (d * m3_frob(C)) * 6.f * sqrtf(3.f) / h;
     return fminf(3.402823466e+38f, h / (sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) + apic_v));
 }
-SPK_DEV float particle_dt_bound(const DevModel& mo, uint32_t flags, const float v[3], const M3& C, float mass, float vol0, float eh, float f00, float h) {
+template <class MO>
+SPK_DEV float particle_dt_bound(const MO& mo, uint32_t flags, const float v[3], const M3& C, float mass, float vol0, float eh, float f00, float h) {
     const float d = (h * h) / 4.f;
     const float apic_v = (d * m3_frob(C)) * 6.f * sqrtf(3.f) / h;
     const float vn = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) + apic_v;
@@ -1364,8 +1369,8 @@ SPK_DEV void apic_gather(const VelTile& vt, const float px[3], const int4& org, 
 // RARE: the instantiation that also carries snow / Rankine / NACC plasticity and the failure model; launched only when a
 // model of the set needs it, so the elastic / Drucker-Prager kernels keep their register budget (inlining that code,
 // or calling it out of line, cost the hot kernel 35 %).
-template <bool RARE, bool WANT_STRESS = false>
-SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevModel& mo, uint32_t flags, const float4& q0, const float4& q1, const float4& q2, const float4& dd,
+template <bool RARE, bool WANT_STRESS = false, class MO = DevModel>
+SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const MO& mo, uint32_t flags, const float4& q0, const float4& q1, const float4& q2, const float4& dd,
                             const float4& kk, const float4* kinvel_i, const float4* aux_i, float phase, const int4& org, const StepParams& S, float inv_h,
                             unsigned* num_invalid, lds_fp park = nullptr) {
     Advected o;
@@ -1409,7 +1414,7 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
     bool sv_valid = false;
     o.store_k = false; o.store_aux = false; o.alpha = 0.f;
     o.T.valid = false; o.T.jm1 = 0.f;
-    if (RARE && mo.ptag > SPARKL_PLASTIC_DRUCKER_PRAGER) {   // snow / Rankine / NACC (plastic_model.update_particle, :102-104)
+    if constexpr (RARE) if (mo.ptag > SPARKL_PLASTIC_DRUCKER_PRAGER) {   // snow / Rankine / NACC (plastic_model.update_particle, :102-104)
         float alpha = mo.ptag == SPARKL_PLASTIC_NACC ? aux_i->z : 0.f;
         const float eh0 = eh, alpha0 = alpha;
         rare_plastic_update(mo, F, Jp, q, eh, alpha);
@@ -1433,6 +1438,7 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
     if (!o.T.valid) jm1 = det_minus_one(E);
     const bool zero_density = (kk.x == 0.f) || !(fabsf(jm1) < 1.0e30f);
     bool newly_failed = false;
+    SPK_HOT(!(zero_density || (flags & FLAG_FAILED) || (!mo.is_fluid && fabsf(F.m[0]) > 1.0e4f)) && !(flags & FLAG_STATIC));
     if (zero_density || (flags & FLAG_FAILED) || (!mo.is_fluid && fabsf(F.m[0]) > 1.0e4f)) {
         newly_failed = !(flags & FLAG_FAILED);
         flags |= FLAG_FAILED;
@@ -1448,7 +1454,7 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
     psi = fmaxf(psi, model_pos_energy(mo, phase, eh, F, E, sv, sv_valid, jm1));
     SPK_MARK("tile_checks");
     // failure model (:134-144): stress of the updated particle; a failed particle keeps phase = 0 from now on
-    if (RARE && mo.has_failure && phase != 0.f && failure_check(mo, phase, eh, F, kk.x, kk.y, Jp, C)) {
+    if constexpr (RARE) if (mo.has_failure && phase != 0.f && failure_check(mo, phase, eh, F, kk.x, kk.y, Jp, C)) {
         phase = 0.f;
         if (!o.store_aux) o.alpha = aux_i->z;
         o.store_aux = true;
@@ -1468,6 +1474,7 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
             if (nl < -1 || nl > 4) in_tile = false;
         }
     }
+    SPK_HOT(!invalid);
     if (invalid) {  // what the next ParticleSet::sort would do (particle_set.rs:129-136)
         newly_failed = true;
         flags |= FLAG_FAILED | FLAG_INVALID;
@@ -1482,6 +1489,102 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const DevMod
     o.eh = eh; o.phase = phase;
     return o;
 }
+// The two halves of g2p_update around the return map, for the kernel that runs the return map on particle PAIRS (k_g2p2g<.., MSET = 2>,
+// device_math.h "packed series path"): every model a corotated solid with Drucker-Prager plasticity, no RARE code.
+struct SandMid {
+    float px[3], vel[3];   // advected position, gathered (or kinematic) velocity
+    M3 C, E;               // velocity gradient; E = F - I BEFORE the deformation-gradient update
+};
+SPK_DEV SandMid sand_mid_zero() {
+    SandMid m;
+    m.px[0] = m.px[1] = m.px[2] = 0.f; m.vel[0] = m.vel[1] = m.vel[2] = 0.f; m.C = m3_zero(); m.E = m3_zero();
+    return m;
+}
+// grid_to_particle.rs:47-86: gather, kinematic override, advection
+SPK_DEV SandMid sand_pre(const VelTile& vt, uint32_t flags, const float4& q0, const float4& q1, const float4& q2, const float4* kinvel_i, const int4& org,
+                         const StepParams& S, float inv_h) {
+    SandMid m;
+    float px[3] = {q0.x, q0.y, q0.z};
+    SPK_MARK("gather");
+    apic_gather(vt, px, org, S, inv_h, m.vel, m.C);
+    SPK_MARK("advect_F");
+    {
+        const bool kin = (flags & FLAG_KINEMATIC) != 0;
+        const float* kp = reinterpret_cast<const float*>(kinvel_i);
+        m.vel[0] = rare_load(kin, kp, m.vel[0]); m.vel[1] = rare_load(kin, kp + 1, m.vel[1]); m.vel[2] = rare_load(kin, kp + 2, m.vel[2]);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) m.px[a] = px[a] + m.vel[a] * S.dt;
+    m.E = M3{{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
+    return m;
+}
+// grid_to_particle.rs:104-144 behind the pair return map: static, fail guards, positive energy, margin / domain checks.
+// `Ep` = E' of the mapped F, `jm1` = det F' - 1, `nsq` = sum max(sigma'_k - 1, 0)^2 (elasticity_corotated_linear.rs:105-118).
+template <class MO>
+SPK_DEV Advected sand_post(const MO& mo, uint32_t flags, const SandMid& m, const M3& Ep, float q, float lvg, float Jp, float psi, const float4& kk, float jm1, float nsq,
+                           const int4& org, const StepParams& S, float inv_h, unsigned* num_invalid) {
+    Advected o;
+    const float h = S.h;
+    const int orgv[3] = {org.x, org.y, org.z};
+    float vel[3] = {m.vel[0], m.vel[1], m.vel[2]};
+    M3 C = m.C, E = Ep;
+    const float eh = kk.z;
+    o.store_k = false; o.store_aux = false; o.alpha = 0.f;
+    o.T.valid = true; o.T.jm1 = jm1;
+    if (flags & FLAG_STATIC) { vel[0] = vel[1] = vel[2] = 0.f; C = m3_zero(); }
+    const bool zero_density = (kk.x == 0.f) || !(fabsf(jm1) < 1.0e30f);
+    bool newly_failed = false;
+    float energy;
+    {
+        const float pos_dev = mo.mu * eh * nsq;
+        const float sph = mo.lambda * eh / 2.f * jm1 * jm1;
+        energy = jm1 < 0.f ? pos_dev : pos_dev + sph;
+    }
+    if (zero_density || (flags & FLAG_FAILED) || fabsf(1.f + E.m[0]) > 1.0e4f) {
+        newly_failed = !(flags & FLAG_FAILED);
+        flags |= FLAG_FAILED;
+        E = m3_zero();
+        C = m3_zero();
+        o.T.valid = false;
+        energy = 0.f;
+    }
+    SPK_MARK("pos_energy");
+    psi = fmaxf(psi, energy);
+    SPK_MARK("tile_checks");
+    bool invalid = false, in_tile = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float r = round_cell(m.px[a], h, inv_h);
+        o.rnew[a] = r;
+        const bool ok = (r >= 1.0f) && (r < (float)(S.dom - 4));
+        if (!ok) invalid = true;
+        else {
+            const int nl = (int)r - 1 - orgv[a];
+            if (nl < -1 || nl > 4) in_tile = false;
+        }
+    }
+    if (invalid) {
+        newly_failed = true;
+        flags |= FLAG_FAILED | FLAG_INVALID;
+        in_tile = false;
+        atomicAdd(num_invalid, 1u);
+        atomicMin(num_invalid + (offsetof(Ctl, dead_dt_bits) - offsetof(Ctl, num_invalid)) / 4, __float_as_uint(velocity_dt_bound(vel, C, h)));
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { o.px[a] = m.px[a]; o.vel[a] = vel[a]; }
+    o.C = C; o.Fe = E; o.q = q; o.lvg = lvg; o.Jp = Jp; o.psi = psi; o.flags = flags; o.newly_failed = newly_failed; o.in_tile = in_tile;
+    o.eh = eh; o.phase = 1.f;
+    return o;
+}
+// lanes 0..31: (own value, the value of lane + 32); lanes 32..63 get a duplicate pair of the lower half (never used)
+SPK_DEV spk_f2 pair_up(int hi_addr, float x) { return spk_f2{x, bperm_f(hi_addr, x)}; }
+// the inverse: lanes 0..31 keep p.x, lanes 32..63 receive p.y of lane - 32 (v_permlane32_swap_b32: the upper half of the first operand
+// is exchanged with the lower half of the second)
+SPK_DEV float pair_down(spk_f2 p) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p.x), __float_as_uint(p.y), false, false);
+    return __uint_as_float(r[0]);
+}
+
 // `defer_c`: q[4], q[5] (C.m[1..8]) are not written; k_regather_c recomputes them if anything but the next fused launch needs
 // them (see StepParams::defer_c)
 SPK_DEV void g2p_store(const ParticleArrays& P, int i, const Advected& o, int defer_c = 0) {
@@ -1566,7 +1669,9 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
 #endif
 
 // REDUCE_STEPS >= 0: DPP pre-reduction over groups of 2^REDUCE_STEPS lanes (p2g_scatter); -1: run tasks (p2g_scatter_runs).
-template <int REDUCE_STEPS, bool RARE, bool LDS_MODELS = true>
+// MSET: 0 = any model table; 1 = every model is a corotated solid with Drucker-Prager plasticity (DpSandModel: no model dispatch);
+// 2 = the same, with the return map run on particle pairs (needs LDS_MODELS)
+template <int REDUCE_STEPS, bool RARE, bool LDS_MODELS = true, int MSET = 0>
 __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
     const int tid = threadIdx.x;
     __shared__ VelTile vt;
@@ -1612,24 +1717,28 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
         const bool active = li < pcount;
         const int i = pfirst + (active ? li : 0);
         const float4 q0 = n0, q1 = n1, q2 = n2, dd = nd, kk = nk;
-        if (it + 1 < niter) {
-            const int inx = pfirst + min(li + BLK_THREADS, pcount - 1);
-            n0 = P.q[0][inx]; n1 = P.q[1][inx]; n2 = P.q[2][inx]; nd = P.d[inx]; nk = P.k[inx];
-        }
+        // the next batch's loads: at the top of the batch, or (pair kernel) behind the return map, whose register peak they would sit through --
+        // store, descriptor and scatter still lie between the request and the first use
+        auto prefetch = [&]() {
+            if (it + 1 < niter) {
+                const int inx = pfirst + min(li + BLK_THREADS, pcount - 1);
+                n0 = P.q[0][inx]; n1 = P.q[1][inx]; n2 = P.q[2][inx]; nd = P.d[inx]; nk = P.k[inx];
+            }
+        };
+        if constexpr (MSET != 2) prefetch();
         const uint32_t flags = __float_as_uint(kk.w);
         bool live = active && !(flags & FLAG_INVALID);
         Scatter sc;
         scatter_clear(sc);
-        if (live) {
-            const DevModel& mo = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
-            const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
-            const lds_fp park = (lds_fp)(&s_A[tid >> 6][0][tid & 63]);
-            const Advected o = g2p_update<RARE, true>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid, park);
+        const lds_fp park = (lds_fp)(&s_A[tid >> 6][0][tid & 63]);
+        // behind the particle update: store, then the scatter descriptor of the advected particle
+        auto finish = [&](const auto& mo, const Advected& o) {
             const bool t_valid = o.T.valid;   // the six components themselves sit in the LDS (see g2p_update's `park`)
             SPK_MARK("store");
             g2p_store(P, i, o, S.defer_c);
             want_sort |= !o.in_tile && !(o.flags & FLAG_INVALID);   // a particle that left the DOMAIN is dead (skipped from now on): no re-bin for it
             live = o.in_tile;
+            SPK_HOT(!S.want_dt);
             if (S.want_dt) {  // the bound the next substep's estimator would compute from this state
                 const float bnd = particle_dt_bound(mo, o.flags, o.vel, o.C, kk.x, kk.y, o.eh, 1.f + o.Fe.m[0], S.h);
                 dt_nan |= bnd != bnd;
@@ -1645,12 +1754,70 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
             }
             SPK_MARK("scatter");
             probe_extra_work(s_A[tid >> 6], tid, o.px, o.vel, sc);   // probe_hooks.h: nothing unless an analysis build asks for it
+        };
+        auto particle = [&](const auto& mo) {
+            const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
+            const Advected o = g2p_update<RARE, true>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid, park);
+            finish(mo, o);
+        };
+        if constexpr (MSET == 2) {
+            // Return map on particle pairs (device_math.h, "packed series path"): gather and advection per lane, then the wave folds in
+            // two -- lane l < 32 runs F update, return map and stress for its own particle and for that of lane l + 32 as float2
+            // arithmetic -- and unfolds for the store and the scatter.  A wave holding a damaged particle (phase != 1), a model with
+            // volume_correction != 1 or a strain beyond the second series tier takes the one-particle path.
+            const int lane = tid & 63;
+            const DevModel& mo_t = s_models[live ? (flags >> FLAG_MODEL_SHIFT) : 0u];
+            const DpSandModel mo(mo_t);
+            SandMid mid = sand_mid_zero();
+            if (live) mid = sand_pre(vt, flags, q0, q1, q2, P.kinvel + i, org, S, inv_h);
+            const bool odd = live && ((flags & FLAG_PHASE_NOT_ONE) != 0u || mo.volume_correction != 1.f);
+            bool paired = false;
+            DpPair pr;
+            SPK_MARK("dp_pack");
+            if (!__any(odd)) {
+                const int hi = ((lane + 32) & 63) << 2;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { pr.E[k] = pair_up(hi, mid.E.m[k]); pr.C[k] = pair_up(hi, mid.C.m[k]); }
+                const float eh = kk.z;
+                pr.alpha = pair_up(hi, live ? dp_alpha(mo, dd.x) : 0.f);
+                pr.lvg = pair_up(hi, live ? dd.y : 0.f);
+                pr.k2 = pair_up(hi, live ? 2.f * mo.mu * eh : 0.f);
+                pr.lam = pair_up(hi, live ? mo.lambda * eh : 0.f);
+                pr.pk = pair_up(hi, live ? mo.p_k : 0.f);
+                SPK_MARK("dp_pair");
+                paired = dp_series_pair(pr, S.dt, lane < 32, park, park + 32);
+            }
+            prefetch();
+            if (paired) {   // wave-uniform
+                SPK_MARK("dp_unpack");
+                M3 Ep;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Ep.m[k] = pair_down(pr.E[k]);
+                const float dq = pair_down(pr.dq), dlvg = pair_down(pr.dlvg), jpf = pair_down(pr.jpf), nsq = pair_down(pr.nsq), jm1 = pair_down(pr.jm1);
+                SPK_MARK("post_dp");
+                if (live) {
+                    const Advected o = sand_post(mo, flags, mid, Ep, dd.x + dq, dd.y + dlvg, dd.z * jpf, dd.w, kk, jm1, nsq, org, S, inv_h, &ctl->num_invalid);
+                    finish(mo, o);
+                }
+#ifndef SPK_EXP_NOFALLBACK
+            } else if (live) {   // one-particle path; E is read again rather than kept in registers across the pair section
+                const float4 r0 = P.q[0][i], r1 = P.q[1][i], r2 = P.q[2][i];
+                const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
+                const Advected o = g2p_update<RARE, true>(G, vt, mo, flags, r0, r1, r2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid, park);
+                finish(mo, o);
+#endif
+            }
+        } else if (live) {
+            const DevModel& mo_t = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
+            if constexpr (MSET == 1) particle(DpSandModel(mo_t));
+            else particle(mo_t);
         }
         shell_used |= wave_or_i32(sc.shell);
         // (a hybrid -- run tasks for regular waves, DPP for ragged ones -- was measured: the two paths in one kernel spill, +15 %)
         if (REDUCE_STEPS < 0) wave_heads += p2g_scatter_runs(tile, sc, live, tid, s_runs[tid >> 6], s_A[tid >> 6]);
         else wave_heads += p2g_scatter<(REDUCE_STEPS < 0 ? 0 : REDUCE_STEPS)>(tile, sc, live, tid);
     }
+    SPK_MARK("epilogue");
     if ((tid & 63) == 0) atomicAdd(&s_heads, wave_heads);
     tile_write(tile, G, pb, tid, shell_used);
     if (tid == 0) {

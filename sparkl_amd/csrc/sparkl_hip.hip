@@ -147,6 +147,7 @@ struct SparklPipeline {
     uint64_t group_rebins = 0, cut_moves = 0;
     bool slab_balance = true;        // sparkl_hip_slab_balance
     bool all_plain_fluid = false;   // every model is a fluid without plastic / failure model: the FLUID_ONLY kernels apply
+    bool all_dp_sand = false;       // every model is a corotated solid with (always active) Drucker-Prager plasticity: k_g2p2g<.., MSET = 1>
     bool mass_tiles_ready = false;  // k_g2p_mass of the previous substep already scattered the next volume sweep's masses
     bool fluid_bound_valid = false; // adaptive step with the volume sweep: the last dt bound seen (predicts the next step length)
     float fluid_bound = 0.f;
@@ -541,11 +542,17 @@ static void launch_g2p(SparklPipeline* p, const ParticleArrays& P, const GridArr
     else SPK_LAUNCH_MODELS(k_g2p, false);
 }
 static void launch_g2p2g(SparklPipeline* p, const ParticleArrays& P, const GridArrays& G, const StepParams& S, hipStream_t st) {
-    const dim3 grid(p->num_pblocks), block(BLK_THREADS);
+    const dim3 grid(G.pb_list ? G.pb_count : p->num_pblocks), block(BLK_THREADS);   // the whole list or the launch's subset (slab groups)
     // SPARKL_HIP_SCATTER=dpp selects the DPP pre-reduction scatter (A/B); the default is the run-task scatter
     static const bool dpp = getenv("SPARKL_HIP_SCATTER") && !strcmp(getenv("SPARKL_HIP_SCATTER"), "dpp");
     if (p->rare_models || S.project_particles) SPK_LAUNCH_MODELS(k_g2p2g, -1, true);
     else if (dpp) SPK_LAUNCH_MODELS(k_g2p2g, SPK_P2G_REDUCE_STEPS, false);
+    else if (p->all_dp_sand && S.num_models <= MAX_LDS_MODELS) {
+        // SPARKL_HIP_MSET=1: the model-specialised kernel without the pair return map (A/B); 0: the generic kernel
+        static const int mset = getenv("SPARKL_HIP_MSET") ? atoi(getenv("SPARKL_HIP_MSET")) : 1;
+        if (mset == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<-1, false, true, 1>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<-1, false, true, 2>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
+    }
     else SPK_LAUNCH_MODELS(k_g2p2g, -1, false);
 }
 
@@ -952,9 +959,11 @@ int sparkl_hip_models_set(SparklPipeline* p, uint32_t n, const SparklParticleMod
     p->any_fluid = any_fluid;
     p->rare_models = false;
     p->all_plain_fluid = n > 0;
+    p->all_dp_sand = n > 0 && !(getenv("SPARKL_HIP_MSET") && !strcmp(getenv("SPARKL_HIP_MSET"), "0"));
     for (const DevModel& d : dm) {
         p->rare_models |= d.ptag > SPARKL_PLASTIC_DRUCKER_PRAGER || d.has_failure;
         p->all_plain_fluid &= d.is_fluid && d.ptag < 0 && !d.has_failure;
+        p->all_dp_sand &= !d.is_fluid && d.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR && d.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER && !d.only_active_when_failed && !d.has_failure;
     }
     if (p->d_ctl) CHK(upload_policy(p));   // the default reorder budget depends on whether a fluid is present
     return SPARKL_OK;
@@ -2258,8 +2267,7 @@ static int launch_subset(SparklPipeline* p, int which, bool fuse_next, bool prim
     if (fuse_next && p->fuse_fixed_dt) {
         S.defer_c = (defer && p->defer_c && !p->rare_models && !S.project_particles) ? 1 : 0;
         if (S.defer_c) p->c_stale_S = p->pending;
-        if (p->rare_models || S.project_particles) SPK_LAUNCH_MODELS(k_g2p2g, -1, true);
-        else SPK_LAUNCH_MODELS(k_g2p2g, -1, false);
+        launch_g2p2g(p, P, G, S, st);
     } else {
         if (p->rare_models || S.project_particles) SPK_LAUNCH_MODELS(k_g2p, true);
         else SPK_LAUNCH_MODELS(k_g2p, false);

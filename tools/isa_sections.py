@@ -4,9 +4,11 @@ Counts are per wave pass over the straight-line code that follows each marker up
 counted: cold paths inflate a section, loops count once)."""
 import collections, os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sub = sys.argv[1] if len(sys.argv) > 1 else "7k_g2p2gILin1ELb0ELb1"
+hot = "--hot" in sys.argv   # -DSPK_HOT_ONLY: cold sides of the branches assumed away (device_math.h, SPK_HOT): the count of the hot path
+args = [a for a in sys.argv[1:] if a != "--hot"]
+sub = args[0] if args else "7k_g2p2gILin1ELb0ELb1ELi1"
 src = os.path.join(root, "sparkl_amd", "csrc", "sparkl_hip.hip")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-fno-slp-vectorize", "-DSPK_MARKS", "-S", "--cuda-device-only",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-fno-slp-vectorize", "-DSPK_MARKS", *(["-DSPK_HOT_ONLY"] if hot else []), "-S", "--cuda-device-only",
                        "-o", "/tmp/marks.s", src], stderr=subprocess.DEVNULL)
 lines = open("/tmp/marks.s").read().splitlines()
 start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN3spk\S*" + re.escape(sub) + r"\S*:", l))
