@@ -544,21 +544,27 @@ SPK_DEV void sym_eigvals(const float a[6], float e[3]) {
 // eps = ln(I + S) / 2 by its series: quartic (the next term is |S|^4 / 5 of the first), or to S^7 (`hi`, wave-uniform)
 template <class T>
 SPK_DEV void hencky_series(const T S[6], T eps[6], bool hi = false) {
-    T P2[6], P3[6], P4[6];
+    // Paterson-Stockmeyer on P2 = S^2 with coefficients linear in S (every factor is a polynomial in S: they commute):
+    //   quartic:  (S/2 - P2/4) + P2 (S/6 - P2/8)                                            two products
+    //   to S^7:   (S/2 - P2/4) + P2 ((S/6 - P2/8) + P2 ((S/10 - P2/12) + P2 (S/14)))        four; at most S, P2 and one running factor live
+    T P2[6], V[6], U[6];
     sym_mul(S, S, P2);
-    sym_mul(S, P2, P3);
-    sym_mul(P2, P2, P4);
     if (hi) {
-        T B[6], U[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) B[i] = 0.1f * S[i] + ((-1.f / 12.f) * P2[i] + (1.f / 14.f) * P3[i]);
-        sym_mul(P4, B, U);
+        for (int i = 0; i < 6; ++i) V[i] = (1.f / 14.f) * S[i];
+        sym_mul(P2, V, U);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) eps[i] = 0.5f * S[i] + (-0.25f * P2[i] + ((1.f / 6.f) * P3[i] + (U[i] - 0.125f * P4[i])));
-        return;
+        for (int i = 0; i < 6; ++i) V[i] = U[i] + (0.1f * S[i] - (1.f / 12.f) * P2[i]);
+        sym_mul(P2, V, U);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) V[i] = U[i] + ((1.f / 6.f) * S[i] - 0.125f * P2[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) V[i] = (1.f / 6.f) * S[i] - 0.125f * P2[i];
     }
+    sym_mul(P2, V, U);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) eps[i] = 0.5f * S[i] + (-0.25f * P2[i] + ((1.f / 6.f) * P3[i] - 0.125f * P4[i]));
+    for (int i = 0; i < 6; ++i) eps[i] = U[i] + (0.5f * S[i] - 0.25f * P2[i]);
 }
 // x - x^2/2 + x^3/6 - x^4/24 = I - exp(-x) to |x|^4 / 120 relative
 template <class T>
@@ -633,16 +639,22 @@ template <class MO>
 SPK_DEV M3 corotated_kirchhoff_fe(const MO& mo, float hardening, const M3& E) {
     float S[6], e[3], re[3], g[3], m6[6];
     strain_metric(E, S);
-    if (SPK_SERIES_MAX > 0.f && __all(series2_ok(S))) {   // wave-uniform; series path: M = I - (I + S)^(-1/2) to S^7 (next term 0.39 |S|^7 relative)
-        float P2[6], P3[6], P4[6], B[6], T[6];
+    if (SPK_SERIES_MAX > 0.f && __all(series2_ok(S))) {   // wave-uniform; series path: M = I - (I + S)^(-1/2)
+        // = S/2 - 3/8 S^2 + 5/16 S^3 - 35/128 S^4 + 63/256 S^5 - 231/1024 S^6 + 429/2048 S^7 (next term 0.39 |S|^7 relative), evaluated like
+        // hencky_series: P2 = S^2, coefficients linear in S, Horner in P2 -- four products, S, P2 and one running factor live
+        float P2[6], V[6], U[6];
         sym_mul(S, S, P2);
-        sym_mul(S, P2, P3);
-        sym_mul(P2, P2, P4);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) B[k] = 0.24609375f * S[k] + (-0.2255859375f * P2[k] + 0.20947265625f * P3[k]);   // 63/256, 231/1024, 429/2048
-        sym_mul(P4, B, T);
+        for (int k = 0; k < 6; ++k) V[k] = 0.20947265625f * S[k];
+        sym_mul(P2, V, U);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) m6[k] = 0.5f * S[k] + (-0.375f * P2[k] + (0.3125f * P3[k] + (T[k] - 0.2734375f * P4[k])));
+        for (int k = 0; k < 6; ++k) V[k] = U[k] + (0.24609375f * S[k] - 0.2255859375f * P2[k]);
+        sym_mul(P2, V, U);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) V[k] = U[k] + (0.3125f * S[k] - 0.2734375f * P2[k]);
+        sym_mul(P2, V, U);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) m6[k] = U[k] + (0.5f * S[k] - 0.375f * P2[k]);
         return sym_to_m3(corotated_tau_e(mo, hardening, E, m6));
     }
     const Eig3 d = log_stretch_s(S, e, re);
@@ -824,165 +836,6 @@ SPK_DEV void dp_update_e(const MO& mo, float phase, float eh, M3& E, float& Jp, 
         T = corotated_tau_e(mo, eh, E, m6, park);
     }
 #endif
-}
-
-// ------------------------------------------------------------------------------ packed series path: two particles per lane
-// The series return map is ~600 straight-line scalar FMAs per particle, and the kernel that runs it is VALU-issue bound.  v_pk_fma_f32
-// retires two f32 per lane for about the cost of one, but packing INSIDE one particle's arithmetic does not pay (the pairs have to be
-// assembled and taken apart: measured, round 3).  So the wave folds itself in two for this section only: lane l < 32 takes the inputs of
-// lane l + 32 beside its own (ds_bpermute: LDS crossbar, no VALU), runs F update -> strain -> return map -> stress ONCE for both as
-// float2 arithmetic while lanes 32..63 sit out, and hands the second particle's results back (v_permlane32_swap_b32, one VALU each).
-// Same formulas as dp_update_series + corotated_tau_e above (plasticity_drucker_prager.rs:68-104, elasticity_corotated_linear.rs:31-78);
-// differences, all below the series' own truncation: the three outcomes (tensile / onto the cone / inside) are selects instead of
-// branches, e^x - 1 is one degree-7 polynomial (|x| < 0.2 here), and det F' - 1 = expm1(tr eps') comes from the return map's own
-// volume bookkeeping instead of the minors of E'.  Requires volume_correction == 1 (the reference's default) and phase == 1 for every
-// particle of the wave, and |S|, |lvg| below SPK_SERIES_MAX2 (else the wave takes the scalar path): the caller checks the first two.
-typedef int spk_i2 __attribute__((ext_vector_type(2)));
-SPK_DEV spk_f2 pk_rcp(spk_f2 x) { return spk_f2{fast_rcp(x.x), fast_rcp(x.y)}; }
-SPK_DEV spk_f2 pk_rsq(spk_f2 x) { return spk_f2{fast_rsq(x.x), fast_rsq(x.y)}; }
-SPK_DEV spk_f2 pk_sqrt(spk_f2 x) { return spk_f2{fast_sqrt(x.x), fast_sqrt(x.y)}; }
-SPK_DEV spk_f2 pk_max(spk_f2 a, spk_f2 b) { return spk_f2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
-SPK_DEV spk_f2 pk_min(spk_f2 a, spk_f2 b) { return spk_f2{fminf(a.x, b.x), fminf(a.y, b.y)}; }
-SPK_DEV spk_f2 pk_abs(spk_f2 a) { return spk_f2{fabsf(a.x), fabsf(a.y)}; }
-SPK_DEV spk_f2 pk_sel(bool cx, bool cy, spk_f2 a, spk_f2 b) { return spk_f2{cx ? a.x : b.x, cy ? a.y : b.y}; }
-SPK_DEV spk_f2 pk_sel(bool cx, bool cy, spk_f2 a, float b) { return spk_f2{cx ? a.x : b, cy ? a.y : b}; }
-// e^x - 1 for |x| < 0.2 (next term x^7 / 40320 relative: 3e-10)
-SPK_DEV spk_f2 pk_expm1(spk_f2 x) {
-    spk_f2 p = x * (1.f / 5040.f) + (1.f / 720.f);
-    p = p * x + (1.f / 120.f);
-    p = p * x + (1.f / 24.f);
-    p = p * x + (1.f / 6.f);
-    p = p * x + 0.5f;
-    p = p * x + 1.f;
-    return p * x;
-}
-// sym_eigvals for two matrices at once
-SPK_DEV void pk_sym_eigvals(const spk_f2 a[6], spk_f2 e[3]) {
-    const spk_f2 q = (a[0] + a[1] + a[2]) * (1.f / 3.f);
-    const spk_f2 d0 = a[0] - q, d1 = a[1] - q, d2 = a[2] - q;
-    const spk_f2 p2r = (d0 * d0 + d1 * d1 + d2 * d2 + 2.f * (a[3] * a[3] + a[4] * a[4] + a[5] * a[5])) * (1.f / 6.f);
-    const bool zx = !(p2r.x > 1.0e-36f), zy = !(p2r.y > 1.0e-36f);
-    const spk_f2 p2 = pk_sel(zx, zy, spk_f2{1.f, 1.f}, p2r);
-    const spk_f2 ip = pk_rsq(p2), p = p2 * ip;
-    const spk_f2 det = d0 * (d1 * d2 - a[5] * a[5]) - a[3] * (a[3] * d2 - a[5] * a[4]) + a[4] * (a[3] * a[5] - d1 * a[4]);
-    const spk_f2 r = pk_min(pk_max(0.5f * det * (ip * ip * ip), spk_f2{-1.f, -1.f}), spk_f2{1.f, 1.f});
-    const spk_f2 ar = pk_abs(r);
-    spk_f2 c = 0.1339746f * ar + 0.8660254f;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const spk_f2 c2 = c * c;
-        c -= ((4.f * c2 - 3.f) * c - ar) * pk_rcp(12.f * c2 - 3.f);
-    }
-    const spk_f2 sn = pk_sqrt(pk_max(1.f - c * c, spk_f2{0.f, 0.f})) * 0.8660254f;
-    const spk_f2 sg = pk_sel(r.x < 0.f, r.y < 0.f, -p, p);
-    e[0] = pk_sel(zx, zy, q, q + sg * (2.f * c));
-    e[1] = pk_sel(zx, zy, q, q + sg * (2.f * sn - c));
-    e[2] = pk_sel(zx, zy, q, q - sg * (c + 2.f * sn));
-}
-struct DpPair {
-    spk_f2 E[9];                       // in: E = F - I before the F update; out: E' (column-major)
-    spk_f2 C[9];                       // in: velocity gradient; the F update is E += dt C (I + E) (grid_to_particle.rs:91-95)
-    spk_f2 alpha, lvg, k2, lam, pk;    // in: dp_alpha(q), pending log_vol_gain, 2 mu eh, lambda eh, (3 lambda + 2 mu) / (2 mu) of the plastic model
-    spk_f2 dq, dlvg, jpf, nsq, jm1;    // out: q += dq, lvg += dlvg, Jp *= jpf; sum of max(sigma'_k - 1, 0)^2; det F' - 1
-};
-// Returns false (nothing written) when a particle of the wave is beyond the second series tier.  `active`: this lane holds a pair (lane < 32).
-// park_lo / park_hi: LDS columns of the two particles for the six stress components (element k at [64 k]).
-SPK_DEV bool dp_series_pair(DpPair& P, float dt, bool active, lds_fp park_lo, lds_fp park_hi) {
-    spk_f2 E[9];
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const spk_f2 x = (P.C[i + 3 * j] + P.C[i] * P.E[3 * j]) + (P.C[i + 3] * P.E[3 * j + 1] + P.C[i + 6] * P.E[3 * j + 2]);
-            E[i + 3 * j] = P.E[i + 3 * j] + dt * x;
-        }
-    spk_f2 S[6];
-    {
-        const int ii[6] = {0, 1, 2, 0, 0, 1}, jj[6] = {0, 1, 2, 1, 2, 2};
-#pragma unroll
-        for (int e = 0; e < 6; ++e) {
-            const int a = ii[e], b = jj[e];
-            S[e] = (E[a + 3 * b] + E[b + 3 * a]) + (E[3 * a] * E[3 * b] + E[3 * a + 1] * E[3 * b + 1] + E[3 * a + 2] * E[3 * b + 2]);
-        }
-    }
-    const spk_f2 n2 = pk_max(sym_frob2(S), P.lvg * P.lvg);
-    const bool ok2 = !active || (n2.x < SPK_SERIES_MAX2 * SPK_SERIES_MAX2 && n2.y < SPK_SERIES_MAX2 * SPK_SERIES_MAX2);
-    if (!__all(ok2)) return false;
-    const bool ok1 = !active || (n2.x < SPK_SERIES_MAX * SPK_SERIES_MAX && n2.y < SPK_SERIES_MAX * SPK_SERIES_MAX);
-    spk_f2 eps[6];
-    hencky_series(S, eps, !__all(ok1));
-    const spk_f2 tre = eps[0] + eps[1] + eps[2], em = tre * (1.f / 3.f), tr = tre + P.lvg;
-    const spk_f2 dev[6] = {eps[0] - em, eps[1] - em, eps[2] - em, eps[3], eps[4], eps[5]};
-    const spk_f2 dn2 = (dev[0] * dev[0] + dev[1] * dev[1] + dev[2] * dev[2]) + 2.f * (dev[3] * dev[3] + dev[4] * dev[4] + dev[5] * dev[5]);
-    const bool tx = dn2.x == 0.f || tr.x > 0.f, ty = dn2.y == 0.f || tr.y > 0.f;          // tensile: sigma' = 1, K = -eps
-    const spk_f2 dn = pk_sqrt(dn2), gamma = dn + P.pk * tr * P.alpha;
-    const bool cx = !tx && gamma.x > 0.f, cy = !ty && gamma.y > 0.f;                      // onto the cone: K = (lvg / 3) I - (gamma / dn) dev(eps)
-    const spk_f2 zero = {0.f, 0.f};
-    const spk_f2 c = pk_sel(tx, ty, -em, pk_sel(cx, cy, P.lvg * (1.f / 3.f), zero));
-    const spk_f2 g = pk_sel(tx, ty, spk_f2{-1.f, -1.f}, pk_sel(cx, cy, -gamma * pk_rcp(dn), zero));
-    P.dq = pk_sel(tx, ty, pk_sqrt(dn2 + tr * tr * (1.f / 3.f)), pk_sel(cx, cy, gamma, zero));
-    const bool mx = tx || cx, my = ty || cy;
-    const spk_f2 sn = tre + 3.f * c;
-    const spk_f2 pm1 = pk_expm1(tre), nm1 = pk_expm1(sn);
-    P.jpf = pk_sel(mx, my, (1.f + pm1) * pk_rcp(1.f + nm1), 1.f);
-    P.dlvg = tre - sn;
-    P.jm1 = pk_sel(mx, my, nm1, pm1);
-    spk_f2 D[6], D2[6], Q[6], D34[6], G[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) D[i] = g * dev[i];
-    sym_mul(D, D, D2);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) Q[i] = (1.f / 6.f) * D[i] + (1.f / 24.f) * D2[i];
-    sym_mul(D2, Q, D34);
-    const spk_f2 xc = pk_expm1(c), ec = 1.f + xc;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) G[i] = ec * (D[i] + (0.5f * D2[i] + D34[i]));
-    G[0] += xc; G[1] += xc; G[2] += xc;
-    {   // E' = E + G + E G
-        const int sidx[9] = {0, 3, 4, 3, 1, 5, 4, 5, 2};   // (i, j) -> index in (xx, yy, zz, xy, xz, yz)
-        spk_f2 En[9];
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-                En[i + 3 * j] = (E[i + 3 * j] + G[sidx[i + 3 * j]]) + (E[i] * G[sidx[3 * j]] + (E[i + 3] * G[sidx[1 + 3 * j]] + E[i + 6] * G[sidx[2 + 3 * j]]));
-#pragma unroll
-        for (int k = 0; k < 9; ++k) E[k] = En[k];
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) eps[i] += D[i];
-    eps[0] += c; eps[1] += c; eps[2] += c;
-    {
-        spk_f2 ev[3];
-        pk_sym_eigvals(eps, ev);
-        spk_f2 nsq = zero;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { const spk_f2 sp = pk_max(pk_expm1(ev[i]), zero); nsq += sp * sp; }
-        P.nsq = nsq;
-    }
-    spk_f2 M[6];
-    one_minus_exp_neg_series(eps, M);
-    {   // corotated_tau_e: tau = 2 mu F M F^T + lambda (J - 1) J I, F = I + E'
-        const int sidx[9] = {0, 3, 4, 3, 1, 5, 4, 5, 2};
-        spk_f2 A[9];
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-                A[i + 3 * j] = M[sidx[i + 3 * j]] + (E[i] * M[sidx[3 * j]] + (E[i + 3] * M[sidx[1 + 3 * j]] + E[i + 6] * M[sidx[2 + 3 * j]]));
-        const spk_f2 sph = P.lam * P.jm1 * (1.f + P.jm1);
-        const int ii[6] = {0, 1, 2, 0, 0, 1}, jj[6] = {0, 1, 2, 1, 2, 2};
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int a = ii[k], b = jj[k];
-            spk_f2 t = P.k2 * (A[a + 3 * b] + (A[a] * E[b] + (A[a + 3] * E[b + 3] + A[a + 6] * E[b + 6])));
-            if (k < 3) t += sph;
-            if (active) { park_lo[64 * k] = t.x; park_hi[64 * k] = t.y; }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) P.E[k] = E[k];
-    return true;
 }
 
 // SnowPlasticity::update_particle (plasticity_snow.rs:26-48)

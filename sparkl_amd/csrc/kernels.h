@@ -1489,102 +1489,6 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const MO& mo
     o.eh = eh; o.phase = phase;
     return o;
 }
-// The two halves of g2p_update around the return map, for the kernel that runs the return map on particle PAIRS (k_g2p2g<.., MSET = 2>,
-// device_math.h "packed series path"): every model a corotated solid with Drucker-Prager plasticity, no RARE code.
-struct SandMid {
-    float px[3], vel[3];   // advected position, gathered (or kinematic) velocity
-    M3 C, E;               // velocity gradient; E = F - I BEFORE the deformation-gradient update
-};
-SPK_DEV SandMid sand_mid_zero() {
-    SandMid m;
-    m.px[0] = m.px[1] = m.px[2] = 0.f; m.vel[0] = m.vel[1] = m.vel[2] = 0.f; m.C = m3_zero(); m.E = m3_zero();
-    return m;
-}
-// grid_to_particle.rs:47-86: gather, kinematic override, advection
-SPK_DEV SandMid sand_pre(const VelTile& vt, uint32_t flags, const float4& q0, const float4& q1, const float4& q2, const float4* kinvel_i, const int4& org,
-                         const StepParams& S, float inv_h) {
-    SandMid m;
-    float px[3] = {q0.x, q0.y, q0.z};
-    SPK_MARK("gather");
-    apic_gather(vt, px, org, S, inv_h, m.vel, m.C);
-    SPK_MARK("advect_F");
-    {
-        const bool kin = (flags & FLAG_KINEMATIC) != 0;
-        const float* kp = reinterpret_cast<const float*>(kinvel_i);
-        m.vel[0] = rare_load(kin, kp, m.vel[0]); m.vel[1] = rare_load(kin, kp + 1, m.vel[1]); m.vel[2] = rare_load(kin, kp + 2, m.vel[2]);
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) m.px[a] = px[a] + m.vel[a] * S.dt;
-    m.E = M3{{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
-    return m;
-}
-// grid_to_particle.rs:104-144 behind the pair return map: static, fail guards, positive energy, margin / domain checks.
-// `Ep` = E' of the mapped F, `jm1` = det F' - 1, `nsq` = sum max(sigma'_k - 1, 0)^2 (elasticity_corotated_linear.rs:105-118).
-template <class MO>
-SPK_DEV Advected sand_post(const MO& mo, uint32_t flags, const SandMid& m, const M3& Ep, float q, float lvg, float Jp, float psi, const float4& kk, float jm1, float nsq,
-                           const int4& org, const StepParams& S, float inv_h, unsigned* num_invalid) {
-    Advected o;
-    const float h = S.h;
-    const int orgv[3] = {org.x, org.y, org.z};
-    float vel[3] = {m.vel[0], m.vel[1], m.vel[2]};
-    M3 C = m.C, E = Ep;
-    const float eh = kk.z;
-    o.store_k = false; o.store_aux = false; o.alpha = 0.f;
-    o.T.valid = true; o.T.jm1 = jm1;
-    if (flags & FLAG_STATIC) { vel[0] = vel[1] = vel[2] = 0.f; C = m3_zero(); }
-    const bool zero_density = (kk.x == 0.f) || !(fabsf(jm1) < 1.0e30f);
-    bool newly_failed = false;
-    float energy;
-    {
-        const float pos_dev = mo.mu * eh * nsq;
-        const float sph = mo.lambda * eh / 2.f * jm1 * jm1;
-        energy = jm1 < 0.f ? pos_dev : pos_dev + sph;
-    }
-    if (zero_density || (flags & FLAG_FAILED) || fabsf(1.f + E.m[0]) > 1.0e4f) {
-        newly_failed = !(flags & FLAG_FAILED);
-        flags |= FLAG_FAILED;
-        E = m3_zero();
-        C = m3_zero();
-        o.T.valid = false;
-        energy = 0.f;
-    }
-    SPK_MARK("pos_energy");
-    psi = fmaxf(psi, energy);
-    SPK_MARK("tile_checks");
-    bool invalid = false, in_tile = true;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float r = round_cell(m.px[a], h, inv_h);
-        o.rnew[a] = r;
-        const bool ok = (r >= 1.0f) && (r < (float)(S.dom - 4));
-        if (!ok) invalid = true;
-        else {
-            const int nl = (int)r - 1 - orgv[a];
-            if (nl < -1 || nl > 4) in_tile = false;
-        }
-    }
-    if (invalid) {
-        newly_failed = true;
-        flags |= FLAG_FAILED | FLAG_INVALID;
-        in_tile = false;
-        atomicAdd(num_invalid, 1u);
-        atomicMin(num_invalid + (offsetof(Ctl, dead_dt_bits) - offsetof(Ctl, num_invalid)) / 4, __float_as_uint(velocity_dt_bound(vel, C, h)));
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { o.px[a] = m.px[a]; o.vel[a] = vel[a]; }
-    o.C = C; o.Fe = E; o.q = q; o.lvg = lvg; o.Jp = Jp; o.psi = psi; o.flags = flags; o.newly_failed = newly_failed; o.in_tile = in_tile;
-    o.eh = eh; o.phase = 1.f;
-    return o;
-}
-// lanes 0..31: (own value, the value of lane + 32); lanes 32..63 get a duplicate pair of the lower half (never used)
-SPK_DEV spk_f2 pair_up(int hi_addr, float x) { return spk_f2{x, bperm_f(hi_addr, x)}; }
-// the inverse: lanes 0..31 keep p.x, lanes 32..63 receive p.y of lane - 32 (v_permlane32_swap_b32: the upper half of the first operand
-// is exchanged with the lower half of the second)
-SPK_DEV float pair_down(spk_f2 p) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p.x), __float_as_uint(p.y), false, false);
-    return __uint_as_float(r[0]);
-}
-
 // `defer_c`: q[4], q[5] (C.m[1..8]) are not written; k_regather_c recomputes them if anything but the next fused launch needs
 // them (see StepParams::defer_c)
 SPK_DEV void g2p_store(const ParticleArrays& P, int i, const Advected& o, int defer_c = 0) {
@@ -1669,8 +1573,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
 #endif
 
 // REDUCE_STEPS >= 0: DPP pre-reduction over groups of 2^REDUCE_STEPS lanes (p2g_scatter); -1: run tasks (p2g_scatter_runs).
-// MSET: 0 = any model table; 1 = every model is a corotated solid with Drucker-Prager plasticity (DpSandModel: no model dispatch);
-// 2 = the same, with the return map run on particle pairs (needs LDS_MODELS)
+// MSET: 0 = any model table; 1 = every model is a corotated solid with Drucker-Prager plasticity (DpSandModel: no model dispatch)
 template <int REDUCE_STEPS, bool RARE, bool LDS_MODELS = true, int MSET = 0>
 __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
     const int tid = threadIdx.x;
@@ -1717,15 +1620,10 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
         const bool active = li < pcount;
         const int i = pfirst + (active ? li : 0);
         const float4 q0 = n0, q1 = n1, q2 = n2, dd = nd, kk = nk;
-        // the next batch's loads: at the top of the batch, or (pair kernel) behind the return map, whose register peak they would sit through --
-        // store, descriptor and scatter still lie between the request and the first use
-        auto prefetch = [&]() {
-            if (it + 1 < niter) {
-                const int inx = pfirst + min(li + BLK_THREADS, pcount - 1);
-                n0 = P.q[0][inx]; n1 = P.q[1][inx]; n2 = P.q[2][inx]; nd = P.d[inx]; nk = P.k[inx];
-            }
-        };
-        if constexpr (MSET != 2) prefetch();
+        if (it + 1 < niter) {
+            const int inx = pfirst + min(li + BLK_THREADS, pcount - 1);
+            n0 = P.q[0][inx]; n1 = P.q[1][inx]; n2 = P.q[2][inx]; nd = P.d[inx]; nk = P.k[inx];
+        }
         const uint32_t flags = __float_as_uint(kk.w);
         bool live = active && !(flags & FLAG_INVALID);
         Scatter sc;
@@ -1760,54 +1658,7 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
             const Advected o = g2p_update<RARE, true>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid, park);
             finish(mo, o);
         };
-        if constexpr (MSET == 2) {
-            // Return map on particle pairs (device_math.h, "packed series path"): gather and advection per lane, then the wave folds in
-            // two -- lane l < 32 runs F update, return map and stress for its own particle and for that of lane l + 32 as float2
-            // arithmetic -- and unfolds for the store and the scatter.  A wave holding a damaged particle (phase != 1), a model with
-            // volume_correction != 1 or a strain beyond the second series tier takes the one-particle path.
-            const int lane = tid & 63;
-            const DevModel& mo_t = s_models[live ? (flags >> FLAG_MODEL_SHIFT) : 0u];
-            const DpSandModel mo(mo_t);
-            SandMid mid = sand_mid_zero();
-            if (live) mid = sand_pre(vt, flags, q0, q1, q2, P.kinvel + i, org, S, inv_h);
-            const bool odd = live && ((flags & FLAG_PHASE_NOT_ONE) != 0u || mo.volume_correction != 1.f);
-            bool paired = false;
-            DpPair pr;
-            SPK_MARK("dp_pack");
-            if (!__any(odd)) {
-                const int hi = ((lane + 32) & 63) << 2;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) { pr.E[k] = pair_up(hi, mid.E.m[k]); pr.C[k] = pair_up(hi, mid.C.m[k]); }
-                const float eh = kk.z;
-                pr.alpha = pair_up(hi, live ? dp_alpha(mo, dd.x) : 0.f);
-                pr.lvg = pair_up(hi, live ? dd.y : 0.f);
-                pr.k2 = pair_up(hi, live ? 2.f * mo.mu * eh : 0.f);
-                pr.lam = pair_up(hi, live ? mo.lambda * eh : 0.f);
-                pr.pk = pair_up(hi, live ? mo.p_k : 0.f);
-                SPK_MARK("dp_pair");
-                paired = dp_series_pair(pr, S.dt, lane < 32, park, park + 32);
-            }
-            prefetch();
-            if (paired) {   // wave-uniform
-                SPK_MARK("dp_unpack");
-                M3 Ep;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) Ep.m[k] = pair_down(pr.E[k]);
-                const float dq = pair_down(pr.dq), dlvg = pair_down(pr.dlvg), jpf = pair_down(pr.jpf), nsq = pair_down(pr.nsq), jm1 = pair_down(pr.jm1);
-                SPK_MARK("post_dp");
-                if (live) {
-                    const Advected o = sand_post(mo, flags, mid, Ep, dd.x + dq, dd.y + dlvg, dd.z * jpf, dd.w, kk, jm1, nsq, org, S, inv_h, &ctl->num_invalid);
-                    finish(mo, o);
-                }
-#ifndef SPK_EXP_NOFALLBACK
-            } else if (live) {   // one-particle path; E is read again rather than kept in registers across the pair section
-                const float4 r0 = P.q[0][i], r1 = P.q[1][i], r2 = P.q[2][i];
-                const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
-                const Advected o = g2p_update<RARE, true>(G, vt, mo, flags, r0, r1, r2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid, park);
-                finish(mo, o);
-#endif
-            }
-        } else if (live) {
+        if (live) {
             const DevModel& mo_t = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
             if constexpr (MSET == 1) particle(DpSandModel(mo_t));
             else particle(mo_t);

@@ -547,12 +547,8 @@ static void launch_g2p2g(SparklPipeline* p, const ParticleArrays& P, const GridA
     static const bool dpp = getenv("SPARKL_HIP_SCATTER") && !strcmp(getenv("SPARKL_HIP_SCATTER"), "dpp");
     if (p->rare_models || S.project_particles) SPK_LAUNCH_MODELS(k_g2p2g, -1, true);
     else if (dpp) SPK_LAUNCH_MODELS(k_g2p2g, SPK_P2G_REDUCE_STEPS, false);
-    else if (p->all_dp_sand && S.num_models <= MAX_LDS_MODELS) {
-        // SPARKL_HIP_MSET=1: the model-specialised kernel without the pair return map (A/B); 0: the generic kernel
-        static const int mset = getenv("SPARKL_HIP_MSET") ? atoi(getenv("SPARKL_HIP_MSET")) : 1;
-        if (mset == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<-1, false, true, 1>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<-1, false, true, 2>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
-    }
+    else if (p->all_dp_sand && S.num_models <= MAX_LDS_MODELS)   // SPARKL_HIP_MSET=0 keeps the generic kernel (A/B)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<-1, false, true, 1>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
     else SPK_LAUNCH_MODELS(k_g2p2g, -1, false);
 }
 
