@@ -490,6 +490,14 @@ int sparkl_hip_substep_status(SparklPipeline* p, uint32_t* steps_done, uint32_t*
  * see sparkl_amd/slab.py).  librccl is loaded on first use (dlopen); SPARKL_ERR_UNSUPPORTED if it is absent. */
 int sparkl_hip_comm_unique_id(void* out_128_bytes);
 int sparkl_hip_comm_init(SparklPipeline* p, const void* unique_id_128_bytes, int rank, int world);
+/* One host thread driving several devices, as `CudaMpmPipeline::step(.., contexts: &mut [SingleGpuMpmContext])` does
+ * (cuda_mpm_pipeline.rs:262-271, make_current :233-237): member i (each on its own device) joins the job as rank first_rank + i; the
+ * ncclCommInitRank calls are grouped, so one thread can own all of them (sparkl_hip_comm_init per member from one thread would deadlock). */
+int sparkl_hip_comm_init_all(SparklPipeline** members, uint32_t n_members, const void* unique_id_128_bytes, int first_rank, int world);
+/* Failure behaviour of the group calls: an error on this rank aborts the communicators of its members (ncclCommAbort), so the peers'
+ * pending operations fail instead of hanging; every host wait behind an RCCL operation polls ncclCommGetAsyncError and gives up after
+ * SPARKL_HIP_COMM_TIMEOUT_S seconds (default 300, 0 = never).  After such an error the handles hold no communicator (a further group
+ * call returns an error until sparkl_hip_comm_init / _init_all gives them a new one). */
 int sparkl_hip_comm_allreduce_sum(SparklPipeline* p, long long* value);     /* host-synchronous; no-op without a communicator */
 int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params,
                               const float gravity[3], float dt, uint32_t nsubsteps);

@@ -307,6 +307,12 @@ public:
         check(sparkl_hip_slab_set(h_, &s));
     }
     void comm_init(const void* unique_id_128_bytes, int rank, int world) { check(sparkl_hip_comm_init(h_, unique_id_128_bytes, rank, world)); }
+    // one host thread, one member per device (cuda_mpm_pipeline.rs:262-271): member i becomes rank first_rank + i
+    static void comm_init_all(const std::vector<MpmPipeline*>& members, const void* unique_id_128_bytes, int first_rank, int world) {
+        std::vector<SparklPipeline*> raw;
+        for (MpmPipeline* m : members) raw.push_back(m->h_);
+        check(sparkl_hip_comm_init_all(raw.data(), (uint32_t)raw.size(), unique_id_128_bytes, first_rank, world));
+    }
     static void group_substeps(const std::vector<MpmPipeline*>& members, const SolverParameters& params, const Vector& gravity, Real dt, uint32_t n) {
         std::vector<SparklPipeline*> raw;
         for (auto* m : members) raw.push_back(m->h_);

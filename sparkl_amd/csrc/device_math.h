@@ -610,13 +610,16 @@ typedef volatile float* lds_fp;
 #else
 typedef volatile __attribute__((address_space(3))) float* lds_fp;
 #endif
+// `jm1_known`: det(F) - 1 when the caller already holds it (the series return map: expm1 of the trace of the mapped Hencky strain).
 template <class MO>
-SPK_DEV SymStress corotated_tau_e(const MO& mo, float hardening, const M3& E, const float m6[6], lds_fp park = nullptr) {
+SPK_DEV SymStress corotated_tau_e(const MO& mo, float hardening, const M3& E, const float m6[6], lds_fp park = nullptr, const float* jm1_known = nullptr) {
     const M3 M = sym6_to_m3(m6);
-    M3 A = m3_mul(E, M);                 // A = F M = M + E M
+    M3 A;                                // A = F M = M + E M, each entry one FMA chain started from M
 #pragma unroll
-    for (int k = 0; k < 9; ++k) A.m[k] += M.m[k];
-    const float jm1 = det_minus_one(E);
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) A.m[i + 3 * j] = M.m[i + 3 * j] + (E.m[i] * M.m[3 * j] + (E.m[i + 3] * M.m[3 * j + 1] + E.m[i + 6] * M.m[3 * j + 2]));
+    const float jm1 = jm1_known != nullptr ? *jm1_known : det_minus_one(E);
     const float sph = mo.lambda * hardening * jm1 * (1.f + jm1);
     const float k2 = 2.f * mo.mu * hardening;
     SymStress S;
@@ -692,6 +695,9 @@ SPK_DEV void dp_update_series(const MO& mo, float phase, float eh, const float S
     const float dn2 = (dev[0] * dev[0] + dev[1] * dev[1] + dev[2] * dev[2]) + 2.f * (dev[3] * dev[3] + dev[4] * dev[4] + dev[5] * dev[5]);
     float c = 0.f, g = 0.f, dq = 0.f;
     bool moved = false;
+    // det(F) - 1 = expm1(tr eps) comes with the volume bookkeeping below (truncation of the series: a few 1e-8 of the strain); the stress
+    // and the caller's guards take it instead of the minors of E'
+    float jm1 = expm1_small(tre);
     if (dn2 == 0.f || tr > 0.f) {            // tensile: sigma' = 1, K = -eps
         dq = fast_sqrt(dn2 + tr * tr * (1.f / 3.f));
         c = -em; g = -1.f;
@@ -707,8 +713,9 @@ SPK_DEV void dp_update_series(const MO& mo, float phase, float eh, const float S
     }
     if (moved) {
         const float so = tre, sn = tre + 3.f * c;
-        const float pm1 = expm1_small(so);
+        const float pm1 = jm1;
         float nm1 = expm1_small(sn), lnew = sn;
+        jm1 = nm1;                       // det F' = prod sigma' = exp(tr eps + 3 c), before the volume correction touches the bookkeeping
         const float diff = nm1 - pm1;
         SPK_HOT(mo.volume_correction == 1.f);
         if (!(diff > 0.f) && mo.volume_correction != 1.f) { nm1 = pm1 + diff * mo.volume_correction; lnew = log1p_small(nm1); }
@@ -728,9 +735,12 @@ SPK_DEV void dp_update_series(const MO& mo, float phase, float eh, const float S
         for (int i = 0; i < 6; ++i) G6[i] = ec * (D[i] + (0.5f * D2[i] + D34[i]));
         G6[0] += xc; G6[1] += xc; G6[2] += xc;
         const M3 G = sym6_to_m3(G6);
-        const M3 EG = m3_mul(E, G);
+        M3 En;                           // E' = E + G + E G, each entry one FMA chain started from E + G
 #pragma unroll
-        for (int i = 0; i < 9; ++i) E.m[i] += G.m[i] + EG.m[i];
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) En.m[i + 3 * j] = (E.m[i + 3 * j] + G.m[i + 3 * j]) + (E.m[i] * G.m[3 * j] + (E.m[i + 3] * G.m[3 * j + 1] + E.m[i + 6] * G.m[3 * j + 2]));
+        E = En;
 #pragma unroll
         for (int i = 0; i < 6; ++i) eps[i] += D[i];
         eps[0] += c; eps[1] += c; eps[2] += c;
@@ -745,7 +755,7 @@ SPK_DEV void dp_update_series(const MO& mo, float phase, float eh, const float S
     if (WANT_STRESS && mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR && phase == 1.f) {
         float m6[6];
         one_minus_exp_neg_series(eps, m6);
-        T = corotated_tau_e(mo, eh, E, m6, park);
+        T = corotated_tau_e(mo, eh, E, m6, park, &jm1);
     }
 }
 

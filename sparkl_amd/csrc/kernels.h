@@ -1507,6 +1507,25 @@ SPK_DEV void g2p_store(const ParticleArrays& P, int i, const Advected& o, int de
     if (o.store_aux) { float* a = reinterpret_cast<float*>(&P.aux[i]); a[0] = o.phase; a[2] = o.alpha; }
 }
 
+// The same store through block-based stream pointers (wave-uniform: SGPR pairs) and ONE 32-bit byte offset per lane shared by every 16-byte
+// stream (global_store ... v_off, s[base]): no 64-bit address arithmetic per access.  `off` = 16 x the particle's index in its block.
+template <class T>
+SPK_DEV T* at_off(T* base, unsigned off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + off); }
+SPK_DEV void g2p_store_at(const ParticleArrays& Pb, unsigned off, const Advected& o, int defer_c = 0) {
+    *at_off(Pb.q[0], off) = make_float4(o.px[0], o.px[1], o.px[2], o.Fe.m[0]);
+    *at_off(Pb.q[1], off) = make_float4(o.Fe.m[1], o.Fe.m[2], o.Fe.m[3], o.Fe.m[4]);
+    *at_off(Pb.q[2], off) = make_float4(o.Fe.m[5], o.Fe.m[6], o.Fe.m[7], o.Fe.m[8]);
+    *at_off(Pb.q[3], off) = make_float4(o.vel[0], o.vel[1], o.vel[2], o.C.m[0]);
+    if (!defer_c || (o.flags & FLAG_INVALID)) {
+        *at_off(Pb.q[4], off) = make_float4(o.C.m[1], o.C.m[2], o.C.m[3], o.C.m[4]);
+        *at_off(Pb.q[5], off) = make_float4(o.C.m[5], o.C.m[6], o.C.m[7], o.C.m[8]);
+    }
+    *at_off(Pb.d, off) = make_float4(o.q, o.lvg, o.Jp, o.psi);
+    if (o.newly_failed) reinterpret_cast<uint32_t*>(at_off(Pb.k, off))[3] = o.flags;
+    if (o.store_k) reinterpret_cast<float*>(at_off(Pb.k, off))[2] = o.eh;
+    if (o.store_aux) { float* a = reinterpret_cast<float*>(at_off(Pb.aux, off)); a[0] = o.phase; a[2] = o.alpha; }
+}
+
 template <bool RARE, bool LDS_MODELS = true>
 __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
     const int tid = threadIdx.x;
@@ -1590,10 +1609,15 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     // Software pipeline: the five float4 of the next batch are in flight while this batch computes.  The first batch is requested
     // before anything else that touches memory (abort flag, model table, velocity tile): every vector load the wave waits for
     // also waits for all older ones, so whatever is issued first pays the HBM latency for the rest.
+    // stream pointers of this block (wave-uniform) + one 32-bit byte offset per lane: see g2p_store_at
+    ParticleArrays Pb = P;
+#pragma unroll
+    for (int sidx = 0; sidx < 6; ++sidx) Pb.q[sidx] = P.q[sidx] + pfirst;
+    Pb.d = P.d + pfirst; Pb.k = P.k + pfirst; Pb.kinvel = P.kinvel + pfirst; Pb.aux = P.aux + pfirst;
     float4 n0, n1, n2, nd, nk;
     {
-        const int i0 = pfirst + min(tid, pcount - 1);
-        n0 = P.q[0][i0]; n1 = P.q[1][i0]; n2 = P.q[2][i0]; nd = P.d[i0]; nk = P.k[i0];
+        const unsigned o0 = (unsigned)min(tid, pcount - 1) << 4;
+        n0 = *at_off(Pb.q[0], o0); n1 = *at_off(Pb.q[1], o0); n2 = *at_off(Pb.q[2], o0); nd = *at_off(Pb.d, o0); nk = *at_off(Pb.k, o0);
     }
     if (ctl->abort_flag[S.parity]) {   // sticky abort: keep every later substep a no-op until the host re-bins
         if (blockIdx.x == 0 && tid == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
@@ -1618,22 +1642,30 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     for (int it = 0; it < niter; ++it) {
         const int li = it * BLK_THREADS + tid;
         const bool active = li < pcount;
-        const int i = pfirst + (active ? li : 0);
+        const unsigned off = (unsigned)(active ? li : 0) << 4;    // byte offset of this lane's particle in the block's 16-byte streams
         const float4 q0 = n0, q1 = n1, q2 = n2, dd = nd, kk = nk;
         if (it + 1 < niter) {
-            const int inx = pfirst + min(li + BLK_THREADS, pcount - 1);
-            n0 = P.q[0][inx]; n1 = P.q[1][inx]; n2 = P.q[2][inx]; nd = P.d[inx]; nk = P.k[inx];
+            const unsigned on = (unsigned)min(li + BLK_THREADS, pcount - 1) << 4;
+            n0 = *at_off(Pb.q[0], on); n1 = *at_off(Pb.q[1], on); n2 = *at_off(Pb.q[2], on); nd = *at_off(Pb.d, on); nk = *at_off(Pb.k, on);
         }
         const uint32_t flags = __float_as_uint(kk.w);
         bool live = active && !(flags & FLAG_INVALID);
+        // a lane without a live particle is never listed by the run-task scatter: only its margin bits have to be defined
         Scatter sc;
-        scatter_clear(sc);
+        if (REDUCE_STEPS < 0) {
+            float u = 0.f; int ui = 0;
+            sc.fx[0] = sc.fx[1] = sc.fx[2] = sc.val_m = sc.qv[0] = sc.qv[1] = sc.qv[2] = __builtin_nondeterministic_value(u);
+#pragma unroll
+            for (int e = 0; e < 9; ++e) sc.A.m[e] = __builtin_nondeterministic_value(u);
+            sc.base = __builtin_nondeterministic_value(ui);
+            sc.shell = 0;
+        } else scatter_clear(sc);
         const lds_fp park = (lds_fp)(&s_A[tid >> 6][0][tid & 63]);
         // behind the particle update: store, then the scatter descriptor of the advected particle
         auto finish = [&](const auto& mo, const Advected& o) {
             const bool t_valid = o.T.valid;   // the six components themselves sit in the LDS (see g2p_update's `park`)
             SPK_MARK("store");
-            g2p_store(P, i, o, S.defer_c);
+            g2p_store_at(Pb, off, o, S.defer_c);
             want_sort |= !o.in_tile && !(o.flags & FLAG_INVALID);   // a particle that left the DOMAIN is dead (skipped from now on): no re-bin for it
             live = o.in_tile;
             SPK_HOT(!S.want_dt);
@@ -1654,8 +1686,8 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
             probe_extra_work(s_A[tid >> 6], tid, o.px, o.vel, sc);   // probe_hooks.h: nothing unless an analysis build asks for it
         };
         auto particle = [&](const auto& mo) {
-            const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
-            const Advected o = g2p_update<RARE, true>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid, park);
+            const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &at_off(Pb.aux, off)->x, 1.f);
+            const Advected o = g2p_update<RARE, true>(G, vt, mo, flags, q0, q1, q2, dd, kk, at_off(Pb.kinvel, off), at_off(Pb.aux, off), phase, org, S, inv_h, &ctl->num_invalid, park);
             finish(mo, o);
         };
         if (live) {
@@ -2813,6 +2845,15 @@ __global__ void k_plane_range(const int4* __restrict__ pb_info, int npb, int axi
     const int plane = (axis == 0 ? o.x : (axis == 1 ? o.y : o.z)) >> 2;
     atomicMin(&out[0], plane);
     atomicMax(&out[1], plane);
+}
+// particles per block plane along the slab axis (index plane + 1; the block keys carry 10 bits per axis with that bias): the histogram
+// the slab cuts are re-chosen on
+__global__ void k_plane_hist(const int4* __restrict__ pb_info, int npb, int axis, long long* hist, int nplanes) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= npb) return;
+    const int4 o = pb_info[2 * j], r = pb_info[2 * j + 1];
+    const int plane = ((axis == 0 ? o.x : (axis == 1 ? o.y : o.z)) >> 2) + 1;
+    if (plane >= 0 && plane < nplanes) atomicAdd((unsigned long long*)&hist[plane], (unsigned long long)r.y);
 }
 // ---- structure validator (cuda_sparse_grid.rs:492-650 `check_active_blocks`, the reference's debug check of the binning) ----
 // counters: [0] particle ids out of range or duplicated, [1] node blocks the hash does not resolve to themselves,

@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstring>
 #include <array>
+#include <chrono>
+#include <thread>
 #include <limits>
 #include <map>
 #include <string>
@@ -140,11 +142,14 @@ struct SparklPipeline {
     // slab group stepping (sparkl_hip_group_substeps): RCCL communicator and exchange buffers live in the handle
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 1;
+    bool comm_aborted = false;   // ncclCommAbort was called on the communicator this handle held (RCCL failure path)
     DevBuf<uint8_t> x_send[2], x_recv[2], x_mig_send[2], x_mig_recv[2];
     uint64_t x_nsend[2] = {0, 0}, x_nrecv[2] = {0, 0};
     DevBuf<long long> x_dev;          // small device staging area for counts / flags
     long long* x_host = nullptr;     // pinned
     uint64_t group_rebins = 0, cut_moves = 0;
+    DevBuf<long long> bal_dev;       // plane histogram + cut list of the slab re-balancing (group_rebalance)
+    long long* bal_host = nullptr; int bal_host_words = 0;
     bool slab_balance = true;        // sparkl_hip_slab_balance
     bool all_plain_fluid = false;   // every model is a fluid without plastic / failure model: the FLUID_ONLY kernels apply
     bool all_dp_sand = false;       // every model is a corotated solid with (always active) Drucker-Prager plasticity: k_g2p2g<.., MSET = 1>
@@ -768,9 +773,10 @@ static int enqueue_fluid_batch(SparklPipeline* p, const SparklSolverParams* sp, 
     return SPARKL_OK;
 }
 
+static int comm_wait(SparklPipeline* p, hipStream_t st);   // hipStreamSynchronize that a dead RCCL peer cannot block for ever (below)
 static int read_ctl(SparklPipeline* p) {
     HIPCHK(hipMemcpyAsync(p->h_ctl, p->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, p->stream));
-    HIPCHK(hipStreamSynchronize(p->stream));
+    CHK(comm_wait(p, p->stream));
     HIPCHK(hipGetLastError());
     return SPARKL_OK;
 }
@@ -842,6 +848,7 @@ void sparkl_hip_pipeline_destroy(SparklPipeline* p) {
     for (int k = 0; k < 2; ++k) { p->x_send[k].release(); p->x_recv[k].release(); p->x_mig_send[k].release(); p->x_mig_recv[k].release(); }
     p->x_dev.release();
     if (p->x_host) (void)hipHostFree(p->x_host);
+    if (p->bal_host) (void)hipHostFree(p->bal_host);
     comm_destroy(p);
     if (p->rb_stream) { (void)hipStreamSynchronize(p->rb_stream); (void)hipStreamDestroy(p->rb_stream); (void)hipEventDestroy(p->rb_gathered); (void)hipEventDestroy(p->rb_done); }
     p->rb_staging.release();
@@ -1976,6 +1983,8 @@ struct Rccl {
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                         // optional (older librccl: absent -> hangs stay hangs)
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
 };
 static Rccl g_rccl;
 static int rccl_load() {
@@ -1988,6 +1997,8 @@ static int rccl_load() {
     SPK_SYM(GroupStart, "ncclGroupStart"); SPK_SYM(GroupEnd, "ncclGroupEnd"); SPK_SYM(Send, "ncclSend"); SPK_SYM(Recv, "ncclRecv");
     SPK_SYM(AllReduce, "ncclAllReduce"); SPK_SYM(GetErrorString, "ncclGetErrorString");
 #undef SPK_SYM
+    *(void**)(&g_rccl.CommAbort) = dlsym(h, "ncclCommAbort");
+    *(void**)(&g_rccl.CommGetAsyncError) = dlsym(h, "ncclCommGetAsyncError");
     g_rccl.lib = h;
     return SPARKL_OK;
 }
@@ -1999,6 +2010,44 @@ static int rccl_load() {
 static void comm_destroy(SparklPipeline* p) {
     if (p->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(p->comm);
     p->comm = nullptr;
+}
+// RCCL failure path.  A rank that leaves the group loop on an error would leave its peers blocked in their next collective for ever, and a
+// rank whose peer has died would sit in hipStreamSynchronize behind an RCCL kernel that never completes.  So (1) every host wait of a
+// pipeline that holds a communicator polls the stream AND ncclCommGetAsyncError, with a deadline (SPARKL_HIP_COMM_TIMEOUT_S, default 300 s),
+// and (2) any error inside a group call aborts the communicators of all members (ncclCommAbort: the peers' pending operations fail with
+// an error instead of hanging) before it is returned.  After an abort the handle has no communicator: the caller tears the job down.
+static double comm_timeout_s() {
+    static const double t = getenv("SPARKL_HIP_COMM_TIMEOUT_S") ? atof(getenv("SPARKL_HIP_COMM_TIMEOUT_S")) : 300.0;
+    return t;
+}
+static int comm_wait(SparklPipeline* p, hipStream_t st) {
+    if (!p->comm || !g_rccl.CommGetAsyncError) { HIPCHK(hipStreamSynchronize(st)); return SPARKL_OK; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return SPARKL_OK;
+        if (q != hipErrorNotReady) return set_error(SPARKL_ERR_HIP, "hipStreamQuery: %s", hipGetErrorString(q));
+        if ((spin & 255u) == 255u) {
+            ncclResult_t ar = ncclSuccess;
+            const ncclResult_t r = g_rccl.CommGetAsyncError(p->comm, &ar);
+            if (r != ncclSuccess || ar != ncclSuccess)
+                return set_error(SPARKL_ERR_HIP, "RCCL communicator of rank %d reports an asynchronous error: %s", p->comm_rank, g_rccl.GetErrorString(r != ncclSuccess ? r : ar));
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (comm_timeout_s() > 0.0 && el > comm_timeout_s())
+                return set_error(SPARKL_ERR_HIP, "rank %d waited %.0f s for its stream behind an RCCL operation (a peer is gone?): giving up (SPARKL_HIP_COMM_TIMEOUT_S)", p->comm_rank, el);
+            if (el > 0.001) std::this_thread::sleep_for(std::chrono::microseconds(50));   // short waits spin, long ones yield the core
+        }
+    }
+}
+static void group_abort(SparklPipeline** members, uint32_t n) {
+    for (uint32_t i = 0; i < n; ++i) {
+        SparklPipeline* p = members[i];
+        if (!p || !p->comm) continue;
+        (void)hipSetDevice(p->device);
+        if (g_rccl.CommAbort) (void)g_rccl.CommAbort(p->comm);
+        p->comm = nullptr;
+        p->comm_aborted = true;
+    }
 }
 
 
@@ -2059,7 +2108,7 @@ static int group_max(const Group& G, const long long* per_member, long long* out
             SparklPipeline* p = G.m[i];
             HIPCHK(hipSetDevice(p->device));
             HIPCHK(hipMemcpyAsync(p->x_host, p->x_dev.p, 2 * sizeof(long long), hipMemcpyDeviceToHost, p->stream));
-            HIPCHK(hipStreamSynchronize(p->stream));
+            CHK(comm_wait(p, p->stream));
             mx = std::max(mx, p->x_host[0]); vx = std::max(vx, p->x_host[1]);
         }
     }
@@ -2102,7 +2151,7 @@ static int group_swap_counts(const Group& G, const uint64_t (*out_counts)[2], ui
         SparklPipeline* p = G.m[i];
         HIPCHK(hipSetDevice(p->device));
         HIPCHK(hipMemcpyAsync(p->x_host, p->x_dev.p, 4 * sizeof(long long), hipMemcpyDeviceToHost, p->stream));
-        HIPCHK(hipStreamSynchronize(p->stream));
+        CHK(comm_wait(p, p->stream));
         for (int side = 0; side < 2; ++side) if (G.nbr(i, side) == -1) in_counts[i][side] = (uint64_t)p->x_host[2 + side];
     }
     return SPARKL_OK;
@@ -2135,42 +2184,88 @@ static int group_exchange(const Group& G, BufPair send, BufPair recv, const uint
     return SPARKL_OK;
 }
 
-// Load re-balancing at a collective re-bin (cuts re-chosen on the particle histogram).  Diffusive and local: the
-// two ranks of a cut see the same two (particle count, occupied block planes) pairs and move the cut by ONE block plane towards
-// the fuller side when that still leaves it the fuller one; the particles of the moved plane then travel as ordinary emigrants.
+// Load re-balancing at a collective re-bin ("cut ... chosen on the block-sorted histogram so each GPU owns ~ N / world").
+// Global: every member bins its particle blocks by block plane along the slab axis (k_plane_hist, <= 1024 planes), the histograms are summed
+// over all members and ranks together with the current cuts (one all-reduce of 1024 + world 64-bit words), and every rank derives the SAME
+// new cut list from it: cut k goes to the plane boundary whose prefix sum is nearest k N / world, at most `max_shift` planes per re-bin and
+// never past a neighbouring cut's old position -- so the particles of the planes that changed owner travel to an ADJACENT rank, as ordinary
+// emigrants of the re-bin that follows (a long way takes several re-bins).  Slabs keep at least two block planes.
+static constexpr int BAL_PLANES = 1024;
 static int group_rebalance(const Group& G) {
-    std::vector<std::array<uint64_t, 2>> mine(G.n), theirs_n(G.n), theirs_w(G.n), width(G.n);
+    const int world = G.rccl ? G.m[0]->comm_world : G.n;
+    if (world < 2) return SPARKL_OK;
+    const int words = BAL_PLANES + world;                 // histogram, then cut k (k = 1 .. world - 1) at [BAL_PLANES + k]
+    auto rank_of = [&](int i) { return G.rccl ? G.m[i]->comm_rank : i; };
+    static const int max_shift = getenv("SPARKL_HIP_BALANCE_SHIFT") ? std::max(1, atoi(getenv("SPARKL_HIP_BALANCE_SHIFT"))) : 4;
+    std::vector<long long> sum(words, 0);
     for (int i = 0; i < G.n; ++i) {
         SparklPipeline* p = G.m[i];
         HIPCHK(hipSetDevice(p->device));
-        int range[2] = {INT32_MAX, INT32_MIN};
-        if (p->num_pblocks > 0) {
-            CHK(p->d_scalars.reserve(8));
-            HIPCHK(hipMemcpyAsync(p->d_scalars.p + 4, range, sizeof(range), hipMemcpyHostToDevice, p->stream));
-            hipLaunchKernelGGL(k_plane_range, dim3(grid_for(p->num_pblocks, 256)), dim3(256), 0, p->stream, p->pb_info.p, p->num_pblocks, p->slab_axis, p->d_scalars.p + 4);
-            HIPCHK(hipMemcpyAsync(range, p->d_scalars.p + 4, sizeof(range), hipMemcpyDeviceToHost, p->stream));
-            HIPCHK(hipStreamSynchronize(p->stream));
+        CHK(p->bal_dev.reserve(words));
+        if (!p->bal_host || p->bal_host_words < words) {
+            if (p->bal_host) HIPCHK(hipHostFree(p->bal_host));
+            HIPCHK(hipHostMalloc((void**)&p->bal_host, words * sizeof(long long)));
+            p->bal_host_words = words;
         }
-        const uint64_t w = range[1] >= range[0] ? (uint64_t)(range[1] - range[0] + 1) : 0;
-        mine[i] = {p->n, p->n};
-        width[i] = {w, w};
+        memset(p->bal_host, 0, words * sizeof(long long));
+        const int r = rank_of(i);
+        if (r + 1 < world) p->bal_host[BAL_PLANES + r + 1] = (long long)p->slab_hi;   // the cut above this slab, announced by its lower rank
+        HIPCHK(hipMemcpyAsync(p->bal_dev.p, p->bal_host, words * sizeof(long long), hipMemcpyHostToDevice, p->stream));
+        if (p->num_pblocks > 0)
+            hipLaunchKernelGGL(k_plane_hist, dim3(grid_for(p->num_pblocks, 256)), dim3(256), 0, p->stream, p->pb_info.p, p->num_pblocks, p->slab_axis, p->bal_dev.p, BAL_PLANES);
     }
-    CHK(group_swap_counts(G, (const uint64_t(*)[2])mine.data(), (uint64_t(*)[2])theirs_n.data()));
-    CHK(group_swap_counts(G, (const uint64_t(*)[2])width.data(), (uint64_t(*)[2])theirs_w.data()));
+    if (G.rccl) {
+        NCCLCHK(g_rccl.GroupStart());
+        for (int i = 0; i < G.n; ++i) NCCLCHK(g_rccl.AllReduce(G.m[i]->bal_dev.p, G.m[i]->bal_dev.p, words, ncclInt64, ncclSum, G.m[i]->comm, G.m[i]->stream));
+        NCCLCHK(g_rccl.GroupEnd());
+    }
     for (int i = 0; i < G.n; ++i) {
         SparklPipeline* p = G.m[i];
-        for (int side = 0; side < 2; ++side) {
-            if (G.nbr(i, side) == -2) continue;
-            // (a, wa) = the low rank of this cut, (b, wb) = the high one: both ranks evaluate the same expression
-            const double a = side == 1 ? (double)p->n : (double)theirs_n[i][side], b = side == 1 ? (double)theirs_n[i][side] : (double)p->n;
-            const double wa = side == 1 ? (double)width[i][0] : (double)theirs_w[i][side], wb = side == 1 ? (double)theirs_w[i][side] : (double)width[i][0];
-            int shift = 0;
-            if (wa > 2.0 && a - b > 2.5 * (a / wa)) shift = -1;        // the low rank hands its top plane up
-            else if (wb > 2.0 && b - a > 2.5 * (b / wb)) shift = +1;   // the high rank hands its bottom plane down
-            if (shift == 0) continue;
-            if (side == 1) p->slab_hi += shift; else p->slab_lo += shift;
+        HIPCHK(hipSetDevice(p->device));
+        HIPCHK(hipMemcpyAsync(p->bal_host, p->bal_dev.p, words * sizeof(long long), hipMemcpyDeviceToHost, p->stream));
+        CHK(comm_wait(p, p->stream));
+        if (G.rccl) { if (i == 0) for (int w = 0; w < words; ++w) sum[w] = p->bal_host[w]; }   // every rank holds the global sum already
+        else for (int w = 0; w < words; ++w) sum[w] += p->bal_host[w];
+    }
+    // prefix[c] = particles in planes (index) < c; plane index = block plane + 1
+    std::vector<long long> prefix(BAL_PLANES + 1, 0);
+    for (int c = 0; c < BAL_PLANES; ++c) prefix[c + 1] = prefix[c] + sum[c];
+    const long long total = prefix[BAL_PLANES];
+    if (total <= 0) return SPARKL_OK;
+    int first = 0, last = BAL_PLANES - 1;
+    while (first < BAL_PLANES && sum[first] == 0) ++first;
+    while (last > first && sum[last] == 0) --last;
+    std::vector<long long> cur(world + 1), nxt(world + 1);
+    cur[0] = (long long)first - 1;                   // in block planes (index - 1); the open ends stand at the occupied range
+    cur[world] = (long long)last;                    // = (last + 1) - 1: first plane beyond the occupied range
+    for (int k = 1; k < world; ++k) cur[k] = sum[BAL_PLANES + k];
+    for (int k = 1; k < world; ++k) if (cur[k] < cur[k - 1]) return SPARKL_OK;   // cuts the histogram cannot vouch for (a slab beyond the particles): leave them
+    nxt = cur;
+    for (int k = 1; k < world; ++k) {
+        const double want = (double)total * k / world;
+        // boundary c (as a plane index: the cut sits between planes c - 1 and c) whose prefix is nearest `want`
+        long long best = cur[k] + 1;
+        double bestd = std::fabs((double)prefix[std::min<long long>(std::max<long long>(best, 0), BAL_PLANES)] - want);
+        for (long long c = std::max<long long>(cur[k] + 1 - max_shift, 0); c <= std::min<long long>(cur[k] + 1 + max_shift, BAL_PLANES); ++c) {
+            const double d = std::fabs((double)prefix[c] - want);
+            if (d < bestd - 0.5) { bestd = d; best = c; }
+        }
+        long long cut = best - 1;                                                  // back to block planes
+        cut = std::max(cut, cur[k - 1] + (k > 1 ? 0 : 2));                          // not past the old neighbouring cuts: emigrants go one rank far
+        cut = std::min(cut, cur[k + 1] - (k + 1 < world ? 0 : 2));
+        nxt[k] = cut;
+    }
+    for (int k = 1; k < world; ++k) nxt[k] = std::max(nxt[k], nxt[k - 1] + 2);     // at least two block planes per slab, low to high ...
+    for (int k = world - 1; k >= 1; --k) nxt[k] = std::min(nxt[k], nxt[k + 1] - 2); // ... and high to low
+    for (int k = 1; k < world; ++k) if (nxt[k] < nxt[k - 1] + 2 || nxt[k] > nxt[k + 1] - 2 || nxt[k] < cur[k - 1] || nxt[k] > cur[k + 1]) return SPARKL_OK;   // no room: keep the cuts
+    for (int i = 0; i < G.n; ++i) {
+        SparklPipeline* p = G.m[i];
+        const int r = rank_of(i);
+        const int lo = r == 0 ? INT32_MIN : (int)nxt[r], hi = r == world - 1 ? INT32_MAX : (int)nxt[r + 1];
+        if (lo != p->slab_lo || hi != p->slab_hi) {
+            p->cut_moves += (lo != p->slab_lo) + (hi != p->slab_hi);
+            p->slab_lo = lo; p->slab_hi = hi;
             p->sorted = false;
-            p->cut_moves++;
         }
     }
     return SPARKL_OK;
@@ -2285,10 +2380,36 @@ int sparkl_hip_comm_init(SparklPipeline* p, const void* unique_id_128_bytes, int
     CHK(rccl_load());
     HIPCHK(hipSetDevice(p->device));
     comm_destroy(p);
+    p->comm_aborted = false;
     ncclUniqueId id;
     memcpy(&id, unique_id_128_bytes, sizeof(id));
     NCCLCHK(g_rccl.CommInitRank(&p->comm, world, id, rank));
     p->comm_rank = rank; p->comm_world = world;
+    return SPARKL_OK;
+}
+/* One host thread, several devices (cuda_mpm_pipeline.rs:262-271 steps `&mut [SingleGpuMpmContext]` from one call): member i joins the job as
+ * rank first_rank + i.  The ncclCommInitRank calls sit inside ncclGroupStart / End -- issued one after the other from one thread they would
+ * deadlock, each waiting for the ranks behind it. */
+int sparkl_hip_comm_init_all(SparklPipeline** members, uint32_t n_members, const void* unique_id_128_bytes, int first_rank, int world) {
+    if (!members || n_members == 0 || !unique_id_128_bytes || world < 1 || first_rank < 0 || first_rank + (int)n_members > world)
+        return set_error(SPARKL_ERR_INVALID_ARGUMENT, "bad argument");
+    for (uint32_t i = 0; i < n_members; ++i) {
+        if (!members[i]) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null member");
+        for (uint32_t j = 0; j < i; ++j)
+            if (members[j]->device == members[i]->device) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "members %u and %u share device %d: RCCL takes one rank per device and process", j, i, members[i]->device);
+    }
+    CHK(rccl_load());
+    ncclUniqueId id;
+    memcpy(&id, unique_id_128_bytes, sizeof(id));
+    for (uint32_t i = 0; i < n_members; ++i) { HIPCHK(hipSetDevice(members[i]->device)); comm_destroy(members[i]); members[i]->comm_aborted = false; }
+    NCCLCHK(g_rccl.GroupStart());
+    for (uint32_t i = 0; i < n_members; ++i) {
+        HIPCHK(hipSetDevice(members[i]->device));
+        const ncclResult_t r = g_rccl.CommInitRank(&members[i]->comm, world, id, first_rank + (int)i);
+        if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return set_error(SPARKL_ERR_HIP, "ncclCommInitRank of member %u failed: %s", i, g_rccl.GetErrorString(r)); }
+    }
+    NCCLCHK(g_rccl.GroupEnd());
+    for (uint32_t i = 0; i < n_members; ++i) { members[i]->comm_rank = first_rank + (int)i; members[i]->comm_world = world; }
     return SPARKL_OK;
 }
 /* SUM over the ranks of the communicator of one 64-bit value (host-synchronous; the bench uses it to count its ranks) */
@@ -2301,12 +2422,26 @@ int sparkl_hip_comm_allreduce_sum(SparklPipeline* p, long long* value) {
     HIPCHK(hipMemcpyAsync(p->x_dev.p, p->x_host, sizeof(long long), hipMemcpyHostToDevice, p->stream));
     NCCLCHK(g_rccl.AllReduce(p->x_dev.p, p->x_dev.p, 1, ncclInt64, ncclSum, p->comm, p->stream));
     HIPCHK(hipMemcpyAsync(p->x_host, p->x_dev.p, sizeof(long long), hipMemcpyDeviceToHost, p->stream));
-    HIPCHK(hipStreamSynchronize(p->stream));
+    CHK(comm_wait(p, p->stream));
     *value = p->x_host[0];
     return SPARKL_OK;
 }
 
+static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params, const float gravity[3], float dt, uint32_t nsubsteps);
+static bool any_comm(SparklPipeline** members, uint32_t n) { for (uint32_t i = 0; members && i < n; ++i) if (members[i] && members[i]->comm) return true; return false; }
+static int aborted_check(SparklPipeline** members, uint32_t n) {
+    for (uint32_t i = 0; members && i < n; ++i)
+        if (members[i] && members[i]->comm_aborted) return set_error(SPARKL_ERR_HIP, "member %u: its RCCL communicator was aborted after an earlier error; create a new one (sparkl_hip_comm_init)", i);
+    return SPARKL_OK;
+}
 int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params, const float gravity[3], float dt, uint32_t nsubsteps) {
+    CHK(aborted_check(members, n_members));
+    const bool with_comm = any_comm(members, n_members);
+    const int rc = group_substeps_impl(members, n_members, params, gravity, dt, nsubsteps);
+    if (rc != SPARKL_OK && with_comm) group_abort(members, n_members);   // peers fail instead of hanging (see comm_wait)
+    return rc;
+}
+static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params, const float gravity[3], float dt, uint32_t nsubsteps) {
     if (!members || n_members == 0 || !params || !gravity) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
     Group G{members, (int)n_members, true, true};
     for (uint32_t i = 0; i < n_members; ++i) if (members[i]) G.balance = G.balance && members[i]->slab_balance;
@@ -2333,7 +2468,23 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
         std::vector<long long> v(G.n, need_rebin ? 1 : 0), veto(G.n, balance_veto(G));
         long long any = 0, no_balance = 0;
         CHK(group_max(G, v.data(), &any, veto.data(), &no_balance));
+        bool first = true;
+        for (int i = 0; i < G.n; ++i) first = first && members[i]->group_rebins == 0;
         if (any) CHK(group_rebin(G, no_balance == 0));
+        // The cuts the caller chose meet the particle histogram once, right behind the first collective re-bin (which builds the block list
+        // the histogram is taken from): a scene at rest may not ask for another re-bin for a long time.  Agreed like every re-bin.
+        std::vector<long long> v2(G.n, any && first ? 1 : 0), veto2(G.n, balance_veto(G));
+        long long any2 = 0, no_balance2 = 0;
+        CHK(group_max(G, v2.data(), &any2, veto2.data(), &no_balance2));
+        if (any2 && no_balance2 == 0) {
+            CHK(group_rebalance(G));
+            bool moved = false;
+            for (int i = 0; i < G.n; ++i) moved = moved || !members[i]->sorted;
+            std::vector<long long> v3(G.n, moved ? 1 : 0);
+            long long any3 = 0;
+            CHK(group_max(G, v3.data(), &any3));
+            if (any3) CHK(group_rebin(G, false));
+        }
     }
     struct StoreMode {   // halo records are stored, not added, while this loop owns the substeps (see k_halo_merge2)
         const Group& g;
@@ -2559,8 +2710,17 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
 // with the dt bound (timestep_estimator.rs:10-51) taken over ALL members and ranks: per substep every member exports its local
 // bound, the MIN travels through RCCL (f32 bits of a non-negative float order like the float), one host read, then one lockstep
 // substep of that length through the same loop as sparkl_hip_group_substeps.
+static int group_step_impl(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params, const float gravity[3], float* simulated_time, uint32_t* num_substeps);
 int sparkl_hip_group_step(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params, const float gravity[3], float* simulated_time,
                           uint32_t* num_substeps) {
+    CHK(aborted_check(members, n_members));
+    const bool with_comm = any_comm(members, n_members);
+    const int rc = group_step_impl(members, n_members, params, gravity, simulated_time, num_substeps);
+    if (rc != SPARKL_OK && with_comm) group_abort(members, n_members);
+    return rc;
+}
+static int group_step_impl(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params, const float gravity[3], float* simulated_time,
+                           uint32_t* num_substeps) {
     if (!members || n_members == 0 || !params || !gravity) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
     if (num_substeps) *num_substeps = 0;
     if (simulated_time) *simulated_time = params->dt;
@@ -2594,7 +2754,7 @@ int sparkl_hip_group_step(SparklPipeline** members, uint32_t n_members, const Sp
             SparklPipeline* p = members[i];
             HIPCHK(hipSetDevice(p->device));
             HIPCHK(hipMemcpyAsync(p->x_host + 16, p->x_dev.p + 16, 4, hipMemcpyDeviceToHost, p->stream));
-            HIPCHK(hipStreamSynchronize(p->stream));
+            CHK(comm_wait(p, p->stream));
             uint32_t b;
             memcpy(&b, p->x_host + 16, 4);
             bits = std::min(bits, b);
@@ -2608,7 +2768,7 @@ int sparkl_hip_group_step(SparklPipeline** members, uint32_t n_members, const Sp
         float dt = std::fmin(std::fmin(remaining, params->max_substep_dt), bound);   // timestep_estimator.rs:25,35,44
         if (dt < min_dt && remaining > min_dt) dt = min_dt;                          // mls_solver.rs:57-59
         if (!(dt > 0.0f)) return set_error(SPARKL_ERR_NAN_TIMESTEP, "substep length %g: the step cannot make progress", (double)dt);
-        CHK(sparkl_hip_group_substeps(members, n_members, params, gravity, dt, 1));
+        CHK(group_substeps_impl(members, n_members, params, gravity, dt, 1));
         ++nsub;
         remaining -= dt;
         if (params->stop_after_one_substep) { if (simulated_time) *simulated_time = dt; break; }

@@ -76,6 +76,14 @@ class MpmPipeline:
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         check(self.L.sparkl_hip_comm_init(self.h, buf, C.c_int(rank), C.c_int(world)))
 
+    @staticmethod
+    def comm_init_all(members, unique_id, first_rank, world):
+        """One host thread, one member per device: member i joins as rank first_rank + i (grouped ncclCommInitRank), the shape of
+        `CudaMpmPipeline::step(.., &mut [SingleGpuMpmContext])` (cuda_mpm_pipeline.rs:262-271)."""
+        arr = (C.c_void_p * len(members))(*[m.h for m in members])
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check(members[0].L.sparkl_hip_comm_init_all(arr, C.c_uint32(len(members)), buf, C.c_int(first_rank), C.c_int(world)))
+
     def comm_allreduce_sum(self, value):
         v = C.c_longlong(int(value))
         check(self.L.sparkl_hip_comm_allreduce_sum(self.h, C.byref(v)))

@@ -293,6 +293,57 @@ def test_group_substeps_over_rccl_world_of_one():
     assert rebins >= 2 and ex < 2e-5 and ev < 2e-4
 
 
+def test_comm_init_all_one_thread_owns_the_communicators():
+    """sparkl_hip_comm_init_all: the grouped ncclCommInitRank one host thread uses to own every device's communicator
+    (cuda_mpm_pipeline.rs:262-271 steps all contexts from one call).  One GPU here, so a world of one member: same result as the
+    plain pipeline; two members on ONE device are refused (RCCL takes one rank per device and process)."""
+    from sparkl_amd._lib import SparklHipError as SparklError
+    from sparkl_amd.pipeline import MpmPipeline
+    from sparkl_amd.slab import INT32_MAX, INT32_MIN
+    sc, dt = _scene("spin")
+    with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.set_slab(0, INT32_MIN, INT32_MAX, id_offset=0)
+        MpmPipeline.comm_init_all([p], MpmPipeline.comm_unique_id(), 0, 1)
+        assert p.comm_allreduce_sum(3) == 3
+        p.load_scene(sc)
+        MpmPipeline.group_substeps([p], sc.params, sc.gravity, dt, 20)
+        got, ids = p.read_particles(), p.read_sorted_particle_ids()
+        with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as q:
+            with pytest.raises(SparklError, match="share device"):
+                MpmPipeline.comm_init_all([p, q], MpmPipeline.comm_unique_id(), 0, 2)
+    with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, dt, 20)
+        ref = p.read_particles()
+    inv = np.argsort(ids)
+    ex = np.abs(got.position["point"][inv] - ref.position["point"]).max() / sc.cell_width
+    assert ex < 2e-5
+
+
+def test_group_error_aborts_the_communicator():
+    """RCCL failure path: an error inside a group call aborts the communicators of the members (their peers fail instead of hanging in
+    the next collective); the handle then refuses group calls until it is given a new communicator."""
+    import copy
+    from sparkl_amd._lib import SparklHipError as SparklError
+    from sparkl_amd.pipeline import MpmPipeline
+    from sparkl_amd.slab import INT32_MAX, INT32_MIN
+    sc, dt = _scene("spin")
+    with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.set_slab(0, INT32_MIN, INT32_MAX, id_offset=0)
+        p.comm_init(MpmPipeline.comm_unique_id(), 0, 1)
+        p.load_scene(sc)
+        MpmPipeline.group_substeps([p], sc.params, sc.gravity, dt, 4)
+        bad = copy.copy(sc.params)
+        bad.damage_model = 1   # DamageModel::Eigenerosion: unsupported -> the call fails on this rank
+        with pytest.raises(SparklError):
+            MpmPipeline.group_substeps([p], bad, sc.gravity, dt, 4)
+        with pytest.raises(SparklError, match="aborted"):
+            MpmPipeline.group_substeps([p], sc.params, sc.gravity, dt, 4)
+        p.comm_init(MpmPipeline.comm_unique_id(), 0, 1)          # a new communicator: back in business
+        MpmPipeline.group_substeps([p], sc.params, sc.gravity, dt, 4)
+        assert p.comm_allreduce_sum(1) == 1
+
+
 def test_group_rebalancing_moves_the_cut_and_changes_nothing(tmp_path):
     """Load re-balancing at collective re-bins: two slabs start 1 : 3 out of balance; the cut must walk towards the middle
     (block planes migrate as ordinary emigrants) and the union must still equal the un-decomposed pipeline."""
