@@ -570,8 +570,14 @@ def main(args):
                 # what a substep of the slab loop costs beyond its particle / node kernels: wall clock per substep minus their spans per
                 # sampled substep (halo pack / exchange / store, flag all-reduce, event hops, the host's look at the control block per
                 # batch).  With the overlapped schedule the kernels of the two streams run side by side, so this is a lower bound there.
-                kernel_ms = (clock.p2g_ms + clock.grid_update_ms + clock.g2p_ms + clock.g2p2g_ms + clock.p2g_mass_ms + clock.grid_update_mass_ms + clock.g2p_volume_ms) / ns
+                # per kind: mean over its WORKING launches (no-op launches behind a re-bin request are counted apart, `noop_*`) times its launches
+                # per sampled substep that did work -- dividing the sums by every sampled substep under-counts the kernels when no-ops occur
+                grid_n = max(int(clock.grid_update_launches), 1)      # one working grid update per working substep
+                kernel_ms = (clock.p2g_ms + clock.grid_update_ms + clock.g2p_ms + clock.g2p2g_ms + clock.p2g_mass_ms + clock.grid_update_mass_ms + clock.g2p_volume_ms) / min(ns, grid_n)
                 out["slab_overhead_us"] = 1e3 * (out["ms_per_step"] - kernel_ms)
+                chosen, us_inline, us_overlap = pipe.overlap_info()
+                out["overlap"] = {"chosen": chosen, "in_line_us_per_substep": us_inline, "overlapped_us_per_substep": us_overlap,
+                                  "note": "schedule of the halo chain between RCCL ranks, chosen on the MAX over the ranks of one 16-substep batch per schedule (-1: not decided / forced by SPARKL_HIP_OVERLAP)"}
         if cold is not None:
             out["cold_window"] = cold
         if late is not None:

@@ -282,6 +282,7 @@ uint64_t sparkl_hip_particles_len(const SparklPipeline* p);
  * the psi_mass / psi_momentum node transfer of particle_to_grid.rs:62-86 runs as three extra kernels per substep then. */
 int sparkl_hip_particles_set_fracture(SparklPipeline* p, const SparklParticleFracture* fracture, uint64_t n);
 int sparkl_hip_particles_read_fracture(SparklPipeline* p, SparklParticleFracture* out, uint64_t n);
+int sparkl_hip_particles_has_fracture(const SparklPipeline* p);   /* 1 once a component was uploaded (it also selects the unfused schedule, see below) */
 
 /* CudaParticleSet::read_* (cuda_particle_set.rs:91-121).  Arrays come back in CALLER order
  * (the library keeps particles physically block-sorted on the device).  `n` must equal len. */
@@ -352,8 +353,9 @@ int sparkl_hip_pipeline_sync(SparklPipeline* p);
  *     place (device only; every block under the DPP scatters, ~0.6 ms at 10M),
  *   - past `rebin_limit` a full re-bin is requested through the same abort chain a margin violation uses.
  * Limits are in heads (the cost of the remedy / the cost of one excess head).  0 = off, < 0 = built-in default
- * (reorder: 0.2 heads per particle, 0.6 when a fluid model is present; full re-bin: off).  Physical results do not depend on the policy beyond
- * f32 summation order. */
+ * (reorder: 0.2 heads per particle, 0.6 when a fluid model is present; full re-bin: off).  Physical results depend on the policy only at
+ * rounding level: the order of the f32 sums, and WHICH particles share a 64-lane wave -- the return map picks its series tier / eigenbasis
+ * path per wave (wave-uniform branches), and the paths agree to ~1e-7 of the strain, not bit for bit. */
 int sparkl_hip_reorder_policy_set(SparklPipeline* p, float reorder_limit, float rebin_limit);
 typedef struct {
     uint32_t last_heads, base_heads;      /* run heads of the last scatter / right after the last re-bin */
@@ -505,6 +507,11 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
  * substep as in the reference); returns the simulated time (params->dt, or the substep length with stop_after_one_substep) */
 int sparkl_hip_group_step(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params,
                           const float gravity[3], float* simulated_time, uint32_t* num_substeps_or_null);
+/* Halo / compute overlap of the group loop (the reference runs its halo work on a second stream, cuda_mpm_pipeline.rs:410-430).  Between
+ * RCCL ranks the schedule is chosen by measurement: the first two undisturbed 16-substep batches run in line and overlapped, the MAX over
+ * the ranks of each wall clock is taken (one all-reduce) and every rank keeps the faster one.  SPARKL_HIP_OVERLAP=0/1 forces a schedule;
+ * members of one process on one device run in line.  *chosen: 1 overlapped, 0 in line, -1 not decided yet. */
+int sparkl_hip_overlap_info(const SparklPipeline* p, int* chosen, double* us_per_substep_2);
 uint64_t sparkl_hip_group_rebins(const SparklPipeline* p);                  /* collective re-bins this member has taken part in */
 /* Load re-balancing (on by default): at a collective re-bin the two ranks of a cut compare particle counts and occupied block
  * planes and move the cut by one block plane towards the fuller side when that still leaves it the fuller one; the particles of

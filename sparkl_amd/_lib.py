@@ -25,7 +25,7 @@ SYMBOLS = [
     "sparkl_hip_slab_emigrant_count", "sparkl_hip_slab_emigrants_pack", "sparkl_hip_slab_immigrants_add", "sparkl_hip_dt_bound_export", "sparkl_hip_flags_export",
     "sparkl_hip_flags_import", "sparkl_hip_substep_begin", "sparkl_hip_halo_count", "sparkl_hip_halo_pack", "sparkl_hip_halo_merge",
     "sparkl_hip_substep_finish", "sparkl_hip_substep_finish_fused", "sparkl_hip_substep_status",
-    "sparkl_hip_comm_unique_id", "sparkl_hip_comm_init", "sparkl_hip_comm_init_all", "sparkl_hip_comm_allreduce_sum", "sparkl_hip_group_substeps", "sparkl_hip_group_step", "sparkl_hip_group_rebins", "sparkl_hip_pipeline_stream", "sparkl_hip_slab_balance", "sparkl_hip_slab_get",
+    "sparkl_hip_comm_unique_id", "sparkl_hip_comm_init", "sparkl_hip_comm_init_all", "sparkl_hip_particles_has_fracture", "sparkl_hip_overlap_info", "sparkl_hip_comm_allreduce_sum", "sparkl_hip_group_substeps", "sparkl_hip_group_step", "sparkl_hip_group_rebins", "sparkl_hip_pipeline_stream", "sparkl_hip_slab_balance", "sparkl_hip_slab_get",
 ]
 
 

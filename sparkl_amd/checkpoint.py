@@ -31,7 +31,8 @@ import numpy as np
 from . import abi
 from .particles import ParticleComponents
 
-NATIVE_VERSION = 1
+NATIVE_VERSION = 2      # 2: carries `has_fracture` / the ParticleFracture component; version 1 files (none) still load
+_LOADABLE_VERSIONS = (1, 2)
 
 
 # ------------------------------------------------------------------------------------------------ native
@@ -79,8 +80,8 @@ def load(path):
     `upload_particles` (`resume` below does)."""
     z = np.load(path)
     header = json.loads(bytes(z["header"]).decode())
-    if header.get("format") != "sparkl_amd-checkpoint" or header.get("version") != NATIVE_VERSION:
-        raise ValueError(f"{path}: not a sparkl_amd checkpoint of version {NATIVE_VERSION}")
+    if header.get("format") != "sparkl_amd-checkpoint" or header.get("version") not in _LOADABLE_VERSIONS:
+        raise ValueError(f"{path}: not a sparkl_amd checkpoint of version {_LOADABLE_VERSIONS}")
     c = ParticleComponents(0)
     for k in ParticleComponents.__slots__:
         a = z[k]
@@ -107,9 +108,12 @@ def load(path):
 
 def save_pipeline(path, pipe, model_set_or_array, params=None, simulated_time=0.0, extra=None):
     """Checkpoint of a live `MpmPipeline`: particle state, and the `ParticleFracture` component if the caller had uploaded one."""
-    fr = pipe.read_fracture()   # never uploaded: every record is the default (factor 0, threshold f32::MAX) -- not worth a component
-    if len(fr) == 0 or (not fr["crack_propagation_factor"].any() and (fr["crack_threshold"] == np.finfo(np.float32).max).all()):
-        fr = None
+    # the component travels whenever the pipeline HOLDS one, whatever its values (an all-default upload is state too: it selects the unfused
+    # schedule and is what ModifiedEigenerosion resumes with); a pipeline that never got one saves none -- under ModifiedEigenerosion the
+    # defaults are then written out explicitly, so that the resumed run sweeps cracks exactly like the original
+    fr = pipe.read_fracture() if pipe.has_fracture() else None
+    if fr is None and params is not None and int(params.damage_model) == abi.DAMAGE_MODIFIED_EIGENEROSION:
+        fr = pipe.read_fracture()
     save(path, pipe.read_particles(), model_set_or_array, pipe.cell_width, params=params, simulated_time=simulated_time, extra=extra, fracture=fr)
 
 

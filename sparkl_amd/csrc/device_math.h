@@ -735,11 +735,11 @@ SPK_DEV void dp_update_series(const MO& mo, float phase, float eh, const float S
         for (int i = 0; i < 6; ++i) G6[i] = ec * (D[i] + (0.5f * D2[i] + D34[i]));
         G6[0] += xc; G6[1] += xc; G6[2] += xc;
         const M3 G = sym6_to_m3(G6);
-        M3 En;                           // E' = E + G + E G, each entry one FMA chain started from E + G
+        M3 En;                           // E' = E + (G + E G): the small part as one FMA chain started from G, ONE rounding at the size of E
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) En.m[i + 3 * j] = (E.m[i + 3 * j] + G.m[i + 3 * j]) + (E.m[i] * G.m[3 * j] + (E.m[i + 3] * G.m[3 * j + 1] + E.m[i + 6] * G.m[3 * j + 2]));
+            for (int i = 0; i < 3; ++i) En.m[i + 3 * j] = E.m[i + 3 * j] + (G.m[i + 3 * j] + (E.m[i] * G.m[3 * j] + (E.m[i + 3] * G.m[3 * j + 1] + E.m[i + 6] * G.m[3 * j + 2])));
         E = En;
 #pragma unroll
         for (int i = 0; i < 6; ++i) eps[i] += D[i];

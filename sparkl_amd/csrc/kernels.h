@@ -137,6 +137,10 @@ struct StepParams {
     // (32 of the 112 B the kernel writes per particle) are only stored by the launch that ends the batch.  If the batch is cut
     // short (re-bin request), k_regather_c rebuilds them from the node velocities of the last substep that ran.
     int defer_c;
+    // standalone P2G kernels (DPP scatter: their heads are lane-GROUP heads, another measure than the fused run-task scatter's distinct cells):
+    // 1 = this launch feeds the disorder policy (Ctl::heads, pb_heads) -- the schedules that scatter with it every substep; 0 = it is the
+    // incidental first scatter of a fused batch and stays out of the books (the policy then only ever sees k_g2p2g's measure)
+    int count_heads;
 };
 
 struct DevCuboid {
@@ -638,6 +642,8 @@ SPK_DEV int p2g_scatter_runs(double (*tile)[ACC_N], const Scatter& sc, bool live
         bool deposit = cnt > 0;
         if (any_split) {   // wave-uniform
             const bool paired = (info & 0x10000) && valid && lane != 63;
+            // (f = 0 times a non-finite neighbour sum would be NaN: sums are finite whenever the particle state is -- a particle whose F or
+            // position has blown up is failed / invalid and scatters nothing -- and a select instead costs two more VALU per value, x 36)
             const float f = paired ? 1.f : 0.f;
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
@@ -746,6 +752,17 @@ SPK_DEV void disorder_policy(Ctl* ctl, int prev, int parity) {
     }
 }
 
+// A scatter's contribution to the disorder books: the launch total (Ctl::heads, read by the next launch's disorder_policy) and the block's own
+// record (pb_heads: .x = heads of the block's last scatter, .y = of its first one since the block was last put in order; k_block_reorder skips
+// the blocks whose count has not grown).  One thread per workgroup.
+SPK_DEV void record_heads(Ctl* ctl, const GridArrays& G, int pb, int slot, int heads) {
+    atomicAdd(&ctl->heads[slot], (uint32_t)heads);
+    int2 hd = G.pb_heads[pb];
+    hd.x = heads;
+    if (hd.y == 0) hd.y = max(heads, 1);
+    G.pb_heads[pb] = hd;
+}
+
 // One workgroup per particle block: scatter its particles into the LDS tile, write the tile once.
 template <int REDUCE_STEPS, bool LDS_MODELS = true>
 __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models,
@@ -801,7 +818,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
     }
     if ((tid & 63) == 0) atomicAdd(&s_heads, wave_heads);
     tile_write(tile, G, pb, tid, shell_used);
-    if (tid == 0) atomicAdd(&ctl->heads[S.parity], (uint32_t)s_heads);
+    if (tid == 0 && S.count_heads) record_heads(ctl, G, pb, S.parity, s_heads);
 }
 
 // k_p2g with two particles per lane (see p2g_scatter_pair).
@@ -851,7 +868,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_pair(ParticleArrays P, Grid
     }
     if ((tid & 63) == 0) atomicAdd(&s_heads, wave_heads);
     tile_write(tile, G, pb, tid, shell_used);
-    if (tid == 0) atomicAdd(&ctl->heads[S.parity], (uint32_t)s_heads);
+    if (tid == 0 && S.count_heads) record_heads(ctl, G, pb, S.parity, s_heads);
 }
 
 // ----------------------------------------------------------------------------------- grid update
@@ -1703,15 +1720,7 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     SPK_MARK("epilogue");
     if ((tid & 63) == 0) atomicAdd(&s_heads, wave_heads);
     tile_write(tile, G, pb, tid, shell_used);
-    if (tid == 0) {
-        atomicAdd(&ctl->heads[(S.parity + 1) & 1], (uint32_t)s_heads);
-        if (REDUCE_STEPS < 0) {   // per-block record (run-task scatter only: the DPP variants count group heads, another measure)
-            int2 hd = G.pb_heads[pb];
-            hd.x = s_heads;
-            if (hd.y == 0) hd.y = max(s_heads, 1);
-            G.pb_heads[pb] = hd;
-        }
-    }
+    if (tid == 0) record_heads(ctl, G, pb, (S.parity + 1) & 1, s_heads);   // (the host clears the books when the measure changes: heads_kind)
     if (__any(want_sort)) {
         if ((tid & 63) == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
     }

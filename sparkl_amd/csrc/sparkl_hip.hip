@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <array>
 #include <chrono>
 #include <thread>
@@ -125,6 +126,10 @@ struct SparklPipeline {
     // hide; off for the members of one process on one device, where the cross-stream events cost more than they hide: 2 slabs of 10 M
     // on one MI355X 1.19 ms per substep in line, 1.23 overlapped), 0 / 1 = SPARKL_HIP_OVERLAP forces it
     int overlap_mode = -1;
+    // automatic mode between RCCL ranks: the first two undisturbed 16-substep batches are timed, one per schedule, the MAX over the ranks of
+    // each time is taken and the faster schedule kept on every rank (0 = nothing measured, 1 = in line measured, 2 = decided)
+    int overlap_cal_state = 0, overlap_choice = -1;
+    double overlap_cal_us[2] = {0.0, 0.0};   // per substep: [0] in line, [1] overlapped
     hipStream_t halo_stream = nullptr;
     hipEvent_t ev_main = nullptr, ev_halo = nullptr, ev_flag = nullptr, ev_grid = nullptr, ev_xfer = nullptr;
     // Tile carry-over between fixed-dt batches and calls: the LAST substep of a fused batch also runs k_g2p2g (complete state stored), so
@@ -151,6 +156,7 @@ struct SparklPipeline {
     DevBuf<long long> bal_dev;       // plane histogram + cut list of the slab re-balancing (group_rebalance)
     long long* bal_host = nullptr; int bal_host_words = 0;
     bool slab_balance = true;        // sparkl_hip_slab_balance
+    int heads_kind = -1;            // which scatter's measure the disorder books hold (note_heads_kind)
     bool all_plain_fluid = false;   // every model is a fluid without plastic / failure model: the FLUID_ONLY kernels apply
     bool all_dp_sand = false;       // every model is a corotated solid with (always active) Drucker-Prager plasticity: k_g2p2g<.., MSET = 1>
     bool mass_tiles_ready = false;  // k_g2p_mass of the previous substep already scattered the next volume sweep's masses
@@ -439,6 +445,7 @@ static int resort(SparklPipeline* p) {
             CHK(p->blk_nbr.reserve((size_t)nb * 27)); CHK(p->blk_tnbr.reserve((size_t)nb * 27)); CHK(p->pblk.reserve(npb)); CHK(p->pb_info.reserve((size_t)npb * 2)); CHK(p->tile_mode.reserve(npb));
             CHK(p->pb_heads.reserve(npb));
             HIPCHK(hipMemsetAsync(p->pb_heads.p, 0, (size_t)npb * sizeof(int2), st));   // new binning: every block is in order, baselines not taken yet
+            p->heads_kind = -1;
             CHK(p->tiles.reserve((size_t)npb * TILE_N)); CHK(p->node_vel.reserve((size_t)nb * 64));
             if (p->capture_mom) CHK(p->node_mom.reserve((size_t)nb * 64));
             HashTable H{p->hash_keys.p, p->hash_vals.p, p->hash_mask};
@@ -465,7 +472,9 @@ static int resort(SparklPipeline* p) {
                     hipLaunchKernelGGL(k_halo_list, dim3(grid_for(nb, 256)), dim3(256), 0, st, p->blk_origin.p, p->blk_nbr.p, nb, p->slab_axis, cut, p->halo_list[side].p, p->d_scalars.p + 2 + side);
                     HIPCHK(hipMemcpyAsync(&p->halo_count[side], p->d_scalars.p + 2 + side, sizeof(int), hipMemcpyDeviceToHost, st));
                 }
-                // interior / cut-adjacent split (stable: both parts keep the Morton order the XCD mapping relies on)
+                // interior / cut-adjacent split: the cut-adjacent part keeps the Morton order, the interior part comes out in REVERSE Morton order
+                // (DevicePartition::Flagged writes the rejected items back to front) -- still one contiguous run of space per XCD chunk, which is
+                // all the XCD mapping needs (speed only)
                 {
                     const int m = std::max(nb, npb);
                     CHK(p->split_flags.reserve((size_t)2 * m));
@@ -509,6 +518,7 @@ static StepParams make_params(const SparklPipeline* p, const SparklSolverParams*
     S.parity = (int)(p->substep_index & 1u); S.dom = p->dom; S.num_cuboids = p->num_cuboids; S.num_heightfields = p->num_heightfields; S.num_trimeshes = p->num_trimeshes; S.want_dt = 0; S.defer_c = 0;
     S.project_particles = sp->enable_boundary_particle_projection ? 1 : 0;
     S.dt_next = dt;
+    S.count_heads = 1;
     S.num_models = (int)p->h_models.size();
     return S;
 }
@@ -532,7 +542,22 @@ static void launch_grid_update(SparklPipeline* p, const GridArrays& G, const Ste
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<__VA_ARGS__, false>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);                                \
     } while (0)
 
-static void launch_p2g(SparklPipeline* p, const ParticleArrays& P, const GridArrays& G, const StepParams& S, hipStream_t st) {
+// The disorder books (Ctl::heads_base / excess_acc, pb_heads) hold ONE measure at a time: 0 = lane-group heads of the standalone DPP scatters,
+// 1 = distinct cells per wave of the fused run-task scatter.  A scatter that feeds them with the other measure starts them afresh
+// (stream-ordered memsets); a re-bin clears them anyway (heads_kind = -1).
+static void note_heads_kind(SparklPipeline* p, int kind, hipStream_t st) {
+    if (p->heads_kind == kind) return;
+    if (p->heads_kind >= 0 && p->num_pblocks > 0) {
+        (void)hipMemsetAsync(p->pb_heads.p, 0, (size_t)p->num_pblocks * sizeof(int2), st);
+        (void)hipMemsetAsync(&p->d_ctl->heads_base, 0, 2 * sizeof(uint32_t), st);   // heads_base, excess_acc
+    }
+    p->heads_kind = kind;
+}
+// `counts`: the launch feeds the disorder policy (StepParams::count_heads)
+static void launch_p2g(SparklPipeline* p, const ParticleArrays& P, const GridArrays& G, const StepParams& S_in, hipStream_t st, bool counts) {
+    StepParams S = S_in;
+    S.count_heads = counts ? 1 : 0;
+    if (counts) note_heads_kind(p, 0, st);
     const dim3 grid(p->num_pblocks), block(BLK_THREADS);
     // standalone P2G (adaptive-dt substeps, first substep of a fused batch): two particles per lane, 0.38 -> 0.357 ms at 10M.
     // SPARKL_HIP_P2G_PAIR=0 selects the one-particle-per-lane kernel (A/B).
@@ -548,6 +573,7 @@ static void launch_g2p(SparklPipeline* p, const ParticleArrays& P, const GridArr
 }
 static void launch_g2p2g(SparklPipeline* p, const ParticleArrays& P, const GridArrays& G, const StepParams& S, hipStream_t st) {
     const dim3 grid(G.pb_list ? G.pb_count : p->num_pblocks), block(BLK_THREADS);   // the whole list or the launch's subset (slab groups)
+    note_heads_kind(p, (getenv("SPARKL_HIP_SCATTER") && !strcmp(getenv("SPARKL_HIP_SCATTER"), "dpp")) ? 0 : 1, st);
     // SPARKL_HIP_SCATTER=dpp selects the DPP pre-reduction scatter (A/B); the default is the run-task scatter
     static const bool dpp = getenv("SPARKL_HIP_SCATTER") && !strcmp(getenv("SPARKL_HIP_SCATTER"), "dpp");
     if (p->rare_models || S.project_particles) SPK_LAUNCH_MODELS(k_g2p2g, -1, true);
@@ -607,7 +633,7 @@ static int enqueue_substep(SparklPipeline* p, const SparklSolverParams* sp, cons
     if (p->clock_on) p->clock_sampled++;
     CHK(maybe_reorder(p, S.parity));
     CHK(clock_begin(p, SPAN_P2G, &t0));
-    launch_p2g(p, P, G, S, st);
+    launch_p2g(p, P, G, S, st, true);       // the unfused schedule scatters with it every substep
     CHK(clock_end(p, t0));
     CHK(clock_begin(p, SPAN_GRID, &t1));
     launch_grid_update(p, G, S, st);
@@ -639,7 +665,7 @@ static int enqueue_adaptive_substep(SparklPipeline* p, const SparklSolverParams*
     CHK(maybe_reorder(p, S.parity));
     if (!reuse_tiles) {
         CHK(clock_begin(p, SPAN_P2G, &t0));
-        launch_p2g(p, P, G, S, st);
+        launch_p2g(p, P, G, S, st, !(dt_guess > 0.f));   // counts in the per-substep (bound-limited) regime, not as the odd scatter between fused ones
         CHK(clock_end(p, t0));
     }
     CHK(clock_begin(p, SPAN_GRID, &t1));
@@ -680,7 +706,7 @@ static int enqueue_fused_batch(SparklPipeline* p, const SparklSolverParams* sp, 
         const StepParams S = make_params(p, sp, g, dt);
         if (was_on && (p->substep_index % p->clock_stride) != 0) p->clock_on = false;
         CHK(clock_begin(p, SPAN_P2G, &tk));
-        launch_p2g(p, P, G, S, st);
+        launch_p2g(p, P, G, S, st, false);
         CHK(clock_end(p, tk));
         p->clock_on = was_on;
     }
@@ -807,7 +833,7 @@ int sparkl_hip_pipeline_create(const SparklPipelineDesc* desc, SparklPipeline** 
     p->fuse_fixed_dt = getenv("SPARKL_HIP_NO_FUSE") == nullptr;
     p->defer_c = !(getenv("SPARKL_HIP_DEFER_C") && !strcmp(getenv("SPARKL_HIP_DEFER_C"), "0"));
     if (const char* e = getenv("SPARKL_HIP_CARRY")) p->carry_on = atoi(e) != 0;
-    if (const char* e = getenv("SPARKL_HIP_OVERLAP")) p->overlap_mode = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("SPARKL_HIP_OVERLAP")) p->overlap_mode = !strcmp(e, "cal") ? -2 : (atoi(e) != 0 ? 1 : 0);   // "cal": calibrate even on one device (tests)
     p->lookahead = !(getenv("SPARKL_HIP_LOOKAHEAD") && !strcmp(getenv("SPARKL_HIP_LOOKAHEAD"), "0"));
     p->lookahead_force = getenv("SPARKL_HIP_LOOKAHEAD") && !strcmp(getenv("SPARKL_HIP_LOOKAHEAD"), "force");
     p->device = desc->device_id;
@@ -1320,6 +1346,9 @@ int sparkl_hip_particles_set_fracture(SparklPipeline* p, const SparklParticleFra
     HIPCHK(hipStreamSynchronize(p->stream));
     return SPARKL_OK;
 }
+/* 1 when the caller has uploaded a ParticleFracture component (sparkl_hip_particles_set_fracture; slab groups under ModifiedEigenerosion
+ * create a default one themselves), 0 when every particle still holds the default */
+int sparkl_hip_particles_has_fracture(const SparklPipeline* p) { return p && p->cur.has_frac ? 1 : 0; }
 int sparkl_hip_particles_read_fracture(SparklPipeline* p, SparklParticleFracture* out, uint64_t n) {
     READ_PROLOGUE
     if (!p->cur.has_frac) {   // never uploaded: every particle holds the default
@@ -1851,7 +1880,7 @@ int sparkl_hip_substep_begin(SparklPipeline* p, const SparklSolverParams* params
     if (params->force_fluids_volume_recomputation && p->any_fluid && !p->halo_store_mode) CHK(enqueue_fluid_volumes(p, p->pending));
     size_t t0 = 0;
     CHK(clock_begin(p, SPAN_P2G, &t0));
-    launch_p2g(p, p->cur.arrays(), G, p->pending, st);
+    launch_p2g(p, p->cur.arrays(), G, p->pending, st, !p->fuse_fixed_dt);   // split-phase / group loop: the fused finish scatters from then on
     CHK(clock_end(p, t0));
     return SPARKL_OK;
 }
@@ -2427,7 +2456,10 @@ int sparkl_hip_comm_allreduce_sum(SparklPipeline* p, long long* value) {
     return SPARKL_OK;
 }
 
-static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params, const float gravity[3], float dt, uint32_t nsubsteps);
+// `pick_dt` (adaptive steps): called once per substep BEHIND the fluid volume sweep of that substep and before its scatter; returns the length
+// the substep is run with (mls_solver.rs:46-59: volumes, then the estimate, then the substep)
+typedef std::function<int(float*)> PickDt;
+static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params, const float gravity[3], float dt, uint32_t nsubsteps, const PickDt* pick_dt = nullptr);
 static bool any_comm(SparklPipeline** members, uint32_t n) { for (uint32_t i = 0; members && i < n; ++i) if (members[i] && members[i]->comm) return true; return false; }
 static int aborted_check(SparklPipeline** members, uint32_t n) {
     for (uint32_t i = 0; members && i < n; ++i)
@@ -2441,7 +2473,7 @@ int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, cons
     if (rc != SPARKL_OK && with_comm) group_abort(members, n_members);   // peers fail instead of hanging (see comm_wait)
     return rc;
 }
-static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params, const float gravity[3], float dt, uint32_t nsubsteps) {
+static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params, const float gravity[3], float dt, uint32_t nsubsteps, const PickDt* pick_dt) {
     if (!members || n_members == 0 || !params || !gravity) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
     Group G{members, (int)n_members, true, true};
     for (uint32_t i = 0; i < n_members; ++i) if (members[i]) G.balance = G.balance && members[i]->slab_balance;
@@ -2493,14 +2525,30 @@ static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, con
     } store_mode(G);
     std::vector<uint32_t> base(G.n);
     for (int i = 0; i < G.n; ++i) { HIPCHK(hipSetDevice(members[i]->device)); CHK(read_ctl(members[i])); base[i] = members[i]->h_ctl->steps_done; }
-    G.overlap = !fluid_sweep && !psi_sweep;
-    for (int i = 0; i < G.n; ++i) G.overlap = G.overlap && (members[i]->overlap_mode < 0 ? G.rccl && members[i]->comm_world > 1 : members[i]->overlap_mode == 1);
-    if (G.overlap) for (int i = 0; i < G.n; ++i) CHK(overlap_resources(members[i]));
+    // Halo / compute overlap: forced by SPARKL_HIP_OVERLAP, else decided by measurement between RCCL ranks (never on one device: see
+    // overlap_mode).  The two-stream schedule uses ONE communicator from two streams (the flag all-reduce and the halo Send / Recv on the
+    // halo stream; the host-synchronous reductions around re-bins on the main stream): correct because every rank issues the same
+    // operations in the same order and the two streams are joined at the end of every substep.
+    const bool overlap_legal = !fluid_sweep && !psi_sweep;
+    bool overlap_auto = overlap_legal;
+    bool overlap_forced = overlap_legal;
+    for (int i = 0; i < G.n; ++i) {
+        overlap_auto = overlap_auto && (members[i]->overlap_mode == -2 || (members[i]->overlap_mode < 0 && G.rccl && members[i]->comm_world > 1));
+        overlap_forced = overlap_forced && members[i]->overlap_mode == 1;
+    }
+    auto schedule_of_batch = [&]() {   // identical on every rank: the calibration state only advances on collectively agreed facts
+        if (!overlap_auto) return overlap_forced;
+        const SparklPipeline* m0 = members[0];
+        return m0->overlap_cal_state == 2 ? m0->overlap_choice == 1 : m0->overlap_cal_state == 1;
+    };
     uint32_t done = 0;
     int guard = 0;
     std::vector<std::array<uint64_t, 2>> bs(G.n), br(G.n);
     while (done < nsubsteps) {
         const uint32_t batch = std::min<uint32_t>(16, nsubsteps - done);
+        G.overlap = schedule_of_batch();
+        if (G.overlap) for (int i = 0; i < G.n; ++i) CHK(overlap_resources(members[i]));
+        const auto batch_t0 = std::chrono::steady_clock::now();
         for (uint32_t j = 0; j < batch; ++j) {
             // 1. the re-bin request of the upcoming substep, MAX over every slab: all ranks skip the same substeps.  In place on the
             //    control blocks: one 4-byte all-reduce (RCCL) or one single-thread kernel (members of one process)
@@ -2595,6 +2643,7 @@ static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, con
                     hipLaunchKernelGGL(k_g2p_volume, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, p->stream, p->cur.arrays(), Gm, p->d_models.p, p->d_ctl, p->pending);
                 }
             }
+            if (pick_dt) CHK((*pick_dt)(&dt));   // adaptive: the length of THIS substep, estimated on the volumes the sweep has just rewritten
             for (int i = 0; i < G.n; ++i) CHK(sparkl_hip_substep_begin(members[i], params, gravity, dt));
             // the fused kernel also closes a batch that another one follows inside this call: the next batch then starts from its tiles
             // instead of a standalone P2G (0.35 + 0.34 -> 0.5 ms per 16 substeps at 10M).  That launch stores C in full (`defer`): the host
@@ -2698,6 +2747,22 @@ static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, con
         std::vector<long long> veto(G.n, balance_veto(G));
         long long no_balance = 0;
         CHK(group_max(G, needs.data(), &need, veto.data(), &no_balance));
+        if (overlap_auto && members[0]->overlap_cal_state < 2 && batch == 16 && ran == done + batch && !need) {
+            // an undisturbed batch: its wall clock (enqueue to control-block read) is this schedule's sample
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - batch_t0).count() / batch;
+            const int which = members[0]->overlap_cal_state;   // 0: this batch ran in line, 1: overlapped
+            for (int i = 0; i < G.n; ++i) { members[i]->overlap_cal_us[which] = us; members[i]->overlap_cal_state = which + 1; }
+            if (which == 1) {
+                std::vector<long long> a(G.n), b(G.n);
+                for (int i = 0; i < G.n; ++i) { a[i] = (long long)(members[i]->overlap_cal_us[0] * 1000.0); b[i] = (long long)(members[i]->overlap_cal_us[1] * 1000.0); }
+                long long amax = 0, bmax = 0;
+                CHK(group_max(G, a.data(), &amax, b.data(), &bmax));   // the slowest rank sets the pace of either schedule
+                for (int i = 0; i < G.n; ++i) {
+                    members[i]->overlap_cal_us[0] = amax * 1e-3; members[i]->overlap_cal_us[1] = bmax * 1e-3;
+                    members[i]->overlap_choice = bmax < amax ? 1 : 0;
+                }
+            }
+        }
         done = ran;
         if (need) {
             CHK(group_rebin(G, no_balance == 0));
@@ -2730,14 +2795,11 @@ static int group_step_impl(SparklPipeline** members, uint32_t n_members, const S
         if (!members[i]) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null member");
         rccl = rccl && members[i]->comm != nullptr;
     }
-    // mls_solver.rs:46-48 recomputes the fluid volumes BEFORE the dt estimate of every substep; the bound exported below is taken
-    // before the sweep that sparkl_hip_group_substeps runs: not the reference's sequence, so refused rather than approximated
-    if (params->force_fluids_volume_recomputation) return set_error(SPARKL_ERR_UNSUPPORTED, "adaptive group step with force_fluids_volume_recomputation: use sparkl_hip_group_substeps");
     const float min_dt = params->dt / (float)params->max_num_substeps;
     float remaining = params->dt;
     uint32_t nsub = 0;
-    while (remaining > 0.0f) {
-        // a member that still has to bin its particles does so inside group_substeps(0 substeps are not possible): bin first
+    // the dt bound over ALL members and ranks (timestep_estimator.rs:10-51), then the substep length (mls_solver.rs:33-59)
+    auto pick = [&](float* out) -> int {
         uint32_t bits = 0x7f7fffffu;
         for (uint32_t i = 0; i < n_members; ++i) {
             SparklPipeline* p = members[i];
@@ -2768,7 +2830,23 @@ static int group_step_impl(SparklPipeline** members, uint32_t n_members, const S
         float dt = std::fmin(std::fmin(remaining, params->max_substep_dt), bound);   // timestep_estimator.rs:25,35,44
         if (dt < min_dt && remaining > min_dt) dt = min_dt;                          // mls_solver.rs:57-59
         if (!(dt > 0.0f)) return set_error(SPARKL_ERR_NAN_TIMESTEP, "substep length %g: the step cannot make progress", (double)dt);
-        CHK(group_substeps_impl(members, n_members, params, gravity, dt, 1));
+        *out = dt;
+        return SPARKL_OK;
+    };
+    const PickDt pick_fn = pick;
+    while (remaining > 0.0f) {
+        float dt = 0.0f;
+        if (params->force_fluids_volume_recomputation) {
+            // mls_solver.rs:46-48 recomputes the fluid volumes BEFORE the dt estimate of every substep: the group loop runs the sweep
+            // (mass planes across the cuts) and asks for the length behind it, in front of the scatter of the same substep.  A substep
+            // that a re-bin request turns into a no-op is repeated by the loop, estimate included; the last answer is the one that ran.
+            dt = std::fmin(remaining, params->max_substep_dt);
+            const PickDt behind_sweep = [&](float* out) -> int { CHK(pick(out)); dt = *out; return SPARKL_OK; };
+            CHK(group_substeps_impl(members, n_members, params, gravity, dt, 1, &behind_sweep));
+        } else {
+            CHK(pick_fn(&dt));
+            CHK(group_substeps_impl(members, n_members, params, gravity, dt, 1));
+        }
         ++nsub;
         remaining -= dt;
         if (params->stop_after_one_substep) { if (simulated_time) *simulated_time = dt; break; }
@@ -2777,6 +2855,14 @@ static int group_step_impl(SparklPipeline** members, uint32_t n_members, const S
     return SPARKL_OK;
 }
 uint64_t sparkl_hip_group_rebins(const SparklPipeline* p) { return p ? p->group_rebins : 0; }
+/* schedule of the slab-group loop between RCCL ranks: *chosen = 1 overlapped, 0 in line, -1 not decided yet (or forced by SPARKL_HIP_OVERLAP:
+ * then the forced value); us_per_substep[2] = the MAX over the ranks of the calibration batches, in line and overlapped (0 before) */
+int sparkl_hip_overlap_info(const SparklPipeline* p, int* chosen, double* us_per_substep_2) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    if (chosen) *chosen = p->overlap_mode >= 0 ? p->overlap_mode : (p->overlap_cal_state == 2 ? p->overlap_choice : -1);
+    if (us_per_substep_2) { us_per_substep_2[0] = p->overlap_cal_us[0]; us_per_substep_2[1] = p->overlap_cal_us[1]; }
+    return SPARKL_OK;
+}
 int sparkl_hip_slab_balance(SparklPipeline* p, int enable) {
     if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
     p->slab_balance = enable != 0;

@@ -84,6 +84,17 @@ class MpmPipeline:
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         check(members[0].L.sparkl_hip_comm_init_all(arr, C.c_uint32(len(members)), buf, C.c_int(first_rank), C.c_int(world)))
 
+    def has_fracture(self):
+        """True once a `ParticleFracture` component was uploaded (set_fracture): part of the state a checkpoint must carry."""
+        return bool(self.L.sparkl_hip_particles_has_fracture(self.h))
+
+    def overlap_info(self):
+        """(chosen, in_line_us, overlapped_us): the group loop's schedule between RCCL ranks (1 overlapped, 0 in line, -1 undecided) and the
+        per-substep wall clock of the two calibration batches (MAX over the ranks)."""
+        ch, us = C.c_int(-1), (C.c_double * 2)()
+        check(self.L.sparkl_hip_overlap_info(self.h, C.byref(ch), us))
+        return int(ch.value), float(us[0]), float(us[1])
+
     def comm_allreduce_sum(self, value):
         v = C.c_longlong(int(value))
         check(self.L.sparkl_hip_comm_allreduce_sum(self.h, C.byref(v)))

@@ -53,8 +53,10 @@ def parity_verdict(got, ref32, ref64, h, x_storage_steps=0, arbiter="f64"):
         eps_v(HIP vs f32 oracle)  <=  eps_v(f32 oracle vs f64 oracle) + 1e-4      (the triangle through the arbiter, no slack beyond it)
 
     `x_storage_steps` (the full-size cases only, tests/test_gpu_full_size_parity.py): the position bound becomes
-    1e-4 + position_storage_allowance(ref64, h, x_storage_steps) -- f32 coordinates of ~10 m cannot hold 1e-4 h over 100 substeps
-    in ANY f32 implementation, the reference's included; the velocity bound is unchanged.
+    1e-4 + min(position_storage_allowance(ref64, h, x_storage_steps), 2 eps_x(f32 oracle vs f64 oracle) - 1e-4) -- f32 coordinates of
+    ~10 m cannot hold 1e-4 h over 100 substeps in ANY f32 implementation, the reference's included, but the slack is tied to what the
+    reference's own arithmetic measurably loses on the case (reported as `x_storage_allowance`), never the worst case alone; the velocity
+    bound is unchanged.
 
     `arbiter="either"` (the 2 M-particle fluid case only): the velocity bound holds against the f64 OR the f32 oracle.  A weakly
     compressible fluid turns the f32 rounding of the node masses (1e-7) into pressure noise (p0 gamma = 7e6 times that), and after
@@ -66,7 +68,10 @@ def parity_verdict(got, ref32, ref64, h, x_storage_steps=0, arbiter="f64"):
     vs32 = particle_errors(got, ref32, h)
     vs64 = particle_errors(got, ref64, h)
     floor = particle_errors(ref32, ref64, h)
-    tol_x = TOL + (position_storage_allowance(ref64, h, x_storage_steps) if x_storage_steps else 0.0)
+    # the storage allowance is a worst-case drift; what the reference's own f32 arithmetic really lost is measured right here (the f32
+    # oracle against the f64 one): the allowance is capped at twice that, so a case whose f32 reference holds 1e-4 gets no slack at all
+    allowance = min(position_storage_allowance(ref64, h, x_storage_steps), max(2.0 * floor["eps_x"] - TOL, 0.0)) if x_storage_steps else 0.0
+    tol_x = TOL + allowance
     bad = []
     if vs64["failed_mismatch"] or vs32["failed_mismatch"]:
         bad.append(f"failed flags differ ({vs32['failed_mismatch']} vs f32, {vs64['failed_mismatch']} vs f64)")
@@ -77,7 +82,8 @@ def parity_verdict(got, ref32, ref64, h, x_storage_steps=0, arbiter="f64"):
         bad.append(f"eps_x vs f32 oracle {vs32['eps_x']:.3e} > {tol_x:.3e}")
     if not vs32["eps_v"] <= floor["eps_v"] + TOL:
         bad.append(f"eps_v vs f32 oracle {vs32['eps_v']:.3e} > eps_v(f32 vs f64 oracle) {floor['eps_v']:.3e} + 1e-4")
-    return {"vs_f32": vs32, "vs_f64": vs64, "oracle_f32_vs_f64": floor, "tol_x": tol_x}, bad
+    return {"vs_f32": vs32, "vs_f64": vs64, "oracle_f32_vs_f64": floor, "tol_x": tol_x, "x_storage_allowance": allowance,
+            "x_storage_allowance_worst_case": position_storage_allowance(ref64, h, x_storage_steps) if x_storage_steps else 0.0}, bad
 
 
 def node_errors(got, ref):

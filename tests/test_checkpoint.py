@@ -96,6 +96,24 @@ def test_bincode_layout_round_trip_and_sizes():
         checkpoint.load_bincode(pb + b"\\0", mb)
 
 
+def test_version_1_checkpoints_still_load(tmp_path):
+    """NATIVE_VERSION 2 added the ParticleFracture component; a version-1 file (no component) must keep loading."""
+    import json
+    sc = scenes.sand_column(4, 4, 4, with_block=False)
+    path = tmp_path / "v2.npz"
+    checkpoint.save(path, sc.particles, sc.models, sc.cell_width)
+    z = dict(np.load(path, allow_pickle=False))
+    header = json.loads(bytes(z["header"]).decode())
+    assert header["version"] == checkpoint.NATIVE_VERSION == 2
+    header["version"] = 1
+    header.pop("has_fracture", None)
+    z["header"] = np.frombuffer(json.dumps(header).encode(), dtype=np.uint8)
+    old = tmp_path / "v1.npz"
+    np.savez(old, **z)
+    c, models, h1, params = checkpoint.load(old)
+    assert h1["version"] == 1 and h1["fracture"] is None and len(c) == len(sc.particles)
+
+
 def test_native_checkpoint_carries_the_fracture_component(tmp_path):
     """ParticleFracture (crack_propagation_factor, crack_threshold) rides in the native checkpoint; a ModifiedEigenerosion checkpoint
     without it is refused (it would resume with the crack sweep silently off)."""

@@ -5,7 +5,9 @@ substep counts are what it finishes in about a minute per case.  Position bound:
 the scene's largest coordinate (tests/parity.py::position_storage_allowance: 3.2e-4 for the 10.8 m cube over 100 substeps -- the f32
 oracle itself is 3.9e-4 from the f64 trajectory there); velocity bound: the plain 1e-4.
   configs[1]  1 M neo-Hookean cube       x 100 substeps
-  configs[2] 10 M Drucker-Prager column  x  10 substeps
+  configs[2] 10 M Drucker-Prager column  x  30 substeps
+  a 1 M-particle FLOWING Drucker-Prager column (sheared from the start) x 100 substeps: in-place reorders, re-bins, grouped (unsorted) waves,
+              both series tiers and the eigenbasis path of the return map meet the oracle at size
   configs[3]  2 M-particle slice of the 20 M fluid dam (64 ppc, volume recompute sweep) x 100 substeps (after 10 the dam has
               barely started to move: max |v| = 0.02 m/s, and eps_v -- relative to it -- only measures the f32 noise of the stiff
               equation of state, 3.5e-4 for the HIP path and 4.2e-4 for the f32 oracle alike)"""
@@ -67,10 +69,61 @@ def test_config2_neo_hookean_1M_100_substeps_vs_oracle():
     _case("full_size_neo1m_k100", sc, 100)
 
 
-def test_config3_drucker_prager_10M_10_substeps_vs_oracle():
+def test_config3_drucker_prager_10M_30_substeps_vs_oracle():
     sc = scenes.baseline_config(2)
     assert len(sc.particles) == 10_000_000
-    _case("full_size_sand10m_k10", sc, 10)
+    _case("full_size_sand10m_k30", sc, 30)
+
+
+def test_flowing_sand_1M_100_substeps_vs_oracle():
+    """The flowing phase at size: a 100^3 Drucker-Prager column with a shear rate that grows along x (up to 10 1/s: the top right corner
+    moves 12 cells in the 100 substeps).  Asserted from the library's own statistics that the paths the lattice never takes DID run --
+    at least one re-bin, one in-place block reorder, waves whose lanes are no longer sorted by cell (the grouped scatter), waves on
+    the quartic tier, on the second tier and beyond both (eigenbasis path) -- and the state is held to the same gate as everywhere."""
+    import ctypes as C
+    from sparkl_amd import _lib
+    from sparkl_amd.pipeline import MpmPipeline
+    sc = scenes.sand_column(100, 100, 100, with_block=False)
+    assert len(sc.particles) == 1_000_000
+    pos = sc.particles.position["point"]
+    rel = (pos - pos.min(0)) / np.ptp(pos, axis=0)
+    rate = 10.0 * rel[:, 0]
+    v = sc.particles.velocity["vector"]
+    v[:, 0] = rate * (pos[:, 1] - pos[:, 1].min())
+    v[:, 1] = -0.3 * rate * (pos[:, 1] - pos[:, 1].min())
+    nsub = 100
+    strain_bins, unsorted_waves = np.zeros(7), 0.0
+    with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        done = 0
+        for k in (25, 50, 75, 100):
+            p.substeps(sc.params, sc.gravity, sc.fixed_dt, k - done)
+            done = k
+            out = (C.c_ulonglong * (13 * 65))()
+            _lib.check(_lib.lib().sparkl_hip_debug_run_stats(p.h, out, C.c_uint64(len(out))))
+            hist = np.array(out, dtype=np.float64).reshape(13, 65)
+            strain_bins += hist[10][:7]          # waves by max |F^T F - I|: < 1e-3, 3e-3, 1e-2, 3e-2, 0.1, 0.3, inf
+            runs, cells = (hist[0] * np.arange(65)).sum(), (hist[2] * np.arange(65)).sum()
+            unsorted_waves += runs - cells       # a wave whose lanes are sorted by cell has as many lane runs as distinct cells
+        got = p.read_particles()
+        chk = p.grid_check()
+        clock = p.clock_read(reset=False)
+        pol = p.reorder_policy_stats()
+    assert all(int(chk[k]) == 0 for k in VIOLATIONS), chk
+    print("flowing sand 1M: re-bins", int(clock.resorts), "block reorders", pol["reorders"], "excess lane runs", unsorted_waves, "waves by strain", strain_bins)
+    assert clock.resorts >= 2, "no re-bin beyond the initial one"
+    assert pol["reorders"] >= 1 and unsorted_waves > 0
+    assert strain_bins[:4].sum() > 0 and strain_bins[4] > 0 and strain_bins[5:].sum() > 0, strain_bins
+    r32, t32 = _oracle_run(sc, nsub, False)
+    r64, t64 = _oracle_run(sc, nsub, True)
+    rep, bad = parity_verdict(got, r32, r64, sc.cell_width, x_storage_steps=nsub)
+    rec = {"test": "flowing_sand1m_k100", "particles": len(sc.particles), "substeps": nsub, "oracle_seconds": [t32, t64], "threads": _threads(),
+           "rebins": int(clock.resorts), "block_reorders": int(pol["reorders"]), **rep}
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "parity.jsonl"), "a") as f:
+        f.write(json.dumps(rec) + "\n")
+    print("flowing_sand1m_k100 vs f64", rep["vs_f64"], "| vs f32", rep["vs_f32"], "| f32 vs f64", rep["oracle_f32_vs_f64"])
+    assert not bad, (bad, rep)
 
 
 def test_config4_fluid_2M_slice_100_substeps_vs_oracle():

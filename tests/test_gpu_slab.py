@@ -293,6 +293,32 @@ def test_group_substeps_over_rccl_world_of_one():
     assert rebins >= 2 and ex < 2e-5 and ev < 2e-4
 
 
+def test_overlap_schedule_is_chosen_by_measurement(monkeypatch):
+    """Between RCCL ranks the group loop times one undisturbed 16-substep batch per schedule (in line / halo chain on a second stream),
+    takes the MAX over the ranks and keeps the faster (sparkl_hip_overlap_info).  SPARKL_HIP_OVERLAP=cal runs the same state machine for
+    two slabs of ONE device: a schedule must have been chosen, both samples recorded, and the result must equal the plain pipeline's."""
+    from sparkl_amd.pipeline import MpmPipeline
+    monkeypatch.setenv("SPARKL_HIP_OVERLAP", "cal")
+    sc = scenes.sand_column(24, 12, 12, with_block=False)
+    dt, nsteps = sc.fixed_dt, 96
+    pipes, gids = _two_slabs(sc)
+    assert pipes[0].overlap_info()[0] == -1
+    MpmPipeline.group_substeps(pipes, sc.params, sc.gravity, dt, nsteps)
+    infos = [p.overlap_info() for p in pipes]
+    got = _gather(pipes, gids, len(sc.particles))
+    for p in pipes:
+        p.close()
+    print("overlap calibration:", infos)
+    assert infos[0] == infos[1] and infos[0][0] in (0, 1) and infos[0][1] > 0 and infos[0][2] > 0, infos
+    pos = got.position["point"]
+    monkeypatch.delenv("SPARKL_HIP_OVERLAP")
+    with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, dt, nsteps)
+        ref = p.read_particles()
+    assert np.abs(pos - ref.position["point"]).max() / sc.cell_width < 2e-5
+
+
 def test_comm_init_all_one_thread_owns_the_communicators():
     """sparkl_hip_comm_init_all: the grouped ncclCommInitRank one host thread uses to own every device's communicator
     (cuda_mpm_pipeline.rs:262-271 steps all contexts from one call).  One GPU here, so a world of one member: same result as the
@@ -344,24 +370,35 @@ def test_group_error_aborts_the_communicator():
         assert p.comm_allreduce_sum(1) == 1
 
 
-def test_group_rebalancing_moves_the_cut_and_changes_nothing(tmp_path):
-    """Load re-balancing at collective re-bins: two slabs start 1 : 3 out of balance; the cut must walk towards the middle
-    (block planes migrate as ordinary emigrants) and the union must still equal the un-decomposed pipeline."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_group_rebalancing_moves_the_cut_and_changes_nothing(tmp_path, world):
+    """Load re-balancing at collective re-bins (global: cuts re-chosen on the summed block-plane histogram): the slabs start
+    badly out of balance -- every rank but the last owns a sliver --; the cuts must walk towards the histogram's quantiles (block planes
+    migrate as ordinary emigrants, one rank far per re-bin) and the union must still equal the un-decomposed pipeline."""
     from sparkl_amd.pipeline import MpmPipeline
     from sparkl_amd.slab import INT32_MAX, INT32_MIN
-    sc, dt = _scene("spin")
+    if world == 2:
+        sc, dt = _scene("spin")
+    else:                                           # a cube long enough for four slabs (9 block planes), spinning at the same rim speed
+        sc = scenes.elastic_cube(64)
+        sc.particles.velocity["vector"] *= np.float32(25.0 * 20 / 64)
+        dt = 2.0e-4
     nsteps = 80
     h = sc.cell_width
     cell = np.round(sc.particles.position["point"][:, 0] / np.float32(h)).astype(np.int64) - 1
     blk = cell >> 2
     cut0 = int(blk.min()) + 1                       # rank 0 owns only the first block plane
-    cuts = [INT32_MIN, cut0, INT32_MAX]
-    gids = [np.nonzero(blk < cut0)[0], np.nonzero(blk >= cut0)[0]]
-    assert 0 < len(gids[0]) < len(gids[1]) // 2
+    if world == 2:
+        cuts = [INT32_MIN, cut0, INT32_MAX]
+    else:                                           # ranks 0..2 own one block plane each, rank 3 the rest
+        cuts = [INT32_MIN, cut0, cut0 + 1, cut0 + 2, INT32_MAX]
+        assert int(blk.max()) - int(blk.min()) + 1 >= 8, "the scene must span enough block planes"
+    gids = [np.nonzero((blk >= cuts[r]) & (blk < cuts[r + 1]))[0] for r in range(world)]
+    assert all(len(g) > 0 for g in gids) and len(gids[0]) < len(gids[-1]) // 2
     id_to_caller = np.concatenate(gids)
     stream = torch.cuda.Stream()
     pipes = []
-    for r in range(2):
+    for r in range(world):
         comps = ParticleComponents(0)
         for k in ParticleComponents.__slots__:
             setattr(comps, k, np.ascontiguousarray(getattr(sc.particles, k)[gids[r]]))
@@ -377,9 +414,17 @@ def test_group_rebalancing_moves_the_cut_and_changes_nothing(tmp_path):
     parts = [(p.read_particles(), id_to_caller[p.read_sorted_particle_ids()]) for p in pipes]
     for p in pipes:
         p.close()
-    print("re-balancing: cut", cut0, "->", slabs[0][2], "moves", slabs[0][3], "particles", [len(g) for g in gids], "->", n_after)
-    assert slabs[0][2] == slabs[1][1] and slabs[0][2] > cut0 and slabs[0][3] >= 1, slabs
-    assert abs(n_after[0] - n_after[1]) < abs(len(gids[0]) - len(gids[1])), "the split must be closer to even than it started"
+    n0 = [len(g) for g in gids]
+    print("re-balancing: cuts", cuts[1:-1], "->", [sl[2] for sl in slabs[:-1]], "moves", [sl[3] for sl in slabs], "particles", n0, "->", n_after)
+    for r in range(world - 1):
+        assert slabs[r][2] == slabs[r + 1][1], slabs          # neighbours agree on every cut
+    assert slabs[0][2] > cut0 and slabs[0][3] >= 1, slabs
+    mean = sum(n_after) / world
+    assert max(n_after) / mean < max(n0) / mean, "the split must be closer to even than it started"
+    if world == 4:
+        # plane granularity bounds what balance can reach: within one block plane's worth of particles of the mean
+        plane = np.bincount((blk - blk.min()).astype(np.int64)).max()
+        assert max(n_after) <= mean + plane, (n_after, mean, plane)
     caller = np.concatenate([c for _, c in parts])
     assert np.array_equal(np.sort(caller), np.arange(len(sc.particles)))
     inv = np.argsort(caller)
@@ -468,6 +513,44 @@ def test_group_substeps_fluid_volume_sweep_across_the_cut():
     # the volumes were really recomputed from both sides' masses: F00 of the particles next to the cut matches too
     dF = np.abs(got.volume["deformation_gradient"][:, 0].astype(np.float64) - r32.volume["deformation_gradient"][:, 0]).max()
     assert dF < 1e-5, dF
+
+
+@pytest.mark.parametrize("frame_dt,max_substep_dt", [(2.0e-2, 6.0e-3), (0.1, 1.0)])
+def test_group_step_adaptive_with_the_fluid_volume_sweep(frame_dt, max_substep_dt):
+    """sparkl_hip_group_step under force_fluids_volume_recomputation: mls_solver.rs:46-59 recomputes the fluid volumes (mass planes across the
+    cut), THEN estimates dt (MIN over the slabs), then runs the substep.  A fluid dam on two slabs, adaptive frames whose substep lengths
+    are set by max_substep_dt / by the estimator's moving bound: same simulated time and substep count as the oracle, particles under the
+    gate of the fixed-dt two-slab fluid test."""
+    from oracle import Oracle
+    from sparkl_amd.pipeline import MpmPipeline
+    from tests.parity import parity_verdict
+    sc = scenes.fluid_dam(32, 16, 16)
+    assert sc.params.force_fluids_volume_recomputation
+    sc.params.dt = frame_dt
+    sc.params.max_substep_dt = max_substep_dt
+    frames = 3
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    o32 = Oracle(sc.cell_width, f64=False, domain_log2_bytes=sc.domain_log2_bytes, threads=threads)
+    o64 = Oracle(sc.cell_width, f64=True, domain_log2_bytes=sc.domain_log2_bytes, threads=threads)
+    o32.load_scene(sc)
+    o64.load_scene(sc)
+    pipes, all_gids = _two_slabs(sc)
+    assert min(len(g) for g in all_gids) > len(sc.particles) // 4
+    for frame in range(frames):
+        t_ref = o32.step(sc.params, sc.gravity)
+        o64.step(sc.params, sc.gravity)
+        t_got, nsub = MpmPipeline.group_step(pipes, sc.params, sc.gravity)
+        assert t_got == pytest.approx(t_ref, rel=1e-7)
+        assert nsub == len(o32.last_dts()), (frame, nsub, o32.last_dts())
+    got = _gather(pipes, all_gids, len(sc.particles))
+    for p in pipes:
+        p.close()
+    rep, bad = parity_verdict(got, o32.get_particles(), o64.get_particles(), sc.cell_width, arbiter="either")
+    print("adaptive fluid dam on two slabs vs oracle:", nsub, "substeps in the last frame", rep["vs_f64"], rep["vs_f32"])
+    o32.close()
+    o64.close()
+    assert not bad, (bad, rep)
+    assert rep["vs_f32"]["eps_v"] < 1e-4 and rep["vs_f32"]["eps_x"] < 3e-5, rep["vs_f32"]
 
 
 def test_group_substeps_modified_eigenerosion_across_the_cut():
