@@ -449,7 +449,7 @@ def main(args):
     run(args.warmup)
     # event spans on every 4th substep of the timed region (every 2nd of a region shorter than 16 substeps): a recorded event is a
     # barrier packet of its own between two kernels that would otherwise be dispatched back to back -- sampling every launch of the
-    # driver's 20-substep window cost it 0.008 - 0.012 ms per substep (tools/debug/driver_window.sh; attaching the events to the dispatch
+    # driver's 20-substep window cost it 0.008 - 0.012 ms per substep (profiles/r03_kernel_experiments.txt section 12; attaching the events to the dispatch
     # with hipExtLaunchKernelGGL costs more, 0.018: tried)
     stride = 4 if args.steps >= 16 else (2 if args.steps >= 4 else 1)
     if not args.no_kernel_clock:

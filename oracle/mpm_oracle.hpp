@@ -358,8 +358,21 @@ template <class R> R neo_hookean_pos_energy(const SparklNeoHookeanElasticity& m,
     R vol = k / R(2) * ((j * j - R(1)) / R(2) - std::log(j));
     return j < R(1) ? dev * pc : (dev + vol) * phase;
 }
-// eos_monaghan_sph.rs:28-37 (powi)
-template <class R> R powi(R x, int n) { R r = 1; for (int i = 0; i < n; ++i) r *= x; return r; }
+// eos_monaghan_sph.rs:28-37 (powi).  Rust's f32::powi is the llvm.powi intrinsic, lowered to compiler-rt's __powisf2 / __powidf2 for a
+// run-time exponent: multiplication by repeated squaring, low bit first (compiler-rt/lib/builtins/powisf2.c) -- restated, so that the
+// rounding sequence is the reference's (gamma = 7: x, x^2, x^4 -> x * x^2 * x^4; a plain loop rounds differently in the last bits, and
+// the equation of state multiplies those bits by p0 gamma = 7e6).
+template <class R> R powi(R x, int n) {
+    const bool recip = n < 0;
+    R r = 1;
+    while (true) {
+        if (n & 1) r *= x;
+        n /= 2;
+        if (n == 0) break;
+        x *= x;
+    }
+    return recip ? R(1) / r : r;
+}
 template <class R> R monaghan_pressure(const SparklMonaghanSphEos& m, R mass, R volume0, R density_fluid) {
     R density0 = mass / volume0;
     return std::max((R)m.pressure0 * (powi(density_fluid / density0, (int)m.gamma) - R(1)), -(R)m.max_neg_pressure);

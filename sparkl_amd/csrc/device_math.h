@@ -207,10 +207,18 @@ struct DpSandModel {
           p_lambda(m.p_lambda), p_mu(m.p_mu), volume_correction(m.volume_correction), p_k(m.p_k) {}
 };
 
+// x^n for the small non-negative exponents of the Monaghan equation of state (gamma = 7 in fluids3.rs): the reference's `powi` multiplies
+// by squaring as well (core::intrinsics::powif32 -> llvm.powi); four multiplications for n = 7 instead of a seven-trip loop
 SPK_DEV float powi_f(float x, int n) {
-    float r = 1.f;
-    for (int i = 0; i < n; ++i) r *= x;
-    return r;
+    float r = 1.f, b = x;
+    unsigned e = (unsigned)(n < 0 ? -n : n);
+#pragma unroll 1
+    while (e) {
+        if (e & 1u) r *= b;
+        e >>= 1;
+        if (e) b *= b;
+    }
+    return n < 0 ? 1.f / r : r;
 }
 
 // tau for the corotated model.  phase == 1 (every particle unless a damage model is active) only needs

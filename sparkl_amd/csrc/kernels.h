@@ -513,7 +513,7 @@ SPK_DEV int wave_shr1_i(int v, int fill) { return __builtin_amdgcn_update_dpp(fi
 // lanes are still sorted by cell (after a re-bin or a block reorder) rank = lane and a run is a range of lanes.  Once particles have
 // crossed cells the members of one cell sit in several separate lane ranges; listed as separate runs they would cost a task triple
 // each and deposit to the SAME nodes in the same ds_add_f64 (same-address atomics serialise in the LDS: 0.07 ms of the launch at
-// substep 700 of the 10M column, tools/debug/ablate.py).  So an unsorted wave (wave-uniform test) groups its lanes by cell first -- one
+// substep 700 of the 10M column, tools/ablate.py).  So an unsorted wave (wave-uniform test) groups its lanes by cell first -- one
 // scalar iteration per distinct cell: readlane the key, ballot the matches -- and moves every descriptor to the lane of its rank (seven
 // ds_permute_b32; the affine part is simply written to its rank's LDS column), after which the task phase is the same for both.
 SPK_DEV float perm_f(int byte_addr, float x) { return __int_as_float(__builtin_amdgcn_ds_permute(byte_addr, __float_as_int(x))); }

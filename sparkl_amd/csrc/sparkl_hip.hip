@@ -300,7 +300,7 @@ static inline int grid_for(size_t n, int threads) { return (int)((n + threads - 
 // Default reorder budget (see Ctl): the excess run heads per particle, summed over the substeps since the last reorder, that make
 // k_block_reorder act.  0.6 while every reorder moved every block (~0.6 ms at 10M, profiles/r01_reorder_policy.txt); since the
 // kernel skips the blocks whose runs have not fragmented (GridArrays::pb_heads) a pass costs what the flowing part of the scene
-// costs and 0.2 is the optimum of tools/debug/reorder_threshold.sh (late / deep phase of the 10M collapse: 0.683 / 0.815 ms per
+// costs and 0.2 is the optimum of a threshold scan (profiles/r03_kernel_experiments.txt section 5) (late / deep phase of the 10M collapse: 0.683 / 0.815 ms per
 // substep at 0.6, 0.673 / 0.797 at 0.2, 0.676 / 0.799 at 0.1).  Since the run-task scatter groups an unsorted wave's lanes by cell its
 // heads are the DISTINCT CELLS of a wave, which grow far slower, and the scan is flat from 0.05 to 2 (profiles/r03_kernel_experiments.txt
 // section 9).  Scenes with a fluid run the DPP scatters (k_vol_p2g, the mass scatter), whose heads are lane-group heads and whose
@@ -2220,6 +2220,53 @@ static int group_exchange(const Group& G, BufPair send, BufPair recv, const uint
 // never past a neighbouring cut's old position -- so the particles of the planes that changed owner travel to an ADJACENT rank, as ordinary
 // emigrants of the re-bin that follows (a long way takes several re-bins).  Slabs keep at least two block planes.
 static constexpr int BAL_PLANES = 1024;
+// The cut list every rank derives from the summed histogram (pure host arithmetic: also behind sparkl_hip_debug_balance_cuts for CPU tests).
+// hist[c] = particles in the block plane of index c (= block plane + 1); cuts[1 .. world - 1] = current cuts in block planes (cut k = first plane
+// of rank k); out[0 .. world]: the new list with the open ends at the occupied range.  false = leave the cuts alone.
+static bool balance_cuts(const long long* hist, int nplanes, const long long* cuts, int world, int max_shift, std::vector<long long>& nxt) {
+    std::vector<long long> prefix(nplanes + 1, 0);          // prefix[c] = particles in planes (index) < c
+    for (int c = 0; c < nplanes; ++c) prefix[c + 1] = prefix[c] + hist[c];
+    const long long total = prefix[nplanes];
+    if (total <= 0 || world < 2) return false;
+    int first = 0, last = nplanes - 1;
+    while (first < nplanes && hist[first] == 0) ++first;
+    while (last > first && hist[last] == 0) --last;
+    std::vector<long long> cur(world + 1);
+    cur[0] = (long long)first - 1;                   // in block planes (index - 1); the open ends stand at the occupied range
+    cur[world] = (long long)last;                    // = (last + 1) - 1: first plane beyond the occupied range
+    for (int k = 1; k < world; ++k) cur[k] = std::min(std::max(cuts[k], cur[0]), cur[world]);   // a cut outside the occupied range owns nothing there: same as at its edge
+    for (int k = 1; k <= world; ++k) if (cur[k] < cur[k - 1]) return false;   // cuts out of order: not this function's to repair
+    nxt = cur;
+    for (int k = 1; k < world; ++k) {   // low to high: cut k settles against the NEW cut below it and the OLD cuts around it
+        const double want = (double)total * k / world;
+        // boundary c (as a plane index: the cut sits between planes c - 1 and c) whose prefix is nearest `want`, within reach of this re-bin
+        long long best = std::min<long long>(std::max<long long>(cur[k] + 1, 0), nplanes);
+        double bestd = std::fabs((double)prefix[best] - want);
+        for (long long c = std::max<long long>(cur[k] + 1 - max_shift, 0); c <= std::min<long long>(cur[k] + 1 + max_shift, nplanes); ++c) {
+            const double d = std::fabs((double)prefix[c] - want);
+            if (d < bestd - 0.5) { bestd = d; best = c; }
+        }
+        long long cut = best - 1;                                                   // back to block planes
+        // emigrants travel one rank far: never past the old neighbouring cuts.  Two block planes per slab where the old cuts leave room
+        // (a sliver the caller started with is widened as fast as its neighbours' old cuts allow), room for the slabs above.
+        const long long lo = std::max(cur[k - 1], nxt[k - 1] + 2);
+        const long long hi = std::min(cur[k + 1], cur[world] - 2ll * (world - k));
+        cut = std::max(cut, lo);
+        cut = std::min(cut, std::max(hi, std::min(cur[k + 1], nxt[k - 1] + 1)));     // lo > hi: as far as the old cut above allows, at least one plane wide
+        cut = std::max(cut, nxt[k - 1] + 1);
+        nxt[k] = cut;
+    }
+    for (int k = 1; k < world; ++k)
+        if (nxt[k] <= nxt[k - 1] || nxt[k] > cur[world] || nxt[k] < cur[k - 1] || nxt[k] > cur[k + 1]) return false;   // no room: keep the cuts
+    return true;
+}
+extern "C" int sparkl_hip_debug_balance_cuts(const long long* hist, int nplanes, const long long* cuts, int world, int max_shift, long long* out) {
+    std::vector<long long> nxt;
+    if (!hist || !cuts || !out || nplanes < 1 || world < 1) return -1;
+    if (!balance_cuts(hist, nplanes, cuts, world, max_shift, nxt)) return 0;
+    for (int k = 0; k <= world; ++k) out[k] = nxt[k];
+    return 1;
+}
 static int group_rebalance(const Group& G) {
     const int world = G.rccl ? G.m[0]->comm_world : G.n;
     if (world < 2) return SPARKL_OK;
@@ -2256,37 +2303,9 @@ static int group_rebalance(const Group& G) {
         if (G.rccl) { if (i == 0) for (int w = 0; w < words; ++w) sum[w] = p->bal_host[w]; }   // every rank holds the global sum already
         else for (int w = 0; w < words; ++w) sum[w] += p->bal_host[w];
     }
-    // prefix[c] = particles in planes (index) < c; plane index = block plane + 1
-    std::vector<long long> prefix(BAL_PLANES + 1, 0);
-    for (int c = 0; c < BAL_PLANES; ++c) prefix[c + 1] = prefix[c] + sum[c];
-    const long long total = prefix[BAL_PLANES];
-    if (total <= 0) return SPARKL_OK;
-    int first = 0, last = BAL_PLANES - 1;
-    while (first < BAL_PLANES && sum[first] == 0) ++first;
-    while (last > first && sum[last] == 0) --last;
-    std::vector<long long> cur(world + 1), nxt(world + 1);
-    cur[0] = (long long)first - 1;                   // in block planes (index - 1); the open ends stand at the occupied range
-    cur[world] = (long long)last;                    // = (last + 1) - 1: first plane beyond the occupied range
-    for (int k = 1; k < world; ++k) cur[k] = sum[BAL_PLANES + k];
-    for (int k = 1; k < world; ++k) if (cur[k] < cur[k - 1]) return SPARKL_OK;   // cuts the histogram cannot vouch for (a slab beyond the particles): leave them
-    nxt = cur;
-    for (int k = 1; k < world; ++k) {
-        const double want = (double)total * k / world;
-        // boundary c (as a plane index: the cut sits between planes c - 1 and c) whose prefix is nearest `want`
-        long long best = cur[k] + 1;
-        double bestd = std::fabs((double)prefix[std::min<long long>(std::max<long long>(best, 0), BAL_PLANES)] - want);
-        for (long long c = std::max<long long>(cur[k] + 1 - max_shift, 0); c <= std::min<long long>(cur[k] + 1 + max_shift, BAL_PLANES); ++c) {
-            const double d = std::fabs((double)prefix[c] - want);
-            if (d < bestd - 0.5) { bestd = d; best = c; }
-        }
-        long long cut = best - 1;                                                  // back to block planes
-        cut = std::max(cut, cur[k - 1] + (k > 1 ? 0 : 2));                          // not past the old neighbouring cuts: emigrants go one rank far
-        cut = std::min(cut, cur[k + 1] - (k + 1 < world ? 0 : 2));
-        nxt[k] = cut;
-    }
-    for (int k = 1; k < world; ++k) nxt[k] = std::max(nxt[k], nxt[k - 1] + 2);     // at least two block planes per slab, low to high ...
-    for (int k = world - 1; k >= 1; --k) nxt[k] = std::min(nxt[k], nxt[k + 1] - 2); // ... and high to low
-    for (int k = 1; k < world; ++k) if (nxt[k] < nxt[k - 1] + 2 || nxt[k] > nxt[k + 1] - 2 || nxt[k] < cur[k - 1] || nxt[k] > cur[k + 1]) return SPARKL_OK;   // no room: keep the cuts
+    std::vector<long long> cuts(world + 1, 0), nxt;
+    for (int k = 1; k < world; ++k) cuts[k] = sum[BAL_PLANES + k];
+    if (!balance_cuts(sum.data(), BAL_PLANES, cuts.data(), world, max_shift, nxt)) return SPARKL_OK;
     for (int i = 0; i < G.n; ++i) {
         SparklPipeline* p = G.m[i];
         const int r = rank_of(i);

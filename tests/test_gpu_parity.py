@@ -867,7 +867,7 @@ def test_particles_trickling_out_of_the_domain_do_not_force_a_rebin_each(Pipelin
     """A block flying through the low face of the SPGrid loses a layer of particles every few substeps.  Each of them is flagged
     failed (particle_set.rs:129-136) and frozen -- and that is all: it is dead weight in its block until the next regular re-bin
     sorts it behind the valid particles.  (Requesting a re-bin for every particle that leaves the domain cost one re-bin per
-    substep: the 10M column went from 0.88 to 6.9 ms per substep once its foot reached the wall, tools/debug/soak.py.)  The
+    substep: the 10M column went from 0.88 to 6.9 ms per substep once its foot reached the wall, a 4000-substep soak, profiles/r02e_soak.txt.)  The
     survivors must still match the oracle."""
     sc = scenes.elastic_cube(12)
     sc.particles.velocity["vector"][:] = np.float32([-20.0, 0.0, 0.0])

@@ -1,12 +1,12 @@
-"""Where k_g2p2g's time goes in a given phase of the 10M collapse: an ANALYSIS build of the library (tools/debug/ablate_build.sh:
+"""Where k_g2p2g's time goes in a given phase of the 10M collapse: an ANALYSIS build of the library (tools/ablate_build.sh:
 a copy of csrc/ with runtime switches patched in, never the product) runs the column to a mark with everything on, then flips one
 switch and times the next few launches.  The switched-off part leaves wrong physics behind, so every (mark, mode) is its own process.
-    python tools/debug/ablate.py [mark ...]       (needs sparkl_amd/lib/ab_ablate.so)
+    python tools/ablate.py [mark ...]       (needs sparkl_amd/lib/ab_ablate.so)
 modes (bit mask): 1 no deposit atomics | 2 deposit to lane-private slots (no address or bank conflicts) | 4 one visit per task |
                   8 gather without its LDS reads | 16 no scatter at all | 64 return map always on its series path |
                   128 no return map and no stress | 256 no positive-energy bookkeeping | 512 no gather (v = 0, C = 0)"""
 import os, subprocess, sys
-root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CODE = r'''
 import os, sys, time
 sys.path.insert(0, %r)

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Builds sparkl_amd/lib/ab_ablate.so: a COPY of csrc/ (under /tmp) with runtime switches patched into k_g2p2g for tools/debug/ablate.py.
+# Builds sparkl_amd/lib/ab_ablate.so: a COPY of csrc/ (under /tmp) with runtime switches patched into k_g2p2g for tools/ablate.py.
 # The product sources carry none of this.
 set -e
-root=$(cd "$(dirname "$0")/../.." && pwd)
+root=$(cd "$(dirname "$0")/.." && pwd)
 w=/tmp/spk_ablate; rm -rf $w; mkdir -p $w/x/y; cp -r $root/sparkl_amd/csrc $w/x/y/csrc; ln -sfn $root/include $w/x/include
 cd $w/x/y/csrc
 python3 - <<'EOF'

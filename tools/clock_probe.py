@@ -1,6 +1,6 @@
 """Shader clock (clock64 / wall_clock64) sampled by a one-wave kernel on a second stream while 10M-sand substeps run."""
 import os, sys, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from sparkl_amd import scenes
 from sparkl_amd.pipeline import MpmPipeline

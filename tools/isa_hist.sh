@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools_isa.sh <kernel-substring> [N]: resource usage + instruction histogram of one kernel (device-only compile)
+# isa_hist.sh <kernel-substring> [N]: resource usage + instruction histogram of one kernel (device-only compile)
 cd "$(dirname "$0")/../sparkl_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -fno-slp-vectorize $EXTRA -S --cuda-device-only -o /tmp/k.s sparkl_hip.hip 2>/dev/null
 for sym in $(grep -E "^_ZN3spk[0-9]+$1.*:" /tmp/k.s | cut -d: -f1); do

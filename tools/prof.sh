@@ -14,7 +14,7 @@ for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)
   timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/pmc_$name -- python3 $R/bench.py --steps 8 --warmup 8 $ARGS > /dev/null 2> $OUT/pmc_$name.err
 done
-python3 $R/tools/tools_pmc_summary.py $OUT > $OUT/pmc_summary.txt
+python3 $R/tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
 # keep the merged-back payload small: the raw traces are not needed
 rm -rf $OUT/trace $OUT/pmc_*/
