@@ -524,7 +524,7 @@ def test_group_step_adaptive_with_the_fluid_volume_sweep(frame_dt, max_substep_d
     from oracle import Oracle
     from sparkl_amd.pipeline import MpmPipeline
     from tests.parity import parity_verdict
-    sc = scenes.fluid_dam(32, 16, 16)
+    sc = scenes.fluid_dam(64, 16, 16)       # 16 cells = 4 block planes along x: the cut runs through the fluid
     assert sc.params.force_fluids_volume_recomputation
     sc.params.dt = frame_dt
     sc.params.max_substep_dt = max_substep_dt
