@@ -207,18 +207,34 @@ struct DpSandModel {
           p_lambda(m.p_lambda), p_mu(m.p_mu), volume_correction(m.volume_correction), p_k(m.p_k) {}
 };
 
+// Compile-time view of a model table whose every entry is a plain fluid (Monaghan equation of state, no plastic or failure model:
+// fluids3.rs): the FLUID_ONLY kernels carry no solid code at all.  Chosen by the host (models_set: all_plain_fluid).
+struct PlainFluidModel {
+    static constexpr int ctag = SPARKL_CONSTITUTIVE_EOS_MONAGHAN_SPH;
+    static constexpr int ptag = -1;
+    static constexpr int is_fluid = 1;
+    static constexpr int only_active_when_failed = 0;
+    static constexpr int has_failure = 0;
+    static constexpr int split_stress_on_failure = 0;
+    static constexpr float cfl_coeff = 0.f, lambda = 0.f, mu = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, p_lambda = 0.f, p_mu = 0.f, volume_correction = 1.f, p_k = 0.f;
+    const float &pressure0, &viscosity, &max_neg_pressure;
+    const int& gamma;
+    __device__ __host__ __forceinline__ explicit PlainFluidModel(const DevModel& m)
+        : pressure0(m.pressure0), viscosity(m.viscosity), max_neg_pressure(m.max_neg_pressure), gamma(m.gamma) {}
+};
+
 // x^n for the small non-negative exponents of the Monaghan equation of state (gamma = 7 in fluids3.rs): the reference's `powi` multiplies
 // by squaring as well (core::intrinsics::powif32 -> llvm.powi); four multiplications for n = 7 instead of a seven-trip loop
-SPK_DEV float powi_f(float x, int n) {
+SPK_DEV float powi_f(float x, int n) {   // n >= 0: the exponent is MonaghanSphEos::gamma, a u32 in the reference
     float r = 1.f, b = x;
-    unsigned e = (unsigned)(n < 0 ? -n : n);
+    unsigned e = (unsigned)n;
 #pragma unroll 1
     while (e) {
         if (e & 1u) r *= b;
         e >>= 1;
         if (e) b *= b;
     }
-    return n < 0 ? 1.f / r : r;
+    return r;
 }
 
 // tau for the corotated model.  phase == 1 (every particle unless a damage model is active) only needs

@@ -41,6 +41,10 @@ enum : uint32_t {
 };
 
 __device__ __forceinline__ int acc_slot(int n) { const int p = n >> 6; return n + 8 * p - 4 * (p & 1); }
+// acc_slot of the (0, 0) node of support plane sz of a particle whose associated cell has tile index `base` (x, y <= 5, so base + sx + 8 sy
+// never carries into the plane bits): the nine nodes of the plane are then this + sx + 8 sy -- constant offsets the ds_add_f64 encodes itself,
+// where acc_slot(base + off) per node costs six integer instructions, 27 times per deposit
+__device__ __forceinline__ int acc_plane_base(int base, int sz) { const int p = (base >> 6) + sz; return base + 64 * sz + 8 * p - 4 * (p & 1); }
 
 struct Ctl {
     uint32_t abort_flag[2];  // parity double-buffer: kernels of substep s read [s&1], G2P of s writes [(s+1)&1]
@@ -378,7 +382,7 @@ SPK_DEV int p2g_scatter(double (*tile)[ACC_N], const Scatter& sc, bool live, int
                                      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4), "v"(f8));
                     }
                     if (live && head) {
-                        const int n = acc_slot(sc.base + sx + TILE_W * sy + TILE_W * TILE_W * sz);
+                        const int n = acc_plane_base(sc.base, sz) + sx + TILE_W * sy;
                         atomicAdd(&tile[0][n], (double)c0);
                         atomicAdd(&tile[1][n], (double)c1);
                         atomicAdd(&tile[2][n], (double)c2);
@@ -394,7 +398,7 @@ SPK_DEV int p2g_scatter(double (*tile)[ACC_N], const Scatter& sc, bool live, int
 #pragma unroll
                 for (int sx = 0; sx < 3; ++sx) {
                     const float w = SW.w[0][sx] * SW.w[1][sy] * SW.w[2][sz];
-                    const int n = acc_slot(sc.base + sx + TILE_W * sy + TILE_W * TILE_W * sz);
+                    const int n = acc_plane_base(sc.base, sz) + sx + TILE_W * sy;
                     atomicAdd(&tile[0][n], (double)(w * sc.val_m));
                     atomicAdd(&tile[1][n], (double)(w * (sc.qv[0] + sx * sc.A.m[0] + sy * sc.A.m[3] + sz * sc.A.m[6])));
                     atomicAdd(&tile[2][n], (double)(w * (sc.qv[1] + sx * sc.A.m[1] + sy * sc.A.m[4] + sz * sc.A.m[7])));
@@ -454,9 +458,8 @@ SPK_DEV int p2g_scatter_pair(double (*tile)[ACC_N], const Scatter& sa, const Sca
                     asm volatile("s_nop 1\n" SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") SPK_FMAC_DPP("4", "%6") SPK_FMAC_DPP("8", "%7")
                                  : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4), "v"(f8));
                 }
-                const int off = sx + TILE_W * sy + TILE_W * TILE_W * sz;
                 if (live_a && head) {
-                    const int n = acc_slot(sa.base + off);
+                    const int n = acc_plane_base(sa.base, sz) + sx + TILE_W * sy;
                     atomicAdd(&tile[0][n], (double)c0);
                     atomicAdd(&tile[1][n], (double)c1);
                     atomicAdd(&tile[2][n], (double)c2);
@@ -464,7 +467,7 @@ SPK_DEV int p2g_scatter_pair(double (*tile)[ACC_N], const Scatter& sa, const Sca
                 }
                 if (any_lone) {   // wave-uniform
                     if (lone_b) {
-                        const int n = acc_slot(sb.base + off);
+                        const int n = acc_plane_base(sb.base, sz) + sx + TILE_W * sy;
                         atomicAdd(&tile[0][n], (double)b01.x);
                         atomicAdd(&tile[1][n], (double)b01.y);
                         atomicAdd(&tile[2][n], (double)b23.x);
@@ -2073,8 +2076,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
         const uint32_t flags = __float_as_uint(kk.w);
         bool live = active && !(flags & FLAG_INVALID);
         float npx[3] = {0.f, 0.f, 0.f};
-        if (live) {
-            const DevModel& mo = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
+        auto particle = [&](const auto& mo) {
             const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
             const Advected o = g2p_update<false>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
             if (FLUID_ONLY) {
@@ -2094,6 +2096,11 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
                 dt_nan |= bnd != bnd;
                 dt_bound = fminf(dt_bound, bnd);
             }
+        };
+        if (live) {
+            const DevModel& mo_t = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
+            if constexpr (FLUID_ONLY) particle(PlainFluidModel(mo_t));   // the host selects FLUID_ONLY when every model is a plain fluid
+            else particle(mo_t);
         }
         mass_scatter(mtile, npx, kk.x, live, org, S.h, tid);
     }
@@ -2157,8 +2164,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
             const uint32_t flags = __float_as_uint(kk.w);
             live[k] = active && !(flags & FLAG_INVALID);
             scatter_clear(sc[k]);
-            if (live[k]) {
-                const DevModel& mo = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
+            auto particle = [&](const auto& mo) {
                 const float px[3] = {q0.x, q0.y, q0.z}, v[3] = {q3.x, q3.y, q3.z};
                 if (mo.is_fluid) {   // fluids_volume.rs:83-110 with the weights of k_g2p_volume
                     const int orgv[3] = {org.x, org.y, org.z};
@@ -2190,6 +2196,11 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
                 const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
                 const float jp = mo.is_fluid ? jp_stored : 1.f;
                 sc[k] = p2g_prepare(mo, flags, px, v, C, F, kk.x, kk.y, kk.z, phase, jp, org, h, inv_h, S.inv_d, S.dt);
+            };
+            if (live[k]) {
+                const DevModel& mo_t = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
+                if constexpr (FLUID_ONLY) particle(PlainFluidModel(mo_t));
+                else particle(mo_t);
             }
         }
 #pragma unroll
