@@ -207,6 +207,20 @@ struct DpSandModel {
           p_lambda(m.p_lambda), p_mu(m.p_mu), volume_correction(m.volume_correction), p_k(m.p_k) {}
 };
 
+// ... and of one whose every entry is a neo-Hookean solid without plasticity or failure model (BASELINE configs[1], the elastic cube).
+struct NeoHookeanOnlyModel {
+    static constexpr int ctag = SPARKL_CONSTITUTIVE_NEO_HOOKEAN;
+    static constexpr int ptag = -1;
+    static constexpr int is_fluid = 0;
+    static constexpr int only_active_when_failed = 0;
+    static constexpr int has_failure = 0;
+    static constexpr int split_stress_on_failure = 0;
+    static constexpr float pressure0 = 0.f, viscosity = 0.f, max_neg_pressure = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, p_lambda = 0.f, p_mu = 0.f, volume_correction = 1.f, p_k = 0.f;
+    static constexpr int gamma = 0;
+    const float &cfl_coeff, &lambda, &mu;
+    __device__ __host__ __forceinline__ explicit NeoHookeanOnlyModel(const DevModel& m) : cfl_coeff(m.cfl_coeff), lambda(m.lambda), mu(m.mu) {}
+};
+
 // Compile-time view of a model table whose every entry is a plain fluid (Monaghan equation of state, no plastic or failure model:
 // fluids3.rs): the FLUID_ONLY kernels carry no solid code at all.  Chosen by the host (models_set: all_plain_fluid).
 struct PlainFluidModel {

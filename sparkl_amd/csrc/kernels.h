@@ -1616,7 +1616,8 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
 #endif
 
 // REDUCE_STEPS >= 0: DPP pre-reduction over groups of 2^REDUCE_STEPS lanes (p2g_scatter); -1: run tasks (p2g_scatter_runs).
-// MSET: 0 = any model table; 1 = every model is a corotated solid with Drucker-Prager plasticity (DpSandModel: no model dispatch)
+// MSET: 0 = any model table; 1 = every model is a corotated solid with Drucker-Prager plasticity (DpSandModel: no model dispatch);
+// 3 = every model is a neo-Hookean solid without plasticity (NeoHookeanOnlyModel)
 template <int REDUCE_STEPS, bool RARE, bool LDS_MODELS = true, int MSET = 0>
 __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
     const int tid = threadIdx.x;
@@ -1717,6 +1718,7 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
         if (live) {
             const DevModel& mo_t = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
             if constexpr (MSET == 1) particle(DpSandModel(mo_t));
+            else if constexpr (MSET == 3) particle(NeoHookeanOnlyModel(mo_t));
             else particle(mo_t);
         }
         shell_used |= wave_or_i32(sc.shell);

@@ -158,6 +158,7 @@ struct SparklPipeline {
     bool slab_balance = true;        // sparkl_hip_slab_balance
     int heads_kind = -1;            // which scatter's measure the disorder books hold (note_heads_kind)
     bool all_plain_fluid = false;   // every model is a fluid without plastic / failure model: the FLUID_ONLY kernels apply
+    bool all_neo_elastic = false;   // every model is a neo-Hookean solid without plasticity / failure: k_g2p2g<.., MSET = 3>
     bool all_dp_sand = false;       // every model is a corotated solid with (always active) Drucker-Prager plasticity: k_g2p2g<.., MSET = 1>
     bool mass_tiles_ready = false;  // k_g2p_mass of the previous substep already scattered the next volume sweep's masses
     bool fluid_bound_valid = false; // adaptive step with the volume sweep: the last dt bound seen (predicts the next step length)
@@ -580,6 +581,8 @@ static void launch_g2p2g(SparklPipeline* p, const ParticleArrays& P, const GridA
     else if (dpp) SPK_LAUNCH_MODELS(k_g2p2g, SPK_P2G_REDUCE_STEPS, false);
     else if (p->all_dp_sand && S.num_models <= MAX_LDS_MODELS)   // SPARKL_HIP_MSET=0 keeps the generic kernel (A/B)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<-1, false, true, 1>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
+    else if (p->all_neo_elastic && S.num_models <= MAX_LDS_MODELS)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<-1, false, true, 3>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
     else SPK_LAUNCH_MODELS(k_g2p2g, -1, false);
 }
 
@@ -989,9 +992,11 @@ int sparkl_hip_models_set(SparklPipeline* p, uint32_t n, const SparklParticleMod
     p->rare_models = false;
     p->all_plain_fluid = n > 0;
     p->all_dp_sand = n > 0 && !(getenv("SPARKL_HIP_MSET") && !strcmp(getenv("SPARKL_HIP_MSET"), "0"));
+    p->all_neo_elastic = p->all_dp_sand;
     for (const DevModel& d : dm) {
         p->rare_models |= d.ptag > SPARKL_PLASTIC_DRUCKER_PRAGER || d.has_failure;
         p->all_plain_fluid &= d.is_fluid && d.ptag < 0 && !d.has_failure;
+        p->all_neo_elastic &= !d.is_fluid && d.ctag == SPARKL_CONSTITUTIVE_NEO_HOOKEAN && d.ptag < 0 && !d.has_failure;
         p->all_dp_sand &= !d.is_fluid && d.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR && d.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER && !d.only_active_when_failed && !d.has_failure;
     }
     if (p->d_ctl) CHK(upload_policy(p));   // the default reorder budget depends on whether a fluid is present

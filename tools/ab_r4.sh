@@ -63,5 +63,32 @@ mkdir -p gpurun_out/r4g
 timeout 1500 python -m pytest tests/test_gpu_full_size_parity.py -m gpu -x -q -k "flowing or fluid" > gpurun_out/r4g/pytest1.txt 2>&1; tail -12 gpurun_out/r4g/pytest1.txt
 timeout 1500 python -m pytest tests/test_gpu_slab.py tests/test_golden_trajectories.py tests/test_gpu_parity.py -m gpu -x -q > gpurun_out/r4g/pytest2.txt 2>&1; tail -12 gpurun_out/r4g/pytest2.txt
 ;;
-*) echo "cases: mset_occupancy pair_return_map diet_counters diet_parts suite_and_soak suite suite_tail" ;;
+final)
+# the round's record: full GPU suite (parity.jsonl), bench lines of the three single-GPU configurations (default and driver-style), rocprofv3 passes
+mkdir -p gpurun_out/r04; rm -f gpurun_out/parity.jsonl
+timeout 3000 python -m pytest tests -m gpu -q > gpurun_out/r04/pytest.txt 2>&1; tail -3 gpurun_out/r04/pytest.txt
+cp gpurun_out/parity.jsonl gpurun_out/r04/r04_parity.jsonl
+python bench.py > gpurun_out/r04/r04_bench_sand.json 2> gpurun_out/r04/bench_sand.err
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r04/r04_bench_sand_driver.json 2>> gpurun_out/r04/bench_sand.err
+for c in neo1m fluid20m; do
+python bench.py --config $c --no-cpu-baseline > gpurun_out/r04/r04_bench_${c%%[0-9]*}.json 2> gpurun_out/r04/bench_$c.err
+python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r04/r04_bench_${c%%[0-9]*}_driver.json 2>> gpurun_out/r04/bench_$c.err
+done
+bash tools/prof.sh r04 sand10m 32 > /dev/null 2>&1; cp gpurun_out/prof_r04_sand10m/kernel_stats.csv gpurun_out/r04/r04_sand10m_kernel_stats.csv; cp gpurun_out/prof_r04_sand10m/pmc_summary.txt gpurun_out/r04/r04_sand10m_pmc_summary.txt
+bash tools/prof.sh r04 fluid20m 32 > /dev/null 2>&1; cp gpurun_out/prof_r04_fluid20m/kernel_stats.csv gpurun_out/r04/r04_fluid20m_kernel_stats.csv; cp gpurun_out/prof_r04_fluid20m/pmc_summary.txt gpurun_out/r04/r04_fluid20m_pmc_summary.txt
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r04/r04_bench_*.json")):
+    try:
+        o = json.loads(open(f).read().strip().splitlines()[-1])
+    except Exception as e:
+        print(f, "FAILED", e); continue
+    r = o.get("roofline") or {}
+    line = f"{f}: {o['ms_per_step']:.4f} ms step {o['step_frac_of_hbm_peak']:.3f} kernel {r.get('kernel')} {r.get('frac', 0):.3f}"
+    for k in ("cold_window", "late_collapse", "deep_collapse"):
+        if o.get(k): line += f" | {k} {o[k]['ms_per_step']:.4f} ({o[k].get('step_frac_of_hbm_peak', 0):.3f})"
+    print(line)
+PY
+;;
+*) echo "cases: mset_occupancy pair_return_map diet_counters diet_parts suite_and_soak suite suite_tail final" ;;
 esac
