@@ -145,6 +145,9 @@ struct StepParams {
     // 1 = this launch feeds the disorder policy (Ctl::heads, pb_heads) -- the schedules that scatter with it every substep; 0 = it is the
     // incidental first scatter of a fused batch and stays out of the books (the policy then only ever sees k_g2p2g's measure)
     int count_heads;
+    // k_grid_update behind k_vol_p2g (fluid volume sweep): the node masses are the ones the sweep's mass pass already merged into node_vel.w
+    // (same particles, same weights), so k_vol_p2g scatters the momentum only and the tiles carry m = 0
+    int mass_from_sweep;
 };
 
 struct DevCuboid {
@@ -256,6 +259,11 @@ SPK_DEV void stage_models(DevModel* s_models, const DevModel* __restrict__ model
     "v_fmac_f32_dpp %1, %1, " M " row_shl:" SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"    \
     "v_fmac_f32_dpp %2, %2, " M " row_shl:" SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"    \
     "v_fmac_f32_dpp %3, %3, " M " row_shl:" SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+
+#define SPK_FMAC_DPP3(SH, M)                                                                     \
+    "v_fmac_f32_dpp %0, %0, " M " row_shl:" SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"    \
+    "v_fmac_f32_dpp %1, %1, " M " row_shl:" SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"    \
+    "v_fmac_f32_dpp %2, %2, " M " row_shl:" SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
 
 // What one particle scatters: node s of its 3x3x3 support receives  w_s * (mass ; qv + sx A0 + sy A1 + sz A2).
 struct Scatter {
@@ -411,7 +419,8 @@ SPK_DEV int p2g_scatter(double (*tile)[ACC_N], const Scatter& sc, bool live, int
 // Two particles per lane (slots 2j, 2j + 1: neighbours in the cell-sorted order, so usually the same cell).  Their node
 // values are added in the lane first, which halves the DPP reduction, the f64 conversions and the LDS atomic
 // instructions per particle; a pair that straddles two cells deposits its second particle on its own.
-template <int REDUCE_STEPS>
+// WITH_MASS = false (k_vol_p2g): the momentum only -- three DPP chains, f64 conversions and atomics per node instead of four; tile[0] stays 0.
+template <int REDUCE_STEPS, bool WITH_MASS = true>
 SPK_DEV int p2g_scatter_pair(double (*tile)[ACC_N], const Scatter& sa, const Scatter& sb, bool live_a, bool live_b, int tid) {
     static_assert(REDUCE_STEPS >= 2 && REDUCE_STEPS <= 4, "");
     if (!__any(live_a | live_b)) return 0;
@@ -449,7 +458,16 @@ SPK_DEV int p2g_scatter_pair(double (*tile)[ACC_N], const Scatter& sa, const Sca
                 const f2v b01 = PB01 * wb, b23 = PB23 * wb;
                 const f2v c01 = PA01 * wa + b01 * fs, c23 = PA23 * wa + b23 * fs;
                 float c0 = c01.x, c1 = c01.y, c2 = c23.x, c3 = c23.y;
-                if (REDUCE_STEPS == 2) {
+                if (!WITH_MASS) {   // (a dependent v_fmac_f32_dpp three instructions behind its producer: the two wait states DPP needs)
+                    if (REDUCE_STEPS == 2) {
+                        asm volatile("s_nop 1\n" SPK_FMAC_DPP3("1", "%3") SPK_FMAC_DPP3("2", "%4") : "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2));
+                    } else if (REDUCE_STEPS == 3) {
+                        asm volatile("s_nop 1\n" SPK_FMAC_DPP3("1", "%3") SPK_FMAC_DPP3("2", "%4") SPK_FMAC_DPP3("4", "%5") : "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4));
+                    } else {
+                        asm volatile("s_nop 1\n" SPK_FMAC_DPP3("1", "%3") SPK_FMAC_DPP3("2", "%4") SPK_FMAC_DPP3("4", "%5") SPK_FMAC_DPP3("8", "%6")
+                                     : "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4), "v"(f8));
+                    }
+                } else if (REDUCE_STEPS == 2) {
                     asm volatile("s_nop 1\n" SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2));
                 } else if (REDUCE_STEPS == 3) {
                     asm volatile("s_nop 1\n" SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") SPK_FMAC_DPP("4", "%6")
@@ -460,7 +478,7 @@ SPK_DEV int p2g_scatter_pair(double (*tile)[ACC_N], const Scatter& sa, const Sca
                 }
                 if (live_a && head) {
                     const int n = acc_plane_base(sa.base, sz) + sx + TILE_W * sy;
-                    atomicAdd(&tile[0][n], (double)c0);
+                    if (WITH_MASS) atomicAdd(&tile[0][n], (double)c0);
                     atomicAdd(&tile[1][n], (double)c1);
                     atomicAdd(&tile[2][n], (double)c2);
                     atomicAdd(&tile[3][n], (double)c3);
@@ -468,7 +486,7 @@ SPK_DEV int p2g_scatter_pair(double (*tile)[ACC_N], const Scatter& sa, const Sca
                 if (any_lone) {   // wave-uniform
                     if (lone_b) {
                         const int n = acc_plane_base(sb.base, sz) + sx + TILE_W * sy;
-                        atomicAdd(&tile[0][n], (double)b01.x);
+                        if (WITH_MASS) atomicAdd(&tile[0][n], (double)b01.x);
                         atomicAdd(&tile[1][n], (double)b01.y);
                         atomicAdd(&tile[2][n], (double)b23.x);
                         atomicAdd(&tile[3][n], (double)b23.y);
@@ -1130,6 +1148,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
         G.node_vel[(size_t)b * 64 + lane] = make_float4(0.f, 0.f, 0.f, m);
         return;
     }
+    if (S.mass_from_sweep) m = G.node_vel[(size_t)b * 64 + lane].w;   // wave-uniform; merged by the MASS_ONLY pass of this substep (halo included)
     // velocity incl. gravity (particle_to_grid.rs:88-89)
     const float im = inv_exact(m);
     float v[3] = {(px + m * S.gx * S.dt) * im, (py + m * S.gy * S.dt) * im, (pz + m * S.gz * S.dt) * im};
@@ -1921,9 +1940,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_mass(ParticleArrays P, Grid
 #pragma unroll
             for (int sy = 0; sy < 3; ++sy) {
                 const float wyz = wgt[1][sy] * wgt[2][sz] * m;
-                float c0 = wgt[0][0] * wyz, c1 = wgt[0][1] * wyz, c2 = wgt[0][2] * wyz, c3 = 0.f;   // c3 pads the four interleaved DPP chains
-                asm volatile("s_nop 1\n" SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") SPK_FMAC_DPP("4", "%6") SPK_FMAC_DPP("8", "%7")
-                             : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4), "v"(f8));
+                float c0 = wgt[0][0] * wyz, c1 = wgt[0][1] * wyz, c2 = wgt[0][2] * wyz;   // three interleaved DPP chains: a dependent one sits two instructions behind
+                asm volatile("s_nop 1\n" SPK_FMAC_DPP3("1", "%3") SPK_FMAC_DPP3("2", "%4") SPK_FMAC_DPP3("4", "%5") SPK_FMAC_DPP3("8", "%6")
+                             : "+v"(c0), "+v"(c1), "+v"(c2) : "v"(f1), "v"(f2), "v"(f4), "v"(f8));
                 if (live && head) {
                     const int n = base + TILE_W * sy + TILE_W * TILE_W * sz;
                     atomicAdd(&tile[n], (double)c0);
@@ -1991,7 +2010,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p_volume(ParticleArrays P, Gr
 
 // Mass-only scatter of one batch (one particle per lane) into a 512-entry f64 tile: same-cell lanes pre-summed over 16-lane rows
 // with DPP (64 particles per cell in the fluid configs), run heads deposit 3 x 9 atomics.
-SPK_DEV void mass_scatter(double* mtile, const float px[3], float mass, bool live, const int4& org, float h, int tid) {
+// `rcell`: round(px / h) as g2p_update already holds it (Advected::rnew); finite in dead lanes too (their sums meet live lanes' in the DPP chains
+// with factor 0, and 0 x NaN is NaN).
+SPK_DEV void mass_scatter(double* mtile, const float px[3], const float rcell[3], float mass, bool live, const int4& org, float h, int tid) {
     if (!__any(live)) return;
     const int r = tid & 15;
     const int orgv[3] = {org.x, org.y, org.z};
@@ -2000,7 +2021,7 @@ SPK_DEV void mass_scatter(double* mtile, const float px[3], float mass, bool liv
     const float inv_h = 1.0f / h;   // wave-uniform: one division, not six per particle
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float rc = round_cell(px[a], h, inv_h);
+        const float rc = rcell[a];
         const float d0 = (rc - 1.0f) * h - px[a];
         eval_all(-d0 * inv_h, wgt[a]);
         lc[a] = (int)rc - 1 - orgv[a] + 1;
@@ -2020,9 +2041,9 @@ SPK_DEV void mass_scatter(double* mtile, const float px[3], float mass, bool liv
 #pragma unroll
         for (int sy = 0; sy < 3; ++sy) {
             const float wyz = wgt[1][sy] * wgt[2][sz] * m;
-            float c0 = wgt[0][0] * wyz, c1 = wgt[0][1] * wyz, c2 = wgt[0][2] * wyz, c3 = 0.f;   // c3 pads the four interleaved DPP chains
-            asm volatile("s_nop 1\n" SPK_FMAC_DPP("1", "%4") SPK_FMAC_DPP("2", "%5") SPK_FMAC_DPP("4", "%6") SPK_FMAC_DPP("8", "%7")
-                         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2), "v"(f4), "v"(f8));
+            float c0 = wgt[0][0] * wyz, c1 = wgt[0][1] * wyz, c2 = wgt[0][2] * wyz;   // three interleaved DPP chains: a dependent one sits two instructions behind
+            asm volatile("s_nop 1\n" SPK_FMAC_DPP3("1", "%3") SPK_FMAC_DPP3("2", "%4") SPK_FMAC_DPP3("4", "%5") SPK_FMAC_DPP3("8", "%6")
+                         : "+v"(c0), "+v"(c1), "+v"(c2) : "v"(f1), "v"(f2), "v"(f4), "v"(f8));
             if (live && head) {
                 const int n = base + TILE_W * sy + TILE_W * TILE_W * sz;
                 atomicAdd(&mtile[n], (double)c0);
@@ -2030,6 +2051,12 @@ SPK_DEV void mass_scatter(double* mtile, const float px[3], float mass, bool liv
                 atomicAdd(&mtile[n + 2], (double)c2);
             }
         }
+}
+
+SPK_DEV void mass_scatter(double* mtile, const float px[3], float mass, bool live, const int4& org, float h, int tid) {
+    const float inv_h = 1.0f / h;
+    const float rc[3] = {round_cell(px[0], h, inv_h), round_cell(px[1], h, inv_h), round_cell(px[2], h, inv_h)};
+    mass_scatter(mtile, px, rc, mass, live, org, h, tid);
 }
 
 // G2P of substep s + mass-only scatter of the advected particles (= the first half of substep s+1's volume sweep).
@@ -2077,7 +2104,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
         }
         const uint32_t flags = __float_as_uint(kk.w);
         bool live = active && !(flags & FLAG_INVALID);
-        float npx[3] = {0.f, 0.f, 0.f};
+        float npx[3] = {0.f, 0.f, 0.f}, nrc[3] = {0.f, 0.f, 0.f};
         auto particle = [&](const auto& mo) {
             const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
             const Advected o = g2p_update<false>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
@@ -2093,6 +2120,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
             want_sort |= !o.in_tile && !(o.flags & FLAG_INVALID);   // a particle that left the DOMAIN is dead (skipped from now on): no re-bin for it
             live = o.in_tile;
             npx[0] = o.px[0]; npx[1] = o.px[1]; npx[2] = o.px[2];
+            nrc[0] = o.rnew[0]; nrc[1] = o.rnew[1]; nrc[2] = o.rnew[2];
             if (S.want_dt) {
                 const float bnd = particle_dt_bound(mo, o.flags, o.vel, o.C, kk.x, kk.y, o.eh, 1.f + o.Fe.m[0], S.h);
                 dt_nan |= bnd != bnd;
@@ -2104,7 +2132,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
             if constexpr (FLUID_ONLY) particle(PlainFluidModel(mo_t));   // the host selects FLUID_ONLY when every model is a plain fluid
             else particle(mo_t);
         }
-        mass_scatter(mtile, npx, kk.x, live, org, S.h, tid);
+        mass_scatter(mtile, npx, nrc, kk.x, live, org, S.h, tid);
     }
     __syncthreads();
     float* out = (float*)(G.tiles + (size_t)pb * TILE_N);   // mass tile: 8^3 scalars at the head of the block's slot
@@ -2168,13 +2196,14 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
             scatter_clear(sc[k]);
             auto particle = [&](const auto& mo) {
                 const float px[3] = {q0.x, q0.y, q0.z}, v[3] = {q3.x, q3.y, q3.z};
+                const float rc[3] = {round_cell(px[0], h, inv_h), round_cell(px[1], h, inv_h), round_cell(px[2], h, inv_h)};   // once for the gather and the scatter
                 if (mo.is_fluid) {   // fluids_volume.rs:83-110 with the weights of k_g2p_volume
                     const int orgv[3] = {org.x, org.y, org.z};
                     float wgt[3][3];
                     int lc[3];
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
-                        const float r = round_cell(px[a], h, inv_h);
+                        const float r = rc[a];
                         const float d0 = (r - 1.0f) * h - px[a];
                         eval_all(-d0 * inv_h, wgt[a]);
                         lc[a] = (int)r - 1 - orgv[a] + 1;
@@ -2197,7 +2226,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
                 const M3 C = {{q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
                 const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
                 const float jp = mo.is_fluid ? jp_stored : 1.f;
-                sc[k] = p2g_prepare(mo, flags, px, v, C, F, kk.x, kk.y, kk.z, phase, jp, org, h, inv_h, S.inv_d, S.dt);
+                sc[k] = p2g_prepare(mo, flags, px, v, C, F, kk.x, kk.y, kk.z, phase, jp, org, h, inv_h, S.inv_d, S.dt, nullptr, rc);
             };
             if (live[k]) {
                 const DevModel& mo_t = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
@@ -2209,7 +2238,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
         for (int k = 0; k < 2; ++k)
             if (f00_store[k]) P.q[0][pfirst + base + 2 * tid + k] = q0_keep[k];
         shell_used |= wave_or_i32(sc[0].shell | sc[1].shell);
-        wave_heads += p2g_scatter_pair<SPK_VOLP2G_STEPS>(tile, sc[0], sc[1], live[0], live[1], tid);
+        wave_heads += p2g_scatter_pair<SPK_VOLP2G_STEPS, false>(tile, sc[0], sc[1], live[0], live[1], tid);   // the mass is on the grid already (StepParams::mass_from_sweep)
     }
     if ((tid & 63) == 0) atomicAdd(&s_heads, wave_heads);
     tile_write(tile, G, pb, tid, shell_used);

@@ -520,6 +520,7 @@ static StepParams make_params(const SparklPipeline* p, const SparklSolverParams*
     S.project_particles = sp->enable_boundary_particle_projection ? 1 : 0;
     S.dt_next = dt;
     S.count_heads = 1;
+    S.mass_from_sweep = 0;
     S.num_models = (int)p->h_models.size();
     return S;
 }
@@ -790,7 +791,11 @@ static int enqueue_fluid_batch(SparklPipeline* p, const SparklSolverParams* sp, 
         }
         CHK(maybe_reorder(p, S.parity));
         CHK(clock_begin(p, SPAN_GRID, &tk));
-        launch_grid_update(p, G, S, st);
+        {
+            StepParams Sg = S;
+            Sg.mass_from_sweep = 1;   // k_vol_p2g scattered the momentum only: the node masses are the ones GUm left in node_vel.w
+            launch_grid_update(p, G, Sg, st);
+        }
         CHK(clock_end(p, tk));
         CHK(clock_begin(p, SPAN_G2P, &tk));
         if (fluid_only) SPK_LAUNCH_MODELS(k_g2p_mass, true); else SPK_LAUNCH_MODELS(k_g2p_mass, false);
