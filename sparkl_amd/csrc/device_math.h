@@ -394,6 +394,10 @@ SPK_DEV float dp_alpha(const MO& mo, float q) {
 
 // e^x - 1 without the cancellation of expf(x) - 1 (plastic strains are ~1e-4: exp rounds 1 + x to ~1e-7 absolute, i.e. 1e-3
 // of the strain)
+// The polynomial alone, for callers that bound |x| themselves (the series return map: |x| < 0.2, truncation x^6 / 5040 < 1e-8 relative).
+// expm1_small's libm side is only three instructions, which the compiler lays out exec-masked WITHOUT a skip: every call then issues
+// v_mul + v_exp (quarter rate) + v_add with no lane enabled -- six calls per particle in the return map.
+SPK_DEV float expm1_poly(float x) { return x * (1.f + x * (0.5f + x * (1.f / 6.f + x * (1.f / 24.f + x * (1.f / 120.f + x * (1.f / 720.f)))))); }
 SPK_DEV float expm1_small(float x) {
     SPK_HOT(fabsf(x) < 0.1f);
     if (fabsf(x) < 0.1f) return x * (1.f + x * (0.5f + x * (1.f / 6.f + x * (1.f / 24.f + x * (1.f / 120.f + x * (1.f / 720.f))))));
@@ -675,11 +679,64 @@ SPK_DEV SymStress corotated_tau_e(const MO& mo, float hardening, const M3& E, co
     return S;
 }
 
+// S_l = F F^T - I = E + E^T + E E^T as (xx, yy, zz, xy, xz, yz): the LEFT metric (same eigenvalues, hence the same Frobenius norm, as strain_metric's)
+SPK_DEV void strain_metric_left(const M3& E, float S[6]) {
+    const int ii[6] = {0, 1, 2, 0, 0, 1}, jj[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+        const int a = ii[e], b = jj[e];
+        S[e] = (E.m[a + 3 * b] + E.m[b + 3 * a]) + (E.m[a] * E.m[b] + E.m[a + 3] * E.m[b + 3] + E.m[a + 6] * E.m[b + 6]);
+    }
+}
+// The same stress through the LEFT stretch, for the series tiers.  With F = V R (V = sqrt(F F^T) symmetric):  (F - R) F^T = V^2 - V, so
+//   tau = 2 mu (I + S_l - sqrt(I + S_l)) + lambda (J - 1) J I,
+//   I + x - sqrt(I + x) = x/2 + x^2/8 - x^3/16 + 5 x^4/128 - 7 x^5/256 + 21 x^6/1024 - 33 x^7/2048 + ...
+// a polynomial in the symmetric S_l alone (Paterson-Stockmeyer on P2 = x^2 like hencky_series: two products to x^4 -- next term 0.055 |x|^4
+// relative, 4e-8 at SPK_SERIES_MAX --, four to x^7 -- 0.026 |x|^7, 3e-9 at SPK_SERIES_MAX2): no M = I - exp(-eps), no A = F M, no A F^T
+// (two 27-FMA products and one series product less than corotated_tau_e, and E is the only matrix live on entry).  The linear part is S_l / 2
+// itself, so the relative precision of the strain is kept as in the right-stretch form.
+template <class MO>
+SPK_DEV SymStress corotated_tau_left(const MO& mo, float hardening, const M3& E, bool hi, lds_fp park = nullptr, const float* jm1_known = nullptr) {
+    float x[6], P2[6], V[6], U[6];
+    strain_metric_left(E, x);
+    sym_mul(x, x, P2);
+    if (hi) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) V[k] = (-33.f / 2048.f) * x[k];
+        sym_mul(P2, V, U);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) V[k] = U[k] + ((-7.f / 256.f) * x[k] + (21.f / 1024.f) * P2[k]);
+        sym_mul(P2, V, U);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) V[k] = U[k] + ((-1.f / 16.f) * x[k] + (5.f / 128.f) * P2[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) V[k] = (-1.f / 16.f) * x[k] + (5.f / 128.f) * P2[k];
+    }
+    sym_mul(P2, V, U);
+    const float jm1 = jm1_known != nullptr ? *jm1_known : det_minus_one(E);
+    const float sph = mo.lambda * hardening * jm1 * (1.f + jm1);
+    const float k2 = 2.f * mo.mu * hardening;
+    SymStress S;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float t = k2 * (U[k] + (0.5f * x[k] + 0.125f * P2[k])) + (k < 3 ? sph : 0.f);
+        if (park != nullptr) { park[64 * k] = t; S.t[k] = 0.f; }
+        else S.t[k] = t;
+    }
+    S.jm1 = jm1;
+    S.valid = true;
+    return S;
+}
+
 // phase == 1 corotated stress of F = I + E
 template <class MO>
 SPK_DEV M3 corotated_kirchhoff_fe(const MO& mo, float hardening, const M3& E) {
     float S[6], e[3], re[3], g[3], m6[6];
     strain_metric(E, S);
+#ifndef SPK_STRESS_RIGHT
+    if (SPK_SERIES_MAX > 0.f && __all(series2_ok(S))) return sym_to_m3(corotated_tau_left(mo, hardening, E, !__all(series_ok(S))));   // wave-uniform, and so is the tier
+#endif
     if (SPK_SERIES_MAX > 0.f && __all(series2_ok(S))) {   // wave-uniform; series path: M = I - (I + S)^(-1/2)
         // = S/2 - 3/8 S^2 + 5/16 S^3 - 35/128 S^4 + 63/256 S^5 - 231/1024 S^6 + 429/2048 S^7 (next term 0.39 |S|^7 relative), evaluated like
         // hencky_series: P2 = S^2, coefficients linear in S, Horner in P2 -- four products, S, P2 and one running factor live
@@ -721,6 +778,7 @@ SPK_DEV M3 corotated_kirchhoff_e(const MO& mo, float hardening, const M3& F) {
 template <bool WANT_STRESS, class MO>
 SPK_DEV void dp_update_series(const MO& mo, float phase, float eh, const float S[6], M3& E, float& Jp, float& q, float& lvg, float sm1[3], bool& sv_valid,
                               SymStress& T, lds_fp park = nullptr, bool hi = false) {
+    // (arguments of expm1_poly below: |S|, |lvg| < 0.1 => |eps| < 0.053, |tr eps| < 0.092, |tr eps + lvg| < 0.2, |c| < 0.034, eigenvalues of eps' < 0.12)
     float eps[6];
     SPK_MARK("dp_series_log");
     hencky_series(S, eps, hi);
@@ -735,7 +793,7 @@ SPK_DEV void dp_update_series(const MO& mo, float phase, float eh, const float S
     bool moved = false;
     // det(F) - 1 = expm1(tr eps) comes with the volume bookkeeping below (truncation of the series: a few 1e-8 of the strain); the stress
     // and the caller's guards take it instead of the minors of E'
-    float jm1 = expm1_small(tre);
+    float jm1 = expm1_poly(tre);
     if (dn2 == 0.f || tr > 0.f) {            // tensile: sigma' = 1, K = -eps
         dq = fast_sqrt(dn2 + tr * tr * (1.f / 3.f));
         c = -em; g = -1.f;
@@ -752,7 +810,7 @@ SPK_DEV void dp_update_series(const MO& mo, float phase, float eh, const float S
     if (moved) {
         const float so = tre, sn = tre + 3.f * c;
         const float pm1 = jm1;
-        float nm1 = expm1_small(sn), lnew = sn;
+        float nm1 = expm1_poly(sn), lnew = sn;
         jm1 = nm1;                       // det F' = prod sigma' = exp(tr eps + 3 c), before the volume correction touches the bookkeeping
         const float diff = nm1 - pm1;
         SPK_HOT(mo.volume_correction == 1.f);
@@ -768,7 +826,7 @@ SPK_DEV void dp_update_series(const MO& mo, float phase, float eh, const float S
 #pragma unroll
         for (int i = 0; i < 6; ++i) Q[i] = (1.f / 6.f) * D[i] + (1.f / 24.f) * D2[i];
         sym_mul(D2, Q, D34);           // D^3/6 + D^4/24
-        const float xc = expm1_small(c), ec = 1.f + xc;
+        const float xc = expm1_poly(c), ec = 1.f + xc;
 #pragma unroll
         for (int i = 0; i < 6; ++i) G6[i] = ec * (D[i] + (0.5f * D2[i] + D34[i]));
         G6[0] += xc; G6[1] += xc; G6[2] += xc;
@@ -787,13 +845,19 @@ SPK_DEV void dp_update_series(const MO& mo, float phase, float eh, const float S
     SPK_MARK("dp_eigvals");
     sym_eigvals(eps, e);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) sm1[i] = expm1_small(e[i]);
+    for (int i = 0; i < 3; ++i) sm1[i] = expm1_poly(e[i]);
     sv_valid = true;
     SPK_MARK("dp_stress");
     if (WANT_STRESS && mo.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR && phase == 1.f) {
+#ifdef SPK_STRESS_RIGHT
         float m6[6];
         one_minus_exp_neg_series(eps, m6);
         T = corotated_tau_e(mo, eh, E, m6, park, &jm1);
+#else
+        // of the mapped F itself, through its left stretch (the mapped strain stays inside the tier of the trial strain: the deviator only shrinks,
+        // and so does |tr| as long as log_vol_gain >= 0; the tier bound covers |lvg| for the rest)
+        T = corotated_tau_left(mo, eh, E, hi, park, &jm1);
+#endif
     }
 }
 

@@ -124,6 +124,7 @@ struct GridArrays {
 struct StepParams {
     float h;
     float inv_d;      // 4 / h^2
+    float inv_h;      // 1 / h (the host's IEEE quotient: the same bits as the device's division, without its twelve instructions per workgroup)
     float dt;
     float gx, gy, gz;
     int boundary_handling;
@@ -207,8 +208,9 @@ SPK_DEV int xcd_remap(int bid, int n) {
 SPK_DEV float round_cell(float x, float h, float inv_h) {
     const float t = x * inv_h;
     const float r = rintf(t);
-    SPK_HOT(!(fabsf(t - r) > 0.5f - 1.0e-6f * fmaxf(fabsf(t), 1.f)));
-    if (fabsf(t - r) > 0.5f - 1.0e-6f * fmaxf(fabsf(t), 1.f)) return roundf(x / h);
+    // (the product is within 2^-23 |t| of the quotient: 1e-6 |t| covers it for every t, no floor at 1 needed)
+    SPK_HOT(!(fabsf(t - r) > 0.5f - 1.0e-6f * fabsf(t)));
+    if (fabsf(t - r) > 0.5f - 1.0e-6f * fabsf(t)) return roundf(x / h);
     return r;
 }
 
@@ -800,7 +802,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
     for (int n = tid; n < ACC_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int pfirst = rng.x, pcount = rng.y;
-    const float h = S.h, inv_h = 1.0f / S.h;
+    const float h = S.h, inv_h = S.inv_h;
     const int niter = (pcount + BLK_THREADS - 1) / BLK_THREADS;
     // software pipeline: the 7 x 16 B of the next batch are in flight while this batch computes
     float4 n0, n1, n2, n3, n4, n5, nk;
@@ -858,7 +860,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_pair(ParticleArrays P, Grid
     for (int n = tid; n < ACC_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int pfirst = rng.x, pcount = rng.y;
-    const float h = S.h, inv_h = 1.0f / S.h;
+    const float h = S.h, inv_h = S.inv_h;
     __syncthreads();
     int shell_used = 0;
     int wave_heads = 0;
@@ -1594,7 +1596,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
     if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
     if (G.primary && blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
     __syncthreads();
-    const float inv_h = 1.0f / S.h;
+    const float inv_h = S.inv_h;
     bool want_sort = false;
     float dt_bound = 3.402823466e+38f;
     bool dt_nan = false;
@@ -1677,7 +1679,7 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     load_vel_tile(vt, G, b, tid);
     if (G.primary && blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
     __syncthreads();
-    const float h = S.h, inv_h = 1.0f / S.h;
+    const float h = S.h, inv_h = S.inv_h;
     bool want_sort = false;
     int shell_used = 0;
     int wave_heads = 0;
@@ -1723,7 +1725,7 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
                 SymStress T2;
                 T2.valid = t_valid; T2.jm1 = 0.f;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) T2.t[k] = t_valid ? park[64 * k] : 0.f;
+                for (int k = 0; k < 6; ++k) T2.t[k] = park[64 * k];   // (unconditionally: whatever the columns hold is ignored unless T2.valid)
                 sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.Fe, kk.x, kk.y, o.eh, o.phase, o.Jp, org, h, inv_h, S.inv_d, S.dt_next, &T2, o.rnew);
             }
             SPK_MARK("scatter");
@@ -1769,7 +1771,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_regather_c(ParticleArrays P, Gr
     const int b = org.w, pfirst = rng.x, pcount = rng.y;
     load_vel_tile(vt, G, b, tid);
     __syncthreads();
-    const float inv_h = 1.0f / S.h;
+    const float inv_h = S.inv_h;
     for (int li = tid; li < pcount; li += BLK_THREADS) {
         const int i = pfirst + li;
         const float4 q0 = P.q[0][i], q3 = P.q[3][i];
@@ -2085,7 +2087,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
     if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
     if (blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
     __syncthreads();
-    const float inv_h = 1.0f / S.h;
+    const float inv_h = S.inv_h;
     bool want_sort = false;
     float dt_bound = 3.402823466e+38f;
     bool dt_nan = false;
@@ -2171,7 +2173,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
         const int nb = G.blk_nbr[b * 27 + (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1)];
         vm[n] = nb >= 0 ? G.node_vel[(size_t)nb * 64 + cx + 4 * cy + 16 * cz].w : 0.f;
     }
-    const float h = S.h, inv_h = 1.0f / S.h;
+    const float h = S.h, inv_h = S.inv_h;
     __syncthreads();
     int shell_used = 0;
     int wave_heads = 0;

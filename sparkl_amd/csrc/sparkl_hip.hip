@@ -513,7 +513,7 @@ static int resort(SparklPipeline* p) {
 // ----------------------------------------------------------------------------------- one substep
 static StepParams make_params(const SparklPipeline* p, const SparklSolverParams* sp, const float g[3], float dt) {
     StepParams S;
-    S.h = p->h; S.inv_d = 4.0f / (p->h * p->h); S.dt = dt;
+    S.h = p->h; S.inv_d = 4.0f / (p->h * p->h); S.inv_h = 1.0f / p->h; S.dt = dt;
     S.gx = g[0]; S.gy = g[1]; S.gz = g[2];
     S.boundary_handling = sp->boundary_handling; S.dofs = sp->simulation_dofs;
     S.parity = (int)(p->substep_index & 1u); S.dom = p->dom; S.num_cuboids = p->num_cuboids; S.num_heightfields = p->num_heightfields; S.num_trimeshes = p->num_trimeshes; S.want_dt = 0; S.defer_c = 0;

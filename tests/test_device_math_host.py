@@ -109,7 +109,11 @@ def test_drucker_prager_return_map_matches_the_f64_oracle(libs, scale):
     for k, w in worst.items():
         assert (w[:3] < bound).all() and w[3] < 10 * bound, (k, scale, w, bound)
     if scale <= 3e-3:   # inside the series domain: never worse than the eigenbasis path by more than rounding
-        assert (worst["series"][:3] <= worst["jacobi"][:3] + 5e-7).all(), worst
+        # (F' and log_vol_gain.  The stress of the series path is that of the STORED F' -- its left stretch, corotated_tau_left: what the
+        # reference's next P2G evaluates -- so it carries the f32 storage of a rotated F', 1e-7 theta / strain, which `bound` above covers;
+        # the eigenbasis path forms it from the unrounded mapped strain it still holds.  Trajectories do not tell them apart:
+        # profiles/r04_parity.jsonl before / after.)
+        assert (worst["series"][[0, 2]] <= worst["jacobi"][[0, 2]] + 5e-7).all(), worst
 
 
 @pytest.mark.parametrize("which", ["devmath_series_max", "devmath_series_max2"])
