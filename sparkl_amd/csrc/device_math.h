@@ -778,7 +778,8 @@ SPK_DEV M3 corotated_kirchhoff_e(const MO& mo, float hardening, const M3& F) {
 template <bool WANT_STRESS, class MO>
 SPK_DEV void dp_update_series(const MO& mo, float phase, float eh, const float S[6], M3& E, float& Jp, float& q, float& lvg, float sm1[3], bool& sv_valid,
                               SymStress& T, lds_fp park = nullptr, bool hi = false) {
-    // (arguments of expm1_poly below: |S|, |lvg| < 0.1 => |eps| < 0.053, |tr eps| < 0.092, |tr eps + lvg| < 0.2, |c| < 0.034, eigenvalues of eps' < 0.12)
+    // (arguments of expm1_poly below: |S| < 0.1 => |eps| < 0.053, |tr eps| < 0.092; on the cone  -0.1 < lvg <= -tr eps  (dp_update_e's tier test), so
+    // |tr eps + lvg| < 0.2 and |c| = |lvg| / 3 < 0.034; tensile: c = -tr eps / 3; eigenvalues of eps' < 0.12)
     float eps[6];
     SPK_MARK("dp_series_log");
     hencky_series(S, eps, hi);
@@ -870,9 +871,18 @@ SPK_DEV void dp_update_e(const MO& mo, float phase, float eh, M3& E, float& Jp, 
     // eps = lin + V diag(dv) V^T throughout: `lin` the first-order matrix, `dv` the remainders in the eigenbasis, e_k its eigenvalues
     float lin[6], e[3], dv[3];
     strain_metric(E, lin);
-    SPK_HOT(__all(series2_ok(lin, lvg)));
-    if (SPK_SERIES_MAX > 0.f && __all(series2_ok(lin, lvg))) {   // wave-uniform, and so is the tier
-        dp_update_series<WANT_STRESS>(mo, phase, eh, lin, E, Jp, q, lvg, sm1, sv_valid, T, park, !__all(series_ok(lin, lvg)));
+    // The pending volume gain only enters the tier test when NEGATIVE (possible with volume_correction != 1 only).  A positive one never reaches a
+    // series: either tr eps + lvg > 0 -- tensile, sigma' = 1, no function of lvg is evaluated -- or lvg <= -tr eps, which |S| already bounds.
+    // (Particles that have flown apart carry log_vol_gain of order 1 for the rest of the run: tested as |lvg| they sent every wave they sit
+    // in down the eigenbasis path.)
+#ifdef SPK_TIER_ABS_LVG
+    const float lvg_t = lvg;
+#else
+    const float lvg_t = fminf(lvg, 0.f);
+#endif
+    SPK_HOT(__all(series2_ok(lin, lvg_t)));
+    if (SPK_SERIES_MAX > 0.f && __all(series2_ok(lin, lvg_t))) {   // wave-uniform, and so is the tier
+        dp_update_series<WANT_STRESS>(mo, phase, eh, lin, E, Jp, q, lvg, sm1, sv_valid, T, park, !__all(series_ok(lin, lvg_t)));
         return;
     }
 #ifndef SPK_HOT_ONLY   // (analysis build: the eigenbasis path compiled out, see SPK_HOT)

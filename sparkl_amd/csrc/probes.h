@@ -108,7 +108,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_run_stats(ParticleArrays P, Gri
         const int nlive = (int)__popcll(__ballot(live));
         // wave maximum of |F^T F - I|_F (what selects the series path of the return map): bin k = first threshold of
         // {1e-3, 3e-3, 1e-2, 3e-2, 1e-1, 3e-1, inf} above it
-        int sbin = 0;
+        int sbin = 0, lbin = 0, mbin = 0;
         {
             const float4 q1 = P.q[1][i], q2 = P.q[2][i];
             const M3 E = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
@@ -117,6 +117,12 @@ __global__ __launch_bounds__(BLK_THREADS) void k_run_stats(ParticleArrays P, Gri
             float f = live ? sqrtf(sym_frob2(S6)) : 0.f;
             for (int o = 32; o > 0; o >>= 1) f = fmaxf(f, __shfl_xor(f, o));
             sbin = f < 1e-3f ? 0 : f < 3e-3f ? 1 : f < 1e-2f ? 2 : f < 3e-2f ? 3 : f < 1e-1f ? 4 : f < 3e-1f ? 5 : 6;
+            // same row, bins 16.. : wave maximum of the pending |log_vol_gain|; bins 32.. : of max(|S|, |lvg|)
+            float g = live ? fabsf(P.d[i].y) : 0.f;
+            for (int o = 32; o > 0; o >>= 1) g = fmaxf(g, __shfl_xor(g, o));
+            lbin = g < 1e-3f ? 0 : g < 3e-3f ? 1 : g < 1e-2f ? 2 : g < 3e-2f ? 3 : g < 1e-1f ? 4 : g < 3e-1f ? 5 : 6;
+            const float m = fmaxf(f, g);
+            mbin = m < 1e-3f ? 0 : m < 3e-3f ? 1 : m < 1e-2f ? 2 : m < 3e-2f ? 3 : m < 1e-1f ? 4 : m < 3e-1f ? 5 : 6;
         }
         if (lane == 0) {
             atomicAdd(&out[RS_NRUNS * RS_BINS + nruns], 1ull);
@@ -129,6 +135,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_run_stats(ParticleArrays P, Gri
             atomicAdd(&out[RS_ROWS * RS_BINS + rows], 1ull);
             atomicAdd(&out[RS_LAYERS * RS_BINS + layers], 1ull);
             atomicAdd(&out[RS_STRAIN * RS_BINS + sbin], 1ull);
+            atomicAdd(&out[RS_STRAIN * RS_BINS + 16 + lbin], 1ull);
+            atomicAdd(&out[RS_STRAIN * RS_BINS + 32 + mbin], 1ull);
             atomicAdd(&out[RS_MAXCELL * RS_BINS + min(maxcell, 64)], 1ull);
             atomicAdd(&out[RS_ITERS_MULTI * RS_BINS + min(iters_multi, 64)], 1ull);
         }

@@ -24,4 +24,5 @@ for spec in args:
     lk = late.get("kernels_avg_launch_ms", {})
     print(f"{name:14s} ms/step {o['ms_per_step']:.4f}  " + " ".join(f"{a}={b:.4f}" for a, b in k.items()) +
           f"  frac {o.get('roofline', {}).get('frac', 0):.3f} | late ms/step {late.get('ms_per_step', 0):.4f} " + " ".join(f"{a}={b:.4f}" for a, b in lk.items()) +
-          f" late_frac {(late.get('roofline') or {}).get('frac', 0):.3f} resorts {late.get('resorts')} reorder_ms {late.get('reorder_ms_total', 0):.2f}", flush=True)
+          f" late_frac {(late.get('roofline') or {}).get('frac', 0):.3f} resorts {late.get('resorts')} reorder_ms {late.get('reorder_ms_total', 0):.2f}" +
+          (f" | deep ms/step {o['deep_collapse']['ms_per_step']:.4f} g2p2g={o['deep_collapse']['kernels_avg_launch_ms'].get('g2p2g', 0):.4f} frac {o['deep_collapse']['roofline']['frac']:.3f}" if o.get("deep_collapse") else ""), flush=True)

@@ -61,6 +61,10 @@ def run_stats(p):
         q = [int(np.searchsorted(cum, x)) for x in (0.1, 0.5, 0.9, 0.99)]
         top = " ".join(f"{i}:{h[i] / tot:.3f}" for i in np.argsort(-h)[:8] if h[i] > 0)
         print(f"  {name:10s} n {int(tot):8d} mean {(h * np.arange(65)).sum() / tot:6.2f} p10/50/90/99 {q}  top {top}")
+    st = a[10]   # waves by wave maximum, thresholds 1e-3 3e-3 1e-2 3e-2 0.1 0.3 inf: |F^T F - I| (bins 0..6), |log_vol_gain| (16..22), the larger (32..38)
+    n = max(st[:7].sum(), 1)
+    for off, name in ((0, "|S|"), (16, "|lvg|"), (32, "max")):
+        print(f"  waves by {name:6s}", " ".join(f"{x / n:.3f}" for x in st[off:off + 7]))
 
 
 def cmd_phase(a):
