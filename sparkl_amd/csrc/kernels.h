@@ -2158,6 +2158,14 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
     __shared__ float vm[TILE_N];          // node masses of the 8^3 tile (the merged mass-only grid)
     __shared__ int s_heads;
     __shared__ DevModel s_models[LDS_MODELS ? MAX_LDS_MODELS : 1];
+    // Pair transposition (one buffer per wave).  Lane j owns records 2j and 2j + 1 of the wave's 128 -- neighbours in the cell-sorted order, so
+    // that their node values can be added in the lane --, and loading them as such makes every dwordx4 touch 16 bytes of each 32 (3.8 TB/s where
+    // k_g2p_mass streams the same arrays at 4.9).  So the wave loads its 128 records with two COALESCED dwordx4 per stream (lane t: records t and
+    // 64 + t) and hands them to their owners through the LDS: record e goes to slot (e >> 1) + 72 (e & 1) -- even records in slots 0..63, odd ones
+    // in 72..135, the 8-slot gap puts the two halves of a 16-lane write pass on different banks --, lane j reads slots j and 72 + j.  LDS
+    // operations of one wave execute in order: no barrier between the streams that reuse the buffer.
+    __shared__ float4 s_xp[BLK_THREADS / 64][136];
+    __shared__ float s_xj[BLK_THREADS / 64][136];
     const int tid = threadIdx.x;
     if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
     if (tid == 0) s_heads = 0;
@@ -2177,38 +2185,57 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
     __syncthreads();
     int shell_used = 0;
     int wave_heads = 0;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int sA = (lane >> 1) + 72 * (lane & 1), sB = sA + 32;   // slots of records lane and 64 + lane
+    float4* xp = s_xp[wv];
+    auto hand_over = [&](const float4& a, const float4& b, float4 out[2]) {
+        xp[sA] = a; xp[sB] = b;
+        __builtin_amdgcn_wave_barrier();
+        out[0] = xp[lane]; out[1] = xp[72 + lane];
+        __builtin_amdgcn_wave_barrier();
+    };
     for (int base = 0; base < pcount; base += 2 * BLK_THREADS) {
         Scatter sc[2];
-        bool live[2];
-        // F00 of both particles is stored behind the pair: a store between the two particles' loads would pin the second particle's
-        // loads behind the first one's arithmetic (the compiler must assume they alias), i.e. two load latencies per batch instead of one
-        bool f00_store[2] = {false, false};
-        float4 q0_keep[2];
+        bool live[2], f00_store[2] = {false, false};
+        const int wbase = base + wv * 128;                                   // first record of this wave's 128 (block-relative)
+        const int eA = pfirst + min(wbase + lane, pcount - 1), eB = pfirst + min(wbase + 64 + lane, pcount - 1);
+        // every load of the batch is issued here; the velocity / affine streams are only waited for behind the volume gather
+        const float4 a0 = P.q[0][eA], b0 = P.q[0][eB], ak = P.k[eA], bk = P.k[eB];
+        const float ja = P.d[eA].z, jb = P.d[eB].z;
+        const float4 a3 = P.q[3][eA], b3 = P.q[3][eB], a4 = P.q[4][eA], b4 = P.q[4][eB], a5 = P.q[5][eA], b5 = P.q[5][eB];
+        float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = a1, a2 = a1, b2 = a1;
+        if (!FLUID_ONLY) { a1 = P.q[1][eA]; b1 = P.q[1][eB]; a2 = P.q[2][eA]; b2 = P.q[2][eB]; }
+        // ---- phase 1: position, mass, flags -> volume gather (F00 = (m / rho_grid) / V0 for fluid particles, fluids_volume.rs:83-110)
+        float4 q0[2], kk[2];
+        float jp_stored[2], rc[2][3];
+        hand_over(a0, b0, q0);
+        hand_over(ak, bk, kk);
+        {
+            float* xj = s_xj[wv];
+            xj[sA] = ja; xj[sB] = jb;
+            __builtin_amdgcn_wave_barrier();
+            jp_stored[0] = xj[lane]; jp_stored[1] = xj[72 + lane];
+            __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int li = base + 2 * tid + k;
-            const bool active = li < pcount;
-            const int i = pfirst + (active ? li : 0);
-            float4 q0 = P.q[0][i];
-            const float4 q3 = P.q[3][i], q4 = P.q[4][i], q5 = P.q[5][i], kk = P.k[i];
-            const float4 q1 = FLUID_ONLY ? make_float4(0.f, 0.f, 0.f, 0.f) : P.q[1][i], q2 = FLUID_ONLY ? make_float4(0.f, 0.f, 0.f, 0.f) : P.q[2][i];   // F - I
-            const float jp_stored = P.d[i].z;
-            const uint32_t flags = __float_as_uint(kk.w);
-            live[k] = active && !(flags & FLAG_INVALID);
+            const uint32_t flags = __float_as_uint(kk[k].w);
+            live[k] = (base + 2 * tid + k < pcount) && !(flags & FLAG_INVALID);
             scatter_clear(sc[k]);
-            auto particle = [&](const auto& mo) {
-                const float px[3] = {q0.x, q0.y, q0.z}, v[3] = {q3.x, q3.y, q3.z};
-                const float rc[3] = {round_cell(px[0], h, inv_h), round_cell(px[1], h, inv_h), round_cell(px[2], h, inv_h)};   // once for the gather and the scatter
-                if (mo.is_fluid) {   // fluids_volume.rs:83-110 with the weights of k_g2p_volume
+            rc[k][0] = rc[k][1] = rc[k][2] = 0.f;
+            auto volume = [&](const auto& mo) {
+                const float px[3] = {q0[k].x, q0[k].y, q0[k].z};
+#pragma unroll
+                for (int a = 0; a < 3; ++a) rc[k][a] = round_cell(px[a], h, inv_h);   // once for the gather and the scatter
+                if (mo.is_fluid) {   // with the weights of k_g2p_volume
                     const int orgv[3] = {org.x, org.y, org.z};
                     float wgt[3][3];
                     int lc[3];
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
-                        const float r = rc[a];
-                        const float d0 = (r - 1.0f) * h - px[a];
+                        const float d0 = (rc[k][a] - 1.0f) * h - px[a];
                         eval_all(-d0 * inv_h, wgt[a]);
-                        lc[a] = (int)r - 1 - orgv[a] + 1;
+                        lc[a] = (int)rc[k][a] - 1 - orgv[a] + 1;
                     }
                     const int vb = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
                     float new_mass = 0.f;
@@ -2220,25 +2247,46 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
                             for (int sx = 0; sx < 3; ++sx)
                                 new_mass += (wgt[0][sx] * wgt[1][sy] * wgt[2][sz]) * vm[vb + sx + TILE_W * sy + TILE_W * TILE_W * sz];
                     // F00 = (m / (M / h^3)) / V0 as one quotient (the reference divides three times: the same number to 1e-7)
-                    q0.w = (kk.x * (h * h * h)) / (new_mass * kk.y) - 1.f;   // stored as F00 - 1
+                    q0[k].w = (kk[k].x * (h * h * h)) / (new_mass * kk[k].y) - 1.f;   // stored as F00 - 1
                     f00_store[k] = true;
                 }
-                q0_keep[k] = q0;
-                const M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};   // F - I as stored
-                const M3 C = {{q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
-                const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
-                const float jp = mo.is_fluid ? jp_stored : 1.f;
-                sc[k] = p2g_prepare(mo, flags, px, v, C, F, kk.x, kk.y, kk.z, phase, jp, org, h, inv_h, S.inv_d, S.dt, nullptr, rc);
             };
             if (live[k]) {
                 const DevModel& mo_t = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
-                if constexpr (FLUID_ONLY) particle(PlainFluidModel(mo_t));
-                else particle(mo_t);
+                if constexpr (FLUID_ONLY) volume(PlainFluidModel(mo_t));
+                else volume(mo_t);
             }
         }
+        // ---- phase 2: velocity, affine (and F1..F8 of solids) -> scatter descriptors
+        float4 q3[2], q4[2], q5[2], q1[2], q2[2];
+        hand_over(a3, b3, q3); hand_over(a4, b4, q4); hand_over(a5, b5, q5);
+        if (!FLUID_ONLY) { hand_over(a1, b1, q1); hand_over(a2, b2, q2); }
+        else { q1[0] = q1[1] = q2[0] = q2[1] = make_float4(0.f, 0.f, 0.f, 0.f); }   // a plain fluid keeps F1..F8 = identity
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-            if (f00_store[k]) P.q[0][pfirst + base + 2 * tid + k] = q0_keep[k];
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t flags = __float_as_uint(kk[k].w);
+            auto prepare = [&](const auto& mo) {
+                const float px[3] = {q0[k].x, q0[k].y, q0[k].z}, v[3] = {q3[k].x, q3[k].y, q3[k].z};
+                const M3 F = {{q0[k].w, q1[k].x, q1[k].y, q1[k].z, q1[k].w, q2[k].x, q2[k].y, q2[k].z, q2[k].w}};   // F - I as stored
+                const M3 C = {{q3[k].w, q4[k].x, q4[k].y, q4[k].z, q4[k].w, q5[k].x, q5[k].y, q5[k].z, q5[k].w}};
+                const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[pfirst + base + 2 * tid + k].x, 1.f);
+                const float jp = mo.is_fluid ? jp_stored[k] : 1.f;
+                sc[k] = p2g_prepare(mo, flags, px, v, C, F, kk[k].x, kk[k].y, kk[k].z, phase, jp, org, h, inv_h, S.inv_d, S.dt, nullptr, rc[k]);
+            };
+            if (live[k]) {
+                const DevModel& mo_t = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
+                if constexpr (FLUID_ONLY) prepare(PlainFluidModel(mo_t));
+                else prepare(mo_t);
+            }
+        }
+        if (__any(f00_store[0] | f00_store[1])) {   // wave-uniform.  The way back: every in-range record is stored (unchanged unless it is a fluid's), coalesced
+            xp[lane] = q0[0]; xp[72 + lane] = q0[1];
+            __builtin_amdgcn_wave_barrier();
+            const float4 ra = xp[sA], rb = xp[sB];
+            __builtin_amdgcn_wave_barrier();
+            if (wbase + lane < pcount) P.q[0][pfirst + wbase + lane] = ra;
+            if (wbase + 64 + lane < pcount) P.q[0][pfirst + wbase + 64 + lane] = rb;
+        }
         shell_used |= wave_or_i32(sc[0].shell | sc[1].shell);
         wave_heads += p2g_scatter_pair<SPK_VOLP2G_STEPS, false>(tile, sc[0], sc[1], live[0], live[1], tid);   // the mass is on the grid already (StepParams::mass_from_sweep)
     }
