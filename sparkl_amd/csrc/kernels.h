@@ -223,6 +223,7 @@ template <int N>
 SPK_DEV int dpp_shl_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xF, 0xF, true); }
 typedef float f2v __attribute__((ext_vector_type(2)));
 SPK_DEV int dpp_shr1_i(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xF, 0xF, false); }
+SPK_DEV float dpp_shr1_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true)); }   // lane i reads lane i - 1 of its row (0 at the row start)
 
 // The model table is read-only for the lifetime of a launch.  Reading it through per-lane global pointers costs a vector load per
 // parameter, each followed by s_waitcnt vmcnt(0) -- which, loads returning in order, also waits for every particle load issued
@@ -420,7 +421,10 @@ SPK_DEV int p2g_scatter(double (*tile)[ACC_N], const Scatter& sc, bool live, int
 
 // Two particles per lane (slots 2j, 2j + 1: neighbours in the cell-sorted order, so usually the same cell).  Their node
 // values are added in the lane first, which halves the DPP reduction, the f64 conversions and the LDS atomic
-// instructions per particle; a pair that straddles two cells deposits its second particle on its own.
+// instructions per particle.  A pair that straddles two cells -- the usual case once cells hold odd counts: the boundary of a cell falls between
+// the two slots of a lane -- hands its second particle to the NEXT lane when that lane's first particle sits in the same cell (one more
+// v_fmac_f32_dpp row_shr:1 per value, behind a wave-uniform test); only what is left (a cell with a single particle between two others, the
+// last lane of a group) deposits on its own.
 // WITH_MASS = false (k_vol_p2g): the momentum only -- three DPP chains, f64 conversions and atomics per node instead of four; tile[0] stays 0.
 template <int REDUCE_STEPS, bool WITH_MASS = true>
 SPK_DEV int p2g_scatter_pair(double (*tile)[ACC_N], const Scatter& sa, const Scatter& sb, bool live_a, bool live_b, int tid) {
@@ -431,11 +435,13 @@ SPK_DEV int p2g_scatter_pair(double (*tile)[ACC_N], const Scatter& sa, const Sca
     const int r = lane & (G - 1);
     const int key = live_a ? sa.base : -1;
     const bool same = live_a & live_b & (sb.base == sa.base);
-    const bool lone_b = live_b & !same;
     const int key_prev = dpp_shr1_i(key, -2), key_next = dpp_shl_i<1>(key);
+    const bool join = live_b & !same & (r + 1 < G) & (key_next == sb.base);   // the next lane's first particle sits in b's cell (key_next >= 0: it is live)
+    const bool lone_b = live_b & !same & !join;
     const bool head = (r == 0) | (key_prev != key);
     const int nheads = (int)__popcll(__ballot(live_a & head)) + (int)__popcll(__ballot(lone_b));
-    const bool any_lone = __any(lone_b);
+    const bool any_lone = __any(lone_b), any_join = __any(join);
+    const float gj = dpp_shr1_f(join ? 1.f : 0.f);   // 1: the previous lane's second particle joins this lane's run
     const int i1 = ((r + 1 < G) & (key_next == key)) ? 1 : 0;
     const int i2 = i1 & dpp_shl_i<1>(i1) & (r + 2 < G ? 1 : 0);
     const int i4 = (REDUCE_STEPS >= 3) ? (i2 & dpp_shl_i<2>(i2) & (r + 4 < G ? 1 : 0)) : 0;
@@ -460,6 +466,15 @@ SPK_DEV int p2g_scatter_pair(double (*tile)[ACC_N], const Scatter& sa, const Sca
                 const f2v b01 = PB01 * wb, b23 = PB23 * wb;
                 const f2v c01 = PA01 * wa + b01 * fs, c23 = PA23 * wa + b23 * fs;
                 float c0 = c01.x, c1 = c01.y, c2 = c23.x, c3 = c23.y;
+                if (any_join) {   // wave-uniform
+                    const float b0 = b01.x, b1 = b01.y, b2 = b23.x, b3 = b23.y;
+                    if (WITH_MASS) asm volatile("s_nop 1\nv_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(c0) : "v"(b0), "v"(gj));
+                    asm volatile("s_nop 1\n"
+                                 "v_fmac_f32_dpp %0, %3, %6 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+                                 "v_fmac_f32_dpp %1, %4, %6 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+                                 "v_fmac_f32_dpp %2, %5, %6 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                                 : "+v"(c1), "+v"(c2), "+v"(c3) : "v"(b1), "v"(b2), "v"(b3), "v"(gj));
+                }
                 if (!WITH_MASS) {   // (a dependent v_fmac_f32_dpp three instructions behind its producer: the two wait states DPP needs)
                     if (REDUCE_STEPS == 2) {
                         asm volatile("s_nop 1\n" SPK_FMAC_DPP3("1", "%3") SPK_FMAC_DPP3("2", "%4") : "+v"(c1), "+v"(c2), "+v"(c3) : "v"(f1), "v"(f2));
