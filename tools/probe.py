@@ -104,6 +104,8 @@ def cmd_soak(a):
         sc.params.dt = a.step
     with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
         p.load_scene(sc)
+        if a.reorder_heads is not None:
+            p.reorder_policy_set(a.reorder_heads * len(sc.particles), 0.0)
         p.clock_enable(True, stride=8)
         for chunk in range(a.chunks):
             p.clock_read(reset=True)
@@ -242,6 +244,7 @@ def main():
     s.add_argument("--chunks", type=int, default=8)
     s.add_argument("--chunk", type=int, default=500)
     s.add_argument("--step", type=float, default=0.0)
+    s.add_argument("--reorder-heads", type=float, default=None)
     s.set_defaults(fn=cmd_soak)
     s = sub.add_parser("slabs")
     s.add_argument("--world", type=int, default=4)
