@@ -157,6 +157,32 @@ def test_corotated_stress_without_plasticity(libs):
             assert w[0] < bound and w[1] < 10 * bound, (k, scale, w)
 
 
+def test_large_positive_volume_gain_stays_on_the_series_path(libs):
+    """A particle that has flown apart carries log_vol_gain of order 1.  No series of the return map ever sees a positive lvg (tensile: sigma' = 1;
+    on the cone lvg <= -tr eps), so the tier test of dp_update_e ignores it: the series build must agree with the eigenbasis build and the f64
+    oracle on tensile AND compressive trial states with lvg up to 2 (before round 4's change these went down the eigenbasis path by |lvg|)."""
+    dp = _DPM.to_core_model().u.drucker_prager
+    cm = _CMM.to_core_model()
+    rng = np.random.default_rng(21)
+    worst = {k: np.zeros(3) for k in libs}
+    for trial in range(150):
+        scale = 10.0 ** rng.uniform(-5, -2.3)
+        E = _trial(rng, scale, 1e-2, trial % 3)
+        F = E + np.eye(3)
+        lvg0 = float(rng.uniform(0.0, 2.0)) if trial % 4 else float(rng.uniform(0.0, 3.0)) * scale   # of order 1, or comparable to the strain (the cone case)
+        F2, Jp, q2, lvg = oracle.dp_update(dp, F, Jp=1.0, q=1.0, lvg=lvg0, f64=True)
+        tau_ref = oracle.kirchhoff_stress(cm, F2, f64=True)
+        strain = max(np.abs(np.linalg.svd(F, compute_uv=False) - 1).max(), 1e-12)
+        for k, L in libs.items():
+            Eo, st, T, psi = _dp(L, E, lvg=lvg0)
+            err = [np.abs(Eo + np.eye(3) - F2).max() / strain, np.abs(T - tau_ref).max() / (2 * _CMM.mu * strain), abs(st[2] - lvg) / max(strain, abs(lvg))]
+            worst[k] = np.maximum(worst[k], err)
+    print(worst)
+    for k, w in worst.items():
+        assert (w < 2e-4).all(), (k, w)     # the storage bound of a rotated F at the smallest strains here (1e-7 theta / strain, strain >= 1e-5)
+    assert (np.abs(worst["series"] - worst["jacobi"]) < 5e-5).all(), worst
+
+
 def test_closed_form_eigenvalues(libs):
     """sym_eigvals against numpy: isolated eigenvalues to 1e-6 |A|, a near-degenerate pair split symmetrically (its sum exact)."""
     rng = np.random.default_rng(5)
