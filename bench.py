@@ -471,6 +471,9 @@ def main(args):
     run(args.steps)   # EXACTLY K substeps; synchronises at the end
     barrier()
     elapsed = time.perf_counter() - t0
+    if wake_pipe is not None:   # (--clock-wake-kind self: freeing it before the window would have been an idle gap)
+        wake_pipe.close()
+        wake_pipe = None
     if world > 1:
         tt = torch.tensor([elapsed], device="cpu" if default_pg_is_cpu else "cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -560,7 +563,7 @@ def main(args):
             "step_gbs": step_bytes * (total_particles / n_particles) / (elapsed / args.steps) / 1e9,
             "step_frac_of_hbm_peak": step_bytes * (total_particles / n_particles) / world / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
             "setup_s": {"generate": gen_s, "upload_and_pack": upload_s},
-            "clock_wake_ms": args.clock_wake_ms,
+            "clock_wake_ms": args.clock_wake_ms, "clock_wake_kind": args.clock_wake_kind if args.clock_wake_ms > 0 else None,
         }
         if clock is not None and clock.sampled_substeps > 0:
             out["roofline"], avg_ms = roofline_of(clock, kb, n_particles, args.config)
