@@ -1203,6 +1203,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
 // Stage the 8^3 node values (vx, vy, vz, mass) of the tile into LDS from the 27 neighbour blocks.
 // The same tile as two arrays, (vx, vy) and vz: the gather then reads a node with ds_read_b64 + ds_read_b32 (2 + 2 LDS cycles per
 // wave) instead of the ds_read_b96 (8 cycles) a float4 tile whose w is unused compiles to, and the tile shrinks from 8 to 6 KB.
+#ifndef SPK_PRIO_GATHER
+#define SPK_PRIO_GATHER 2
+#endif
 struct VelTile {
     float2 xy[TILE_N];
     float z[TILE_N];
@@ -1440,7 +1443,12 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const MO& mo
     float vel[3];
     M3 C;
     SPK_MARK("gather");
+    // the gather is 54 LDS reads with short arithmetic between them: at a raised issue priority its reads go out ahead of the other waves' VALU
+    // work instead of queueing behind it (-1.1 % of the launch; the same hint around the scatter's visits or the epilogue does nothing, around
+    // the prologue it doubles the launch time: profiles/r04_kernel_experiments.txt, experiment 12)
+    __builtin_amdgcn_s_setprio(SPK_PRIO_GATHER);
     apic_gather(vt, px, org, S, inv_h, vel, C);
+    __builtin_amdgcn_s_setprio(0);
     SPK_MARK("advect_F");
     const float div = C.m[0] + C.m[4] + C.m[8];
     // kinematic override, advection (grid_to_particle.rs:82-86)
