@@ -247,6 +247,25 @@ SPK_DEV float rare_load(bool cond, const float* p, float dflt) {
 constexpr int MAX_LDS_MODELS = 16;
 constexpr int MODEL_WORDS = (int)(sizeof(DevModel) / 4);
 static_assert(sizeof(DevModel) % 4 == 0, "");
+// The same copy in two halves for a prologue that cannot afford the round trip in the middle: the loads go out first (ahead of the caller's particle
+// loads: vector loads return in order), the LDS writes follow where stage_models used to stand.  Words beyond the first 512 (tables of 16 models) take the loop.
+struct ModelWords { uint32_t w0, w1; };
+SPK_DEV ModelWords stage_models_load(const DevModel* __restrict__ models, int num_models, int tid) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(models);
+    const int n = min(num_models, MAX_LDS_MODELS) * MODEL_WORDS;
+    ModelWords m = {0u, 0u};
+    if (tid < n) m.w0 = src[tid];
+    if (tid + BLK_THREADS < n) m.w1 = src[tid + BLK_THREADS];
+    return m;
+}
+SPK_DEV void stage_models_store(DevModel* s_models, const DevModel* __restrict__ models, int num_models, int tid, const ModelWords& m) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(models);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(s_models);
+    const int n = min(num_models, MAX_LDS_MODELS) * MODEL_WORDS;
+    if (tid < n) dst[tid] = m.w0;
+    if (tid + BLK_THREADS < n) dst[tid + BLK_THREADS] = m.w1;
+    for (int w = tid + 2 * BLK_THREADS; w < n; w += BLK_THREADS) dst[w] = src[w];
+}
 SPK_DEV void stage_models(DevModel* s_models, const DevModel* __restrict__ models, int num_models, int tid) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(models);
     uint32_t* dst = reinterpret_cast<uint32_t*>(s_models);
@@ -1210,16 +1229,34 @@ struct VelTile {
     float2 xy[TILE_N];
     float z[TILE_N];
 };
-SPK_DEV void load_vel_tile(VelTile& vt, const GridArrays& G, int b, int tid) {
-    for (int n = tid; n < TILE_N; n += BLK_THREADS) {
+// Both nodes of a thread at once, every load issued before the first wait.  `my_nb` (optional): entry min(lane, 26) of the block's neighbour table,
+// loaded by the caller BEFORE its particle loads (vector loads return in order: behind them it would arrive with them) and handed out with
+// ds_bpermute -- the staging is then ONE dependent round trip per workgroup; with the table read here it is two, and the loop this replaces made
+// four (one per node and hop).  A workgroup spends a quarter of its life in this prologue with nothing to issue, which the other three workgroups
+// of the CU cover at three waves per SIMD instead of four: -1.2 % of the 10 M launch for the batching alone (profiles/r04_kernel_experiments.txt, 13).
+// A missing neighbour reads node 0 of block 0 and is zeroed by a select: no branch around the second load.
+SPK_DEV void load_vel_tile(VelTile& vt, const GridArrays& G, int b, int tid, const int* my_nb = nullptr) {
+    static_assert(TILE_N == 2 * BLK_THREADS, "");
+    int nbv[2], off[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int n = tid + k * BLK_THREADS;
         const int tx = n & 7, ty = (n >> 3) & 7, tz = n >> 6;
         const int dx = tx == 0 ? -1 : (tx <= 4 ? 0 : 1), dy = ty == 0 ? -1 : (ty <= 4 ? 0 : 1), dz = tz == 0 ? -1 : (tz <= 4 ? 0 : 1);
         const int cx = tx - 1 - 4 * dx, cy = ty - 1 - 4 * dy, cz = tz - 1 - 4 * dz;
-        const int nb = G.blk_nbr[b * 27 + (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1)];
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (nb >= 0) v = G.node_vel[(size_t)nb * 64 + cx + 4 * cy + 16 * cz];
-        vt.xy[n] = make_float2(v.x, v.y);
-        vt.z[n] = v.z;
+        const int slot = (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1);
+        nbv[k] = my_nb ? __builtin_amdgcn_ds_bpermute(slot << 2, *my_nb) : G.blk_nbr[b * 27 + slot];
+        off[k] = cx + 4 * cy + 16 * cz;
+    }
+    float4 v[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) v[k] = G.node_vel[(size_t)max(nbv[k], 0) * 64 + (nbv[k] >= 0 ? off[k] : 0)];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int n = tid + k * BLK_THREADS;
+        const bool ok = nbv[k] >= 0;
+        vt.xy[n] = make_float2(ok ? v[k].x : 0.f, ok ? v[k].y : 0.f);
+        vt.z[n] = ok ? v[k].z : 0.f;
     }
 }
 SPK_DEV void load_vel_tile(float4* vt, const GridArrays& G, int b, int tid) {
@@ -1671,6 +1708,8 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     __shared__ int s_runs[BLK_THREADS / 64][64];   // run list of each wave (run-task scatter)
     __shared__ float s_A[BLK_THREADS / 64][9][64]; // affine part of the scatter descriptors, per wave
     __shared__ DevModel s_models[LDS_MODELS ? MAX_LDS_MODELS : 1];
+    // (read first: its scalar round trip then overlaps the block-list lookup's instead of following it)
+    const uint32_t aborted = ctl->abort_flag[S.parity];
     const int pb = launch_pblock(G);
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int b = org.w, pfirst = rng.x, pcount = rng.y;
@@ -1683,12 +1722,17 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
 #pragma unroll
     for (int sidx = 0; sidx < 6; ++sidx) Pb.q[sidx] = P.q[sidx] + pfirst;
     Pb.d = P.d + pfirst; Pb.k = P.k + pfirst; Pb.kinvel = P.kinvel + pfirst; Pb.aux = P.aux + pfirst;
+    // the small loads of the prologue go out AHEAD of the particle loads (vector loads return in order): the neighbour table of the velocity
+    // tile (load_vel_tile) and the model table (stage_models_load); what used to be four dependent round trips before the first barrier is one
+    const int my_nb = G.blk_nbr[b * 27 + min(tid & 63, 26)];
+    ModelWords mw = {0u, 0u};
+    if (LDS_MODELS) mw = stage_models_load(models, S.num_models, tid);
     float4 n0, n1, n2, nd, nk;
     {
         const unsigned o0 = (unsigned)min(tid, pcount - 1) << 4;
         n0 = *at_off(Pb.q[0], o0); n1 = *at_off(Pb.q[1], o0); n2 = *at_off(Pb.q[2], o0); nd = *at_off(Pb.d, o0); nk = *at_off(Pb.k, o0);
     }
-    if (ctl->abort_flag[S.parity]) {   // sticky abort: keep every later substep a no-op until the host re-bins
+    if (aborted) {   // sticky abort: keep every later substep a no-op until the host re-bins
         if (blockIdx.x == 0 && tid == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
         return;
     }
@@ -1698,8 +1742,8 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     for (int n = tid; n < ACC_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
     // the particle loads above are already in flight: the L2 round trips of the model table and the velocity tile overlap
     // with their HBM latency instead of preceding it
-    if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
-    load_vel_tile(vt, G, b, tid);
+    if (LDS_MODELS) stage_models_store(s_models, models, S.num_models, tid, mw);
+    load_vel_tile(vt, G, b, tid, &my_nb);
     if (G.primary && blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
     __syncthreads();
     const float h = S.h, inv_h = S.inv_h;
