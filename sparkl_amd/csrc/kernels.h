@@ -113,6 +113,7 @@ struct GridArrays {
     const int* pb_list; int pb_count;
     const int* nb_list; int nb_count;
     int primary;
+    int pb_plain;              // 1: pb_list is a launch order, indexed by blockIdx.x itself (k_order_keys); 0: a subset in Morton order, indexed through xcd_remap
     uint32_t* dt_partial;      // [gridDim] per-workgroup minimum of the dt bound (float bits), reduced by k_dt_reduce
     const DevCuboid* cuboids;  // the collider arrays, for enable_boundary_particle_projection (G2P tail)
     const DevHeightField* heightfields;
@@ -189,7 +190,7 @@ struct DevTriMesh {
 SPK_DEV int xcd_remap(int bid, int n);
 // particle block of this workgroup: the whole list or the launch's subset
 SPK_DEV int launch_pblock(const GridArrays& G) {
-    if (G.pb_list) return G.pb_list[xcd_remap(blockIdx.x, G.pb_count)];
+    if (G.pb_list) return G.pb_plain ? G.pb_list[blockIdx.x] : G.pb_list[xcd_remap(blockIdx.x, G.pb_count)];
     return xcd_remap(blockIdx.x, G.num_pblocks);
 }
 // Observed placement is workgroup b -> XCD b % 8: give each XCD a contiguous run of Morton-ordered
@@ -832,7 +833,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
     if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
     if (tid == 0) s_heads = 0;
     if (blockIdx.x == 0 && tid == 0) disorder_policy(ctl, (S.parity + 1) & 1, S.parity);
-    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    const int pb = launch_pblock(G);
     for (int n = tid; n < ACC_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int pfirst = rng.x, pcount = rng.y;
@@ -890,7 +891,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_pair(ParticleArrays P, Grid
     if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
     if (tid == 0) s_heads = 0;
     if (blockIdx.x == 0 && tid == 0) disorder_policy(ctl, (S.parity + 1) & 1, S.parity);
-    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    const int pb = launch_pblock(G);
     for (int n = tid; n < ACC_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int pfirst = rng.x, pcount = rng.y;
@@ -1866,7 +1867,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_block_reorder(ParticleArrays
     __shared__ int hist[8][TILE_N];   // [slot-order segment = iteration * 4 + wave][cell]: count, then start offset
     __shared__ int wave_sum[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    const int pb = launch_pblock(G);
     {   // a block whose run count has not grown by an eighth since it was last in order has nothing to gain (workgroup-uniform)
         const int2 hd = G.pb_heads[pb];
         if (hd.y > 0 && hd.x <= hd.y + (hd.y >> 3)) return;
@@ -1968,7 +1969,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_mass(ParticleArrays P, Grid
     // per cell in the fluid configs: without it every one of the 27 atomics of a wave hits one address 64 times)
     __shared__ double tile[TILE_N];
     const int tid = threadIdx.x;
-    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    const int pb = launch_pblock(G);
     for (int n = tid; n < TILE_N; n += BLK_THREADS) tile[n] = 0.0;
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int pfirst = rng.x, pcount = rng.y;
@@ -2031,7 +2032,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p_volume(ParticleArrays P, Gr
     if (ctl->abort_flag[S.parity]) return;
     __shared__ float4 vt[TILE_N];
     const int tid = threadIdx.x;
-    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    const int pb = launch_pblock(G);
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int b = org.w, pfirst = rng.x, pcount = rng.y;
     load_vel_tile(vt, G, b, tid);
@@ -2139,7 +2140,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
     __shared__ VelTile vt;
     __shared__ double mtile[TILE_N];
     __shared__ DevModel s_models[LDS_MODELS ? MAX_LDS_MODELS : 1];
-    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    const int pb = launch_pblock(G);
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int b = org.w, pfirst = rng.x, pcount = rng.y;
     const int niter = (pcount + BLK_THREADS - 1) / BLK_THREADS;
@@ -2237,7 +2238,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
     if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
     if (tid == 0) s_heads = 0;
     if (blockIdx.x == 0 && tid == 0) disorder_policy(ctl, (S.parity + 1) & 1, S.parity);
-    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    const int pb = launch_pblock(G);
     for (int n = tid; n < ACC_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int b = org.w, pfirst = rng.x, pcount = rng.y;
@@ -2372,7 +2373,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_psi(ParticleArrays P, GridA
     if (ctl->abort_flag[S.parity]) return;
     __shared__ double ta[TILE_N], tb[TILE_N];
     const int tid = threadIdx.x;
-    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    const int pb = launch_pblock(G);
     for (int n = tid; n < TILE_N; n += BLK_THREADS) { ta[n] = 0.0; tb[n] = 0.0; }
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int pfirst = rng.x, pcount = rng.y;
@@ -2428,7 +2429,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p_psi(ParticleArrays P, GridA
     if (ctl->abort_flag[S.parity]) return;
     __shared__ float vp[TILE_N];
     const int tid = threadIdx.x;
-    const int pb = xcd_remap(blockIdx.x, G.num_pblocks);
+    const int pb = launch_pblock(G);
     const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
     const int b = org.w, pfirst = rng.x, pcount = rng.y;
     for (int n = tid; n < TILE_N; n += BLK_THREADS) {
@@ -2575,6 +2576,18 @@ __global__ void k_permute(ParticleArrays src, ParticleArrays dst, const uint32_t
 }
 
 // 27 candidate node blocks around every particle block
+// Launch order of the particle blocks (GridArrays::pb_list with pb_plain = 1, of a pipeline that is not split into slab subsets): the fullest blocks
+// first, so that the workgroups still running when the grid runs out are the short ones (largest-processing-time-first list scheduling).  Consecutive
+// workgroups go to the XCDs round robin, so every XCD gets every eighth block of the sorted list; the spatial run per XCD that xcd_remap keeps is given
+// up -- measured: the 20 M dam (6 256 blocks of 0 - 4 096 particles on 1 024 workgroup slots) -7.3 %, the 10 M column deep in its collapse -2.4 %, the
+// lattice at rest unchanged; the same order inside each XCD's run: -1.4 % / nothing (profiles/r04_kernel_experiments.txt, 14).
+// Key = 0xffffff - count: one stable radix sort of (key, block index) gives the list (ties stay in Morton order).
+__global__ void k_order_keys(const uint32_t* __restrict__ pb_counts, int npb, uint32_t* keys, uint32_t* vals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npb) return;
+    keys[i] = 0xffffffu - min(pb_counts[i], 0xffffffu);
+    vals[i] = (uint32_t)i;
+}
 __global__ void k_candidates(const uint64_t* __restrict__ pb_keys, int npb, uint32_t* cand) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= npb * 27) return;
