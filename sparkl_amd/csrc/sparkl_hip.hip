@@ -465,10 +465,11 @@ static int resort(SparklPipeline* p) {
             // launch order: fullest blocks first (kernels.h, k_order_keys)
             p->pb_order_valid = false;
             {
-                static const bool order_on = !(getenv("SPARKL_HIP_BLOCK_ORDER") && !strcmp(getenv("SPARKL_HIP_BLOCK_ORDER"), "0"));
+                const char* oe = getenv("SPARKL_HIP_BLOCK_ORDER");   // "0": off, "1": on whatever the size (tests), unset: by size
+                const bool order_on = !(oe && !strcmp(oe, "0")), order_forced = oe && !strcmp(oe, "1");
                 // (only for scenes that do not fit the 256 MB last-level cache anyway -- ~180 B per particle --: the 1 M cube, which does, loses 3 % without its
                 // Morton launch order)
-                if (order_on && p->n >= 2000000ull) {
+                if (order_on && (order_forced || p->n >= 2000000ull)) {
                     CHK(p->pb_order.reserve(npb)); CHK(p->order_keys.reserve(npb)); CHK(p->order_keys_out.reserve(npb)); CHK(p->order_vals.reserve(npb));
                     hipLaunchKernelGGL(k_order_keys, dim3(grid_for(npb, 256)), dim3(256), 0, st, p->pb_counts.p, npb, p->order_keys.p, p->order_vals.p);
                     size_t tbo = 0;

@@ -553,6 +553,39 @@ def test_reorder_policy_does_not_change_results(Pipeline):
     assert e["eps_x"] <= 1e-5 and e["eps_v"] <= 1e-4 and e["failed_mismatch"] == 0
 
 
+@pytest.mark.parametrize("kind", ["sand", "fluid"])
+def test_block_launch_order_changes_nothing(Pipeline, monkeypatch, kind):
+    """The fullest-first launch order of the particle blocks (built at every re-bin from 2 M particles up; SPARKL_HIP_BLOCK_ORDER=1 forces it on a small
+    scene, =0 turns it off): which workgroup runs when must not matter -- both orders against each other (f32 summation order of the tiles only) and the
+    ordered run against the oracle, through the fused sand kernel and the fused fluid sweep."""
+    if kind == "sand":
+        sc = scenes.sand_column(16, 10, 12, with_block=True)
+        nsub = 60
+    else:
+        sc = scenes.fluid_dam(24, 16, 16)
+        nsub = 60
+    dt = sc.fixed_dt
+    o, o64 = _oracle(sc), _oracle(sc, f64=True)
+    for _ in range(nsub):
+        o.substep_fixed(sc.params, sc.gravity, dt)
+        o64.substep_fixed(sc.params, sc.gravity, dt)
+    out = {}
+    for tag in ("0", "1"):
+        monkeypatch.setenv("SPARKL_HIP_BLOCK_ORDER", tag)
+        with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+            p.load_scene(sc)
+            p.substeps(sc.params, sc.gravity, dt, nsub // 2)
+            p.substeps(sc.params, sc.gravity, dt, nsub - nsub // 2)
+            out[tag] = p.read_particles()
+            chk = p.grid_check()
+            assert all(int(chk[k]) == 0 for k in ("bad_particle_ids", "blocks_not_in_hash", "particles_outside_their_block", "missing_neighbour_blocks", "coverage_errors")), chk
+    e = particle_errors(out["1"], out["0"], sc.cell_width)
+    rep, bad = parity_verdict(out["1"], o.get_particles(), o64.get_particles(), sc.cell_width)
+    _report(f"block_launch_order_{kind}", {**rep, "vs_morton_eps_x": e["eps_x"], "vs_morton_eps_v": e["eps_v"]})
+    assert e["eps_x"] <= 1e-5 and e["eps_v"] <= 1e-4 and e["failed_mismatch"] == 0, e
+    assert not bad, (bad, rep)
+
+
 def test_adaptive_step_matches_oracle(Pipeline):
     """`MpmPipeline::step` with dt = 1/60: same substep count and lengths as the CPU path (mls_solver.rs:33-59)."""
     sc = scenes.sand_column(16, 10, 12, with_block=True)
