@@ -19,7 +19,11 @@ void set_particles(Oracle<R>& o, uint64_t n, const SparklParticleStatus* st, con
                    const SparklParticleData* data, const SparklVelocityGradient* vg) {
     o.particles.resize(n);
     o.order.resize(n);   // ParticleSet::set_particles: order = (0..n).collect() (particle_set.rs:48-51)
+    // parallel fill = first touch: the pages of the particle vector land on the NUMA nodes of the threads that fill them, not all on the
+    // loading thread's node (o.particles does not value-initialise: no_init_allocator)
+#pragma omp parallel for schedule(static) num_threads(o.num_threads)
     for (uint64_t i = 0; i < n; ++i) o.order[i] = i;
+#pragma omp parallel for schedule(static) num_threads(o.num_threads)
     for (uint64_t i = 0; i < n; ++i) {
         Particle<R>& p = o.particles[i];
         p.model = st[i].model_index;
@@ -291,6 +295,15 @@ void oracle_get_grid_indices(void* hv, uint64_t* out) {
     Handle* h = (Handle*)hv;
     if (h->f64) { for (size_t i = 0; i < h->od->particles.size(); ++i) out[i] = h->od->particles[i].grid_index; }
     else { for (size_t i = 0; i < h->of->particles.size(); ++i) out[i] = h->of->particles[i].grid_index; }
+}
+
+// the stable parallel merge sort of ParticleSet::sort on caller-supplied keys (tests/test_oracle_kats.py checks it against numpy's stable argsort):
+// out_idx[i] = index of the i-th key in stable order
+void oracle_debug_parallel_sort(const uint64_t* keys, uint64_t n, int threads, uint64_t* out_idx) {
+    std::vector<KeyIdx, no_init_allocator<KeyIdx>> a(n), tmp;
+    for (uint64_t i = 0; i < n; ++i) a[i] = KeyIdx{keys[i], (size_t)i};
+    parallel_stable_sort_pairs(a, tmp, threads);
+    for (uint64_t i = 0; i < n; ++i) out_idx[i] = a[i].idx;
 }
 
 // ---- slab-decomposition checker hooks (tests/test_slab_gloo.py): region-wise access to (mass, momentum)

@@ -478,3 +478,21 @@ def test_modified_eigenerosion_threshold_kat():
         ph = o.get_particles().phase["phase"]
         o.close()
         assert (ph == want).all(), (factor, thr, np.unique(ph))
+
+
+def test_parallel_stable_sort_is_the_sequential_stable_order():
+    """ParticleSet::sort uses rayon's `par_sort_by_key` (particle_set.rs:142), a STABLE sort: the accumulation order of P2G follows from
+    it.  The oracle's parallel merge sort (co-ranked merges) must give exactly numpy's stable argsort, ties included, at every thread
+    count and for sizes around the chunk boundaries."""
+    import ctypes as C
+    from oracle import lib
+    L = lib()
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 7, 4096 * 2 - 1, 4096 * 8 + 3, 200_003):
+        for nkeys in (3, 1000, 1 << 40):
+            keys = rng.integers(0, nkeys, size=n, dtype=np.uint64)
+            want = np.argsort(keys, kind="stable").astype(np.uint64)
+            for threads in (1, 2, 3, 8, 16):
+                out = np.empty(n, dtype=np.uint64)
+                L.oracle_debug_parallel_sort(keys.ctypes.data_as(C.c_void_p), C.c_uint64(n), C.c_int(threads), out.ctypes.data_as(C.c_void_p))
+                assert np.array_equal(out, want), (n, nkeys, threads)
