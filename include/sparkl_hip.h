@@ -214,6 +214,28 @@ typedef struct {
     uint8_t _pad[2];
 } SparklTriMeshCollider;
 
+/* `CudaColliderOptions` (src/cuda/cuda_collider_set.rs:22-38): what the reference's GPU path lets a caller choose PER COLLIDER, beside the
+ * collider itself.  Given to sparkl_hip_colliders_set_*_options, one record per collider of that kind, in the order of the matching
+ * sparkl_hip_colliders_set_* call (which resets every collider of its kind to the defaults).
+ *   grid_boundary_handling  SPARKL_BOUNDARY_* for this collider, or SPARKL_COLLIDER_HANDLING_FROM_PARAMS (-1, the default): whatever
+ *                           SolverParameters::boundary_handling says -- the CPU path's single switch (grid_update.rs:84-128), which is what
+ *                           every collider did until round 5.  SPARKL_BOUNDARY_NONE takes the collider out of the grid update.
+ *                           SPARKL_BOUNDARY_FRICTION_Z_UP given HERE follows the GPU rule (src_kernels/cuda/grid_update.rs:166-170: friction only
+ *                           where the normal has z >= 0, nothing elsewhere), with the CPU path's normal (direction of the projection); given
+ *                           through SolverParameters it is the CPU path's, i.e. the same as SPARKL_BOUNDARY_FRICTION.
+ *   penalty_stiffness       force (proj - x) * stiffness on a particle found inside the collider (src_kernels/cuda/particle_updater.rs:200-225;
+ *                           compiled out there -- `if false` -- so this is the INTENDED rule): enters the momentum the particle scatters
+ *                           next, m v + f dt (src_kernels/cuda/g2p2g.rs:286-287).  0 (default) = none.
+ *   flip_interior           heightfields (with below_is_solid) and oriented triangle meshes: swaps inside and outside
+ *                           (src_kernels/gpu_collider.rs:58-92).  For a triangle mesh it overrides SparklTriMeshCollider::flip_interior. */
+enum { SPARKL_COLLIDER_HANDLING_FROM_PARAMS = -1 };
+typedef struct {
+    int32_t grid_boundary_handling;
+    float penalty_stiffness;
+    uint8_t flip_interior;
+    uint8_t _pad[3];
+} SparklColliderOptions;
+
 /* ------------------------------------------------------------------- timings
  * reference: CudaTimestepTimings / CudaSubstepTimings / CudaDeviceTimings
  * (src/cuda/cuda_mpm_pipeline.rs:28-85).  Milliseconds from hipEvents, summed over the
@@ -231,6 +253,21 @@ typedef struct {
     float halo_ms;                  /* pack + merge of ghost planes (multi-GPU slabs) */
     float total_ms;
 } SparklTimings;
+
+/* One entry of `CudaTimestepTimings::substeps` (`CudaSubstepTimings` + the one `CudaDeviceTimings` of a single-device step,
+ * src/cuda/cuda_mpm_pipeline.rs:38-85): step length and device milliseconds of ONE substep of the last sparkl_hip_pipeline_step call that was
+ * given a SparklTimings.  A re-bin and the estimator pass are booked on the substep they precede; total_ms is the sum of the others
+ * (device time of the substep's own launches: gaps between launches are in SparklTimings::total_ms only). */
+typedef struct {
+    float dt;
+    float grid_resize_and_sort_ms;
+    float estimate_timestep_ms;
+    float p2g_ms;
+    float grid_update_ms;
+    float g2p_ms;
+    float halo_ms;
+    float total_ms;
+} SparklSubstepTimings;
 
 /* ------------------------------------------------------------------ pipeline */
 typedef struct SparklPipeline SparklPipeline;
@@ -318,6 +355,11 @@ int sparkl_hip_colliders_set_heightfields(SparklPipeline* p, uint32_t n, const S
 /* CudaColliderSet::from_collider_set (triangle meshes); applied after the heightfields.  The mesh is copied and indexed by
  * a uniform grid of its bounding box built on the host. */
 int sparkl_hip_colliders_set_trimeshes(SparklPipeline* p, uint32_t n, const SparklTriMeshCollider* colliders);
+/* CudaColliderSet::from_collider_set's `options: Vec<CudaColliderOptions>` (cuda_collider_set.rs:46-58), per collider kind: n must equal the
+ * number of colliders of that kind currently set (options == NULL with n == 0 is fine).  Defaults: see SparklColliderOptions. */
+int sparkl_hip_colliders_set_cuboid_options(SparklPipeline* p, uint32_t n, const SparklColliderOptions* options);
+int sparkl_hip_colliders_set_heightfield_options(SparklPipeline* p, uint32_t n, const SparklColliderOptions* options);
+int sparkl_hip_colliders_set_trimesh_options(SparklPipeline* p, uint32_t n, const SparklColliderOptions* options);
 
 /* MpmPipeline::step / CudaMpmPipeline::step
  * (src/pipelines/mpm_pipeline.rs:15-42, src/cuda/cuda_mpm_pipeline.rs:262-271):
@@ -326,6 +368,10 @@ int sparkl_hip_colliders_set_trimeshes(SparklPipeline* p, uint32_t n, const Spar
 int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params,
                              const float gravity[3], SparklTimings* timings_or_null,
                              float* simulated_time);
+
+/* `timings.substeps` of the last sparkl_hip_pipeline_step call that was given a SparklTimings: *n_out = number of substeps of that call,
+ * the first min(cap, *n_out) records are written to `out` (cap = 0 just asks for the count). */
+int sparkl_hip_pipeline_step_substep_timings(SparklPipeline* p, SparklSubstepTimings* out, uint32_t cap, uint32_t* n_out);
 
 /* ---- extensions (no reference counterpart; used by bench / parity tests) ---- */
 /* Run `nsubsteps` substeps of fixed length `dt` with NO host synchronisation inside

@@ -280,6 +280,18 @@ public:
     void set_heightfields(const std::vector<SparklHeightFieldCollider>& hfs) { check(sparkl_hip_colliders_set_heightfields(h_, (uint32_t)hfs.size(), hfs.data())); }
     // triangle meshes (rapier `ColliderBuilder::trimesh`); the mesh is copied
     void set_trimeshes(const std::vector<SparklTriMeshCollider>& meshes) { check(sparkl_hip_colliders_set_trimeshes(h_, (uint32_t)meshes.size(), meshes.data())); }
+    // timings.substeps of the last step() that asked for timings (cuda_mpm_pipeline.rs:28-85)
+    std::vector<SparklSubstepTimings> step_substep_timings() {
+        uint32_t n = 0;
+        check(sparkl_hip_pipeline_step_substep_timings(h_, nullptr, 0, &n));
+        std::vector<SparklSubstepTimings> out(n);
+        if (n) check(sparkl_hip_pipeline_step_substep_timings(h_, out.data(), n, &n));
+        return out;
+    }
+    // CudaColliderOptions per collider kind (cuda_collider_set.rs:22-58), in the order of the matching set_* call
+    void set_cuboid_options(const std::vector<SparklColliderOptions>& o) { check(sparkl_hip_colliders_set_cuboid_options(h_, (uint32_t)o.size(), o.data())); }
+    void set_heightfield_options(const std::vector<SparklColliderOptions>& o) { check(sparkl_hip_colliders_set_heightfield_options(h_, (uint32_t)o.size(), o.data())); }
+    void set_trimesh_options(const std::vector<SparklColliderOptions>& o) { check(sparkl_hip_colliders_set_trimesh_options(h_, (uint32_t)o.size(), o.data())); }
     // per-frame render readback (testbed_plugin.rs:533-588): pinned buffers, copies overlapped with the next step
     template <class T> static T* host_alloc(size_t count) { void* ptr = nullptr; check(sparkl_hip_host_alloc(&ptr, count * sizeof(T))); return (T*)ptr; }
     static void host_free(void* ptr) { check(sparkl_hip_host_free(ptr)); }

@@ -168,6 +168,14 @@ template <class R> static bool region_active(Oracle<R>& o, uint64_t id) { for (a
 
 #define DISPATCH(h, expr_f, expr_d) (((Handle*)(h))->f64 ? (expr_d) : (expr_f))
 
+// SparklColliderOptions per collider kind (0 cuboids, 1 heightfields, 2 trimeshes), in the order of the matching oracle_set_* call
+template <class R>
+void set_options(Oracle<R>& o, int kind, uint32_t n, const SparklColliderOptions* opt) {
+    auto put = [&](ColliderOpts& dst, const SparklColliderOptions& s) { dst.handling = s.grid_boundary_handling; dst.penalty = s.penalty_stiffness; dst.flip_interior = s.flip_interior != 0; };
+    if (kind == 0) for (uint32_t i = 0; i < n && i < o.cuboids.size(); ++i) put(o.cuboids[i].opts, opt[i]);
+    if (kind == 1) for (uint32_t i = 0; i < n && i < o.heightfields.size(); ++i) put(o.heightfields[i].opts, opt[i]);
+    if (kind == 2) for (uint32_t i = 0; i < n && i < o.trimeshes.size(); ++i) { put(o.trimeshes[i].opts, opt[i]); o.trimeshes[i].flip_interior = opt[i].flip_interior != 0; }
+}
 extern "C" {
 
 void* oracle_create(int use_f64, float cell_width, uint32_t domain_log2_bytes) {
@@ -213,6 +221,10 @@ void oracle_set_heightfields(void* hv, uint32_t n, const SparklHeightFieldCollid
 void oracle_set_trimeshes(void* hv, uint32_t n, const SparklTriMeshCollider* c) {
     Handle* h = (Handle*)hv;
     if (h->f64) set_trimeshes(*h->od, n, c); else set_trimeshes(*h->of, n, c);
+}
+void oracle_set_collider_options(void* hv, int kind, uint32_t n, const SparklColliderOptions* opt) {
+    Handle* h = (Handle*)hv;
+    if (h->f64) set_options(*h->od, kind, n, opt); else set_options(*h->of, kind, n, opt);
 }
 void oracle_trimesh_project(const SparklTriMeshCollider* c, const double pt[3], double out[3], int* is_inside) {
     TriMesh<double> m;

@@ -617,7 +617,10 @@ template <class R> bool maximum_stress_failed(const SparklMaximumStressFailure& 
 // --------------------------------------------------------------------------- cuboid projection
 // parry3d 0.13 Cuboid (= local Aabb [-he, he]) project_local_point, restated; unpinned.
 template <class R> struct Projection { bool is_inside; Vec3<R> point; };
-template <class R> struct Cuboid { Vec3<R> he; R q[4]; Vec3<R> t; R friction; };
+// CudaColliderOptions (src/cuda/cuda_collider_set.rs:22-38) of one collider: own boundary handling (-1 = the solver parameters'), penalty
+// stiffness (src_kernels/cuda/particle_updater.rs:200-225, compiled out in the reference: the intended rule), flip_interior (gpu_collider.rs:58-92)
+struct ColliderOpts { int handling = -1; double penalty = 0.0; bool flip_interior = false; };
+template <class R> struct Cuboid { Vec3<R> he; R q[4]; Vec3<R> t; R friction; ColliderOpts opts; };
 template <class R> Vec3<R> quat_rotate(const R q[4], const Vec3<R>& v, bool inverse) {
     // q = (i, j, k, w); v' = v + 2 w (u x v) + 2 u x (u x v)
     R s = inverse ? R(-1) : R(1);
@@ -681,7 +684,7 @@ template <class R> Vec3<R> closest_on_triangle(const Vec3<R>& p, const Vec3<R>& 
 // parry3d 0.13 HeightField (rows along z, columns along x, cell = triangles (p00,p10,p01) + (p10,p11,p01));
 // project_local_point brute-forces every triangle; is_inside is never set on the CPU path.  `below_is_solid` adds the
 // CUDA path's rule (src_kernels/gpu_collider.rs:69-91).
-template <class R> struct HeightField { int nrows, ncols; std::vector<R> heights; Vec3<R> scale; R q[4]; Vec3<R> t; R friction; bool below_is_solid; };
+template <class R> struct HeightField { int nrows, ncols; std::vector<R> heights; Vec3<R> scale; R q[4]; Vec3<R> t; R friction; bool below_is_solid; ColliderOpts opts; };
 template <class R> Projection<R> heightfield_project_point(const HeightField<R>& hf, const Vec3<R>& pt_world) {
     Vec3<R> rel{{pt_world[0] - hf.t[0], pt_world[1] - hf.t[1], pt_world[2] - hf.t[2]}};
     Vec3<R> lp = quat_rotate(hf.q, rel, true);
@@ -703,7 +706,7 @@ template <class R> Projection<R> heightfield_project_point(const HeightField<R>&
     bool inside = false;
     if (hf.below_is_solid) {
         R ux = lp[0] / hf.scale[0] + R(0.5), uz = lp[2] / hf.scale[2] + R(0.5);
-        inside = ux >= 0 && ux <= 1 && uz >= 0 && uz <= 1 && lp[1] <= bp[1];
+        inside = ux >= 0 && ux <= 1 && uz >= 0 && uz <= 1 && (hf.opts.flip_interior ? lp[1] >= bp[1] : lp[1] <= bp[1]);   // gpu_collider.rs:81-89
     }
     Vec3<R> w = quat_rotate(hf.q, bp, false);
     return Projection<R>{inside, Vec3<R>{{w[0] + hf.t[0], w[1] + hf.t[1], w[2] + hf.t[2]}}};
@@ -718,7 +721,7 @@ template <class R> struct TriMesh {
     std::vector<Vec3<double>> vn;                                 // per vertex
     std::vector<std::array<Vec3<double>, 3>> en;                  // per triangle: edges ab, ac, bc
     std::vector<Vec3<double>> fn;
-    R q[4]; Vec3<R> t; R friction; bool oriented, flip_interior;
+    R q[4]; Vec3<R> t; R friction; bool oriented, flip_interior; ColliderOpts opts;
     void compute_pseudo_normals() {
         vn.assign(v.size(), Vec3<double>{{0, 0, 0}});
         fn.assign(idx.size(), Vec3<double>{{0, 0, 0}});
@@ -1016,8 +1019,11 @@ struct Oracle {
                 GridNode<R>& cell = node(cell_id);
                 for (int a = 0; a < 3; ++a)
                     if (dofs & (1u << a)) { cell.momentum[a] = 0; cell.velocity[a] = 0; }
-                auto apply = [&](const Projection<R>& proj, R friction) {
+                const int params_handling = boundary_handling;
+                auto apply = [&](const Projection<R>& proj, R friction, const ColliderOpts& opts) {
                     if (!(cell.flags & 2u) && proj.is_inside) cell.flags |= 2u;
+                    // the collider's own switch where one was given (CudaColliderOptions::grid_boundary_handling, src_kernels/cuda/grid_update.rs:150-170)
+                    const int boundary_handling = opts.handling >= 0 ? opts.handling : params_handling;
                     if (boundary_handling == SPARKL_BOUNDARY_NONE) return;
                     if (boundary_handling == SPARKL_BOUNDARY_STICK) {
                         if (proj.is_inside) cell.velocity[0] = cell.velocity[1] = cell.velocity[2] = 0;
@@ -1028,6 +1034,7 @@ struct Oracle {
                     if (!(dist > R(1.0e-5))) return;  // Unit::try_new_and_get(.., 1e-5)
                     Vec3<R> normal{{dv[0] / dist, dv[1] / dist, dv[2] / dist}};
                     if (proj.is_inside) for (int a = 0; a < 3; ++a) normal[a] = -normal[a];
+                    if (opts.handling == SPARKL_BOUNDARY_FRICTION_Z_UP && !(normal[2] >= R(0))) return;   // GPU rule (grid_update.rs:166-170), per collider only
                     Vec3<R> vel{{cell.velocity[0], cell.velocity[1], cell.velocity[2]}};
                     R normal_vel = dot(vel, normal);
                     if (normal_vel < R(0)) {
@@ -1046,9 +1053,9 @@ struct Oracle {
                         }
                     }
                 };
-                for (const auto& col : cuboids) apply(cuboid_project_point(col, cell_pos), col.friction);
-                for (const auto& hf : heightfields) apply(heightfield_project_point(hf, cell_pos), hf.friction);
-                for (const auto& tm : trimeshes) apply(trimesh_project_point(tm, cell_pos), tm.friction);
+                for (const auto& col : cuboids) apply(cuboid_project_point(col, cell_pos), col.friction, col.opts);
+                for (const auto& hf : heightfields) apply(heightfield_project_point(hf, cell_pos), hf.friction, hf.opts);
+                for (const auto& tm : trimeshes) apply(trimesh_project_point(tm, cell_pos), tm.friction, tm.opts);
             }
         }
     }
@@ -1136,6 +1143,22 @@ struct Oracle {
                     for (const auto& col : cuboids) fix(cuboid_project_point(col, p.position));
                     for (const auto& hf : heightfields) fix(heightfield_project_point(hf, p.position));
                     for (const auto& tm : trimeshes) fix(trimesh_project_point(tm, p.position));
+                }
+                // penalty force of colliders with a stiffness (particle_updater.rs:200-225, `if false` there: the intended rule): a particle
+                // inside feels f = (proj - x) k, and the momentum it scatters next is m v + f dt (g2p2g.rs:286-287) -- the kick on the
+                // stored velocity, which nothing but the next scatter and the dt estimate reads before G2P overwrites it
+                {
+                    Vec3<R> f{{0, 0, 0}};
+                    bool any = false;
+                    auto push = [&](const Projection<R>& proj, const ColliderOpts& o) {
+                        if (!proj.is_inside) return;
+                        any = true;
+                        for (int a = 0; a < 3; ++a) f[a] += (proj.point[a] - p.position[a]) * (R)o.penalty;
+                    };
+                    for (const auto& col : cuboids) if (col.opts.penalty > 0) push(cuboid_project_point(col, p.position), col.opts);
+                    for (const auto& hf : heightfields) if (hf.opts.penalty > 0) push(heightfield_project_point(hf, p.position), hf.opts);
+                    for (const auto& tm : trimeshes) if (tm.opts.penalty > 0) push(trimesh_project_point(tm, p.position), tm.opts);
+                    if (any) { const R k = dt * inv_exact(p.mass); for (int a = 0; a < 3; ++a) p.velocity[a] += f[a] * k; }
                 }
             }
         }

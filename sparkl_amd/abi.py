@@ -136,6 +136,20 @@ class CuboidColliderC(C.Structure):
                 ("translation", C.c_float * 3), ("friction", C.c_float)]
 
 
+class ColliderOptionsC(C.Structure):
+    """`CudaColliderOptions` (src/cuda/cuda_collider_set.rs:22-38) without the handle: one per collider of a kind, in set_* order."""
+    _fields_ = [("grid_boundary_handling", C.c_int32), ("penalty_stiffness", C.c_float), ("flip_interior", C.c_uint8), ("_pad", C.c_uint8 * 3)]
+
+
+COLLIDER_HANDLING_FROM_PARAMS = -1
+
+
+def collider_options(grid_boundary_handling=COLLIDER_HANDLING_FROM_PARAMS, penalty_stiffness=0.0, flip_interior=False):
+    o = ColliderOptionsC()
+    o.grid_boundary_handling, o.penalty_stiffness, o.flip_interior = int(grid_boundary_handling), float(penalty_stiffness), int(bool(flip_interior))
+    return o
+
+
 class HeightFieldColliderC(C.Structure):
     _fields_ = [("nrows", C.c_uint32), ("ncols", C.c_uint32), ("heights", C.POINTER(C.c_float)), ("scale", C.c_float * 3),
                 ("rotation", C.c_float * 4), ("translation", C.c_float * 3), ("friction", C.c_float),
@@ -184,6 +198,12 @@ class TimingsC(C.Structure):
                 ("grid_resize_and_sort_ms", C.c_float), ("reset_grid_ms", C.c_float),
                 ("estimate_timestep_ms", C.c_float), ("p2g_ms", C.c_float), ("grid_update_ms", C.c_float),
                 ("g2p_ms", C.c_float), ("halo_ms", C.c_float), ("total_ms", C.c_float)]
+
+
+class SubstepTimingsC(C.Structure):
+    """One entry of `CudaTimestepTimings::substeps` (cuda_mpm_pipeline.rs:38-85): SparklSubstepTimings."""
+    _fields_ = [("dt", C.c_float), ("grid_resize_and_sort_ms", C.c_float), ("estimate_timestep_ms", C.c_float), ("p2g_ms", C.c_float),
+                ("grid_update_ms", C.c_float), ("g2p_ms", C.c_float), ("halo_ms", C.c_float), ("total_ms", C.c_float)]
 
 
 class KernelClockC(C.Structure):

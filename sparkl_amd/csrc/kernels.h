@@ -1,7 +1,7 @@
 // HIP kernels of the MI355X MPM hot path (gfx950, wave64).  See DESIGN.md for the data layout.
 //
 // Particles live in HBM as eight float4 streams, physically ordered by (home block, cell):
-//   Q0 = (x, y, z, F0)  Q1 = (F1..F4)  Q2 = (F5..F8)        F column-major
+//   Q0 = (x, y, z, F0)  Q1 = (F1..F4)  Q2 = (F5..F8)        F column-major, stored as F - I; (x, y, z) RELATIVE TO THE HOME BLOCK, in cells (cell_frac)
 //   Q3 = (vx, vy, vz, C0) Q4 = (C1..C4) Q5 = (C5..C8)       C = velocity_gradient (APIC affine)
 //   D  = (plastic_hardening, log_vol_gain, plastic_def_grad_det, psi_pos)
 //   K  = (mass, volume0, elastic_hardening, flags)           read-only on the hot path
@@ -115,6 +115,11 @@ struct GridArrays {
     int primary;
     int pb_plain;              // 1: pb_list is a launch order, indexed by blockIdx.x itself (k_order_keys); 0: a subset in Morton order, indexed through xcd_remap
     uint32_t* dt_partial;      // [gridDim] per-workgroup minimum of the dt bound (float bits), reduced by k_dt_reduce
+    // Projection cache of the grid update (the reference's GPU path keeps `projection_status` / `projection_scaled_dir` in its grid nodes,
+    // src_kernels/cuda/grid_update.rs:111-146): [heightfield | trimesh collider][B][64] (proj.xyz, status) of the node's projection on that
+    // collider -- colliders are static between two sparkl_hip_colliders_set_* calls, node blocks between two re-bins, and both clear the
+    // cache.  status (bits of .w): 0 not computed, 1 nothing within reach, 2 outside, 3 inside.  NULL = off (SPARKL_HIP_PROJ_CACHE=0).
+    float4* node_proj;
     const DevCuboid* cuboids;  // the collider arrays, for enable_boundary_particle_projection (G2P tail)
     const DevHeightField* heightfields;
     const DevTriMesh* trimeshes;
@@ -127,6 +132,7 @@ struct StepParams {
     float inv_d;      // 4 / h^2
     float inv_h;      // 1 / h (the host's IEEE quotient: the same bits as the device's division, without its twelve instructions per workgroup)
     float dt;
+    float dt_h;       // dt / h: advection of the block-relative positions (cells per unit of velocity)
     float gx, gy, gz;
     int boundary_handling;
     uint32_t dofs;
@@ -136,6 +142,8 @@ struct StepParams {
     int num_heightfields;
     int num_trimeshes;
     int project_particles;   // SolverParameters::enable_boundary_particle_projection
+    int collider_handling;   // some collider carries its own grid_boundary_handling (SparklColliderOptions): the grid update may not skip on boundary_handling == None
+    int penalty;             // some collider has a penalty_stiffness: the RARE G2P kernels apply the force
     int want_dt;      // G2P also reduces the next substep's dt bound into ctl->dt_bits (adaptive stepping)
     int num_models;   // entries of the model table (<= MAX_LDS_MODELS: the particle kernels stage it in LDS)
     float dt_next;    // k_g2p2g: the step length the fused scatter (P2G of the NEXT substep) is built for; = dt for fixed-dt batches
@@ -152,11 +160,14 @@ struct StepParams {
     int mass_from_sweep;
 };
 
+// `handling`, `penalty`: SparklColliderOptions (per collider: -1 = SolverParameters::boundary_handling; 0 = no penalty force)
 struct DevCuboid {
     float he[3];
     float q[4];
     float t[3];
     float friction;
+    int handling;
+    float penalty;
 };
 struct DevHeightField {
     const float* heights;   // nrows x ncols, column-major
@@ -169,6 +180,9 @@ struct DevHeightField {
     float ymin, ymax;       // range of heights * scale[1] (local frame): a point farther above than the search reach cannot be near the surface
     const float2* coarse;   // [(nrows + 2) / 4][(ncols + 2) / 4] (min, max) of heights * scale[1] over blocks of 4 x 4 heightfield cells, column-major like `heights`
     int crows, ccols;
+    int handling;
+    float penalty;
+    int flip_interior;      // with below_is_solid: inside = ABOVE the surface (gpu_collider.rs:82-88)
 };
 
 // Triangle mesh: 30 floats per triangle (a, b, c | pseudo-normals of a, b, c | of the edges ab, ac, bc | face normal; the
@@ -185,6 +199,8 @@ struct DevTriMesh {
     float t[3];
     float friction;
     int oriented, flip_interior;
+    int handling;
+    float penalty;
 };
 
 SPK_DEV int xcd_remap(int bid, int n);
@@ -203,16 +219,61 @@ SPK_DEV int xcd_remap(int bid, int n) {
     return (bid & 7) * per + (bid >> 3);
 }
 
-// round(x / h) as the reference computes it (sp_grid.rs:217: f32::round, half away from zero), but through one multiply and
-// v_rndne: the quotient is only re-done with the exact division when x * (1/h) lands within a few ulp of a .5 tie (away from
-// ties, round-to-nearest-even of the product and round-half-away of the exact quotient are the same integer).
-SPK_DEV float round_cell(float x, float h, float inv_h) {
-    const float t = x * inv_h;
-    const float r = rintf(t);
-    // (the product is within 2^-23 |t| of the quotient: 1e-6 |t| covers it for every t, no floor at 1 needed)
-    SPK_HOT(!(fabsf(t - r) > 0.5f - 1.0e-6f * fabsf(t)));
-    if (fabsf(t - r) > 0.5f - 1.0e-6f * fabsf(t)) return roundf(x / h);
-    return r;
+// ---- block-relative positions (round 5) ----------------------------------------------------------------------------------------------
+// A particle that belongs to a particle block (slot < n_binned) stores its position RELATIVE TO THE ORIGIN OF ITS HOME BLOCK, IN CELLS:
+//   u = x / h - origin        (origin = cell coordinate of node (0, 0, 0) of the block; u in [-0.5, 5.5) while the particle is inside its tile).
+// The associated cell (sp_grid.rs:216-226) is then  rint(u) - 1  in tile coordinates -- no multiply by 1/h, no tie test against the exact
+// quotient, no subtraction of the origin --, the B-spline argument is  fx = u - (rint(u) - 1)  in [0.5, 1.5] (kernel.rs:63-73), exact up to
+// the final + 1, and the coordinate keeps 2^-24 .. 2^-21 of a cell where a world coordinate of 10 m at h = 0.2 keeps 2^-18: the f32 position
+// storage was the one place where this path was only as good as the reference's arithmetic.  The tail of the particle
+// arrays (slots >= n_binned: fresh uploads, appended particles, emigrants, particles that left the domain) is stored in WORLD coordinates;
+// the re-bin converts in both directions (k_compute_keys, k_permute), the read-back kernels convert to world f32 with one rounding
+// (world_from_rel).  The C ABI is unchanged: world f32 in, world f32 out.
+// A cell tie (u exactly k + 0.5) goes to the even cell where the reference's f32::round goes away from zero: the weights are continuous
+// across the tie (the far node's weight is exactly 0 there), so which of the two cells is "associated" changes nothing but the rounding.
+SPK_DEV void cell_frac_r(const float u[3], const float r[3] /* rint(u) */, float fx[3], int lc[3]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        fx[a] = (u[a] - r[a]) + 1.0f;   // u - r is exact
+        lc[a] = (int)r[a];              // tile coordinate of the associated cell: rint(u) - 1 (block coordinate) + 1 (the tile's margin cell)
+    }
+}
+SPK_DEV void cell_frac(const float u[3], float fx[3], int lc[3]) {
+    const float r[3] = {rintf(u[0]), rintf(u[1]), rintf(u[2])};
+    cell_frac_r(u, r, fx, lc);
+}
+// world coordinate of a block-relative one and back, one rounding each (cold paths only: re-bin, read-back, collider projection of particles)
+SPK_DEV float world_from_rel(float u, int org, float h) { return (float)(((double)org + (double)u) * (double)h); }
+SPK_DEV float rel_from_world(float x, int org, float h) { return (float)((double)x / (double)h - (double)org); }
+// round(x / h) of a WORLD coordinate as the reference computes it (sp_grid.rs:217: f32::round of the f32 quotient, half away from zero)
+SPK_DEV float round_cell_world(float x, float h) { return roundf(x / h); }
+// Home block of slot i < n_binned: the particle blocks tile [0, n_binned) in order (pb_info[2 j + 1].x = first slot of block j).
+SPK_DEV int slot_pblock(const int4* __restrict__ pb_info, int npb, int i) {
+    int lo = 0, hi = npb - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pb_info[2 * mid + 1].x <= i) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+// world position of slot i, whichever part of the arrays it sits in
+struct BinnedView { const int4* pb_info; int npb; int n_binned; float h; };
+SPK_DEV void slot_world_pos(const BinnedView& B, const float4& q0, int i, float out[3]) {
+    if (i < B.n_binned) {
+        const int4 org = B.pb_info[2 * slot_pblock(B.pb_info, B.npb, i)];
+        out[0] = world_from_rel(q0.x, org.x, B.h); out[1] = world_from_rel(q0.y, org.y, B.h); out[2] = world_from_rel(q0.z, org.z, B.h);
+    } else { out[0] = q0.x; out[1] = q0.y; out[2] = q0.z; }
+}
+// Is the associated cell of a block-relative position inside the home block's tile AND inside the SPGrid domain?
+//   tile: rint(u) in [0, 5];   domain (sp_grid.rs, particle_set.rs:129-136): 1 <= origin + rint(u) < dom - 4
+// Every block whose tile lies inside the domain (origin >= 1 and origin + 5 < dom - 4 on every axis: all of them but those on the border
+// of the grid) only needs the tile test, on the integer cell the scatter needs anyway: three unsigned compares and one NaN test of the
+// coordinate sum (v_cvt_i32_f32 turns NaN into 0, which would pass).  `border` (wave-uniform, one SGPR) sends the others to the full test.
+struct TileRange { bool border; };
+SPK_DEV TileRange tile_range(const int4& org, int dom) {
+    TileRange t;
+    t.border = org.x < 1 || org.y < 1 || org.z < 1 || org.x + 5 >= dom - 4 || org.y + 5 >= dom - 4 || org.z + 5 >= dom - 4;
+    return t;
 }
 
 // DPP row shifts inside a 16-lane row: lane i reads lane i + N (zero beyond the row end).
@@ -301,22 +362,18 @@ struct Scatter {
 // particle_to_grid.rs:42-59: stress, affine, weights.  `org` = cell origin of the home block.
 // `T` (fused kernel only): the corotated stress the Drucker-Prager return map of this very thread formed from the decomposition
 // of F it held (corotated_tau_e) -- no second decomposition.
-// `Fe` = F - I, as the particle stores it.
+// `Fe` = F - I, as the particle stores it.  `fx`, `lc`: cell_frac of the particle's block-relative position.
 template <class MO>
-SPK_DEV Scatter p2g_prepare(const MO& mo, uint32_t flags, const float px[3], const float v[3], const M3& C, const M3& Fe, float mass, float vol0, float eh,
-                            float phase, float fluid_jp, const int4& org, float h, float inv_h, float inv_d, float dt, const SymStress* T = nullptr, const float* rcell = nullptr) {
+SPK_DEV Scatter p2g_prepare(const MO& mo, uint32_t flags, const float fx[3], const int lc[3], const float v[3], const M3& C, const M3& Fe, float mass, float vol0, float eh,
+                            float phase, float fluid_jp, float h, float inv_d, float dt, const SymStress* T = nullptr) {
     Scatter sc;
     M3 F = Fe;
     F.m[0] += 1.f; F.m[4] += 1.f; F.m[8] += 1.f;
     float d0[3];
-    int lc[3];
-    const int orgv[3] = {org.x, org.y, org.z};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float r = rcell ? rcell[a] : round_cell(px[a], h, inv_h);
-        d0[a] = (r - 1.0f) * h - px[a];
-        sc.fx[a] = -d0[a] * inv_h;
-        lc[a] = (int)r - 1 - orgv[a] + 1;  // tile coordinate of the associated cell, in [0, 5]
+        sc.fx[a] = fx[a];
+        d0[a] = -fx[a] * h;   // first support node - particle (particle.rs:110-120), world units
     }
     sc.base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
     sc.shell = (lc[0] < 1 ? 1 : 0) | (lc[0] > 4 ? 2 : 0) | (lc[1] < 1 ? 4 : 0) | (lc[1] > 4 ? 8 : 0) | (lc[2] < 1 ? 16 : 0) | (lc[2] > 4 ? 32 : 0);
@@ -835,9 +892,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
     if (blockIdx.x == 0 && tid == 0) disorder_policy(ctl, (S.parity + 1) & 1, S.parity);
     const int pb = launch_pblock(G);
     for (int n = tid; n < ACC_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
-    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int4 rng = G.pb_info[2 * pb + 1];
     const int pfirst = rng.x, pcount = rng.y;
-    const float h = S.h, inv_h = S.inv_h;
+    const float h = S.h;
     const int niter = (pcount + BLK_THREADS - 1) / BLK_THREADS;
     // software pipeline: the 7 x 16 B of the next batch are in flight while this batch computes
     float4 n0, n1, n2, n3, n4, n5, nk;
@@ -863,13 +920,15 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g(ParticleArrays P, GridArray
         Scatter sc;
         scatter_clear(sc);
         if (live) {
-            const float px[3] = {q0.x, q0.y, q0.z}, v[3] = {q3.x, q3.y, q3.z};
+            const float u[3] = {q0.x, q0.y, q0.z}, v[3] = {q3.x, q3.y, q3.z};
+            float fx[3]; int lc[3];
+            cell_frac(u, fx, lc);
             const M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};   // F - I as stored
             const M3 C = {{q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
             const DevModel& mo = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
             const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
             const float jp = mo.is_fluid ? P.d[i].z : 1.f;
-            sc = p2g_prepare(mo, flags, px, v, C, F, kk.x, kk.y, kk.z, phase, jp, org, h, inv_h, S.inv_d, S.dt);
+            sc = p2g_prepare(mo, flags, fx, lc, v, C, F, kk.x, kk.y, kk.z, phase, jp, h, S.inv_d, S.dt);
         }
         shell_used |= wave_or_i32(sc.shell);
         wave_heads += p2g_scatter<REDUCE_STEPS>(tile, sc, live, tid);
@@ -893,9 +952,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_pair(ParticleArrays P, Grid
     if (blockIdx.x == 0 && tid == 0) disorder_policy(ctl, (S.parity + 1) & 1, S.parity);
     const int pb = launch_pblock(G);
     for (int n = tid; n < ACC_N; n += BLK_THREADS) { tile[0][n] = 0.0; tile[1][n] = 0.0; tile[2][n] = 0.0; tile[3][n] = 0.0; }
-    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int4 rng = G.pb_info[2 * pb + 1];
     const int pfirst = rng.x, pcount = rng.y;
-    const float h = S.h, inv_h = S.inv_h;
+    const float h = S.h;
     __syncthreads();
     int shell_used = 0;
     int wave_heads = 0;
@@ -912,13 +971,15 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_pair(ParticleArrays P, Grid
             live[k] = active && !(flags & FLAG_INVALID);
             scatter_clear(sc[k]);
             if (live[k]) {
-                const float px[3] = {q0.x, q0.y, q0.z}, v[3] = {q3.x, q3.y, q3.z};
+                const float u[3] = {q0.x, q0.y, q0.z}, v[3] = {q3.x, q3.y, q3.z};
+                float fx[3]; int lc[3];
+                cell_frac(u, fx, lc);
                 const M3 F = {{q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};   // F - I as stored
                 const M3 C = {{q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
                 const DevModel& mo = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
                 const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
                 const float jp = mo.is_fluid ? P.d[i].z : 1.f;
-                sc[k] = p2g_prepare(mo, flags, px, v, C, F, kk.x, kk.y, kk.z, phase, jp, org, h, inv_h, S.inv_d, S.dt);
+                sc[k] = p2g_prepare(mo, flags, fx, lc, v, C, F, kk.x, kk.y, kk.z, phase, jp, h, S.inv_d, S.dt);
             }
         }
         shell_used |= wave_or_i32(sc[0].shell | sc[1].shell);
@@ -1092,14 +1153,18 @@ SPK_DEV bool heightfield_project(const DevHeightField& hf, const float ptw[3], f
         }
     if (best > reach * reach) return false;
     inside = false;
-    if (hf.below_is_solid) inside = (ux >= 0.f) && (ux <= 1.f) && (uz >= 0.f) && (uz <= 1.f) && (lp[1] <= bp[1]);
+    if (hf.below_is_solid) inside = (ux >= 0.f) && (ux <= 1.f) && (uz >= 0.f) && (uz <= 1.f) && (hf.flip_interior ? lp[1] >= bp[1] : lp[1] <= bp[1]);
     quat_rot(hf.q, bp, 1.f, projw);
     projw[0] += hf.t[0]; projw[1] += hf.t[1]; projw[2] += hf.t[2];
     return true;
 }
 
-// grid_update.rs:84-128 for one collider: `proj` = projection of the node position, `inside` = proj.is_inside
-SPK_DEV void boundary_rule(float v[3], const float cpos[3], const float proj[3], bool inside, float friction, int boundary_handling, float h, float dt) {
+// grid_update.rs:84-128 for one collider: `proj` = projection of the node position, `inside` = proj.is_inside.
+// `own_handling` (SparklColliderOptions::grid_boundary_handling, -1 = none given): the collider's own switch as the reference's GPU path has it
+// (src_kernels/cuda/grid_update.rs:150-170): None takes it out, FrictionZUp applies the friction rule only where the normal has z >= 0.
+SPK_DEV void boundary_rule(float v[3], const float cpos[3], const float proj[3], bool inside, float friction, int boundary_handling, int own_handling, float h, float dt) {
+    if (own_handling >= 0) boundary_handling = own_handling;
+    if (boundary_handling == SPARKL_BOUNDARY_NONE) return;
     if (boundary_handling == SPARKL_BOUNDARY_STICK) {
         if (inside) { v[0] = v[1] = v[2] = 0.f; }
         return;
@@ -1109,6 +1174,7 @@ SPK_DEV void boundary_rule(float v[3], const float cpos[3], const float proj[3],
     if (!(dist > 1.0e-5f)) return;
     float nrm[3] = {dv[0] / dist, dv[1] / dist, dv[2] / dist};
     if (inside) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
+    if (own_handling == SPARKL_BOUNDARY_FRICTION_Z_UP && !(nrm[2] >= 0.f)) return;
     const float nv = v[0] * nrm[0] + v[1] * nrm[1] + v[2] * nrm[2];
     if (nv < 0.f) {
         const float dwm = dist - h;
@@ -1193,26 +1259,43 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
     if (S.dofs & 1u) { px = 0.f; v[0] = 0.f; }
     if (S.dofs & 2u) { py = 0.f; v[1] = 0.f; }
     if (S.dofs & 4u) { pz = 0.f; v[2] = 0.f; }
-    if ((S.num_cuboids > 0 || HEIGHTFIELDS) && S.boundary_handling != SPARKL_BOUNDARY_NONE) {
+    if ((S.num_cuboids > 0 || HEIGHTFIELDS) && (S.boundary_handling != SPARKL_BOUNDARY_NONE || S.collider_handling)) {
         const int4 org = G.blk_origin[b];
         const float cpos[3] = {(float)(org.x + cx) * S.h, (float)(org.y + cy) * S.h, (float)(org.z + cz) * S.h};
         for (int ci = 0; ci < S.num_cuboids; ++ci) {
             const DevCuboid col = cuboids[ci];
             float proj[3];
             const bool inside = cuboid_project(col, cpos, proj);
-            boundary_rule(v, cpos, proj, inside, col.friction, S.boundary_handling, S.h, S.dt);
+            boundary_rule(v, cpos, proj, inside, col.friction, S.boundary_handling, col.handling, S.h, S.dt);
         }
+        // Heightfields and triangle meshes search triangles: the projection of a node on a static collider is computed once per binning and
+        // kept (GridArrays::node_proj); a cached record replays the very floats the search returned, so the velocities are bit for bit those
+        // of the uncached kernel.  Colliders of both kinds in the order of the uncached loop.
+        const size_t cache_stride = (size_t)G.num_blocks * 64;
+        auto cached = [&](int slot, auto&& search, float friction, int own_handling) {
+            float proj[3] = {0.f, 0.f, 0.f};
+            bool inside = false, hit;
+            float4* rec = G.node_proj ? G.node_proj + (size_t)slot * cache_stride + (size_t)b * 64 + lane : nullptr;
+            const float4 c = rec ? *rec : make_float4(0.f, 0.f, 0.f, 0.f);
+            const uint32_t status = __float_as_uint(c.w);
+            if (status != 0u) {
+                hit = status >= 2u; inside = status == 3u;
+                proj[0] = c.x; proj[1] = c.y; proj[2] = c.z;
+            } else {
+                hit = search(proj, inside);
+                if (rec) *rec = make_float4(proj[0], proj[1], proj[2], __uint_as_float(hit ? (inside ? 3u : 2u) : 1u));
+            }
+            if (hit) boundary_rule(v, cpos, proj, inside, friction, S.boundary_handling, own_handling, S.h, S.dt);
+        };
         if (HEIGHTFIELDS) for (int hi = 0; hi < S.num_heightfields; ++hi) {
-            const DevHeightField hf = heightfields[hi];
-            float proj[3];
-            bool inside = false;
-            if (heightfield_project(hf, cpos, 4.0f * S.h, proj, inside)) boundary_rule(v, cpos, proj, inside, hf.friction, S.boundary_handling, S.h, S.dt);
+            const DevHeightField& hf = heightfields[hi];
+            if (hf.handling == SPARKL_BOUNDARY_NONE || (hf.handling < 0 && S.boundary_handling == SPARKL_BOUNDARY_NONE)) continue;
+            cached(hi, [&](float proj[3], bool& inside) { return heightfield_project(hf, cpos, 4.0f * S.h, proj, inside); }, hf.friction, hf.handling);
         }
         if (HEIGHTFIELDS) for (int ti = 0; ti < S.num_trimeshes; ++ti) {
-            const DevTriMesh tm = trimeshes[ti];
-            float proj[3];
-            bool inside = false;
-            if (trimesh_project(tm, cpos, 4.0f * S.h, proj, inside)) boundary_rule(v, cpos, proj, inside, tm.friction, S.boundary_handling, S.h, S.dt);
+            const DevTriMesh& tm = trimeshes[ti];
+            if (tm.handling == SPARKL_BOUNDARY_NONE || (tm.handling < 0 && S.boundary_handling == SPARKL_BOUNDARY_NONE)) continue;
+            cached(S.num_heightfields + ti, [&](float proj[3], bool& inside) { return trimesh_project(tm, cpos, 4.0f * S.h, proj, inside); }, tm.friction, tm.handling);
         }
     }
     G.node_vel[(size_t)b * 64 + lane] = make_float4(v[0], v[1], v[2], m);
@@ -1355,11 +1438,15 @@ __global__ void k_dt_check(Ctl* ctl, float remaining, float max_substep_dt, floa
 
 // grid_to_particle.rs:146-163 (enable_boundary_particle_projection): a particle found inside a collider is put back on its
 // surface and its velocity corrected by the displacement / dt.  Colliders in the order of the grid update.
-SPK_DEV void project_particle_on_colliders(const GridArrays& G, const StepParams& S, float px[3], float vel[3]) {
+// `u`: block-relative position (cells), converted to world coordinates for the projection and back.
+SPK_DEV void project_particle_on_colliders(const GridArrays& G, const StepParams& S, const int orgv[3], float u[3], float vel[3]) {
     const float inv_dt = 1.0f / S.dt;
+    float px[3] = {world_from_rel(u[0], orgv[0], S.h), world_from_rel(u[1], orgv[1], S.h), world_from_rel(u[2], orgv[2], S.h)};
+    bool moved = false;
     for (int ci = 0; ci < S.num_cuboids; ++ci) {
         float proj[3];
         if (cuboid_project(G.cuboids[ci], px, proj)) {
+            moved = true;
 #pragma unroll
             for (int a = 0; a < 3; ++a) { vel[a] += (proj[a] - px[a]) * inv_dt; px[a] = proj[a]; }
         }
@@ -1368,6 +1455,7 @@ SPK_DEV void project_particle_on_colliders(const GridArrays& G, const StepParams
         float proj[3];
         bool inside = false;
         if (heightfield_project(G.heightfields[hi], px, 4.0f * S.h, proj, inside) && inside) {
+            moved = true;
 #pragma unroll
             for (int a = 0; a < 3; ++a) { vel[a] += (proj[a] - px[a]) * inv_dt; px[a] = proj[a]; }
         }
@@ -1376,15 +1464,48 @@ SPK_DEV void project_particle_on_colliders(const GridArrays& G, const StepParams
         float proj[3];
         bool inside = false;
         if (trimesh_project(G.trimeshes[ti], px, 4.0f * S.h, proj, inside) && inside) {
+            moved = true;
 #pragma unroll
             for (int a = 0; a < 3; ++a) { vel[a] += (proj[a] - px[a]) * inv_dt; px[a] = proj[a]; }
         }
     }
+    if (moved) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) u[a] = rel_from_world(px[a], orgv[a], S.h);
+    }
+}
+
+// SparklColliderOptions::penalty_stiffness (src_kernels/cuda/particle_updater.rs:200-225, compiled out there): a particle found inside a collider
+// with a stiffness feels  f = (proj - x) k;  the reference adds f dt to the momentum the particle scatters next (g2p2g.rs:286-287: m v + f dt).
+// The stored velocity is what the next scatter multiplies by the mass, and G2P overwrites it from the grid every substep, so the kick
+// v += f dt / m on the stored velocity -- behind the advection, which used the gathered velocity -- IS that momentum term.
+SPK_DEV void penalty_kick(const GridArrays& G, const StepParams& S, const int orgv[3], const float u[3], float mass, float vel[3]) {
+    const float px[3] = {world_from_rel(u[0], orgv[0], S.h), world_from_rel(u[1], orgv[1], S.h), world_from_rel(u[2], orgv[2], S.h)};
+    const float reach = 100.0f * S.h, k = S.dt * inv_exact(mass);
+    float f[3] = {0.f, 0.f, 0.f};
+    for (int ci = 0; ci < S.num_cuboids; ++ci) {
+        float proj[3];
+        if (G.cuboids[ci].penalty > 0.f && cuboid_project(G.cuboids[ci], px, proj))
+            for (int a = 0; a < 3; ++a) f[a] += (proj[a] - px[a]) * G.cuboids[ci].penalty;
+    }
+    for (int hi = 0; hi < S.num_heightfields; ++hi) {
+        float proj[3];
+        bool inside = false;
+        if (G.heightfields[hi].penalty > 0.f && heightfield_project(G.heightfields[hi], px, reach, proj, inside) && inside)
+            for (int a = 0; a < 3; ++a) f[a] += (proj[a] - px[a]) * G.heightfields[hi].penalty;
+    }
+    for (int ti = 0; ti < S.num_trimeshes; ++ti) {
+        float proj[3];
+        bool inside = false;
+        if (G.trimeshes[ti].penalty > 0.f && trimesh_project(G.trimeshes[ti], px, reach, proj, inside) && inside)
+            for (int a = 0; a < 3; ++a) f[a] += (proj[a] - px[a]) * G.trimeshes[ti].penalty;
+    }
+    vel[0] += f[0] * k; vel[1] += f[1] * k; vel[2] += f[2] * k;
 }
 
 // State of one particle after grid_to_particle.rs:62-164 (gather .. psi_pos), before it is written back.
 struct Advected {
-    float px[3], vel[3];
+    float px[3], vel[3]; // px: block-relative, in cells (cell_frac)
     M3 C, Fe;            // Fe = F - I: what the particle stores
     float q, lvg, Jp, psi;
     float eh, phase;     // elastic hardening (snow changes it) and phase (a failure model zeroes it) as P2G must see them
@@ -1394,27 +1515,24 @@ struct Advected {
     float alpha;
     bool newly_failed;   // flags word must be stored
     bool in_tile;        // the NEW position still scatters inside the home block's tile (and inside the domain)
-    float rnew[3];       // round(new position / h): computed once for the margin check, reused by the fused scatter
+    float rnew[3];       // rint(new position): taken once, the fused scatter derives its cell_frac from it (cell_frac_r)
     SymStress T;         // corotated stress of the final F, formed by the Drucker-Prager return map (fused kernel: scattered next substep)
 };
 
 // APIC gather of one particle from the staged velocity tile: v = sum w v_n, C = sum (w inv_d) v_n dpt^T
-// (grid_to_particle.rs:47-60).  `px` is the position the weights are evaluated at (the particle BEFORE advection).
-// CLAMP (k_regather_c only): `px` was reconstructed and may round into the cell next to the one the tile covers; the weights
+// (grid_to_particle.rs:47-60).  `u` is the block-relative position the weights are evaluated at (the particle BEFORE advection).
+// CLAMP (k_regather_c only): `u` was reconstructed and may round into the cell next to the one the tile covers; the weights
 // are continuous across the cell face, so the covered cell is used.
 template <bool CLAMP = false>
-SPK_DEV void apic_gather(const VelTile& vt, const float px[3], const int4& org, const StepParams& S, float inv_h, float vel[3], M3& C) {
+SPK_DEV void apic_gather(const VelTile& vt, const float u[3], const StepParams& S, float vel[3], M3& C) {
     const float h = S.h;
-    float d0[3], wgt[3][3];
+    float fx[3], wgt[3][3];
     int lc[3];
-    const int orgv[3] = {org.x, org.y, org.z};
+    cell_frac(u, fx, lc);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        float r = round_cell(px[a], h, inv_h);
-        lc[a] = (int)r - 1 - orgv[a] + 1;
-        if (CLAMP) { lc[a] = min(max(lc[a], 0), 5); r = (float)(lc[a] + orgv[a]); }
-        d0[a] = (r - 1.0f) * h - px[a];
-        eval_all(-d0[a] * inv_h, wgt[a]);
+        if (CLAMP) { const int c = min(max(lc[a], 0), 5); fx[a] += (float)(lc[a] - c); lc[a] = c; }
+        eval_all(fx[a], wgt[a]);
     }
     const int base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
     // APIC gather in separable form (grid_to_particle.rs:47-60):
@@ -1458,12 +1576,13 @@ SPK_DEV void apic_gather(const VelTile& vt, const float px[3], const int4& org, 
     }
     const float V0[3] = {V0p.x, V0p.y, V0z}, Vx[3] = {Vxp.x, Vxp.y, Vxz}, Vy[3] = {Vyp.x, Vyp.y, Vyz}, Vz[3] = {Vzp.x, Vzp.y, Vzz};
     vel[0] = V0[0]; vel[1] = V0[1]; vel[2] = V0[2];
+    // with d0 = -fx h (first support node - particle):  inv_d (v d0^T + h [Vx Vy Vz])  =  (h inv_d) ([Vx Vy Vz] - v fx^T)
     const float hid = h * S.inv_d;
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
-        C.m[e] = (S.inv_d * V0[e]) * d0[0] + hid * Vx[e];
-        C.m[3 + e] = (S.inv_d * V0[e]) * d0[1] + hid * Vy[e];
-        C.m[6 + e] = (S.inv_d * V0[e]) * d0[2] + hid * Vz[e];
+        C.m[e] = hid * (Vx[e] - fx[0] * V0[e]);
+        C.m[3 + e] = hid * (Vy[e] - fx[1] * V0[e]);
+        C.m[6 + e] = hid * (Vz[e] - fx[2] * V0[e]);
     }
 }
 
@@ -1472,11 +1591,11 @@ SPK_DEV void apic_gather(const VelTile& vt, const float px[3], const int4& org, 
 // or calling it out of line, cost the hot kernel 35 %).
 template <bool RARE, bool WANT_STRESS = false, class MO = DevModel>
 SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const MO& mo, uint32_t flags, const float4& q0, const float4& q1, const float4& q2, const float4& dd,
-                            const float4& kk, const float4* kinvel_i, const float4* aux_i, float phase, const int4& org, const StepParams& S, float inv_h,
+                            const float4& kk, const float4* kinvel_i, const float4* aux_i, float phase, const int4& org, const TileRange& tr, const StepParams& S,
                             unsigned* num_invalid, lds_fp park = nullptr) {
     Advected o;
     const float h = S.h, dt = S.dt;
-    float px[3] = {q0.x, q0.y, q0.z};
+    float px[3] = {q0.x, q0.y, q0.z};   // block-relative, in cells
     const int orgv[3] = {org.x, org.y, org.z};
     float vel[3];
     M3 C;
@@ -1485,7 +1604,7 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const MO& mo
     // work instead of queueing behind it (-1.1 % of the launch; the same hint around the scatter's visits or the epilogue does nothing, around
     // the prologue it doubles the launch time: profiles/r04_kernel_experiments.txt, experiment 12)
     __builtin_amdgcn_s_setprio(SPK_PRIO_GATHER);
-    apic_gather(vt, px, org, S, inv_h, vel, C);
+    apic_gather(vt, px, S, vel, C);
     __builtin_amdgcn_s_setprio(0);
     SPK_MARK("advect_F");
     const float div = C.m[0] + C.m[4] + C.m[8];
@@ -1495,7 +1614,7 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const MO& mo
         const float* kp = reinterpret_cast<const float*>(kinvel_i);
         vel[0] = rare_load(kin, kp, vel[0]); vel[1] = rare_load(kin, kp + 1, vel[1]); vel[2] = rare_load(kin, kp + 2, vel[2]);
     }
-    px[0] += vel[0] * dt; px[1] += vel[1] * dt; px[2] += vel[2] * dt;
+    px[0] += vel[0] * S.dt_h; px[1] += vel[1] * S.dt_h; px[2] += vel[2] * S.dt_h;   // x += v dt, in cells
     // deformation gradient update (:91-100)
     // the particle stores E = F - I; Drucker-Prager particles carry E through the update and the return map (device_math.h,
     // "strain-form arithmetic"), everything else works on F and hands F - I back
@@ -1566,21 +1685,23 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const MO& mo
         o.store_aux = true;
         if (!(flags & FLAG_PHASE_NOT_ONE)) { flags |= FLAG_PHASE_NOT_ONE; newly_failed = true; }   // the flags word must be stored
     }
-    if (RARE && S.project_particles) project_particle_on_colliders(G, S, px, vel);
-    // does the particle still sit inside its home block's tile, and inside the domain?
-    bool invalid = false, in_tile = true;
+    if (RARE && S.project_particles) project_particle_on_colliders(G, S, orgv, px, vel);
+    if (RARE && S.penalty) penalty_kick(G, S, orgv, px, kk.x, vel);
+    // does the particle still sit inside its home block's tile, and inside the domain?  One test against the block's box (TileRange: the
+    // tile, cut by the domain where the block touches its border); a NaN coordinate fails it like the reference's range test does.
+    o.rnew[0] = rintf(px[0]); o.rnew[1] = rintf(px[1]); o.rnew[2] = rintf(px[2]);
+    // rint(u) in [0, 5] on every axis, as |r - 2.5| <= 2.5: two VALU per axis, false for NaN, and no integer cell kept alive across the store
+    bool in_tile = (fabsf(o.rnew[0] - 2.5f) <= 2.5f) && (fabsf(o.rnew[1] - 2.5f) <= 2.5f) && (fabsf(o.rnew[2] - 2.5f) <= 2.5f);
+    bool invalid = false;
+    SPK_HOT(in_tile && !tr.border);
+    if (!in_tile || tr.border) {   // cold: out of the tile (re-bin) or out of the domain?  0 <= assoc, assoc + 5 < dom  (sp_grid.rs / particle_set.rs:129-136)
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float r = round_cell(px[a], h, inv_h);
-        o.rnew[a] = r;
-        const bool ok = (r >= 1.0f) && (r < (float)(S.dom - 4));   // 0 <= assoc, assoc + 5 < dom
-        if (!ok) invalid = true;
-        else {
-            const int nl = (int)r - 1 - orgv[a];
-            if (nl < -1 || nl > 4) in_tile = false;
+        for (int a = 0; a < 3; ++a) {
+            // round(x / h) in integers (nothing for the compiler to hoist out of the particle loop into registers that only this cold side reads)
+            const int rw = orgv[a] + (int)fminf(fmaxf(o.rnew[a], -1.0e6f), 1.0e6f);
+            if (!(o.rnew[a] == o.rnew[a]) || rw < 1 || rw >= S.dom - 4) invalid = true;
         }
     }
-    SPK_HOT(!invalid);
     if (invalid) {  // what the next ParticleSet::sort would do (particle_set.rs:129-136)
         newly_failed = true;
         flags |= FLAG_FAILED | FLAG_INVALID;
@@ -1657,7 +1778,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
     if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
     if (G.primary && blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
     __syncthreads();
-    const float inv_h = S.inv_h;
+    const TileRange tr = tile_range(org, S.dom);
     bool want_sort = false;
     float dt_bound = 3.402823466e+38f;
     bool dt_nan = false;
@@ -1671,7 +1792,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
         if (flags & FLAG_INVALID) continue;
         const DevModel& mo = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
         const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
-        const Advected o = g2p_update<RARE>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
+        const Advected o = g2p_update<RARE>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, tr, S, &ctl->num_invalid);
         g2p_store(P, i, o);
         want_sort |= !o.in_tile && !(o.flags & FLAG_INVALID);   // a particle that left the DOMAIN is dead (skipped from now on): no re-bin for it
         if (S.want_dt) {  // the bound the next substep's estimator would compute from this state
@@ -1728,10 +1849,10 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     const int my_nb = G.blk_nbr[b * 27 + min(tid & 63, 26)];
     ModelWords mw = {0u, 0u};
     if (LDS_MODELS) mw = stage_models_load(models, S.num_models, tid);
-    float4 n0, n1, n2, nd, nk;
+    float4 n0, n1, n2, nk;
     {
         const unsigned o0 = (unsigned)min(tid, pcount - 1) << 4;
-        n0 = *at_off(Pb.q[0], o0); n1 = *at_off(Pb.q[1], o0); n2 = *at_off(Pb.q[2], o0); nd = *at_off(Pb.d, o0); nk = *at_off(Pb.k, o0);
+        n0 = *at_off(Pb.q[0], o0); n1 = *at_off(Pb.q[1], o0); n2 = *at_off(Pb.q[2], o0); nk = *at_off(Pb.k, o0);
     }
     if (aborted) {   // sticky abort: keep every later substep a no-op until the host re-bins
         if (blockIdx.x == 0 && tid == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
@@ -1747,7 +1868,8 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     load_vel_tile(vt, G, b, tid, &my_nb);
     if (G.primary && blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
     __syncthreads();
-    const float h = S.h, inv_h = S.inv_h;
+    const float h = S.h;
+    const TileRange tr = tile_range(org, S.dom);
     bool want_sort = false;
     int shell_used = 0;
     int wave_heads = 0;
@@ -1757,10 +1879,16 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
         const int li = it * BLK_THREADS + tid;
         const bool active = li < pcount;
         const unsigned off = (unsigned)(active ? li : 0) << 4;    // byte offset of this lane's particle in the block's 16-byte streams
-        const float4 q0 = n0, q1 = n1, q2 = n2, dd = nd, kk = nk;
+        const float4 q0 = n0, q1 = n1, q2 = n2, kk = nk;
+        // The plastic scalars (D stream) are not prefetched an iteration ahead like the rest: nothing reads them before the return map, ~350
+        // instructions into the iteration, so their load is issued HERE, ahead of the next batch's (vector loads return in order: the wait
+        // for it leaves the four younger loads in flight), and the four registers are free while the previous iteration's scatter runs --
+        // the point where this kernel's register pressure peaks (with them prefetched the allocator spilled a float4 of the next batch
+        // right behind its load, i.e. waited for the whole prefetch at the top of every iteration: +5 % on the launch).
+        const float4 dd = *at_off(Pb.d, off);
         if (it + 1 < niter) {
             const unsigned on = (unsigned)min(li + BLK_THREADS, pcount - 1) << 4;
-            n0 = *at_off(Pb.q[0], on); n1 = *at_off(Pb.q[1], on); n2 = *at_off(Pb.q[2], on); nd = *at_off(Pb.d, on); nk = *at_off(Pb.k, on);
+            n0 = *at_off(Pb.q[0], on); n1 = *at_off(Pb.q[1], on); n2 = *at_off(Pb.q[2], on); nk = *at_off(Pb.k, on);
         }
         const uint32_t flags = __float_as_uint(kk.w);
         bool live = active && !(flags & FLAG_INVALID);
@@ -1794,14 +1922,16 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
                 T2.valid = t_valid; T2.jm1 = 0.f;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) T2.t[k] = park[64 * k];   // (unconditionally: whatever the columns hold is ignored unless T2.valid)
-                sc = p2g_prepare(mo, o.flags, o.px, o.vel, o.C, o.Fe, kk.x, kk.y, o.eh, o.phase, o.Jp, org, h, inv_h, S.inv_d, S.dt_next, &T2, o.rnew);
+                float fxn[3]; int lcn[3];
+                cell_frac_r(o.px, o.rnew, fxn, lcn);
+                sc = p2g_prepare(mo, o.flags, fxn, lcn, o.vel, o.C, o.Fe, kk.x, kk.y, o.eh, o.phase, o.Jp, h, S.inv_d, S.dt_next, &T2);
             }
             SPK_MARK("scatter");
             probe_extra_work(s_A[tid >> 6], tid, o.px, o.vel, sc);   // probe_hooks.h: nothing unless an analysis build asks for it
         };
         auto particle = [&](const auto& mo) {
             const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &at_off(Pb.aux, off)->x, 1.f);
-            const Advected o = g2p_update<RARE, true>(G, vt, mo, flags, q0, q1, q2, dd, kk, at_off(Pb.kinvel, off), at_off(Pb.aux, off), phase, org, S, inv_h, &ctl->num_invalid, park);
+            const Advected o = g2p_update<RARE, true>(G, vt, mo, flags, q0, q1, q2, dd, kk, at_off(Pb.kinvel, off), at_off(Pb.aux, off), phase, org, tr, S, &ctl->num_invalid, park);
             finish(mo, o);
         };
         if (live) {
@@ -1839,7 +1969,6 @@ __global__ __launch_bounds__(BLK_THREADS) void k_regather_c(ParticleArrays P, Gr
     const int b = org.w, pfirst = rng.x, pcount = rng.y;
     load_vel_tile(vt, G, b, tid);
     __syncthreads();
-    const float inv_h = S.inv_h;
     for (int li = tid; li < pcount; li += BLK_THREADS) {
         const int i = pfirst + li;
         const float4 q0 = P.q[0][i], q3 = P.q[3][i];
@@ -1847,9 +1976,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_regather_c(ParticleArrays P, Gr
         if (flags & FLAG_INVALID) continue;
         M3 C = m3_zero();
         if (!(flags & (FLAG_STATIC | FLAG_FAILED))) {
-            const float px[3] = {q0.x - q3.x * S.dt, q0.y - q3.y * S.dt, q0.z - q3.z * S.dt};
+            const float u[3] = {q0.x - q3.x * S.dt_h, q0.y - q3.y * S.dt_h, q0.z - q3.z * S.dt_h};
             float vel[3];
-            apic_gather<true>(vt, px, org, S, inv_h, vel, C);
+            apic_gather<true>(vt, u, S, vel, C);
         }
         P.q[4][i] = make_float4(C.m[1], C.m[2], C.m[3], C.m[4]);
         P.q[5][i] = make_float4(C.m[5], C.m[6], C.m[7], C.m[8]);
@@ -1873,10 +2002,8 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_block_reorder(ParticleArrays
         if (hd.y > 0 && hd.x <= hd.y + (hd.y >> 3)) return;
         if (tid == 0) G.pb_heads[pb] = make_int2(0, 0);   // re-armed: the next scatter records the new baseline
     }
-    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int4 rng = G.pb_info[2 * pb + 1];
     const int pfirst = rng.x, pcount = rng.y;
-    const float inv_h = 1.0f / h;
-    const int orgv[3] = {org.x, org.y, org.z};
     for (int c0 = 0; c0 < pcount; c0 += 2 * BLK_THREADS) {
         const int cnt = min(2 * BLK_THREADS, pcount - c0);
         for (int n = tid; n < 8 * TILE_N; n += BLK_THREADS) (&hist[0][0])[n] = 0;
@@ -1890,12 +2017,12 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_block_reorder(ParticleArrays
             const int i = pfirst + c0 + (valid ? li : 0);
             src[k] = i;
             r0[k] = P.q[0][i];
-            const float px[3] = {r0[k].x, r0[k].y, r0[k].z};
+            const float u[3] = {r0[k].x, r0[k].y, r0[k].z};
             int kk = 0;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const float rc = round_cell(px[a], h, inv_h);
-                const int lc = min(max((rc == rc ? (int)rc : 0) - orgv[a], 0), TILE_W - 1);   // tile coordinate of the associated cell
+                const float rc = rintf(u[a]);
+                const int lc = min(max(rc == rc ? (int)rc : 0, 0), TILE_W - 1);   // tile coordinate of the associated cell
                 kk += lc << (3 * a);
             }
             key[k] = kk;
@@ -1971,10 +2098,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_mass(ParticleArrays P, Grid
     const int tid = threadIdx.x;
     const int pb = launch_pblock(G);
     for (int n = tid; n < TILE_N; n += BLK_THREADS) tile[n] = 0.0;
-    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int4 rng = G.pb_info[2 * pb + 1];
     const int pfirst = rng.x, pcount = rng.y;
     __syncthreads();
-    const float h = S.h;
     const int lane = tid & 63, r = lane & 15;
     const int niter = (pcount + BLK_THREADS - 1) / BLK_THREADS;
     for (int it = 0; it < niter; ++it) {
@@ -1984,17 +2110,13 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_mass(ParticleArrays P, Grid
         const float4 q0 = P.q[0][i], kk = P.k[i];
         const bool live = active && !(__float_as_uint(kk.w) & FLAG_INVALID);
         if (!__any(live)) continue;
-        const float px[3] = {q0.x, q0.y, q0.z};
-        const int orgv[3] = {org.x, org.y, org.z};
-        float wgt[3][3];
+        // (the same weights as mass_scatter and the momentum scatter: cell_frac of the stored block-relative position)
+        const float u[3] = {q0.x, q0.y, q0.z};
+        float fx[3], wgt[3][3];
         int lc[3];
+        cell_frac(u, fx, lc);
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float rc = roundf(px[a] / h);
-            const float d0 = (rc - 1.0f) * h - px[a];
-            eval_all(-d0 / h, wgt[a]);
-            lc[a] = (int)rc - 1 - orgv[a] + 1;
-        }
+        for (int a = 0; a < 3; ++a) eval_all(fx[a], wgt[a]);
         const int base = live ? lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2] : 0;
         const float m = live ? kk.x : 0.f;
         const int key = live ? base : -1;
@@ -2044,17 +2166,12 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p_volume(ParticleArrays P, Gr
         const uint32_t flags = __float_as_uint(kk.w);
         if (flags & FLAG_INVALID) continue;
         if (!models[flags >> FLAG_MODEL_SHIFT].is_fluid) continue;
-        const float px[3] = {q0.x, q0.y, q0.z};
-        const int orgv[3] = {org.x, org.y, org.z};
-        float wgt[3][3];
+        const float u[3] = {q0.x, q0.y, q0.z};
+        float fx[3], wgt[3][3];
         int lc[3];
+        cell_frac(u, fx, lc);
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float r = roundf(px[a] / h);
-            const float d0 = (r - 1.0f) * h - px[a];
-            eval_all(-d0 / h, wgt[a]);
-            lc[a] = (int)r - 1 - orgv[a] + 1;
-        }
+        for (int a = 0; a < 3; ++a) eval_all(fx[a], wgt[a]);
         const int base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
         float new_mass = 0.f;
 #pragma unroll
@@ -2080,22 +2197,14 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p_volume(ParticleArrays P, Gr
 
 // Mass-only scatter of one batch (one particle per lane) into a 512-entry f64 tile: same-cell lanes pre-summed over 16-lane rows
 // with DPP (64 particles per cell in the fluid configs), run heads deposit 3 x 9 atomics.
-// `rcell`: round(px / h) as g2p_update already holds it (Advected::rnew); finite in dead lanes too (their sums meet live lanes' in the DPP chains
-// with factor 0, and 0 x NaN is NaN).
-SPK_DEV void mass_scatter(double* mtile, const float px[3], const float rcell[3], float mass, bool live, const int4& org, float h, int tid) {
+// `fx`, `lc`: cell_frac of the particle's block-relative position (g2p_update already holds it: Advected::fxn, lcn); finite in dead lanes too
+// (their sums meet live lanes' in the DPP chains with factor 0, and 0 x NaN is NaN).
+SPK_DEV void mass_scatter(double* mtile, const float fx[3], const int lc[3], float mass, bool live, int tid) {
     if (!__any(live)) return;
     const int r = tid & 15;
-    const int orgv[3] = {org.x, org.y, org.z};
     float wgt[3][3];
-    int lc[3];
-    const float inv_h = 1.0f / h;   // wave-uniform: one division, not six per particle
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float rc = rcell[a];
-        const float d0 = (rc - 1.0f) * h - px[a];
-        eval_all(-d0 * inv_h, wgt[a]);
-        lc[a] = (int)rc - 1 - orgv[a] + 1;
-    }
+    for (int a = 0; a < 3; ++a) eval_all(fx[a], wgt[a]);
     const int base = live ? lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2] : 0;
     const float m = live ? mass : 0.f;
     const int key = live ? base : -1;
@@ -2123,10 +2232,11 @@ SPK_DEV void mass_scatter(double* mtile, const float px[3], const float rcell[3]
         }
 }
 
-SPK_DEV void mass_scatter(double* mtile, const float px[3], float mass, bool live, const int4& org, float h, int tid) {
-    const float inv_h = 1.0f / h;
-    const float rc[3] = {round_cell(px[0], h, inv_h), round_cell(px[1], h, inv_h), round_cell(px[2], h, inv_h)};
-    mass_scatter(mtile, px, rc, mass, live, org, h, tid);
+SPK_DEV void mass_scatter(double* mtile, const float u[3], float mass, bool live, int tid) {
+    float fx[3];
+    int lc[3];
+    cell_frac(u, fx, lc);
+    mass_scatter(mtile, fx, lc, mass, live, tid);
 }
 
 // G2P of substep s + mass-only scatter of the advected particles (= the first half of substep s+1's volume sweep).
@@ -2155,7 +2265,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
     if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
     if (blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
     __syncthreads();
-    const float inv_h = S.inv_h;
+    const TileRange tr = tile_range(org, S.dom);
     bool want_sort = false;
     float dt_bound = 3.402823466e+38f;
     bool dt_nan = false;
@@ -2174,10 +2284,11 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
         }
         const uint32_t flags = __float_as_uint(kk.w);
         bool live = active && !(flags & FLAG_INVALID);
-        float npx[3] = {0.f, 0.f, 0.f}, nrc[3] = {0.f, 0.f, 0.f};
+        float nfx[3] = {1.f, 1.f, 1.f};
+        int nlc[3] = {0, 0, 0};
         auto particle = [&](const auto& mo) {
             const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
-            const Advected o = g2p_update<false>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, S, inv_h, &ctl->num_invalid);
+            const Advected o = g2p_update<false>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, tr, S, &ctl->num_invalid);
             if (FLUID_ONLY) {
                 P.q[0][i] = make_float4(o.px[0], o.px[1], o.px[2], o.Fe.m[0]);
                 P.q[3][i] = make_float4(o.vel[0], o.vel[1], o.vel[2], o.C.m[0]);
@@ -2189,8 +2300,9 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
             }
             want_sort |= !o.in_tile && !(o.flags & FLAG_INVALID);   // a particle that left the DOMAIN is dead (skipped from now on): no re-bin for it
             live = o.in_tile;
-            npx[0] = o.px[0]; npx[1] = o.px[1]; npx[2] = o.px[2];
-            nrc[0] = o.rnew[0]; nrc[1] = o.rnew[1]; nrc[2] = o.rnew[2];
+            if (live) {   // (a particle outside its tile scatters nothing; its cell index may be anything)
+                cell_frac_r(o.px, o.rnew, nfx, nlc);
+            }
             if (S.want_dt) {
                 const float bnd = particle_dt_bound(mo, o.flags, o.vel, o.C, kk.x, kk.y, o.eh, 1.f + o.Fe.m[0], S.h);
                 dt_nan |= bnd != bnd;
@@ -2202,7 +2314,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
             if constexpr (FLUID_ONLY) particle(PlainFluidModel(mo_t));   // the host selects FLUID_ONLY when every model is a plain fluid
             else particle(mo_t);
         }
-        mass_scatter(mtile, npx, nrc, kk.x, live, org, S.h, tid);
+        mass_scatter(mtile, nfx, nlc, kk.x, live, tid);
     }
     __syncthreads();
     float* out = (float*)(G.tiles + (size_t)pb * TILE_N);   // mass tile: 8^3 scalars at the head of the block's slot
@@ -2249,7 +2361,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
         const int nb = G.blk_nbr[b * 27 + (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1)];
         vm[n] = nb >= 0 ? G.node_vel[(size_t)nb * 64 + cx + 4 * cy + 16 * cz].w : 0.f;
     }
-    const float h = S.h, inv_h = S.inv_h;
+    const float h = S.h;
     __syncthreads();
     int shell_used = 0;
     int wave_heads = 0;
@@ -2275,7 +2387,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
         if (!FLUID_ONLY) { a1 = P.q[1][eA]; b1 = P.q[1][eB]; a2 = P.q[2][eA]; b2 = P.q[2][eB]; }
         // ---- phase 1: position, mass, flags -> volume gather (F00 = (m / rho_grid) / V0 for fluid particles, fluids_volume.rs:83-110)
         float4 q0[2], kk[2];
-        float jp_stored[2], rc[2][3];
+        float jp_stored[2], cfx[2][3];
+        int clc[2][3];
         hand_over(a0, b0, q0);
         hand_over(ak, bk, kk);
         {
@@ -2290,22 +2403,16 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
             const uint32_t flags = __float_as_uint(kk[k].w);
             live[k] = (base + 2 * tid + k < pcount) && !(flags & FLAG_INVALID);
             scatter_clear(sc[k]);
-            rc[k][0] = rc[k][1] = rc[k][2] = 0.f;
+            cfx[k][0] = cfx[k][1] = cfx[k][2] = 1.f;
+            clc[k][0] = clc[k][1] = clc[k][2] = 0;
             auto volume = [&](const auto& mo) {
-                const float px[3] = {q0[k].x, q0[k].y, q0[k].z};
-#pragma unroll
-                for (int a = 0; a < 3; ++a) rc[k][a] = round_cell(px[a], h, inv_h);   // once for the gather and the scatter
+                const float u[3] = {q0[k].x, q0[k].y, q0[k].z};
+                cell_frac(u, cfx[k], clc[k]);   // once for the gather and the scatter
                 if (mo.is_fluid) {   // with the weights of k_g2p_volume
-                    const int orgv[3] = {org.x, org.y, org.z};
                     float wgt[3][3];
-                    int lc[3];
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        const float d0 = (rc[k][a] - 1.0f) * h - px[a];
-                        eval_all(-d0 * inv_h, wgt[a]);
-                        lc[a] = (int)rc[k][a] - 1 - orgv[a] + 1;
-                    }
-                    const int vb = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
+                    for (int a = 0; a < 3; ++a) eval_all(cfx[k][a], wgt[a]);
+                    const int vb = clc[k][0] + TILE_W * clc[k][1] + TILE_W * TILE_W * clc[k][2];
                     float new_mass = 0.f;
 #pragma unroll
                     for (int sz = 0; sz < 3; ++sz)
@@ -2334,12 +2441,12 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
         for (int k = 0; k < 2; ++k) {
             const uint32_t flags = __float_as_uint(kk[k].w);
             auto prepare = [&](const auto& mo) {
-                const float px[3] = {q0[k].x, q0[k].y, q0[k].z}, v[3] = {q3[k].x, q3[k].y, q3[k].z};
+                const float v[3] = {q3[k].x, q3[k].y, q3[k].z};
                 const M3 F = {{q0[k].w, q1[k].x, q1[k].y, q1[k].z, q1[k].w, q2[k].x, q2[k].y, q2[k].z, q2[k].w}};   // F - I as stored
                 const M3 C = {{q3[k].w, q4[k].x, q4[k].y, q4[k].z, q4[k].w, q5[k].x, q5[k].y, q5[k].z, q5[k].w}};
                 const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[pfirst + base + 2 * tid + k].x, 1.f);
                 const float jp = mo.is_fluid ? jp_stored[k] : 1.f;
-                sc[k] = p2g_prepare(mo, flags, px, v, C, F, kk[k].x, kk[k].y, kk[k].z, phase, jp, org, h, inv_h, S.inv_d, S.dt, nullptr, rc[k]);
+                sc[k] = p2g_prepare(mo, flags, cfx[k], clc[k], v, C, F, kk[k].x, kk[k].y, kk[k].z, phase, jp, h, S.inv_d, S.dt);
             };
             if (live[k]) {
                 const DevModel& mo_t = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
@@ -2360,7 +2467,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
     }
     if ((tid & 63) == 0) atomicAdd(&s_heads, wave_heads);
     tile_write(tile, G, pb, tid, shell_used);
-    if (tid == 0) atomicAdd(&ctl->heads[S.parity], (uint32_t)s_heads);
+    if (tid == 0) record_heads(ctl, G, pb, S.parity, s_heads);   // launch total + the block's own record (k_block_reorder skips blocks whose count has not grown)
 }
 
 // ---- DamageModel::ModifiedEigenerosion: the psi_mass / psi_momentum node transfer -----------------------------------------
@@ -2375,7 +2482,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_psi(ParticleArrays P, GridA
     const int tid = threadIdx.x;
     const int pb = launch_pblock(G);
     for (int n = tid; n < TILE_N; n += BLK_THREADS) { ta[n] = 0.0; tb[n] = 0.0; }
-    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int4 rng = G.pb_info[2 * pb + 1];
     const int pfirst = rng.x, pcount = rng.y;
     __syncthreads();
     const int niter = (pcount + BLK_THREADS - 1) / BLK_THREADS;
@@ -2388,9 +2495,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_psi(ParticleArrays P, GridA
         const bool live = active && !(flags & FLAG_INVALID);
         const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
         const float psi_mass = (live && phase > 0.f && fr.x != 0.f && !(flags & FLAG_FAILED)) ? kk.x : 0.f;
-        const float px[3] = {q0.x, q0.y, q0.z};
-        mass_scatter(ta, px, psi_mass, live, org, S.h, tid);
-        mass_scatter(tb, px, psi_mass * dd.w, live, org, S.h, tid);
+        const float u[3] = {q0.x, q0.y, q0.z};
+        mass_scatter(ta, u, psi_mass, live, tid);
+        mass_scatter(tb, u, psi_mass * dd.w, live, tid);
     }
     __syncthreads();
     float2* out = psi_tiles + (size_t)pb * TILE_N;
@@ -2450,17 +2557,12 @@ __global__ __launch_bounds__(BLK_THREADS) void k_g2p_psi(ParticleArrays P, GridA
         if (flags & FLAG_INVALID) continue;
         const float phase = (flags & FLAG_PHASE_NOT_ONE) ? P.aux[i].x : 1.f;
         if (!(phase > 0.f)) continue;
-        const float px[3] = {q0.x, q0.y, q0.z};
-        const int orgv[3] = {org.x, org.y, org.z};
-        float wgt[3][3];
+        const float u[3] = {q0.x, q0.y, q0.z};
+        float fx[3], wgt[3][3];
         int lc[3];
+        cell_frac(u, fx, lc);
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float r = roundf(px[a] / h);
-            const float d0 = (r - 1.0f) * h - px[a];
-            eval_all(-d0 / h, wgt[a]);
-            lc[a] = (int)r - 1 - orgv[a] + 1;
-        }
+        for (int a = 0; a < 3; ++a) eval_all(fx[a], wgt[a]);
         const int base = lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2];
         float g = 0.f;
 #pragma unroll
@@ -2513,41 +2615,41 @@ SPK_DEV uint32_t compact10(uint32_t x) {
 // block key = Morton code of the block coordinate biased by +1 (blocks at -1 are legal node blocks)
 SPK_DEV uint32_t block_key(int bx, int by, int bz) { return spread10(bx + 1) | (spread10(by + 1) << 1) | (spread10(bz + 1) << 2); }
 
-// tail classes of the sort: every valid key is < 2^36, these have all high bits set and sort after them
-constexpr uint64_t KEY_EMIG_LO = ~0ull - 3;      // home block below the slab's low cut
-constexpr uint64_t KEY_EMIG_HI = ~0ull - 2;      // home block beyond the slab's high cut
-constexpr uint64_t KEY_INVALID = ~0ull - 1;      // outside the SPGrid domain (frozen, failed)
-constexpr uint64_t KEY_REMOVED = ~0ull;          // already handed to a neighbour slab: dropped by this re-bin
+// Sort keys: (block key << 6) | cell in block, as 32-bit words whenever they fit (3 x block_bits + 6 + 1 <= 32: every domain up to 2^33
+// bytes; the default 2^30-byte grid uses 28 bits), else 64-bit: the radix sort then moves 8 instead of 12 bytes per pair and pass.
+// Tail classes: every valid key is < 2^(bits - 1), these are the four largest words and sort after them.
+template <class KeyT>
+struct TailKeys {
+    static constexpr KeyT EMIG_LO = (KeyT)(~(KeyT)0 - 3);      // home block below the slab's low cut
+    static constexpr KeyT EMIG_HI = (KeyT)(~(KeyT)0 - 2);      // home block beyond the slab's high cut
+    static constexpr KeyT INVALID = (KeyT)(~(KeyT)0 - 1);      // outside the SPGrid domain (frozen, failed)
+    static constexpr KeyT REMOVED = (KeyT)(~(KeyT)0);          // already handed to a neighbour slab: dropped by this re-bin
+};
+// what k_compute_keys leaves for k_permute beside the key: the origin the particle's stored position is relative to (block coordinates,
+// 10 bits each), or OORG_WORLD for a particle of the tail (world coordinates)
+constexpr uint32_t OORG_WORLD = 0xffffffffu;
+SPK_DEV uint32_t pack_org(int ox, int oy, int oz) { return (uint32_t)(ox >> 2) | ((uint32_t)(oy >> 2) << 10) | ((uint32_t)(oz >> 2) << 20); }
 
-__global__ void k_compute_keys(ParticleArrays P, uint64_t* keys, uint32_t* idx, int n, float h, int dom, int slab_axis, int slab_lo, int slab_hi, Ctl* ctl) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 q0 = P.q[0][i];
+// `c`: associated cell (world cell coordinates) when `ok`; `ok` = inside the domain
+template <class KeyT>
+SPK_DEV void emit_key(const ParticleArrays& P, KeyT* keys, uint32_t* idx, uint32_t* oorg, int i, const int c[3], bool ok, uint32_t org_word, float h,
+                      int slab_axis, int slab_lo, int slab_hi, Ctl* ctl) {
     uint32_t flags = reinterpret_cast<const uint32_t*>(&P.k[i])[3];
-    const float px[3] = {q0.x, q0.y, q0.z};
-    int c[3];
-    bool ok = true;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float r = roundf(px[a] / h);
-        if (!((r >= 1.0f) && (r < (float)(dom - 4)))) ok = false;
-        c[a] = ok ? (int)r - 1 : 0;
-    }
-    uint64_t key = KEY_INVALID;
+    KeyT key = TailKeys<KeyT>::INVALID;
     if (flags & FLAG_REMOVED) {
-        key = KEY_REMOVED;
+        key = TailKeys<KeyT>::REMOVED;
     } else if (ok) {
         const uint32_t bk = block_key(c[0] >> 2, c[1] >> 2, c[2] >> 2);
-        key = ((uint64_t)bk << 6) | (uint64_t)((c[0] & 3) | ((c[1] & 3) << 2) | ((c[2] & 3) << 4));
+        key = ((KeyT)bk << 6) | (KeyT)((c[0] & 3) | ((c[1] & 3) << 2) | ((c[2] & 3) << 4));
         if (flags & FLAG_INVALID) { flags &= ~FLAG_INVALID; reinterpret_cast<uint32_t*>(&P.k[i])[3] = flags; }
         const int bs = c[slab_axis] >> 2;
-        if (bs < slab_lo) key = KEY_EMIG_LO;
-        else if (bs >= slab_hi) key = KEY_EMIG_HI;
+        if (bs < slab_lo) key = TailKeys<KeyT>::EMIG_LO;
+        else if (bs >= slab_hi) key = TailKeys<KeyT>::EMIG_HI;
     } else if ((flags & (FLAG_INVALID | FLAG_FAILED)) != (FLAG_INVALID | FLAG_FAILED)) {
         flags |= FLAG_INVALID | FLAG_FAILED;  // particle_set.rs:132-135
         reinterpret_cast<uint32_t*>(&P.k[i])[3] = flags;
     }
-    if (key == KEY_INVALID) {   // outside the domain: only its velocity bound still takes part in the adaptive step (Ctl::dead_dt_bits)
+    if (key == TailKeys<KeyT>::INVALID) {   // outside the domain: only its velocity bound still takes part in the adaptive step (Ctl::dead_dt_bits)
         const float4 q3 = P.q[3][i], q4 = P.q[4][i], q5 = P.q[5][i];
         const float v[3] = {q3.x, q3.y, q3.z};
         const M3 C = {{q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w}};
@@ -2555,19 +2657,80 @@ __global__ void k_compute_keys(ParticleArrays P, uint64_t* keys, uint32_t* idx, 
     }
     keys[i] = key;
     idx[i] = (uint32_t)i;
+    oorg[i] = org_word;
+}
+// slots [first, n): the tail of the arrays, WORLD coordinates (fresh uploads, appended particles, immigrants, emigrants, dead particles)
+template <class KeyT>
+__global__ void k_compute_keys_world(ParticleArrays P, KeyT* keys, uint32_t* idx, uint32_t* oorg, int first, int n, float h, int dom, int slab_axis, int slab_lo, int slab_hi, Ctl* ctl) {
+    const int i = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 q0 = P.q[0][i];
+    const float px[3] = {q0.x, q0.y, q0.z};
+    int c[3];
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float r = round_cell_world(px[a], h);
+        if (!((r >= 1.0f) && (r < (float)(dom - 4)))) ok = false;
+        c[a] = ok ? (int)r - 1 : 0;
+    }
+    emit_key(P, keys, idx, oorg, i, c, ok, OORG_WORLD, h, slab_axis, slab_lo, slab_hi, ctl);
+}
+// slots [0, n_binned): one workgroup per particle block of the OLD binning, block-relative coordinates
+template <class KeyT>
+__global__ __launch_bounds__(BLK_THREADS) void k_compute_keys_binned(ParticleArrays P, const int4* __restrict__ pb_info, KeyT* keys, uint32_t* idx, uint32_t* oorg, float h, int dom,
+                                                                     int slab_axis, int slab_lo, int slab_hi, Ctl* ctl) {
+    const int pb = blockIdx.x;
+    const int4 org = pb_info[2 * pb], rng = pb_info[2 * pb + 1];
+    const int orgv[3] = {org.x, org.y, org.z};
+    const uint32_t ow = pack_org(org.x, org.y, org.z);
+    for (int li = threadIdx.x; li < rng.y; li += BLK_THREADS) {
+        const int i = rng.x + li;
+        const float4 q0 = P.q[0][i];
+        const float u[3] = {q0.x, q0.y, q0.z};
+        int c[3];
+        bool ok = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float r = rintf(u[a]);
+            const int rw = orgv[a] + (int)fminf(fmaxf(r, -1.0e6f), 1.0e6f);   // round(x / h)
+            if (!(u[a] == u[a]) || rw < 1 || rw >= dom - 4) ok = false;
+            c[a] = ok ? rw - 1 : 0;
+        }
+        emit_key(P, keys, idx, oorg, i, c, ok, ow, h, slab_axis, slab_lo, slab_hi, ctl);
+    }
 }
 
-__global__ void k_shift_keys(const uint64_t* __restrict__ keys, uint64_t* bkeys, int n) {
+template <class KeyT>
+__global__ void k_shift_keys(const KeyT* __restrict__ keys, uint64_t* bkeys, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) bkeys[i] = keys[i] >> 6;
+    if (i < n) bkeys[i] = (uint64_t)(keys[i] >> 6);   // (the four tail classes share one block key, larger than every valid one)
 }
 
-__global__ void k_permute(ParticleArrays src, ParticleArrays dst, const uint32_t* __restrict__ perm, int n) {
+// Moves every stream to the sorted order and re-bases the positions: a particle that lands in a block gets its position relative to THAT
+// block's origin (decoded from its key) -- from the origin it was relative to (oorg) by adding the integer difference, which leaves the
+// coordinate of a particle that stays in its block bit for bit alone, or from world coordinates with one rounding --; a particle that lands
+// in the tail goes back to world coordinates.
+template <class KeyT>
+__global__ void k_permute(ParticleArrays src, ParticleArrays dst, const uint32_t* __restrict__ perm, const KeyT* __restrict__ keys_sorted, const uint32_t* __restrict__ oorg, int n, float h) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t s = perm[i];
+    const KeyT key = keys_sorted[i];
+    const uint32_t ow = oorg[s];
+    float4 q0 = src.q[0][s];
+    const int ox = (int)(ow & 1023u) * 4, oy = (int)((ow >> 10) & 1023u) * 4, oz = (int)((ow >> 20) & 1023u) * 4;
+    if (key < TailKeys<KeyT>::EMIG_LO) {
+        const uint32_t bk = (uint32_t)(key >> 6);
+        const int nx = ((int)compact10(bk) - 1) * 4, ny = ((int)compact10(bk >> 1) - 1) * 4, nz = ((int)compact10(bk >> 2) - 1) * 4;
+        if (ow == OORG_WORLD) { q0.x = rel_from_world(q0.x, nx, h); q0.y = rel_from_world(q0.y, ny, h); q0.z = rel_from_world(q0.z, nz, h); }
+        else { q0.x += (float)(ox - nx); q0.y += (float)(oy - ny); q0.z += (float)(oz - nz); }
+    } else if (ow != OORG_WORLD) {
+        q0.x = world_from_rel(q0.x, ox, h); q0.y = world_from_rel(q0.y, oy, h); q0.z = world_from_rel(q0.z, oz, h);
+    }
+    dst.q[0][i] = q0;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) dst.q[a][i] = src.q[a][s];
+    for (int a = 1; a < 6; ++a) dst.q[a][i] = src.q[a][s];
     dst.d[i] = src.d[s];
     dst.k[i] = src.k[s];
     dst.kinvel[i] = src.kinvel[s];
@@ -2669,12 +2832,11 @@ __global__ void k_link_tile_nbrs(const int* __restrict__ nbr, const int4* __rest
 // --------------------------------------------------------------------------------------- readback
 // scatter a component back to caller order: out[id - id_base] = value(i); id_base < 0 keeps device order
 SPK_DEV size_t out_slot(const ParticleArrays& P, int i, long long id_base) { return id_base < 0 ? (size_t)i : (size_t)((long long)particle_id(P, i) - id_base); }
-__global__ void k_read_positions(ParticleArrays P, float* out, int n, long long id_base) {
+__global__ void k_read_positions(ParticleArrays P, float* out, int n, long long id_base, BinnedView B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float4 q0 = P.q[0][i];
     float* o = out + 3 * out_slot(P, i, id_base);
-    o[0] = q0.x; o[1] = q0.y; o[2] = q0.z;
+    slot_world_pos(B, P.q[0][i], i, o);
 }
 __global__ void k_read_velocities(ParticleArrays P, float* out, int n, long long id_base) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2750,11 +2912,11 @@ __global__ void k_read_struct(ParticleArrays P, uint32_t* out, int n, long long 
     }
 }
 // the three per-frame render components in one pass (any output may be null)
-__global__ void k_read_render(ParticleArrays P, float* pos, float* vel, float* phase, int n, long long id_base) {
+__global__ void k_read_render(ParticleArrays P, float* pos, float* vel, float* phase, int n, long long id_base, BinnedView B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const size_t o = out_slot(P, i, id_base);
-    if (pos) { const float4 q0 = P.q[0][i]; pos[3 * o] = q0.x; pos[3 * o + 1] = q0.y; pos[3 * o + 2] = q0.z; }
+    if (pos) slot_world_pos(B, P.q[0][i], i, pos + 3 * o);
     if (vel) { const float4 q3 = P.q[3][i]; vel[3 * o] = q3.x; vel[3 * o + 1] = q3.y; vel[3 * o + 2] = q3.z; }
     if (phase) { phase[2 * o] = P.aux[i].x; phase[2 * o + 1] = P.d[i].w; }
 }
@@ -2815,12 +2977,12 @@ __global__ void k_unpack_particles(ParticleArrays P, int first, int count, const
 }
 // first index of every tail class in the sorted key array: out[k] = first i with class(i) >= k,
 // classes 0..3 = EMIG_LO, EMIG_HI, INVALID, REMOVED (out[] preset to n)
-__global__ void k_tail_bounds(const uint64_t* __restrict__ keys, int n, int* out) {
+template <class KeyT>
+__global__ void k_tail_bounds(const KeyT* __restrict__ keys, int n, int* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint64_t M = (1ull << 37) - 1;   // the sort only looked at these bits
-    const uint64_t a = keys[i] & M, b = i ? (keys[i - 1] & M) : 0ull;
-    const uint64_t T[4] = {KEY_EMIG_LO & M, KEY_EMIG_HI & M, KEY_INVALID & M, KEY_REMOVED & M};
+    const KeyT a = keys[i], b = i ? keys[i - 1] : (KeyT)0;
+    const KeyT T[4] = {TailKeys<KeyT>::EMIG_LO, TailKeys<KeyT>::EMIG_HI, TailKeys<KeyT>::INVALID, TailKeys<KeyT>::REMOVED};
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (a >= T[k] && (i == 0 || b < T[k])) atomicMin(&out[k], i);
@@ -3079,14 +3241,14 @@ __global__ __launch_bounds__(BLK_THREADS) void k_check_particles(ParticleArrays 
         const float4 q0 = P.q[0][i];
         const uint32_t flags = reinterpret_cast<const uint32_t*>(&P.k[i])[3];
         if (flags & FLAG_INVALID) continue;
-        const float px[3] = {q0.x, q0.y, q0.z};
+        const float u[3] = {q0.x, q0.y, q0.z};   // block-relative, in cells
         bool bad = false;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const float r = roundf(px[a] / h);
-            if (!((r >= 1.0f) && (r < (float)(dom - 4)))) { bad = true; continue; }
-            const int nl = (int)r - 1 - orgv[a];
-            if (nl < -1 || nl > 4) bad = true;     // one cell of drift around the block is what the tile covers
+            const float r = rintf(u[a]);
+            if (!(r >= 0.0f && r <= 5.0f)) { bad = true; continue; }       // one cell of drift around the block is what the tile covers
+            const int rw = orgv[a] + (int)r;                                // round(x / h)
+            if (!(rw >= 1 && rw < dom - 4)) bad = true;
         }
         if (bad) atomicAdd(&cnt[2], 1ull);
     }

@@ -14,10 +14,9 @@ enum { RS_NRUNS = 0, RS_MAXLEN = 1, RS_DISTINCT = 2, RS_CHUNKS4 = 3, RS_ROUNDS =
 __global__ __launch_bounds__(BLK_THREADS) void k_run_stats(ParticleArrays P, GridArrays G, float h, unsigned long long* out) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int pb = blockIdx.x;
-    const int4 org = G.pb_info[2 * pb], rng = G.pb_info[2 * pb + 1];
+    const int4 rng = G.pb_info[2 * pb + 1];
     const int pfirst = rng.x, pcount = rng.y;
     const int niter = (pcount + BLK_THREADS - 1) / BLK_THREADS;
-    const float inv_h = 1.0f / h;
     if (tid == 0) atomicAdd(&out[RS_PCOUNT64 * RS_BINS + min(pcount >> 6, 64)], 1ull);
     for (int it = 0; it < niter; ++it) {
         const int li = it * BLK_THREADS + tid;
@@ -26,7 +25,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_run_stats(ParticleArrays P, Gri
         const float4 q0 = P.q[0][i];
         const uint32_t flags = __float_as_uint(P.k[i].w);
         bool live = active && !(flags & FLAG_INVALID);
-        const int lx = (int)round_cell(q0.x, h, inv_h) - 1 - org.x + 1, ly = (int)round_cell(q0.y, h, inv_h) - 1 - org.y + 1, lz = (int)round_cell(q0.z, h, inv_h) - 1 - org.z + 1;
+        const int lx = (int)rintf(q0.x), ly = (int)rintf(q0.y), lz = (int)rintf(q0.z);   // block-relative positions (kernels.h, cell_frac)
         live = live && lx >= 0 && lx <= 5 && ly >= 0 && ly <= 5 && lz >= 0 && lz <= 5;
         const int key = live ? lx + 8 * ly + 64 * lz : -1;
         if (!__any(live)) continue;

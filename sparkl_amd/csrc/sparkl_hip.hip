@@ -22,6 +22,7 @@
 
 #include "kernels.h"
 #include "probes.h"
+#include "host_transport.h"
 
 using namespace spk;
 
@@ -101,6 +102,9 @@ struct SparklPipeline {
 
     // particles
     uint64_t n = 0;
+    // slots [0, n_binned) belong to the particle blocks of the current binning and hold BLOCK-RELATIVE positions (kernels.h, cell_frac); the
+    // tail [n_binned, n) -- fresh uploads, appended particles, immigrants, emigrants, particles outside the domain -- holds world coordinates
+    uint64_t n_binned = 0;
     ParticleStore cur, alt;
     uint32_t max_model_index = 0;
     // slab decomposition (multi-GPU): owned home blocks along `slab_axis` are [slab_lo, slab_hi)
@@ -116,6 +120,12 @@ struct SparklPipeline {
     bool in_substep = false;
     bool pending_clock_saved = false;
     bool tiles_ready = false;      // the previous substep_finish_fused already scattered this substep's tiles
+    // how the last split-phase substep ended (substep_finish_impl): decides whether the standalone P2G of substep_begin feeds the disorder
+    // books.  A schedule that finishes fused scatters with k_g2p2g from then on and reaches the standalone P2G only behind a re-bin (an
+    // incidental launch: stays out of the books); one that finishes plain (sparkl_hip_group_step: adaptive, one substep per call; slab.py's
+    // step()) scatters with it EVERY substep and is the only measure the policy will ever see (it was never counted there, so
+    // k_block_reorder and disorder re-bins never fired for adaptive multi-slab runs).  Survives re-bins on purpose.
+    bool last_finish_fused = false;
     bool halo_store_mode = false;  // inside sparkl_hip_group_substeps: halo records are stored, not added (no per-substep memset)
     // interior / cut-adjacent split of a slab (built by the re-bin): split_pb = [cut-adjacent particle blocks in Morton order | interior
     // ones], split_nb likewise for node blocks; the slab-group loop runs the cut-adjacent part on `halo_stream` behind the exchange
@@ -168,6 +178,14 @@ struct SparklPipeline {
     uint64_t fluid_fused_substeps = 0, fluid_fused_mismatches = 0;
     DevBuf<DevCuboid> d_cuboids;
     int num_cuboids = 0;
+    // host copies of the collider records (SparklColliderOptions patches them), what the options add up to, and the projection cache
+    std::vector<DevCuboid> h_cuboids;
+    std::vector<DevHeightField> h_heightfields;
+    std::vector<DevTriMesh> h_trimeshes;
+    bool collider_handling = false, collider_penalty = false, rare_by_models = false;
+    DevBuf<float4> node_proj;        // GridArrays::node_proj: [heightfields + trimeshes][num_blocks][64]
+    bool proj_cache_on = true;       // SPARKL_HIP_PROJ_CACHE=0: off (A/B, tests)
+    bool proj_cache_clear = true;    // colliders changed or a re-bin rebuilt the node blocks: zero the cache before the next grid update
     DevBuf<DevHeightField> d_heightfields;
     std::vector<float*> d_heights;   // one device array per heightfield
     int num_heightfields = 0;
@@ -195,7 +213,7 @@ struct SparklPipeline {
 
     // re-bin scratch
     DevBuf<uint64_t> keys_a, keys_b, pb_keys, bkeys;
-    DevBuf<uint32_t> idx_a, idx_b, pb_counts, pb_first, cand_a, cand_b;
+    DevBuf<uint32_t> idx_a, idx_b, pb_counts, pb_first, cand_a, cand_b, oorg;
     DevBuf<uint8_t> cub_temp;
     DevBuf<int> d_scalars;  // [0] num_runs, [1] num_unique
     DevBuf<DevTriMesh> d_trimeshes;
@@ -230,8 +248,12 @@ struct SparklPipeline {
     uint64_t clock_sampled = 0;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
-    struct Span { size_t a, b; int kind; };
+    struct Span { size_t a, b; int kind; uint32_t sub; };   // sub = substep_index when the span was opened (per-substep log of step())
     std::vector<Span> spans;
+    // per-substep record of the last sparkl_hip_pipeline_step(.., timings != NULL) (CudaTimestepTimings::substeps, cuda_mpm_pipeline.rs:28-85)
+    bool sublog_on = false;
+    uint32_t sublog_base = 0;
+    std::vector<SparklSubstepTimings> sublog;
     SparklKernelClock clock{};
     float span_ref_ms[16] = {0.f};       // duration of a working launch per span kind (see clock_collect)
     uint64_t total_resorts = 0;
@@ -249,7 +271,7 @@ static int clock_begin(SparklPipeline* p, int kind, size_t* tok, hipStream_t st 
         for (size_t i = old; i < p->ev_pool.size(); ++i) HIPCHK(hipEventCreate(&p->ev_pool[i]));
     }
     *tok = p->spans.size();
-    p->spans.push_back({p->ev_used, p->ev_used + 1, kind});
+    p->spans.push_back({p->ev_used, p->ev_used + 1, kind, p->substep_index});
     HIPCHK(hipEventRecord(p->ev_pool[p->ev_used], st));
     p->ev_used += 2;
     return SPARKL_OK;
@@ -279,6 +301,23 @@ static int clock_collect(SparklPipeline* p) {
         const bool kernel_span = s.kind == SPAN_P2G || s.kind == SPAN_GRID || s.kind == SPAN_G2P || s.kind == SPAN_FUSED || s.kind == SPAN_P2G_MASS || s.kind == SPAN_GRID_MASS ||
                                  s.kind == SPAN_G2P_VOLUME;
         if (kernel_span && t < 0.25f * longest[s.kind]) { p->clock.noop_ms += t; p->clock.noop_launches++; continue; }
+        if (p->sublog_on && s.sub - p->sublog_base < 65536u) {
+            // A planned substep that did not run leaves no-op spans (dropped above) and its index is reused by the substep that does run, so
+            // summing by index gives every executed substep exactly its own launches; a re-bin or an estimator pass carries the index of the
+            // substep it precedes ("at the start of the substep", like the reference's grid_resize_and_sort / estimate_timestep).
+            const uint32_t k = s.sub - p->sublog_base;
+            if (k >= p->sublog.size()) p->sublog.resize(k + 1, SparklSubstepTimings{});
+            SparklSubstepTimings& L = p->sublog[k];
+            switch (s.kind) {
+                case SPAN_P2G: case SPAN_P2G_MASS: L.p2g_ms += t; break;
+                case SPAN_GRID: case SPAN_GRID_MASS: L.grid_update_ms += t; break;
+                case SPAN_G2P: case SPAN_FUSED: case SPAN_G2P_VOLUME: L.g2p_ms += t; break;
+                case SPAN_SORT: case SPAN_REORDER: L.grid_resize_and_sort_ms += t; break;
+                case SPAN_DT: L.estimate_timestep_ms += t; break;
+                default: L.halo_ms += t; break;
+            }
+            L.total_ms += t;
+        }
         switch (s.kind) {
             case SPAN_P2G: p->clock.p2g_ms += t; p->clock.p2g_launches++; break;
             case SPAN_GRID: p->clock.grid_update_ms += t; p->clock.grid_update_launches++; break;
@@ -320,6 +359,7 @@ static GridArrays grid_arrays(const SparklPipeline* p) {
     GridArrays g;
     g.blk_origin = p->blk_origin.p; g.blk_pfirst = p->blk_pfirst.p; g.blk_pcount = p->blk_pcount.p; g.blk_nbr = p->blk_nbr.p; g.blk_tnbr = p->blk_tnbr.p; g.dt_partial = p->dt_partial.p;
     g.cuboids = p->d_cuboids.p; g.heightfields = p->d_heightfields.p; g.trimeshes = p->d_trimeshes.p;
+    g.node_proj = nullptr;   // only launch_grid_update hands the cache out (it also sizes and clears it, in stream order)
     g.pblk = p->pblk.p; g.pb_info = p->pb_info.p; g.tile_mode = p->tile_mode.p; g.pb_heads = p->pb_heads.p; g.tiles = p->tiles.p; g.node_vel = p->node_vel.p; g.node_mom = p->capture_mom ? p->node_mom.p : nullptr;
     g.halo_in = (p->slab_on && p->num_blocks) ? p->halo_in.p : nullptr;
     g.halo_axis = p->slab_axis; g.halo_lo = p->slab_lo; g.halo_hi = p->slab_hi;
@@ -368,46 +408,55 @@ static int resort(SparklPipeline* p) {
         p->c_stale = false;
         p->c_regathers++;
     }
+    const int old_npb = p->num_pblocks, old_binned = (int)std::min<uint64_t>(p->n_binned, p->n);
     p->num_blocks = p->num_pblocks = 0;
     p->pb_order_valid = false;
     if (n > 0) {
-        CHK(p->keys_a.reserve(n)); CHK(p->keys_b.reserve(n)); CHK(p->idx_a.reserve(n)); CHK(p->idx_b.reserve(n));
+        CHK(p->keys_a.reserve(n)); CHK(p->keys_b.reserve(n)); CHK(p->idx_a.reserve(n)); CHK(p->idx_b.reserve(n)); CHK(p->oorg.reserve(n));
         CHK(p->bkeys.reserve(n)); CHK(p->pb_keys.reserve(n)); CHK(p->pb_counts.reserve(n)); CHK(p->pb_first.reserve(n));
         CHK(p->d_scalars.reserve(8));
         p->alt.has_frac = p->cur.has_frac;
         CHK(p->alt.reserve(p->cur.q[0].cap));
+        CHK(p->d_tail.reserve(4));
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dead_dt_bits, 0x7f7fffff, 1, st));   // rebuilt from the particles that are outside the domain now
-        hipLaunchKernelGGL(k_compute_keys, dim3(grid_for(n, 256)), dim3(256), 0, st, p->cur.arrays(), p->keys_a.p, p->idx_a.p, n, p->h, p->dom, p->slab_axis,
-                           p->slab_on ? p->slab_lo : INT32_MIN, p->slab_on ? p->slab_hi : INT32_MAX, p->d_ctl);
         // key bits actually in use: Morton code of the block coordinate biased by +1 (3 x block_bits) + 6 cell bits; the tail
         // classes (emigrants, out of domain, removed) are all-ones words, so ONE more bit keeps them behind every valid key and
         // their two low bits order them among themselves.  dom = 256 (the default 2^30-byte grid): 28 bits = 4 radix passes
-        // instead of the 5 that the worst case (37 bits) needs.
+        // instead of the 5 that the worst case (37 bits) needs -- and 32-bit keys: 8 instead of 12 bytes per pair and pass.
         int block_bits = 1;
         while ((1 << block_bits) < p->dom / 4 + 2) ++block_bits;
         const int end_bit = std::min(37, 3 * block_bits + 6 + 1);
-        size_t tb = 0;
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, p->keys_a.p, p->keys_b.p, p->idx_a.p, p->idx_b.p, n, 0, end_bit, st));
-        CHK(cub_reserve(p, tb));
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(p->cub_temp.p, tb, p->keys_a.p, p->keys_b.p, p->idx_a.p, p->idx_b.p, n, 0, end_bit, st));
-        hipLaunchKernelGGL(k_permute, dim3(grid_for(n, 256)), dim3(256), 0, st, p->cur.arrays(), p->alt.arrays(), p->idx_b.p, n);
+        auto sort_and_move = [&](auto key_tag) -> int {
+            using KeyT = decltype(key_tag);
+            KeyT* ka = reinterpret_cast<KeyT*>(p->keys_a.p);
+            KeyT* kb = reinterpret_cast<KeyT*>(p->keys_b.p);
+            const int slo = p->slab_on ? p->slab_lo : INT32_MIN, shi = p->slab_on ? p->slab_hi : INT32_MAX;
+            // the particles of the old binning (block-relative positions), one workgroup per old particle block, then the tail (world coordinates)
+            if (old_binned > 0 && old_npb > 0)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_compute_keys_binned<KeyT>), dim3(old_npb), dim3(BLK_THREADS), 0, st, p->cur.arrays(), (const int4*)p->pb_info.p, ka, p->idx_a.p,
+                                   p->oorg.p, p->h, p->dom, p->slab_axis, slo, shi, p->d_ctl);
+            if (n > old_binned)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_compute_keys_world<KeyT>), dim3(grid_for(n - old_binned, 256)), dim3(256), 0, st, p->cur.arrays(), ka, p->idx_a.p, p->oorg.p,
+                                   old_binned, n, p->h, p->dom, p->slab_axis, slo, shi, p->d_ctl);
+            size_t tb = 0;
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, ka, kb, p->idx_a.p, p->idx_b.p, n, 0, end_bit, st));
+            CHK(cub_reserve(p, tb));
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(p->cub_temp.p, tb, ka, kb, p->idx_a.p, p->idx_b.p, n, 0, end_bit, st));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_permute<KeyT>), dim3(grid_for(n, 256)), dim3(256), 0, st, p->cur.arrays(), p->alt.arrays(), p->idx_b.p, (const KeyT*)kb,
+                               (const uint32_t*)p->oorg.p, n, p->h);
+            // block keys of the sorted particles (run-length encoded below) and the tail classes
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shift_keys<KeyT>), dim3(grid_for(n, 256)), dim3(256), 0, st, (const KeyT*)kb, p->bkeys.p, n);
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)p->d_tail.p, n, 4, st));   // no host staging buffer to outlive
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tail_bounds<KeyT>), dim3(grid_for(n, 256)), dim3(256), 0, st, (const KeyT*)kb, n, p->d_tail.p);
+            return SPARKL_OK;
+        };
+        if (end_bit <= 32) CHK(sort_and_move(uint32_t{})); else CHK(sort_and_move(uint64_t{}));
         std::swap(p->cur, p->alt);
-        // block keys of the sorted particles, run-length encoded
-        {
-            uint64_t* keys = p->keys_b.p;
-            uint64_t* bk = p->bkeys.p;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shift_keys), dim3(grid_for(n, 256)), dim3(256), 0, st, keys, bk, n);
-        }
         size_t tb2 = 0;
         HIPCHK(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb2, p->bkeys.p, p->pb_keys.p, p->pb_counts.p, p->d_scalars.p, n, st));
         CHK(cub_reserve(p, tb2));
         HIPCHK(hipcub::DeviceRunLengthEncode::Encode(p->cub_temp.p, tb2, p->bkeys.p, p->pb_keys.p, p->pb_counts.p, p->d_scalars.p, n, st));
         // tail classes (removed | emigrants low | emigrants high | out of domain) sit after the valid keys
-        CHK(p->d_tail.reserve(4));
-        {
-            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)p->d_tail.p, n, 4, st));   // no host staging buffer to outlive
-            hipLaunchKernelGGL(k_tail_bounds, dim3(grid_for(n, 256)), dim3(256), 0, st, p->keys_b.p, n, p->d_tail.p);
-        }
         int h_runs = 0, tail[4] = {n, n, n, n};
         HIPCHK(hipMemcpyAsync(&h_runs, p->d_scalars.p, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(tail, p->d_tail.p, sizeof(tail), hipMemcpyDeviceToHost, st));
@@ -419,6 +468,7 @@ static int resort(SparklPipeline* p) {
         p->emig_first[0] = tail[0]; p->n_emig[0] = tail[1] - tail[0];
         p->emig_first[1] = tail[1]; p->n_emig[1] = tail[2] - tail[1];
         p->n = (uint64_t)tail[3];   // particles already handed to a neighbour slab are dropped here
+        p->n_binned = (uint64_t)tail[0];   // k_permute left block-relative positions in front of the tail classes, world coordinates behind
         const int npb = h_runs;
         if (npb > 0) {
             size_t tb3 = 0;
@@ -523,6 +573,8 @@ static int resort(SparklPipeline* p) {
     CHK(upload_policy(p));
     HIPCHK(hipGetLastError());
     CHK(clock_end(p, tok));
+    if (n == 0) p->n_binned = 0;
+    p->proj_cache_clear = true;   // the node blocks are new
     p->sorted = true;
     p->tiles_ready = false;
     p->mass_tiles_ready = false;
@@ -534,11 +586,13 @@ static int resort(SparklPipeline* p) {
 // ----------------------------------------------------------------------------------- one substep
 static StepParams make_params(const SparklPipeline* p, const SparklSolverParams* sp, const float g[3], float dt) {
     StepParams S;
-    S.h = p->h; S.inv_d = 4.0f / (p->h * p->h); S.inv_h = 1.0f / p->h; S.dt = dt;
+    S.h = p->h; S.inv_d = 4.0f / (p->h * p->h); S.inv_h = 1.0f / p->h; S.dt = dt; S.dt_h = dt / p->h;
     S.gx = g[0]; S.gy = g[1]; S.gz = g[2];
     S.boundary_handling = sp->boundary_handling; S.dofs = sp->simulation_dofs;
     S.parity = (int)(p->substep_index & 1u); S.dom = p->dom; S.num_cuboids = p->num_cuboids; S.num_heightfields = p->num_heightfields; S.num_trimeshes = p->num_trimeshes; S.want_dt = 0; S.defer_c = 0;
     S.project_particles = sp->enable_boundary_particle_projection ? 1 : 0;
+    S.collider_handling = p->collider_handling ? 1 : 0;
+    S.penalty = p->collider_penalty ? 1 : 0;
     S.dt_next = dt;
     S.count_heads = 1;
     S.mass_from_sweep = 0;
@@ -550,7 +604,20 @@ static StepParams make_params(const SparklPipeline* p, const SparklSolverParams*
 #define SPK_P2G_REDUCE_STEPS 4   // 16-lane groups: same speed as 3 on the aligned initial lattice, 5-8 % faster once cells hold uneven counts
 #endif
 
-static void launch_grid_update(SparklPipeline* p, const GridArrays& G, const StepParams& S, hipStream_t st) {
+// the projection cache of the grid update: sized for the current node blocks, zeroed (= "not computed") when they or the colliders changed
+static void prepare_proj_cache(SparklPipeline* p, hipStream_t st) {
+    const size_t slots = (size_t)(p->num_heightfields + p->num_trimeshes);
+    if (!p->proj_cache_on || slots == 0 || p->num_blocks == 0) return;
+    const size_t need = slots * (size_t)p->num_blocks * 64;
+    if (need > p->node_proj.cap) { if (p->node_proj.reserve(need) != SPARKL_OK) { p->node_proj.release(); return; } p->proj_cache_clear = true; }
+    if (p->proj_cache_clear) { (void)hipMemsetAsync(p->node_proj.p, 0, need * sizeof(float4), st); p->proj_cache_clear = false; }
+}
+static void launch_grid_update(SparklPipeline* p, const GridArrays& G_in, const StepParams& S, hipStream_t st) {
+    GridArrays G = G_in;
+    if (p->num_heightfields + p->num_trimeshes > 0) {
+        prepare_proj_cache(p, st);
+        G.node_proj = (p->proj_cache_on && p->node_proj.p && !p->proj_cache_clear) ? p->node_proj.p : nullptr;
+    }
     const dim3 grid((p->num_blocks + 3) / 4), block(BLK_THREADS);
     if (p->num_heightfields > 0 || p->num_trimeshes > 0)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, true>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);
@@ -781,6 +848,7 @@ static int enqueue_fluid_batch(SparklPipeline* p, const SparklSolverParams* sp, 
     const dim3 grid(p->num_pblocks), block(BLK_THREADS), ggrid((p->num_blocks + 3) / 4);
     size_t tk = 0;
     const bool fluid_only = p->all_plain_fluid && !sp->enable_boundary_particle_projection;
+    note_heads_kind(p, 0, st);   // k_vol_p2g counts lane-group heads like the standalone P2G: one measure in the books at a time
     if (!p->mass_tiles_ready) {
         const StepParams S = make_params(p, sp, g, dt);
         if (was_on && (p->substep_index % p->clock_stride) != 0) p->clock_on = false;
@@ -862,6 +930,7 @@ int sparkl_hip_pipeline_create(const SparklPipelineDesc* desc, SparklPipeline** 
     p->fuse_fixed_dt = getenv("SPARKL_HIP_NO_FUSE") == nullptr;
     p->defer_c = !(getenv("SPARKL_HIP_DEFER_C") && !strcmp(getenv("SPARKL_HIP_DEFER_C"), "0"));
     if (const char* e = getenv("SPARKL_HIP_CARRY")) p->carry_on = atoi(e) != 0;
+    if (const char* e = getenv("SPARKL_HIP_PROJ_CACHE")) p->proj_cache_on = atoi(e) != 0;
     if (const char* e = getenv("SPARKL_HIP_OVERLAP")) p->overlap_mode = !strcmp(e, "cal") ? -2 : (atoi(e) != 0 ? 1 : 0);   // "cal": calibrate even on one device (tests)
     p->lookahead = !(getenv("SPARKL_HIP_LOOKAHEAD") && !strcmp(getenv("SPARKL_HIP_LOOKAHEAD"), "0"));
     p->lookahead_force = getenv("SPARKL_HIP_LOOKAHEAD") && !strcmp(getenv("SPARKL_HIP_LOOKAHEAD"), "force");
@@ -899,6 +968,8 @@ void sparkl_hip_pipeline_destroy(SparklPipeline* p) {
     p->keys_a.release(); p->keys_b.release(); p->pb_keys.release(); p->bkeys.release(); p->idx_a.release(); p->idx_b.release();
     p->pb_counts.release(); p->pb_first.release(); p->cand_a.release(); p->cand_b.release(); p->cub_temp.release(); p->d_scalars.release();
     p->staging.release(); p->node_staging.release(); p->d_count.release(); p->dt_partial.release(); p->psi_tiles.release(); p->node_psi.release();
+    p->oorg.release(); p->node_proj.release(); p->pb_order.release(); p->order_keys.release(); p->order_keys_out.release(); p->order_vals.release();
+    p->split_pb.release(); p->split_nb.release(); p->split_flags.release(); p->bal_dev.release();
     p->halo_list[0].release(); p->halo_list[1].release(); p->halo_in.release(); p->d_tail.release();
     for (int k = 0; k < 2; ++k) { p->x_send[k].release(); p->x_recv[k].release(); p->x_mig_send[k].release(); p->x_mig_recv[k].release(); }
     p->x_dev.release();
@@ -1015,20 +1086,75 @@ int sparkl_hip_models_set(SparklPipeline* p, uint32_t n, const SparklParticleMod
     HIPCHK(hipStreamSynchronize(p->stream));
     p->h_models = dm;
     p->any_fluid = any_fluid;
-    p->rare_models = false;
+    p->rare_by_models = false;
     p->all_plain_fluid = n > 0;
     p->all_dp_sand = n > 0 && !(getenv("SPARKL_HIP_MSET") && !strcmp(getenv("SPARKL_HIP_MSET"), "0"));
     p->all_neo_elastic = p->all_dp_sand;
     for (const DevModel& d : dm) {
-        p->rare_models |= d.ptag > SPARKL_PLASTIC_DRUCKER_PRAGER || d.has_failure;
+        p->rare_by_models |= d.ptag > SPARKL_PLASTIC_DRUCKER_PRAGER || d.has_failure;
         p->all_plain_fluid &= d.is_fluid && d.ptag < 0 && !d.has_failure;
         p->all_neo_elastic &= !d.is_fluid && d.ctag == SPARKL_CONSTITUTIVE_NEO_HOOKEAN && d.ptag < 0 && !d.has_failure;
         p->all_dp_sand &= !d.is_fluid && d.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR && d.ptag == SPARKL_PLASTIC_DRUCKER_PRAGER && !d.only_active_when_failed && !d.has_failure;
     }
+    p->rare_models = p->rare_by_models || p->collider_penalty;
     if (p->d_ctl) CHK(upload_policy(p));   // the default reorder budget depends on whether a fluid is present
     return SPARKL_OK;
 }
 
+// what the per-collider options add up to (make_params), which kernels they need, and a stale projection cache
+static void collider_options_changed(SparklPipeline* p) {
+    p->collider_handling = false; p->collider_penalty = false;
+    for (const auto& c : p->h_cuboids) { p->collider_handling |= c.handling >= 0; p->collider_penalty |= c.penalty > 0.f; }
+    for (const auto& c : p->h_heightfields) { p->collider_handling |= c.handling >= 0; p->collider_penalty |= c.penalty > 0.f; }
+    for (const auto& c : p->h_trimeshes) { p->collider_handling |= c.handling >= 0; p->collider_penalty |= c.penalty > 0.f; }
+    p->rare_models = p->rare_by_models || p->collider_penalty;   // the penalty force lives in the RARE instantiations of the G2P kernels
+    p->proj_cache_clear = true;
+    p->carry_valid = false;
+}
+static int check_options(uint32_t n, const SparklColliderOptions* o, size_t have, const char* kind) {
+    if (n != have) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "%u option records for %zu %s colliders", n, have, kind);
+    if (n && !o) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    for (uint32_t i = 0; i < n; ++i) {
+        if (o[i].grid_boundary_handling < SPARKL_COLLIDER_HANDLING_FROM_PARAMS || o[i].grid_boundary_handling > SPARKL_BOUNDARY_NONE)
+            return set_error(SPARKL_ERR_INVALID_ARGUMENT, "%s collider %u: grid_boundary_handling %d", kind, i, (int)o[i].grid_boundary_handling);
+        if (!(o[i].penalty_stiffness >= 0.f)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "%s collider %u: penalty_stiffness must be >= 0", kind, i);
+    }
+    return SPARKL_OK;
+}
+int sparkl_hip_colliders_set_cuboid_options(SparklPipeline* p, uint32_t n, const SparklColliderOptions* o) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    CHK(check_options(n, o, p->h_cuboids.size(), "cuboid"));
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    for (uint32_t i = 0; i < n; ++i) { p->h_cuboids[i].handling = o[i].grid_boundary_handling; p->h_cuboids[i].penalty = o[i].penalty_stiffness; }
+    if (n) HIPCHK(hipMemcpy(p->d_cuboids.p, p->h_cuboids.data(), n * sizeof(DevCuboid), hipMemcpyHostToDevice));
+    collider_options_changed(p);
+    return SPARKL_OK;
+}
+int sparkl_hip_colliders_set_heightfield_options(SparklPipeline* p, uint32_t n, const SparklColliderOptions* o) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    CHK(check_options(n, o, p->h_heightfields.size(), "heightfield"));
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    for (uint32_t i = 0; i < n; ++i) {
+        p->h_heightfields[i].handling = o[i].grid_boundary_handling; p->h_heightfields[i].penalty = o[i].penalty_stiffness; p->h_heightfields[i].flip_interior = o[i].flip_interior ? 1 : 0;
+    }
+    if (n) HIPCHK(hipMemcpy(p->d_heightfields.p, p->h_heightfields.data(), n * sizeof(DevHeightField), hipMemcpyHostToDevice));
+    collider_options_changed(p);
+    return SPARKL_OK;
+}
+int sparkl_hip_colliders_set_trimesh_options(SparklPipeline* p, uint32_t n, const SparklColliderOptions* o) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    CHK(check_options(n, o, p->h_trimeshes.size(), "trimesh"));
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    for (uint32_t i = 0; i < n; ++i) {
+        p->h_trimeshes[i].handling = o[i].grid_boundary_handling; p->h_trimeshes[i].penalty = o[i].penalty_stiffness; p->h_trimeshes[i].flip_interior = o[i].flip_interior ? 1 : 0;
+    }
+    if (n) HIPCHK(hipMemcpy(p->d_trimeshes.p, p->h_trimeshes.data(), n * sizeof(DevTriMesh), hipMemcpyHostToDevice));
+    collider_options_changed(p);
+    return SPARKL_OK;
+}
 int sparkl_hip_colliders_set_cuboids(SparklPipeline* p, uint32_t n, const SparklCuboidCollider* c) {
     if (!p || (n && !c)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
     HIPCHK(hipSetDevice(p->device));
@@ -1038,10 +1164,13 @@ int sparkl_hip_colliders_set_cuboids(SparklPipeline* p, uint32_t n, const Sparkl
         for (int a = 0; a < 4; ++a) dc[i].q[a] = c[i].rotation[a];
         dc[i].friction = c[i].friction;
     }
+    for (auto& d : dc) { d.handling = SPARKL_COLLIDER_HANDLING_FROM_PARAMS; d.penalty = 0.f; }
     CHK(p->d_cuboids.reserve(std::max<uint32_t>(n, 1)));
     if (n) HIPCHK(hipMemcpyAsync(p->d_cuboids.p, dc.data(), n * sizeof(DevCuboid), hipMemcpyHostToDevice, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     p->num_cuboids = (int)n;
+    p->h_cuboids = dc;
+    collider_options_changed(p);
     return SPARKL_OK;
 }
 
@@ -1065,6 +1194,7 @@ int sparkl_hip_colliders_set_heightfields(SparklPipeline* p, uint32_t n, const S
         for (int a = 0; a < 3; ++a) { dh[i].scale[a] = c[i].scale[a]; dh[i].t[a] = c[i].translation[a]; }
         for (int a = 0; a < 4; ++a) dh[i].q[a] = c[i].rotation[a];
         dh[i].friction = c[i].friction; dh[i].below_is_solid = c[i].below_is_solid;
+        dh[i].handling = SPARKL_COLLIDER_HANDLING_FROM_PARAMS; dh[i].penalty = 0.f; dh[i].flip_interior = 0;
         {
             float lo = c[i].heights[0] * c[i].scale[1], hi = lo;
             for (size_t k = 1; k < cnt; ++k) { const float y = c[i].heights[k] * c[i].scale[1]; lo = std::min(lo, y); hi = std::max(hi, y); }
@@ -1093,6 +1223,8 @@ int sparkl_hip_colliders_set_heightfields(SparklPipeline* p, uint32_t n, const S
     CHK(p->d_heightfields.reserve(std::max<uint32_t>(n, 1)));
     if (n) HIPCHK(hipMemcpy(p->d_heightfields.p, dh.data(), n * sizeof(DevHeightField), hipMemcpyHostToDevice));
     p->num_heightfields = (int)n;
+    p->h_heightfields = dh;
+    collider_options_changed(p);
     return SPARKL_OK;
 }
 
@@ -1211,10 +1343,13 @@ int sparkl_hip_colliders_set_trimeshes(SparklPipeline* p, uint32_t n, const Spar
         for (int a = 0; a < 3; ++a) d.t[a] = c[i].translation[a];
         for (int a = 0; a < 4; ++a) d.q[a] = c[i].rotation[a];
         d.friction = c[i].friction; d.oriented = c[i].oriented; d.flip_interior = c[i].flip_interior;
+        d.handling = SPARKL_COLLIDER_HANDLING_FROM_PARAMS; d.penalty = 0.f;
     }
     CHK(p->d_trimeshes.reserve(std::max<uint32_t>(n, 1)));
     if (n) HIPCHK(hipMemcpy(p->d_trimeshes.p, dm.data(), n * sizeof(DevTriMesh), hipMemcpyHostToDevice));
     p->num_trimeshes = (int)n;
+    p->h_trimeshes = dm;
+    collider_options_changed(p);
     return SPARKL_OK;
 }
 
@@ -1269,6 +1404,7 @@ int sparkl_hip_particles_upload(SparklPipeline* p, uint64_t n, const SparklParti
     p->cur.has_frac = false;
     CHK(p->cur.reserve(std::max<uint64_t>(n, 1)));
     p->n = n;
+    p->n_binned = 0;   // world coordinates until the first re-bin
     p->max_model_index = 0;
     if (n) CHK(upload_range(p, 0, n, status, pos, vel, volume, phase, data, vg));
     p->sorted = false;
@@ -1278,6 +1414,7 @@ int sparkl_hip_particles_upload(SparklPipeline* p, uint64_t n, const SparklParti
 uint64_t sparkl_hip_particles_len(const SparklPipeline* p) { return p ? p->n : 0; }
 
 // id_base >= 0: scatter to out[id - id_base] (caller order); id_base < 0: device (sorted) order
+static BinnedView binned_view(const SparklPipeline* p) { return BinnedView{p->pb_info.p, p->num_pblocks, p->num_pblocks > 0 ? (int)p->n_binned : 0, p->h}; }
 static int launch_read(SparklPipeline* p, int what, size_t floats_per, long long id_base) {
     const int n = (int)p->n;
     CHK(p->staging.reserve(std::max<size_t>((size_t)n * floats_per, 1)));
@@ -1285,7 +1422,7 @@ static int launch_read(SparklPipeline* p, int what, size_t floats_per, long long
     hipStream_t st = p->stream;
     const dim3 g(grid_for(n, 256)), b(256);
     switch (what) {
-        case 0: hipLaunchKernelGGL(k_read_positions, g, b, 0, st, P, p->staging.p, n, id_base); break;
+        case 0: hipLaunchKernelGGL(k_read_positions, g, b, 0, st, P, p->staging.p, n, id_base, binned_view(p)); break;
         case 1: hipLaunchKernelGGL(k_read_velocities, g, b, 0, st, P, p->staging.p, n, id_base); break;
         default: hipLaunchKernelGGL(k_read_velgrad, g, b, 0, st, P, p->staging.p, n, id_base); break;
     }
@@ -1332,7 +1469,7 @@ int sparkl_hip_particles_read_statuses(SparklPipeline* p, SparklParticleStatus* 
 int sparkl_hip_particles_read_phases(SparklPipeline* p, SparklParticlePhase* out, uint64_t n) {
     READ_PROLOGUE
     CHK(p->staging.reserve(n * 2));
-    hipLaunchKernelGGL(k_read_render, dim3(grid_for(n, 256)), dim3(256), 0, p->stream, p->cur.arrays(), (float*)nullptr, (float*)nullptr, p->staging.p, (int)n, read_base(p));
+    hipLaunchKernelGGL(k_read_render, dim3(grid_for(n, 256)), dim3(256), 0, p->stream, p->cur.arrays(), (float*)nullptr, (float*)nullptr, p->staging.p, (int)n, read_base(p), binned_view(p));
     HIPCHK(hipMemcpyAsync(out, p->staging.p, n * sizeof(SparklParticlePhase), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     return SPARKL_OK;
@@ -1420,7 +1557,7 @@ int sparkl_hip_readback_begin(SparklPipeline* p, SparklParticlePosition* pos, Sp
     CHK(p->rb_staging.reserve((size_t)n * 8));
     float* d_pos = p->rb_staging.p, *d_vel = d_pos + 3 * n, *d_phase = d_vel + 3 * n;
     hipLaunchKernelGGL(k_read_render, dim3(grid_for(n, 256)), dim3(256), 0, p->stream, p->cur.arrays(), pos ? d_pos : nullptr, vel ? d_vel : nullptr,
-                       phase ? d_phase : nullptr, (int)n, read_base(p));
+                       phase ? d_phase : nullptr, (int)n, read_base(p), binned_view(p));
     HIPCHK(hipEventRecord(p->rb_gathered, p->stream));
     HIPCHK(hipStreamWaitEvent(p->rb_stream, p->rb_gathered, 0));
     if (pos) HIPCHK(hipMemcpyAsync(pos, d_pos, n * sizeof(SparklParticlePosition), hipMemcpyDeviceToHost, p->rb_stream));
@@ -1551,7 +1688,18 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
     CHK(ensure_ready(p));
     const bool was_clock = p->clock_on;
     SparklKernelClock saved = p->clock;
-    if (timings) { p->clock_on = true; memset(&p->clock, 0, sizeof(p->clock)); }
+    const uint32_t saved_stride = p->clock_stride;
+    p->sublog_on = false;
+    if (timings) {
+        p->clock_on = true; memset(&p->clock, 0, sizeof(p->clock));
+        p->clock_stride = 1; p->sublog_on = true; p->sublog_base = p->substep_index; p->sublog.clear();
+    }
+    auto note_dt = [&](uint32_t index, float d) {   // the step length of an EXECUTED substep (per-substep log)
+        if (!timings) return;
+        const uint32_t k = index - p->sublog_base;
+        if (k >= p->sublog.size()) p->sublog.resize(k + 1, SparklSubstepTimings{});
+        p->sublog[k].dt = d;
+    };
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timings) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, p->stream)); }
     const float min_dt = params->dt / (float)params->max_num_substeps;  // mls_solver.rs:33
@@ -1601,6 +1749,7 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
             if (p->h_ctl->steps_done == done0 + 1) {          // the substep ran: the prediction held
                 memcpy(&p->fluid_bound, &p->h_ctl->dt_bits, 4);
                 p->fluid_fused_substeps++;
+                note_dt(idx0, d);
                 ++nsub;
                 remaining -= d;
                 have_bound = false;
@@ -1686,7 +1835,7 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
                 HIPCHK(hipGetLastError());
                 CHK(read_ctl(p));
                 const uint32_t executed = std::min<uint32_t>(p->h_ctl->steps_done - base_done, (uint32_t)plan.size());
-                for (uint32_t k = 0; k < executed; ++k) { remaining -= plan[k]; ++nsub; }
+                for (uint32_t k = 0; k < executed; ++k) { remaining -= plan[k]; ++nsub; note_dt(base_index + k, plan[k]); }
                 p->lookahead_substeps += executed;
                 have_bound = true;
                 if (executed == plan.size()) {
@@ -1719,6 +1868,7 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
             }
         }
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dt_bits, (int)init_bits, 1, p->stream));
+        note_dt(p->substep_index, dt);
         CHK(enqueue_adaptive_substep(p, params, gravity, dt, reuse, dt_guess));
         HIPCHK(hipGetLastError());
         pending = 1;
@@ -1747,6 +1897,8 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
         timings->total_ms = ms;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         p->clock = saved; p->clock_on = was_clock;
+        p->clock_stride = saved_stride; p->sublog_on = false;
+        p->sublog.resize(nsub, SparklSubstepTimings{});   // (spans of a re-bin requested by the LAST substep would open one more entry: it belongs to the next call)
     } else if (p->clock_on) {
         CHK(clock_collect(p));
         p->clock.substeps += nsub;
@@ -1756,6 +1908,12 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
 }
 
 // cuda_sparse_grid.rs:492-650 (`check_active_blocks`, the reference's debug validator of the binning), on the current state
+int sparkl_hip_pipeline_step_substep_timings(SparklPipeline* p, SparklSubstepTimings* out, uint32_t cap, uint32_t* n_out) {
+    if (!p || !n_out || (cap && !out)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    *n_out = (uint32_t)p->sublog.size();
+    for (uint32_t k = 0; k < cap && k < p->sublog.size(); ++k) out[k] = p->sublog[k];
+    return SPARKL_OK;
+}
 int sparkl_hip_grid_check(SparklPipeline* p, SparklGridCheck* out) {
     if (!p || !out) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
     memset(out, 0, sizeof(*out));
@@ -1911,7 +2069,7 @@ int sparkl_hip_substep_begin(SparklPipeline* p, const SparklSolverParams* params
     if (params->force_fluids_volume_recomputation && p->any_fluid && !p->halo_store_mode) CHK(enqueue_fluid_volumes(p, p->pending));
     size_t t0 = 0;
     CHK(clock_begin(p, SPAN_P2G, &t0));
-    launch_p2g(p, p->cur.arrays(), G, p->pending, st, !p->fuse_fixed_dt);   // split-phase / group loop: the fused finish scatters from then on
+    launch_p2g(p, p->cur.arrays(), G, p->pending, st, !p->fuse_fixed_dt || !p->last_finish_fused);   // counts unless the schedule finishes fused (see last_finish_fused)
     CHK(clock_end(p, t0));
     return SPARKL_OK;
 }
@@ -1969,6 +2127,7 @@ static int substep_finish_impl(SparklPipeline* p, bool fuse_next, bool defer_c =
         CHK(clock_end(p, t1));
     }
     if (!(part & 2)) return SPARKL_OK;
+    p->last_finish_fused = fuse_next && p->fuse_fixed_dt;
     if (fuse_next && p->fuse_fixed_dt) {
         // G2P of this substep + P2G of the next one (same dt) in one kernel; the next substep_begin is then free
         // defer_c: only from sparkl_hip_group_substeps, which owns the batch and rebuilds C if it is cut (the public
@@ -2049,6 +2208,16 @@ struct Rccl {
 static Rccl g_rccl;
 static int rccl_load() {
     if (g_rccl.lib) return SPARKL_OK;
+    // SPARKL_HIP_TRANSPORT=host: the same function table on shared memory + host staging (host_transport.h) -- the TEST transport that lets
+    // several OS processes sharing ONE GPU run the group loop with world > 1 (RCCL refuses two ranks on one device)
+    if (const char* tr = getenv("SPARKL_HIP_TRANSPORT"); tr && !strcmp(tr, "host")) {
+        g_rccl.GetUniqueId = hostcomm::GetUniqueId; g_rccl.CommInitRank = hostcomm::CommInitRank; g_rccl.CommDestroy = hostcomm::CommDestroy;
+        g_rccl.GroupStart = hostcomm::GroupStart; g_rccl.GroupEnd = hostcomm::GroupEnd; g_rccl.Send = hostcomm::Send; g_rccl.Recv = hostcomm::Recv;
+        g_rccl.AllReduce = hostcomm::AllReduce; g_rccl.GetErrorString = hostcomm::GetErrorString; g_rccl.CommAbort = hostcomm::CommAbort;
+        g_rccl.CommGetAsyncError = hostcomm::CommGetAsyncError;
+        g_rccl.lib = (void*)&g_rccl;
+        return SPARKL_OK;
+    }
     void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return set_error(SPARKL_ERR_UNSUPPORTED, "cannot load librccl.so.1: %s", dlerror());
@@ -2422,6 +2591,7 @@ static int launch_subset(SparklPipeline* p, int which, bool fuse_next, bool prim
         G.nb_count = bnd ? p->nb_bnd : p->num_blocks - p->nb_bnd;
         if (G.nb_count == 0) return SPARKL_OK;
         const dim3 grid((G.nb_count + 3) / 4), block(BLK_THREADS);
+        G.node_proj = nullptr;   // (two streams: the projection cache is only handed out by the single-stream launch_grid_update)
         if (p->num_heightfields > 0 || p->num_trimeshes > 0)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, true>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);
         else
@@ -2517,11 +2687,17 @@ static int aborted_check(SparklPipeline** members, uint32_t n) {
         if (members[i] && members[i]->comm_aborted) return set_error(SPARKL_ERR_HIP, "member %u: its RCCL communicator was aborted after an earlier error; create a new one (sparkl_hip_comm_init)", i);
     return SPARKL_OK;
 }
+// A group call that fails BEHIND its first collective leaves the peers waiting in theirs: the members' communicators are aborted so that they
+// fail (their own comm_wait: asynchronous error, or the SPARKL_HIP_COMM_TIMEOUT_S deadline -- a local ncclCommAbort does not reliably wake a
+// peer on intra-node transports, the deadline is what releases it).  A call that fails in validation, before anything was issued, has not
+// desynchronised anybody: the communicator stays (a caller's mistake used to destroy it).
+static thread_local bool g_group_engaged = false;
 int sparkl_hip_group_substeps(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params, const float gravity[3], float dt, uint32_t nsubsteps) {
     CHK(aborted_check(members, n_members));
     const bool with_comm = any_comm(members, n_members);
+    g_group_engaged = false;
     const int rc = group_substeps_impl(members, n_members, params, gravity, dt, nsubsteps);
-    if (rc != SPARKL_OK && with_comm) group_abort(members, n_members);   // peers fail instead of hanging (see comm_wait)
+    if (rc != SPARKL_OK && with_comm && g_group_engaged) group_abort(members, n_members);
     return rc;
 }
 static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params, const float gravity[3], float dt, uint32_t nsubsteps, const PickDt* pick_dt) {
@@ -2545,6 +2721,7 @@ static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, con
     const bool psi_sweep = params->damage_model == SPARKL_DAMAGE_MODIFIED_EIGENEROSION;
     if (psi_sweep) for (int i = 0; i < G.n; ++i) CHK(ensure_fracture(members[i]));
     for (int i = 0; i < G.n; ++i) { HIPCHK(hipSetDevice(members[i]->device)); CHK(x_staging(members[i])); }
+    g_group_engaged = true;   // validation is over: from here on an error leaves peers waiting (see sparkl_hip_group_substeps)
     bool need_rebin = false;
     for (int i = 0; i < G.n; ++i) need_rebin |= !members[i]->sorted || members[i]->group_rebins == 0;
     {   // a member that still has to (re-)bin makes the whole job do it: the re-bin is collective
@@ -2556,9 +2733,13 @@ static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, con
         if (any) CHK(group_rebin(G, no_balance == 0));
         // The cuts the caller chose meet the particle histogram once, right behind the first collective re-bin (which builds the block list
         // the histogram is taken from): a scene at rest may not ask for another re-bin for a long time.  Agreed like every re-bin.
-        std::vector<long long> v2(G.n, any && first ? 1 : 0), veto2(G.n, balance_veto(G));
+        // (`any` is the reduction's result and `first` counts collective re-bins: both are the same on every rank, so the second agreement --
+        // a host-synchronous all-reduce -- only runs behind the first collective re-bin, not on every call: ADVICE r04)
         long long any2 = 0, no_balance2 = 0;
-        CHK(group_max(G, v2.data(), &any2, veto2.data(), &no_balance2));
+        if (any && first) {
+            std::vector<long long> v2(G.n, 1), veto2(G.n, balance_veto(G));
+            CHK(group_max(G, v2.data(), &any2, veto2.data(), &no_balance2));
+        }
         if (any2 && no_balance2 == 0) {
             CHK(group_rebalance(G));
             bool moved = false;
@@ -2831,8 +3012,9 @@ int sparkl_hip_group_step(SparklPipeline** members, uint32_t n_members, const Sp
                           uint32_t* num_substeps) {
     CHK(aborted_check(members, n_members));
     const bool with_comm = any_comm(members, n_members);
+    g_group_engaged = false;
     const int rc = group_step_impl(members, n_members, params, gravity, simulated_time, num_substeps);
-    if (rc != SPARKL_OK && with_comm) group_abort(members, n_members);
+    if (rc != SPARKL_OK && with_comm && g_group_engaged) group_abort(members, n_members);
     return rc;
 }
 static int group_step_impl(SparklPipeline** members, uint32_t n_members, const SparklSolverParams* params, const float gravity[3], float* simulated_time,
@@ -2859,6 +3041,7 @@ static int group_step_impl(SparklPipeline** members, uint32_t n_members, const S
             CHK(sparkl_hip_dt_bound_export(p, p->x_dev.p + 16));
         }
         if (rccl) {
+            g_group_engaged = true;
             NCCLCHK(g_rccl.GroupStart());
             for (uint32_t i = 0; i < n_members; ++i) NCCLCHK(g_rccl.AllReduce(members[i]->x_dev.p + 16, members[i]->x_dev.p + 16, 1, ncclUint32, ncclMin, members[i]->comm, members[i]->stream));
             NCCLCHK(g_rccl.GroupEnd());

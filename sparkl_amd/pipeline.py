@@ -159,6 +159,14 @@ class MpmPipeline:
         arr = (abi.TriMeshColliderC * max(len(trimeshes), 1))(*trimeshes)
         check(self.L.sparkl_hip_colliders_set_trimeshes(self.h, C.c_uint32(len(trimeshes)), arr))
 
+    def set_collider_options(self, kind, options):
+        """`CudaColliderSet::from_collider_set(.., options)`: one abi.collider_options(..) per collider of `kind` ("cuboid", "heightfield",
+        "trimesh"), in the order of the matching set_* call (which resets the options of its kind to the defaults)."""
+        fn = {"cuboid": self.L.sparkl_hip_colliders_set_cuboid_options, "heightfield": self.L.sparkl_hip_colliders_set_heightfield_options,
+              "trimesh": self.L.sparkl_hip_colliders_set_trimesh_options}[kind]
+        arr = (abi.ColliderOptionsC * max(len(options), 1))(*options)
+        check(fn(self.h, C.c_uint32(len(options)), arr))
+
     # ---- CudaParticleSet
     def _args(self, c):
         return (C.c_uint64(len(c)), abi.ptr(c.status, abi.STATUS_DTYPE), abi.ptr(c.position, abi.POSITION_DTYPE),
@@ -224,6 +232,14 @@ class MpmPipeline:
         """Limits in excess run heads: 0 = off, < 0 = built-in default (see sparkl_hip_reorder_policy_set)."""
         check(self.L.sparkl_hip_reorder_policy_set(self.h, C.c_float(reorder_limit), C.c_float(rebin_limit)))
 
+    def step_substep_timings(self):
+        """`timings.substeps` of the last step(.., timings=True): a list of abi.SubstepTimingsC, one per substep."""
+        n = C.c_uint32(0)
+        check(self.L.sparkl_hip_pipeline_step_substep_timings(self.h, None, C.c_uint32(0), C.byref(n)))
+        arr = (abi.SubstepTimingsC * max(n.value, 1))()
+        check(self.L.sparkl_hip_pipeline_step_substep_timings(self.h, arr, C.c_uint32(n.value), C.byref(n)))
+        return list(arr)[:n.value]
+
     def step_stats(self):
         """Counters of the adaptive step: fused-scatter hits / misses, look-ahead substeps / mismatches."""
         out = (C.c_uint64 * 7)()
@@ -278,6 +294,8 @@ class MpmPipeline:
         self.set_colliders(scene.colliders)
         self.set_heightfields(getattr(scene, "heightfields", []))
         self.set_trimeshes(getattr(scene, "trimeshes", []))
+        for kind, opts in getattr(scene, "collider_options", {}).items():
+            self.set_collider_options(kind, opts)
         self.upload_particles(scene.particles)
 
     # ---- stepping

@@ -1,0 +1,169 @@
+"""`CudaColliderOptions` (src/cuda/cuda_collider_set.rs:22-38) through the C ABI (SparklColliderOptions, round 5) against the oracle, one
+test per option, and the grid update's projection cache (src_kernels/cuda/grid_update.rs:111-146) against the uncached kernel."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+from sparkl_amd import abi, scenes
+from sparkl_amd._lib import SparklHipError
+from tests.parity import parity_verdict
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def Pipeline():
+    from sparkl_amd.pipeline import MpmPipeline
+    return MpmPipeline
+
+
+def _threads():
+    return max(1, min(16, len(os.sched_getaffinity(0))))
+
+
+def _oracles(sc, nsteps, dt):
+    from oracle import Oracle
+    out = []
+    for f64 in (False, True):
+        o = Oracle(sc.cell_width, f64=f64, domain_log2_bytes=sc.domain_log2_bytes, threads=_threads())
+        o.load_scene(sc)
+        for _ in range(nsteps):
+            o.substep_fixed(sc.params, sc.gravity, dt)
+        out.append(o.get_particles())
+        o.close()
+    return out
+
+
+def _hip(Pipeline, sc, nsteps, dt):
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, dt, nsteps)
+        return p.read_particles()
+
+
+def _falling_sand():
+    sc = scenes.sand_column(12, 6, 10, with_block=False)
+    sc.particles.velocity["vector"][:, 1] = -2.0
+    sc.particles.velocity["vector"][:, 0] = 1.5
+    return sc
+
+
+@pytest.mark.parametrize("handling", [abi.BOUNDARY_STICK, abi.BOUNDARY_NONE, abi.BOUNDARY_FRICTION, 2])
+def test_per_collider_boundary_handling_overrides_the_solver_parameters(Pipeline, handling):
+    """Two floors' worth of switch: SolverParameters says Friction; the collider's own grid_boundary_handling says Stick / None / Friction /
+    FrictionZUp.  HIP path vs oracle under the gate, and the override must MATTER (Stick and None end elsewhere than the default)."""
+    sc = _falling_sand()
+    dt, n = 2.5e-4, 100
+    base = _hip(Pipeline, sc, n, dt)
+    sc.collider_options = {"cuboid": [abi.collider_options(grid_boundary_handling=handling)]}
+    got = _hip(Pipeline, sc, n, dt)
+    r32, r64 = _oracles(sc, n, dt)
+    rep, bad = parity_verdict(got, r32, r64, sc.cell_width)
+    moved = np.abs(got.position["point"] - base.position["point"]).max() / sc.cell_width
+    print("collider handling", handling, "vs f64", rep["vs_f64"]["eps_x"], rep["vs_f64"]["eps_v"], "| differs from the default by", moved, "h")
+    assert not bad, (bad, rep)
+    if handling in (abi.BOUNDARY_STICK, abi.BOUNDARY_NONE):
+        assert moved > 1e-2, moved
+    else:
+        assert moved < 1e-6, moved     # Friction = the default; FrictionZUp on a floor whose normal points up (+y, z = 0 >= 0) is Friction too
+
+
+def test_solver_parameters_none_with_one_collider_opting_in(Pipeline):
+    """boundary_handling = None in the solver parameters used to skip the colliders altogether; a collider that carries its own handling
+    still acts."""
+    sc = _falling_sand()
+    sc.params = copy.copy(sc.params)
+    sc.params.boundary_handling = abi.BOUNDARY_NONE
+    dt, n = 2.5e-4, 100
+    free = _hip(Pipeline, sc, n, dt)
+    sc.collider_options = {"cuboid": [abi.collider_options(grid_boundary_handling=abi.BOUNDARY_FRICTION)]}
+    got = _hip(Pipeline, sc, n, dt)
+    r32, r64 = _oracles(sc, n, dt)
+    rep, bad = parity_verdict(got, r32, r64, sc.cell_width)
+    assert not bad, (bad, rep)
+    assert np.abs(got.position["point"] - free.position["point"]).max() / sc.cell_width > 1e-2
+
+
+@pytest.mark.parametrize("flip", [False, True])
+def test_heightfield_flip_interior(Pipeline, flip):
+    """gpu_collider.rs:81-89: with below_is_solid the solid side of a heightfield is below the surface, flip_interior puts it above.  Stick
+    handling makes the difference visible: only nodes INSIDE are stopped."""
+    # a sheet one cell thick, one cell above the valley bottom: every node it touches lies within the 4 h the grid update searches around a
+    # node (the reference's GPU path looks 2 h far, its CPU path without limit: beyond the reach "inside" is simply never reported here)
+    sc = scenes.sand_on_heightfield(16, 2, 12, below_is_solid=True)
+    sc.particles.position["point"][:, 1] -= np.float32(sc.cell_width)
+    sc.particles.velocity["vector"][:, 1] = -3.0
+    sc.params = copy.copy(sc.params)
+    sc.params.boundary_handling = abi.BOUNDARY_STICK
+    sc.collider_options = {"heightfield": [abi.collider_options(flip_interior=flip)]}
+    dt, n = 2.5e-4, 60
+    got = _hip(Pipeline, sc, n, dt)
+    r32, r64 = _oracles(sc, n, dt)
+    rep, bad = parity_verdict(got, r32, r64, sc.cell_width)
+    vy = got.velocity["vector"][:, 1]
+    print("heightfield flip_interior", flip, "vs f64", rep["vs_f64"]["eps_x"], rep["vs_f64"]["eps_v"], "mean vy", float(vy.mean()))
+    assert not bad, (bad, rep)
+    if flip:
+        assert (np.abs(vy) < 1e-3).mean() > 0.5      # the column starts ABOVE the surface = inside the flipped solid: stuck at once
+    else:
+        assert vy.mean() < -0.2                        # falls (and is being stopped by the ground it has reached by now)
+
+
+def test_penalty_stiffness_pushes_particles_out(Pipeline):
+    """particle_updater.rs:200-225 (intended rule): a block that starts half inside a cuboid with a penalty stiffness and NO grid boundary
+    handling is pushed out by f = (proj - x) k; without the stiffness it falls through.  HIP vs oracle under the gate."""
+    sc = scenes.sand_column(8, 6, 8, with_block=False)
+    sc.params = copy.copy(sc.params)
+    sc.params.boundary_handling = abi.BOUNDARY_NONE
+    sc.particles.position["point"][:, 1] -= np.float32(1.25 * sc.cell_width)     # the lowest two layers sit inside the floor cuboid (top at 3.5 h)
+    dt, n = 2.5e-4, 80
+    free = _hip(Pipeline, sc, n, dt)
+    sc.collider_options = {"cuboid": [abi.collider_options(penalty_stiffness=2.0e5)]}
+    got = _hip(Pipeline, sc, n, dt)
+    r32, r64 = _oracles(sc, n, dt)
+    rep, bad = parity_verdict(got, r32, r64, sc.cell_width)
+    dy = float((got.position["point"][:, 1] - free.position["point"][:, 1]).mean()) / sc.cell_width
+    print("penalty force: vs f64", rep["vs_f64"]["eps_x"], rep["vs_f64"]["eps_v"], "| mean lift over the free fall", dy, "h")
+    assert not bad, (bad, rep)
+    assert dy > 0.02, dy
+
+
+def test_options_are_validated_and_reset(Pipeline):
+    sc = _falling_sand()
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        with pytest.raises(SparklHipError):
+            p.set_collider_options("cuboid", [])                                   # one record per collider
+        with pytest.raises(SparklHipError):
+            p.set_collider_options("cuboid", [abi.collider_options(grid_boundary_handling=7)])
+        with pytest.raises(SparklHipError):
+            p.set_collider_options("heightfield", [abi.collider_options()])       # there is no heightfield
+        p.set_collider_options("cuboid", [abi.collider_options(grid_boundary_handling=abi.BOUNDARY_NONE)])
+        p.set_colliders(sc.colliders)                                              # set_* resets the options of its kind
+        p.substeps(sc.params, sc.gravity, 2.5e-4, 100)
+        got = p.read_particles()
+    base = _hip(Pipeline, sc, 100, 2.5e-4)
+    np.testing.assert_array_equal(got.position["point"], base.position["point"])
+
+
+@pytest.mark.parametrize("kind", ["heightfield", "trimesh"])
+def test_projection_cache_is_bit_identical_and_survives_rebins(Pipeline, kind, monkeypatch):
+    """The cache replays the floats the triangle search returned: with it on (default) and off (SPARKL_HIP_PROJ_CACHE=0) the particle
+    state after 240 substeps -- several re-bins, which rebuild the node blocks and clear the cache -- must be the same bits."""
+    sc = scenes.sand_on_heightfield(16, 8, 12, below_is_solid=True) if kind == "heightfield" else scenes.sand_on_trimesh(16, 8, 12, oriented=True)
+    sc.particles.velocity["vector"][:, 1] = -3.0
+    sc.particles.velocity["vector"][:, 0] = 8.0
+    dt, n = 2.5e-4, 240
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.clock_enable(True)
+        p.substeps(sc.params, sc.gravity, dt, n)
+        on = p.read_particles()
+        rebins = int(p.clock_read().resorts)
+    monkeypatch.setenv("SPARKL_HIP_PROJ_CACHE", "0")
+    off = _hip(Pipeline, sc, n, dt)
+    assert rebins >= 2
+    for k in ("position", "velocity", "volume", "velocity_gradient"):
+        assert getattr(on, k).tobytes() == getattr(off, k).tobytes(), k

@@ -44,13 +44,19 @@ def test_readback_is_caller_order(Pipeline):
     sc = scenes.sand_column(12, 10, 8, with_block=True)
     with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
         p.load_scene(sc)
+        np.testing.assert_array_equal(p.read_particles().position["point"], sc.particles.position["point"])   # not binned yet: world coordinates as uploaded
         # force a re-bin without stepping: zero-length call is a no-op, so run one substep with dt = 0
         p.substeps(sc.params, (0, 0, 0), 0.0, 1)
         got = p.read_particles()
         ids = p.read_sorted_particle_ids()
     assert sorted(ids.tolist()) == list(range(len(sc.particles)))
     assert (ids != np.arange(len(ids))).any(), "particles should have been physically re-ordered"
-    np.testing.assert_array_equal(got.position["point"], sc.particles.position["point"])
+    # positions are re-based to the home block by the re-bin (block-relative storage, kernels.h cell_frac) and converted back on read:
+    # one rounding each way, so a coordinate next to the world origin (where the f32 world coordinate is the finer of the two) may come
+    # back one ulp off; before the first re-bin (below) and for every other component the read-back is bit for bit the upload
+    want = sc.particles.position["point"]
+    assert (np.abs(got.position["point"].astype(np.float64) - want) <= np.spacing(np.abs(want))).all()
+    assert (got.position["point"] == want).mean() > 0.9
     np.testing.assert_array_equal(got.volume["mass"], sc.particles.volume["mass"])
     np.testing.assert_array_equal(got.volume["radius0"], sc.particles.volume["radius0"])
     np.testing.assert_array_equal(got.status["model_index"], sc.particles.status["model_index"])
@@ -598,6 +604,14 @@ def test_adaptive_step_matches_oracle(Pipeline):
             t_got, tim = p.step(sc.params, sc.gravity, timings=True)
             assert t_got == pytest.approx(t_ref, rel=1e-7)
             assert tim.num_substeps == len(o.last_dts())
+            # `timings.substeps` (cuda_mpm_pipeline.rs:28-85): one record per substep, the oracle's step lengths, device time in each
+            subs = p.step_substep_timings()
+            assert len(subs) == tim.num_substeps
+            np.testing.assert_allclose([s.dt for s in subs], o.last_dts(), rtol=1e-6)
+            assert all(s.total_ms > 0.0 and s.g2p_ms > 0.0 and s.grid_update_ms > 0.0 for s in subs), [(s.dt, s.total_ms) for s in subs]
+            assert sum(s.total_ms for s in subs) <= tim.total_ms * 1.001
+            for key in ("p2g_ms", "grid_update_ms", "g2p_ms", "estimate_timestep_ms"):
+                assert sum(getattr(s, key) for s in subs) == pytest.approx(getattr(tim, key), rel=1e-3, abs=1e-3), key
         rep, bad = parity_verdict(p.read_particles(), o.get_particles(), o64.get_particles(), sc.cell_width)
     _report("adaptive_step", rep)
     assert not bad, (bad, rep)
@@ -873,8 +887,13 @@ def test_incremental_append_and_remove_follow_vec_semantics(Pipeline):
         assert len(p) == len(a) + len(b) - (hi - lo)
         got2 = p.read_particles()
         keep = np.r_[0:lo, hi:len(a) + len(b)]
-        for k in ("position", "velocity", "volume", "status", "phase", "data", "velocity_gradient"):
+        for k in ("velocity", "volume", "status", "phase", "data", "velocity_gradient"):
             assert getattr(got2, k).tobytes() == getattr(got, k)[keep].tobytes(), k
+        # positions: remove_range re-bins, and the re-bin re-bases the appended particles from world coordinates to their home blocks
+        # (block-relative storage, kernels.h cell_frac): back in world coordinates they may be one ulp off; the resident ones are bit for bit
+        x2, x1 = got2.position["point"], got.position["point"][keep]
+        assert (np.abs(x2.astype(np.float64) - x1) <= np.spacing(np.abs(x1))).all()
+        assert x2[:lo].tobytes() == x1[:lo].tobytes()
         p.substeps(sc.params, sc.gravity, 2.5e-4, 4)          # and the set still steps
         assert np.isfinite(p.read_positions()["point"]).all()
         p.truncate(10)
@@ -921,7 +940,21 @@ def test_particles_trickling_out_of_the_domain_do_not_force_a_rebin_each(Pipelin
     assert failed.sum() >= 200 and (~failed).sum() >= 200, "the scene must lose part of the block through the wall"
     assert k.resorts <= 16, f"{int(k.resorts)} re-bins in 240 substeps: particles leaving the domain must not force one each"
     assert all(chk[c] == 0 for c in ("bad_particle_ids", "blocks_not_in_hash", "particles_outside_their_block", "missing_neighbour_blocks", "coverage_errors")), chk
-    rep, bad = parity_verdict(got, o32.get_particles(), ref, sc.cell_width)
+    # A particle dies in the substep whose advection carries round(x / h) below 1, i.e. x / h below 0.5, and is frozen where that substep
+    # left it.  One whose coordinate lands within rounding noise of that face (positions differ by ~1e-5 h between any two arithmetics after
+    # 200 substeps at 20 m/s) dies one substep earlier in one of them and sits v dt = 0.025 h apart for ever: a threshold event, not a
+    # divergence.  Dead particles frozen within 1e-4 h of the face are therefore compared modulo that one advection; all others by the gate.
+    r32 = o32.get_particles()
+    h = sc.cell_width
+    face = 0.5
+    near = failed & ((np.abs(got.position["point"][:, 0] / h - face) < 1e-4) | (np.abs(ref.position["point"][:, 0] / h - face) < 1e-4))
+    assert near.sum() <= 8, int(near.sum())
+    step = 20.0 * dt / h
+    dx_near = np.abs(got.position["point"][near].astype(np.float64) - ref.position["point"][near]) / h
+    assert ((dx_near[:, 0] < 1e-4) | (np.abs(dx_near[:, 0] - step) < 1e-4)).all() and (dx_near[:, 1:] < 1e-4).all(), dx_near
+    for comps in (got, r32, ref):   # the gate sees those few at the oracle's position
+        comps.position["point"][near] = ref.position["point"][near]
+    rep, bad = parity_verdict(got, r32, ref, sc.cell_width)
     assert not bad, (bad, rep)
 
 

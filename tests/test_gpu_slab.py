@@ -99,13 +99,6 @@ def _free_port():
     return p
 
 
-def _match(pos_a, pos_b):
-    """order-free matching of two particle sets through a lexicographic sort of (rounded) positions"""
-    ka = np.lexsort(np.round(pos_a.astype(np.float64) * 1e4).T)
-    kb = np.lexsort(np.round(pos_b.astype(np.float64) * 1e4).T)
-    return ka, kb
-
-
 @pytest.mark.parametrize("kind,nsteps", [("spin", 40), ("sand", 30)])
 def test_two_slabs_one_gpu_match_single_pipeline(tmp_path, kind, nsteps):
     from sparkl_amd.pipeline import MpmPipeline
@@ -121,7 +114,11 @@ def test_two_slabs_one_gpu_match_single_pipeline(tmp_path, kind, nsteps):
     vel = np.concatenate([q["vel"] for q in parts])
     F = np.concatenate([q["F"] for q in parts])
     assert len(pos) == len(sc.particles), "particles lost or duplicated across slabs"
-    ka, kb = _match(pos, ref.position["point"])
+    # matched by the ids that travel with the particles (an order-free match on rounded positions pairs the wrong particles as soon as the two
+    # runs differ in the last digits, which slabs with their own home blocks -- block-relative positions -- do)
+    caller = np.concatenate([q["caller"] for q in parts])
+    assert np.array_equal(np.sort(caller), np.arange(len(sc.particles)))
+    ka, kb = np.argsort(caller), np.arange(len(sc.particles))
     h = sc.cell_width
     vmax = np.abs(ref.velocity["vector"]).max()
     ex = np.abs(pos[ka] - ref.position["point"][kb]).max() / h
@@ -153,7 +150,8 @@ def test_two_slabs_adaptive_step_matches_single_pipeline(tmp_path):
     pos = np.concatenate([q["pos"] for q in parts])
     vel = np.concatenate([q["vel"] for q in parts])
     assert len(pos) == len(sc.particles)
-    ka, kb = _match(pos, ref.position["point"])
+    caller = np.concatenate([q["caller"] for q in parts])
+    ka, kb = np.argsort(caller), np.arange(len(sc.particles))    # by the ids that travel with the particles
     ex = np.abs(pos[ka] - ref.position["point"][kb]).max() / sc.cell_width
     ev = np.abs(vel[ka] - ref.velocity["vector"][kb]).max() / np.abs(ref.velocity["vector"]).max()
     print("adaptive slab vs single:", ex, ev, nsub)
@@ -347,8 +345,10 @@ def test_comm_init_all_one_thread_owns_the_communicators():
 
 
 def test_group_error_aborts_the_communicator():
-    """RCCL failure path: an error inside a group call aborts the communicators of the members (their peers fail instead of hanging in
-    the next collective); the handle then refuses group calls until it is given a new communicator."""
+    """RCCL failure path.  A group call that fails in VALIDATION (nothing issued yet: nobody is out of step) leaves the communicator alone
+    (ADVICE r04); one that fails behind its first collective aborts the members' communicators, and the handle then refuses group calls
+    until it is given a new one.  (What happens to the PEER of a rank that fails or dies is tests/test_gpu_slab_procs.py, with two
+    processes.)"""
     import copy
     from sparkl_amd._lib import SparklHipError as SparklError
     from sparkl_amd.pipeline import MpmPipeline
@@ -360,9 +360,17 @@ def test_group_error_aborts_the_communicator():
         p.load_scene(sc)
         MpmPipeline.group_substeps([p], sc.params, sc.gravity, dt, 4)
         bad = copy.copy(sc.params)
-        bad.damage_model = 1   # DamageModel::Eigenerosion: unsupported -> the call fails on this rank
+        bad.damage_model = 1   # DamageModel::Eigenerosion: unsupported -> refused in validation, before any collective
         with pytest.raises(SparklError):
             MpmPipeline.group_substeps([p], bad, sc.gravity, dt, 4)
+        MpmPipeline.group_substeps([p], sc.params, sc.gravity, dt, 4)          # the communicator survived the caller's mistake
+        # an error BEHIND the first collective: an infinite velocity makes the adaptive step's bound h / |v| zero -- the step cannot make
+        # progress (the reference panics on its NotNan, timestep_estimator.rs:46) -- and the call fails after its dt all-reduce
+        fast = copy.deepcopy(sc.particles)
+        fast.velocity["vector"][0, 0] = np.float32("inf")
+        p.upload_particles(fast)
+        with pytest.raises(SparklError):
+            MpmPipeline.group_step([p], sc.params, sc.gravity)
         with pytest.raises(SparklError, match="aborted"):
             MpmPipeline.group_substeps([p], sc.params, sc.gravity, dt, 4)
         p.comm_init(MpmPipeline.comm_unique_id(), 0, 1)          # a new communicator: back in business
@@ -505,14 +513,17 @@ def test_group_substeps_fluid_volume_sweep_across_the_cut():
         p.close()
     r32, r64 = _oracles(sc, nsteps, dt)
     # the f32 arithmetic of the stiff equation of state sits 2.5e-4 from its f64 trajectory on this 4.8 m deep dam, the reference's
-    # own included (tests/parity.py, arbiter="either"): held to the f32 oracle (8e-6), bounded against the f64 one
+    # own included (tests/parity.py, arbiter="either").  Until round 4 the HIP path shared that noise (8e-6 from the f32 oracle); with
+    # positions held relative to the home block it sits 5e-5 from the F64 trajectory instead -- most of the f32 noise of this scene was the
+    # position storage feeding the volume gather -- and 2e-4 from the f32 oracle.  Held to the gate, and to 1e-4 of the nearer oracle.
     rep, bad = parity_verdict(got, r32, r64, sc.cell_width, arbiter="either")
     print("fluid dam on two slabs vs oracle:", rep["vs_f64"], rep["vs_f32"], rep["oracle_f32_vs_f64"])
-    assert rep["vs_f32"]["eps_v"] < 3e-5 and rep["vs_f32"]["eps_x"] < 3e-5, rep["vs_f32"]
+    assert min(rep["vs_f32"]["eps_v"], rep["vs_f64"]["eps_v"]) < 1e-4 and min(rep["vs_f32"]["eps_x"], rep["vs_f64"]["eps_x"]) < 3e-5, (rep["vs_f32"], rep["vs_f64"])
     assert not bad, (bad, rep)
     # the volumes were really recomputed from both sides' masses: F00 of the particles next to the cut matches too
-    dF = np.abs(got.volume["deformation_gradient"][:, 0].astype(np.float64) - r32.volume["deformation_gradient"][:, 0]).max()
-    assert dF < 1e-5, dF
+    f00 = got.volume["deformation_gradient"][:, 0].astype(np.float64)
+    dF = min(np.abs(f00 - r32.volume["deformation_gradient"][:, 0]).max(), np.abs(f00 - r64.volume["deformation_gradient"][:, 0]).max())
+    assert dF < 5e-5, dF
 
 
 @pytest.mark.parametrize("frame_dt,max_substep_dt", [(2.0e-2, 6.0e-3), (0.1, 1.0)])
@@ -627,3 +638,42 @@ def test_group_step_adaptive_two_slabs_in_the_library():
     ev = np.abs(vel - ref.velocity["vector"]).max() / np.abs(ref.velocity["vector"]).max()
     print("group_step vs pipeline_step:", ex, ev, nsub)
     assert ex < 2e-5 and ev < 2e-4
+
+
+def test_group_step_feeds_the_disorder_policy():
+    """the adaptive multi-slab schedule (`sparkl_hip_group_step`: one substep per call, plain finish) scatters with the
+    standalone P2G every substep, and that launch did not count its run heads when the fused schedule was compiled in -- the disorder books
+    stayed empty, so neither k_block_reorder nor a disorder re-bin could ever fire while the scene flowed.  A sheared column stepped frame
+    by frame through the group loop must now show a measured baseline, and -- with the reorder armed low -- at least one in-place reorder."""
+    from sparkl_amd.pipeline import MpmPipeline
+    world = 2
+    sc = scenes.sand_column(24, 24, 16, with_block=False)
+    pos = sc.particles.position["point"]
+    rel = (pos - pos.min(0)) / np.ptp(pos, axis=0)
+    sc.particles.velocity["vector"][:, 0] = 6.0 * rel[:, 1] * (0.5 + rel[:, 0])      # shear: the top moves ~a cell per frame
+    cuts, all_gids = _ownership(sc, world)
+    stream = torch.cuda.Stream()
+    pipes = []
+    for r in range(world):
+        comps = ParticleComponents(0)
+        for k in ParticleComponents.__slots__:
+            setattr(comps, k, np.ascontiguousarray(getattr(sc.particles, k)[all_gids[r]]))
+        pipe = MpmPipeline(sc.cell_width, device_id=0, domain_log2_bytes=sc.domain_log2_bytes, stream=stream.cuda_stream)
+        pipe.set_slab(0, cuts[r], cuts[r + 1], id_offset=int(sum(len(g) for g in all_gids[:r])))
+        pipe.set_models(sc.models)
+        pipe.set_colliders(sc.colliders)
+        pipe.upload_particles(comps)
+        pipe.reorder_policy_set(0.02 * len(comps), 0.0)
+        pipes.append(pipe)
+    nsub = 0
+    for _ in range(12):
+        _, n = MpmPipeline.group_step(pipes, sc.params, sc.gravity)
+        nsub += n
+    stats = [p.reorder_policy_stats() for p in pipes]
+    ok = [np.isfinite(p.read_particles().position["point"]).all() for p in pipes]
+    for p in pipes:
+        p.close()
+    print("group_step disorder books:", nsub, stats)
+    assert all(ok)
+    assert all(s["base_heads"] > 0 and s["last_heads"] > 0 for s in stats), stats      # the scatter of every substep is counted
+    assert sum(s["reorders"] for s in stats) >= 1, stats
