@@ -75,7 +75,28 @@ struct Ctl {
     // them in the set with their last v and C, so `adaptive_timestep_length` (timestep_estimator.rs:25-35) still sees them, while no
     // kernel here visits them any more.  Rebuilt at every re-bin, extended by G2P when a particle dies; k_dt_reduce folds it in.
     uint32_t dead_dt_bits;
+    // Two words of PINNED HOST memory the device can write (hipHostMalloc, mapped): [0] is set to 1 by whatever RAISES the abort chain (margin
+    // violation, disorder policy, dt mismatch), [1] mirrors steps_done.  The host enqueues a fixed-dt batch ahead of the GPU; with these it
+    // stays only a few substeps ahead (polling [1], no events, no synchronisation) and stops enqueueing the moment [0] is raised -- the rest
+    // of a 128-substep batch used to run as ~60 no-op launches behind every re-bin request of the flowing phases.  NULL = not used.
+    uint32_t* host_words;
 };
+// The host words are written through a GLOBAL-address-space pointer.  `ctl->host_words` loaded from memory is a generic pointer, a store
+// through it is a FLAT instruction, and behind a path that may have issued one the compiler can no longer count the vector-memory
+// operations in flight: every s_waitcnt vmcnt(N) of the kernels that inline this -- the prologue's "small loads first, particle loads stay
+// in flight" among them -- became vmcnt(0): +20 % on the 1 M cube, measured (profiles/r05_kernel_experiments.txt).
+typedef __attribute__((address_space(1))) uint32_t* global_u32p;
+// raise the abort chain for the substeps from parity `np` on (and tell the host, see Ctl::host_words)
+SPK_DEV void raise_abort(Ctl* ctl, int np) {
+    ctl->abort_flag[np] = 1u;
+    const global_u32p hw = (global_u32p)ctl->host_words;
+    if (hw) hw[0] = 1u;
+}
+SPK_DEV void note_step(Ctl* ctl) {
+    const uint32_t v = atomicAdd(&ctl->steps_done, 1u) + 1u;
+    const global_u32p hw = (global_u32p)ctl->host_words;
+    if (hw) hw[1] = v;
+}
 
 struct ParticleArrays {
     float4* q[6];
@@ -269,11 +290,12 @@ SPK_DEV void slot_world_pos(const BinnedView& B, const float4& q0, int i, float 
 // Every block whose tile lies inside the domain (origin >= 1 and origin + 5 < dom - 4 on every axis: all of them but those on the border
 // of the grid) only needs the tile test, on the integer cell the scatter needs anyway: three unsigned compares and one NaN test of the
 // coordinate sum (v_cvt_i32_f32 turns NaN into 0, which would pass).  `border` (wave-uniform, one SGPR) sends the others to the full test.
-struct TileRange { bool border; };
+// (a plain int handed on BY VALUE: as a one-byte struct passed by reference through the particle lambdas the flag was not scalarised -- the
+// compiler parked it in 256 B of LDS, one byte per thread, and read it back every iteration)
+typedef int TileRange;
 SPK_DEV TileRange tile_range(const int4& org, int dom) {
-    TileRange t;
-    t.border = org.x < 1 || org.y < 1 || org.z < 1 || org.x + 5 >= dom - 4 || org.y + 5 >= dom - 4 || org.z + 5 >= dom - 4;
-    return t;
+    const bool border = org.x < 1 || org.y < 1 || org.z < 1 || org.x + 5 >= dom - 4 || org.y + 5 >= dom - 4 || org.z + 5 >= dom - 4;
+    return __builtin_amdgcn_readfirstlane(border ? 1 : 0);
 }
 
 // DPP row shifts inside a 16-lane row: lane i reads lane i + N (zero beyond the row end).
@@ -861,7 +883,7 @@ SPK_DEV void disorder_policy(Ctl* ctl, int prev, int parity) {
         ctl->excess_acc = acc;
         if (ctl->reorder_limit > 0.f && acc > ctl->reorder_limit) ctl->reorder_request = 1u;
         if (ctl->excess_limit > 0.f && acc > ctl->excess_limit && !ctl->abort_flag[(parity + 1) & 1]) {
-            ctl->abort_flag[(parity + 1) & 1] = 1u;
+            raise_abort(ctl, (parity + 1) & 1);
             ctl->disorder_aborts += 1u;
         }
     }
@@ -1416,7 +1438,7 @@ __global__ __launch_bounds__(1024) void k_dt_reduce(const uint32_t* __restrict__
         m = min(m, ctl->dead_dt_bits);
         ctl->dt_bits = m;
         if (expect_bits != 0u && (m != expect_bits || ctl->dt_nan) && !ctl->abort_flag[next_parity]) {
-            ctl->abort_flag[next_parity] = 1u;
+            raise_abort(ctl, next_parity);
             ctl->dt_mismatch = 1u;
         }
     }
@@ -1431,7 +1453,7 @@ __global__ void k_dt_check(Ctl* ctl, float remaining, float max_substep_dt, floa
     float d = fminf(fminf(remaining, max_substep_dt), bound);
     if (d < min_dt && remaining > min_dt) d = min_dt;
     if ((__float_as_uint(d) != expect_dt_bits || ctl->dt_nan) && !ctl->abort_flag[parity]) {
-        ctl->abort_flag[parity] = 1u;
+        raise_abort(ctl, parity);
         ctl->dt_mismatch = 1u;
     }
 }
@@ -1591,7 +1613,7 @@ SPK_DEV void apic_gather(const VelTile& vt, const float u[3], const StepParams& 
 // or calling it out of line, cost the hot kernel 35 %).
 template <bool RARE, bool WANT_STRESS = false, class MO = DevModel>
 SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const MO& mo, uint32_t flags, const float4& q0, const float4& q1, const float4& q2, const float4& dd,
-                            const float4& kk, const float4* kinvel_i, const float4* aux_i, float phase, const int4& org, const TileRange& tr, const StepParams& S,
+                            const float4& kk, const float4* kinvel_i, const float4* aux_i, float phase, const int4& org, const TileRange tr_border, const StepParams& S,
                             unsigned* num_invalid, lds_fp park = nullptr) {
     Advected o;
     const float h = S.h, dt = S.dt;
@@ -1693,8 +1715,8 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const MO& mo
     // rint(u) in [0, 5] on every axis, as |r - 2.5| <= 2.5: two VALU per axis, false for NaN, and no integer cell kept alive across the store
     bool in_tile = (fabsf(o.rnew[0] - 2.5f) <= 2.5f) && (fabsf(o.rnew[1] - 2.5f) <= 2.5f) && (fabsf(o.rnew[2] - 2.5f) <= 2.5f);
     bool invalid = false;
-    SPK_HOT(in_tile && !tr.border);
-    if (!in_tile || tr.border) {   // cold: out of the tile (re-bin) or out of the domain?  0 <= assoc, assoc + 5 < dom  (sp_grid.rs / particle_set.rs:129-136)
+    SPK_HOT(in_tile && !tr_border);
+    if (!in_tile || tr_border) {   // cold: out of the tile (re-bin) or out of the domain?  0 <= assoc, assoc + 5 < dom  (sp_grid.rs / particle_set.rs:129-136)
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             // round(x / h) in integers (nothing for the compiler to hoist out of the particle loop into registers that only this cold side reads)
@@ -1776,7 +1798,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
     }
     load_vel_tile(vt, G, b, tid);
     if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
-    if (G.primary && blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
+    if (G.primary && blockIdx.x == 0 && tid == 0) note_step(ctl);
     __syncthreads();
     const TileRange tr = tile_range(org, S.dom);
     bool want_sort = false;
@@ -1802,7 +1824,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
         }
     }
     if (__any(want_sort)) {
-        if ((tid & 63) == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
+        if ((tid & 63) == 0) raise_abort(ctl, (S.parity + 1) & 1);
     }
     if (S.want_dt) {
         dt_block_min_store(G.dt_partial, dt_bound, dt_nan, ctl, tid);
@@ -1849,10 +1871,15 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     const int my_nb = G.blk_nbr[b * 27 + min(tid & 63, 26)];
     ModelWords mw = {0u, 0u};
     if (LDS_MODELS) mw = stage_models_load(models, S.num_models, tid);
-    float4 n0, n1, n2, nk;
+    // The plastic scalars (D stream): prefetched an iteration ahead like the rest where the update reads them early (PREFETCH_D: the
+    // neo-Hookean view -- no return map in front of their first use, so a load issued at the top of the iteration is waited for in full:
+    // +15 % on the 1 M cube), loaded at the top of the iteration that uses them where the return map sits in front (see the loop).
+    constexpr bool PREFETCH_D = MSET == 3;
+    float4 n0, n1, n2, nk, nd = make_float4(0.f, 0.f, 0.f, 0.f);
     {
         const unsigned o0 = (unsigned)min(tid, pcount - 1) << 4;
         n0 = *at_off(Pb.q[0], o0); n1 = *at_off(Pb.q[1], o0); n2 = *at_off(Pb.q[2], o0); nk = *at_off(Pb.k, o0);
+        if (PREFETCH_D) nd = *at_off(Pb.d, o0);
     }
     if (aborted) {   // sticky abort: keep every later substep a no-op until the host re-bins
         if (blockIdx.x == 0 && tid == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
@@ -1866,7 +1893,7 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     // with their HBM latency instead of preceding it
     if (LDS_MODELS) stage_models_store(s_models, models, S.num_models, tid, mw);
     load_vel_tile(vt, G, b, tid, &my_nb);
-    if (G.primary && blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
+    if (G.primary && blockIdx.x == 0 && tid == 0) note_step(ctl);
     __syncthreads();
     const float h = S.h;
     const TileRange tr = tile_range(org, S.dom);
@@ -1885,10 +1912,11 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
         // for it leaves the four younger loads in flight), and the four registers are free while the previous iteration's scatter runs --
         // the point where this kernel's register pressure peaks (with them prefetched the allocator spilled a float4 of the next batch
         // right behind its load, i.e. waited for the whole prefetch at the top of every iteration: +5 % on the launch).
-        const float4 dd = *at_off(Pb.d, off);
+        const float4 dd = PREFETCH_D ? nd : *at_off(Pb.d, off);
         if (it + 1 < niter) {
             const unsigned on = (unsigned)min(li + BLK_THREADS, pcount - 1) << 4;
             n0 = *at_off(Pb.q[0], on); n1 = *at_off(Pb.q[1], on); n2 = *at_off(Pb.q[2], on); nk = *at_off(Pb.k, on);
+            if (PREFETCH_D) nd = *at_off(Pb.d, on);
         }
         const uint32_t flags = __float_as_uint(kk.w);
         bool live = active && !(flags & FLAG_INVALID);
@@ -1950,7 +1978,7 @@ __global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(Par
     tile_write(tile, G, pb, tid, shell_used);
     if (tid == 0) record_heads(ctl, G, pb, (S.parity + 1) & 1, s_heads);   // (the host clears the books when the measure changes: heads_kind)
     if (__any(want_sort)) {
-        if ((tid & 63) == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
+        if ((tid & 63) == 0) raise_abort(ctl, (S.parity + 1) & 1);
     }
     if (S.want_dt) {
         dt_block_min_store(G.dt_partial, dt_bound, dt_nan, ctl, tid);
@@ -2263,7 +2291,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
     for (int n = tid; n < TILE_N; n += BLK_THREADS) mtile[n] = 0.0;
     load_vel_tile(vt, G, b, tid);
     if (LDS_MODELS) stage_models(s_models, models, S.num_models, tid);
-    if (blockIdx.x == 0 && tid == 0) atomicAdd(&ctl->steps_done, 1u);
+    if (blockIdx.x == 0 && tid == 0) note_step(ctl);
     __syncthreads();
     const TileRange tr = tile_range(org, S.dom);
     bool want_sort = false;
@@ -2321,7 +2349,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
     for (int n = tid; n < TILE_N; n += BLK_THREADS) out[n] = (float)mtile[n];
     if (tid == 0) G.tile_mode[pb] = TILE_MODE_MASS;
     if (__any(want_sort)) {
-        if ((tid & 63) == 0) ctl->abort_flag[(S.parity + 1) & 1] = 1u;
+        if ((tid & 63) == 0) raise_abort(ctl, (S.parity + 1) & 1);
     }
     if (S.want_dt) dt_block_min_store(G.dt_partial, dt_bound, dt_nan, ctl, tid);
 }
@@ -2950,7 +2978,7 @@ __global__ void k_fracture(ParticleArrays P, float2* host_order, int first, int 
 // a rank that owns no particle block still has to take part in the step counting / abort chain
 __global__ void k_bump_steps(Ctl* ctl, int parity) {
     if (ctl->abort_flag[parity]) ctl->abort_flag[(parity + 1) & 1] = 1u;
-    else atomicAdd(&ctl->steps_done, 1u);
+    else note_step(ctl);
 }
 // Migration record: the eleven float4 of one particle (176 B; the last is ParticleFracture or its default).
 constexpr int MIG_F4 = 11;

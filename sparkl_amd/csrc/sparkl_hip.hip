@@ -195,6 +195,12 @@ struct SparklPipeline {
     bool ctl_fresh = false;          // h_ctl->steps_done is the device's as of substep `ctl_fresh_index` (set where sparkl_hip_pipeline_substeps returns)
     uint32_t ctl_fresh_index = 0;
     Ctl* h_ctl = nullptr;  // pinned
+    volatile uint32_t* h_words = nullptr;   // Ctl::host_words: [0] abort raised, [1] steps_done mirror (pinned, device-mapped)
+    uint32_t enq_steps = 0;                 // steps_done the device will show once everything enqueued so far has run (valid while nothing aborts)
+    // substeps a fixed-dt batch may be enqueued ahead of the GPU.  -1 (default) = by size: ~2 ms of work, i.e. 4 substeps of a 10 M scene and
+    // 40 of a 1 M one (a small scene runs 0.07 ms substeps: four of them are gone before the host has enqueued the next); SPARKL_HIP_AHEAD=N
+    // forces N, 0 = no limit (batches enqueued whole, as before round 5)
+    int ahead_limit = -1;
     uint32_t substep_index = 0;  // parity source
     bool sorted = false;
 
@@ -396,9 +402,14 @@ static int maybe_reorder(SparklPipeline* p, int parity) {
     return SPARKL_OK;
 }
 
+static bool may_enqueue_next(SparklPipeline* p);
 static int resort(SparklPipeline* p) {
     hipStream_t st = p->stream;
     p->carry_valid = false;   // the tiles belong to the old binning
+    if (p->h_words) {   // the host-visible abort word is cleared once nothing that could still raise it is in flight (the callers re-bin behind a read of the control block: the stream is idle)
+        if (hipStreamQuery(st) != hipSuccess) HIPCHK(hipStreamSynchronize(st));
+        p->h_words[0] = 0u;
+    }
     const int n = (int)p->n;
     size_t tok = 0;
     CHK(clock_begin(p, SPAN_SORT, &tok));
@@ -803,6 +814,7 @@ static int enqueue_fused_batch(SparklPipeline* p, const SparklSolverParams* sp, 
         p->clock_on = was_on;
     }
     for (uint32_t j = 0; j < n; ++j) {
+        if (j > 0 && !may_enqueue_next(p)) return SPARKL_OK;   // a re-bin request is up: the caller reads the control block and re-bins (carry_valid stays false)
         const StepParams S = make_params(p, sp, g, dt);
         if (was_on && (p->substep_index % p->clock_stride) != 0) p->clock_on = false;
         if (p->clock_on) p->clock_sampled++;
@@ -829,6 +841,7 @@ static int enqueue_fused_batch(SparklPipeline* p, const SparklSolverParams* sp, 
         }
         p->clock_on = was_on;
         p->substep_index++;
+        p->enq_steps++;
     }
     if (carry_out) { p->carry_valid = true; p->carry_dt = dt; p->carry_index = p->substep_index; }
     return SPARKL_OK;
@@ -901,7 +914,21 @@ static int read_ctl(SparklPipeline* p) {
     HIPCHK(hipMemcpyAsync(p->h_ctl, p->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, p->stream));
     CHK(comm_wait(p, p->stream));
     HIPCHK(hipGetLastError());
+    p->enq_steps = p->h_ctl->steps_done;   // the stream is idle: nothing is enqueued ahead
     return SPARKL_OK;
+}
+// Before enqueueing one more substep of a fixed-dt batch: wait until the GPU is at most `ahead_limit` substeps behind (polling the
+// steps_done mirror in pinned memory: no event, no synchronisation, the queue never drains -- four substeps are ~2 ms of work), and report
+// whether the abort chain has been raised (false = stop enqueueing: everything behind it would be a no-op launch).
+static bool may_enqueue_next(SparklPipeline* p) {
+    if (!p->h_words || p->ahead_limit == 0) return true;
+    const int limit = p->ahead_limit > 0 ? p->ahead_limit : (int)std::max<uint64_t>(4, std::min<uint64_t>(64, 40000000ull / std::max<uint64_t>(p->n, 1)));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+        if (p->h_words[0]) return false;
+        if ((int32_t)(p->enq_steps - p->h_words[1]) < limit) return true;
+        if ((spin & 1023u) == 1023u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) return true;   // never a hang: fall back to enqueueing
+    }
 }
 
 static int validate_models(const SparklPipeline* p) {
@@ -950,6 +977,16 @@ int sparkl_hip_pipeline_create(const SparklPipelineDesc* desc, SparklPipeline** 
     (void)hipMemset(p->d_ctl, 0, sizeof(Ctl));
     (void)hipMemsetD32((hipDeviceptr_t)&p->d_ctl->dead_dt_bits, 0x7f7fffff, 1);
     memset(p->h_ctl, 0, sizeof(Ctl));
+    if (const char* e = getenv("SPARKL_HIP_AHEAD")) p->ahead_limit = atoi(e);
+    if (p->ahead_limit != 0) {   // the host-visible words of the control block (Ctl::host_words); without them the batches are enqueued whole
+        uint32_t* hw = nullptr;
+        if (hipHostMalloc((void**)&hw, 64, hipHostMallocMapped) == hipSuccess) {
+            hw[0] = hw[1] = 0u;
+            void* dev = nullptr;
+            if (hipHostGetDevicePointer(&dev, hw, 0) == hipSuccess && hipMemcpy(&p->d_ctl->host_words, &dev, sizeof(void*), hipMemcpyHostToDevice) == hipSuccess) p->h_words = hw;
+            else (void)hipHostFree(hw);
+        }
+    }
     *out = p;
     return SPARKL_OK;
 }
@@ -983,6 +1020,7 @@ void sparkl_hip_pipeline_destroy(SparklPipeline* p) {
     for (hipEvent_t e : {p->ev_main, p->ev_halo, p->ev_flag, p->ev_grid, p->ev_xfer}) if (e) (void)hipEventDestroy(e);
     if (p->d_ctl) (void)hipFree(p->d_ctl);
     if (p->h_ctl) (void)hipHostFree(p->h_ctl);
+    if (p->h_words) (void)hipHostFree((void*)p->h_words);
     if (p->own_stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
