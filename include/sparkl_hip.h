@@ -383,9 +383,9 @@ int sparkl_hip_pipeline_step_substep_timings(SparklPipeline* p, SparklSubstepTim
  * component is uploaded -- sparkl_hip_particles_set_fracture -- and turns the fused G2P->P2G schedule off);
  * SPARKL_DAMAGE_CDMPM / SPARKL_DAMAGE_EIGENEROSION return SPARKL_ERR_UNSUPPORTED everywhere, and the
  * sparkl_hip_group_substeps accepts both as well (the psi planes and, with force_fluids_volume_recomputation, the mass planes of
- * the cuts travel in extra halo rounds); the split-phase entry points (sparkl_hip_substep_begin ...) accept SPARKL_DAMAGE_NONE only.  Substeps are enqueued in batches; the host reads the control block
- * (72 bytes) back once per batch (a stream sync) to learn whether a re-bin is needed, so the call returns
- * when the last batch has been read. */
+ * the cuts travel in extra halo rounds); the split-phase entry points (sparkl_hip_substep_begin ...) accept SPARKL_DAMAGE_NONE only.  Substeps are enqueued in batches; the host stays a few substeps
+ * ahead of the GPU (it polls two words of pinned memory the kernels write: the step counter and the re-bin request) and reads the control block
+ * (80 bytes) back once per batch (a stream sync), so the call returns when the last batch has been read. */
 int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* params,
                                  const float gravity[3], float dt, uint32_t nsubsteps);
 int sparkl_hip_pipeline_sync(SparklPipeline* p);

@@ -141,6 +141,7 @@ struct GridArrays {
     // collider -- colliders are static between two sparkl_hip_colliders_set_* calls, node blocks between two re-bins, and both clear the
     // cache.  status (bits of .w): 0 not computed, 1 nothing within reach, 2 outside, 3 inside.  NULL = off (SPARKL_HIP_PROJ_CACHE=0).
     float4* node_proj;
+    int* node_proj_blk;        // [collider][B]: 0 not computed, 1 no node of the block is within reach of the collider (the wave skips it without touching node_proj), 2 some are
     const DevCuboid* cuboids;  // the collider arrays, for enable_boundary_particle_projection (G2P tail)
     const DevHeightField* heightfields;
     const DevTriMesh* trimeshes;
@@ -165,6 +166,7 @@ struct StepParams {
     int project_particles;   // SolverParameters::enable_boundary_particle_projection
     int collider_handling;   // some collider carries its own grid_boundary_handling (SparklColliderOptions): the grid update may not skip on boundary_handling == None
     int penalty;             // some collider has a penalty_stiffness: the RARE G2P kernels apply the force
+    int jp_one;              // every particle was uploaded with plastic_deformation_gradient_det == 1 and every model is a plain fluid (nothing changes it): k_vol_p2g does not read it
     int want_dt;      // G2P also reduces the next substep's dt bound into ctl->dt_bits (adaptive stepping)
     int num_models;   // entries of the model table (<= MAX_LDS_MODELS: the particle kernels stage it in LDS)
     float dt_next;    // k_g2p2g: the step length the fused scatter (P2G of the NEXT substep) is built for; = dt for fixed-dt batches
@@ -1297,15 +1299,23 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
         auto cached = [&](int slot, auto&& search, float friction, int own_handling) {
             float proj[3] = {0.f, 0.f, 0.f};
             bool inside = false, hit;
+            // one word per node block first (wave-uniform: one node block per wave): most blocks of a scene are nowhere near the collider
+            int* blk_rec = G.node_proj ? G.node_proj_blk + (size_t)slot * G.num_blocks + b : nullptr;
+            const int blk_status = blk_rec ? __builtin_amdgcn_readfirstlane(*blk_rec) : 0;
+            if (blk_status == 1) return;
             float4* rec = G.node_proj ? G.node_proj + (size_t)slot * cache_stride + (size_t)b * 64 + lane : nullptr;
-            const float4 c = rec ? *rec : make_float4(0.f, 0.f, 0.f, 0.f);
-            const uint32_t status = __float_as_uint(c.w);
-            if (status != 0u) {
+            if (blk_status == 2) {
+                const float4 c = *rec;
+                const uint32_t status = __float_as_uint(c.w);
                 hit = status >= 2u; inside = status == 3u;
                 proj[0] = c.x; proj[1] = c.y; proj[2] = c.z;
             } else {
                 hit = search(proj, inside);
-                if (rec) *rec = make_float4(proj[0], proj[1], proj[2], __uint_as_float(hit ? (inside ? 3u : 2u) : 1u));
+                if (rec) {
+                    const bool any_hit = __any(hit);
+                    if (any_hit) *rec = make_float4(proj[0], proj[1], proj[2], __uint_as_float(hit ? (inside ? 3u : 2u) : 1u));
+                    if (lane == 0) *blk_rec = any_hit ? 2 : 1;
+                }
             }
             if (hit) boundary_rule(v, cpos, proj, inside, friction, S.boundary_handling, own_handling, S.h, S.dt);
         };
@@ -1608,6 +1618,9 @@ SPK_DEV void apic_gather(const VelTile& vt, const float u[3], const StepParams& 
     }
 }
 
+#ifndef SPK_RARE_MIN_BLOCKS_G2P
+#define SPK_RARE_MIN_BLOCKS_G2P 3
+#endif
 // RARE: the instantiation that also carries snow / Rankine / NACC plasticity and the failure model; launched only when a
 // model of the set needs it, so the elastic / Drucker-Prager kernels keep their register budget (inlining that code,
 // or calling it out of line, cost the hot kernel 35 %).
@@ -1776,7 +1789,7 @@ SPK_DEV void g2p_store_at(const ParticleArrays& Pb, unsigned off, const Advected
 }
 
 template <bool RARE, bool LDS_MODELS = true>
-__global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
+__global__ __launch_bounds__(BLK_THREADS, (RARE ? SPK_RARE_MIN_BLOCKS_G2P : 4)) void k_g2p(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
     const int tid = threadIdx.x;
     __shared__ DevModel s_models[LDS_MODELS ? MAX_LDS_MODELS : 1];
     if (ctl->abort_flag[S.parity]) {
@@ -1843,8 +1856,11 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p(ParticleArrays P, GridAr
 // REDUCE_STEPS >= 0: DPP pre-reduction over groups of 2^REDUCE_STEPS lanes (p2g_scatter); -1: run tasks (p2g_scatter_runs).
 // MSET: 0 = any model table; 1 = every model is a corotated solid with Drucker-Prager plasticity (DpSandModel: no model dispatch);
 // 3 = every model is a neo-Hookean solid without plasticity (NeoHookeanOnlyModel)
+#ifndef SPK_RARE_MIN_BLOCKS
+#define SPK_RARE_MIN_BLOCKS 3   // three workgroups per CU (168 VGPRs) instead of four with 244 B/lane of scratch: 1 M snow block k_g2p2g 0.121 -> 0.095 ms (two: 0.115), profiles/r05_kernel_experiments.txt
+#endif
 template <int REDUCE_STEPS, bool RARE, bool LDS_MODELS = true, int MSET = 0>
-__global__ __launch_bounds__(BLK_THREADS, SPK_G2P2G_MIN_BLOCKS) void k_g2p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
+__global__ __launch_bounds__(BLK_THREADS, (RARE ? SPK_RARE_MIN_BLOCKS : SPK_G2P2G_MIN_BLOCKS)) void k_g2p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
     const int tid = threadIdx.x;
     __shared__ VelTile vt;
     __shared__ double tile[4][ACC_N];
@@ -2409,7 +2425,11 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
         const int eA = pfirst + min(wbase + lane, pcount - 1), eB = pfirst + min(wbase + 64 + lane, pcount - 1);
         // every load of the batch is issued here; the velocity / affine streams are only waited for behind the volume gather
         const float4 a0 = P.q[0][eA], b0 = P.q[0][eB], ak = P.k[eA], bk = P.k[eB];
-        const float ja = P.d[eA].z, jb = P.d[eB].z;
+        // plastic_deformation_gradient_det, the "fluid J" of the stress (eos_monaghan_sph.rs glue).  Nothing ever changes it for a plain fluid, and
+        // every particle generator leaves it at 1: when the host saw only ones at upload (StepParams::jp_one) the D stream -- 16 B per particle of
+        // which 4 are used: the 12 % of this kernel's HBM traffic beyond its algorithmic bytes, r04 PMC -- is not read at all
+        float ja = 1.f, jb = 1.f;
+        if (!(FLUID_ONLY && S.jp_one)) { ja = P.d[eA].z; jb = P.d[eB].z; }
         const float4 a3 = P.q[3][eA], b3 = P.q[3][eB], a4 = P.q[4][eA], b4 = P.q[4][eB], a5 = P.q[5][eA], b5 = P.q[5][eB];
         float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = a1, a2 = a1, b2 = a1;
         if (!FLUID_ONLY) { a1 = P.q[1][eA]; b1 = P.q[1][eB]; a2 = P.q[2][eA]; b2 = P.q[2][eB]; }
@@ -2419,7 +2439,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
         int clc[2][3];
         hand_over(a0, b0, q0);
         hand_over(ak, bk, kk);
-        {
+        jp_stored[0] = jp_stored[1] = 1.f;
+        if (!(FLUID_ONLY && S.jp_one)) {
             float* xj = s_xj[wv];
             xj[sA] = ja; xj[sB] = jb;
             __builtin_amdgcn_wave_barrier();

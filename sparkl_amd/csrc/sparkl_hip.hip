@@ -107,6 +107,7 @@ struct SparklPipeline {
     uint64_t n_binned = 0;
     ParticleStore cur, alt;
     uint32_t max_model_index = 0;
+    bool all_jp_one = true;   // every particle uploaded so far carries plastic_deformation_gradient_det == 1 (StepParams::jp_one)
     // slab decomposition (multi-GPU): owned home blocks along `slab_axis` are [slab_lo, slab_hi)
     bool slab_on = false;
     int slab_axis = 0, slab_lo = INT32_MIN, slab_hi = INT32_MAX;
@@ -184,6 +185,7 @@ struct SparklPipeline {
     std::vector<DevTriMesh> h_trimeshes;
     bool collider_handling = false, collider_penalty = false, rare_by_models = false;
     DevBuf<float4> node_proj;        // GridArrays::node_proj: [heightfields + trimeshes][num_blocks][64]
+    DevBuf<int> node_proj_blk;       // GridArrays::node_proj_blk: [heightfields + trimeshes][num_blocks]
     bool proj_cache_on = true;       // SPARKL_HIP_PROJ_CACHE=0: off (A/B, tests)
     bool proj_cache_clear = true;    // colliders changed or a re-bin rebuilt the node blocks: zero the cache before the next grid update
     DevBuf<DevHeightField> d_heightfields;
@@ -365,7 +367,7 @@ static GridArrays grid_arrays(const SparklPipeline* p) {
     GridArrays g;
     g.blk_origin = p->blk_origin.p; g.blk_pfirst = p->blk_pfirst.p; g.blk_pcount = p->blk_pcount.p; g.blk_nbr = p->blk_nbr.p; g.blk_tnbr = p->blk_tnbr.p; g.dt_partial = p->dt_partial.p;
     g.cuboids = p->d_cuboids.p; g.heightfields = p->d_heightfields.p; g.trimeshes = p->d_trimeshes.p;
-    g.node_proj = nullptr;   // only launch_grid_update hands the cache out (it also sizes and clears it, in stream order)
+    g.node_proj = nullptr; g.node_proj_blk = nullptr;   // only launch_grid_update hands the cache out (it also sizes and clears it, in stream order)
     g.pblk = p->pblk.p; g.pb_info = p->pb_info.p; g.tile_mode = p->tile_mode.p; g.pb_heads = p->pb_heads.p; g.tiles = p->tiles.p; g.node_vel = p->node_vel.p; g.node_mom = p->capture_mom ? p->node_mom.p : nullptr;
     g.halo_in = (p->slab_on && p->num_blocks) ? p->halo_in.p : nullptr;
     g.halo_axis = p->slab_axis; g.halo_lo = p->slab_lo; g.halo_hi = p->slab_hi;
@@ -604,6 +606,7 @@ static StepParams make_params(const SparklPipeline* p, const SparklSolverParams*
     S.project_particles = sp->enable_boundary_particle_projection ? 1 : 0;
     S.collider_handling = p->collider_handling ? 1 : 0;
     S.penalty = p->collider_penalty ? 1 : 0;
+    S.jp_one = (p->all_jp_one && p->all_plain_fluid && !p->slab_on) ? 1 : 0;   // (slabs receive immigrants whose value the host has not seen)
     S.dt_next = dt;
     S.count_heads = 1;
     S.mass_from_sweep = 0;
@@ -619,15 +622,20 @@ static StepParams make_params(const SparklPipeline* p, const SparklSolverParams*
 static void prepare_proj_cache(SparklPipeline* p, hipStream_t st) {
     const size_t slots = (size_t)(p->num_heightfields + p->num_trimeshes);
     if (!p->proj_cache_on || slots == 0 || p->num_blocks == 0) return;
-    const size_t need = slots * (size_t)p->num_blocks * 64;
-    if (need > p->node_proj.cap) { if (p->node_proj.reserve(need) != SPARKL_OK) { p->node_proj.release(); return; } p->proj_cache_clear = true; }
-    if (p->proj_cache_clear) { (void)hipMemsetAsync(p->node_proj.p, 0, need * sizeof(float4), st); p->proj_cache_clear = false; }
+    const size_t need = slots * (size_t)p->num_blocks * 64, need_blk = slots * (size_t)p->num_blocks;
+    if (need > p->node_proj.cap || need_blk > p->node_proj_blk.cap) {
+        if (p->node_proj.reserve(need) != SPARKL_OK || p->node_proj_blk.reserve(need_blk) != SPARKL_OK) { p->node_proj.release(); p->node_proj_blk.release(); return; }
+        p->proj_cache_clear = true;
+    }
+    // only the per-block words are cleared: a node record is never read before its block's word says "computed"
+    if (p->proj_cache_clear) { (void)hipMemsetAsync(p->node_proj_blk.p, 0, need_blk * sizeof(int), st); p->proj_cache_clear = false; }
 }
 static void launch_grid_update(SparklPipeline* p, const GridArrays& G_in, const StepParams& S, hipStream_t st) {
     GridArrays G = G_in;
     if (p->num_heightfields + p->num_trimeshes > 0) {
         prepare_proj_cache(p, st);
-        G.node_proj = (p->proj_cache_on && p->node_proj.p && !p->proj_cache_clear) ? p->node_proj.p : nullptr;
+        G.node_proj = (p->proj_cache_on && p->node_proj.p && p->node_proj_blk.p && !p->proj_cache_clear) ? p->node_proj.p : nullptr;
+        G.node_proj_blk = p->node_proj_blk.p;
     }
     const dim3 grid((p->num_blocks + 3) / 4), block(BLK_THREADS);
     if (p->num_heightfields > 0 || p->num_trimeshes > 0)
@@ -1005,7 +1013,7 @@ void sparkl_hip_pipeline_destroy(SparklPipeline* p) {
     p->keys_a.release(); p->keys_b.release(); p->pb_keys.release(); p->bkeys.release(); p->idx_a.release(); p->idx_b.release();
     p->pb_counts.release(); p->pb_first.release(); p->cand_a.release(); p->cand_b.release(); p->cub_temp.release(); p->d_scalars.release();
     p->staging.release(); p->node_staging.release(); p->d_count.release(); p->dt_partial.release(); p->psi_tiles.release(); p->node_psi.release();
-    p->oorg.release(); p->node_proj.release(); p->pb_order.release(); p->order_keys.release(); p->order_keys_out.release(); p->order_vals.release();
+    p->oorg.release(); p->node_proj.release(); p->node_proj_blk.release(); p->pb_order.release(); p->order_keys.release(); p->order_keys_out.release(); p->order_vals.release();
     p->split_pb.release(); p->split_nb.release(); p->split_flags.release(); p->bal_dev.release();
     p->halo_list[0].release(); p->halo_list[1].release(); p->halo_in.release(); p->d_tail.release();
     for (int k = 0; k < 2; ++k) { p->x_send[k].release(); p->x_recv[k].release(); p->x_mig_send[k].release(); p->x_mig_recv[k].release(); }
@@ -1399,6 +1407,7 @@ static int upload_range(SparklPipeline* p, uint64_t first, uint64_t n, const Spa
     static_assert(sizeof(SparklParticleStatus) == 24 && sizeof(SparklParticlePosition) == 12 && sizeof(SparklParticleVelocity) == 12 &&
                   sizeof(SparklParticleVolume) == 52 && sizeof(SparklParticlePhase) == 8 && sizeof(SparklParticleData) == 16 && sizeof(SparklVelocityGradient) == 36, "");
     for (uint64_t i = 0; i < n; ++i) p->max_model_index = std::max(p->max_model_index, (uint32_t)status[i].model_index);
+    for (uint64_t i = 0; i < n && p->all_jp_one; ++i) p->all_jp_one = volume[i].plastic_deformation_gradient_det == 1.0f;
     hipStream_t st = p->stream;
     // chunks bound the staging area (40 floats per particle) for very large sets
     const uint64_t CHUNK = 1ull << 24;
@@ -1444,6 +1453,7 @@ int sparkl_hip_particles_upload(SparklPipeline* p, uint64_t n, const SparklParti
     p->n = n;
     p->n_binned = 0;   // world coordinates until the first re-bin
     p->max_model_index = 0;
+    p->all_jp_one = true;
     if (n) CHK(upload_range(p, 0, n, status, pos, vel, volume, phase, data, vg));
     p->sorted = false;
     return SPARKL_OK;
