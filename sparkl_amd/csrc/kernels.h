@@ -134,7 +134,7 @@ struct GridArrays {
     const int* pb_list; int pb_count;
     const int* nb_list; int nb_count;
     int primary;
-    int pb_plain;              // 1: pb_list is a launch order, indexed by blockIdx.x itself (k_order_keys); 0: a subset in Morton order, indexed through xcd_remap
+    int pb_plain;              // 1: pb_list is a launch order, indexed by blockIdx.x itself (k_order_keys); 2: the same list read back to front; 0: a subset in Morton order, indexed through xcd_remap
     uint32_t* dt_partial;      // [gridDim] per-workgroup minimum of the dt bound (float bits), reduced by k_dt_reduce
     // Projection cache of the grid update (the reference's GPU path keeps `projection_status` / `projection_scaled_dir` in its grid nodes,
     // src_kernels/cuda/grid_update.rs:111-146): [heightfield | trimesh collider][B][64] (proj.xyz, status) of the node's projection on that
@@ -229,7 +229,7 @@ struct DevTriMesh {
 SPK_DEV int xcd_remap(int bid, int n);
 // particle block of this workgroup: the whole list or the launch's subset
 SPK_DEV int launch_pblock(const GridArrays& G) {
-    if (G.pb_list) return G.pb_plain ? G.pb_list[blockIdx.x] : G.pb_list[xcd_remap(blockIdx.x, G.pb_count)];
+    if (G.pb_list) return G.pb_plain == 1 ? G.pb_list[blockIdx.x] : (G.pb_plain == 2 ? G.pb_list[G.pb_count - 1 - (int)blockIdx.x] : G.pb_list[xcd_remap(blockIdx.x, G.pb_count)]);
     return xcd_remap(blockIdx.x, G.num_pblocks);
 }
 // Observed placement is workgroup b -> XCD b % 8: give each XCD a contiguous run of Morton-ordered
@@ -3075,6 +3075,11 @@ __global__ void k_split_flags(const int4* __restrict__ pb_info, int npb, const i
         const long long pl = (axis == 0 ? o.x : (axis == 1 ? o.y : o.z)) >> 2;
         nb_flag[j] = (pl == lo || pl == hi || pl + 1 == lo || pl + 1 == hi) ? 1 : 0;
     }
+}
+// the particle-block flags in the order of a launch list (fullest first): what DevicePartition::Flagged needs beside that list
+__global__ void k_gather_flags(const uint32_t* __restrict__ order, const unsigned char* __restrict__ flag, int n, unsigned char* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = flag[order[i]];
 }
 // this slab's partial (mass, momentum) of node (cx, cy, cz) of block b, gathered from its own tiles
 SPK_DEV float4 halo_node_sum(const GridArrays& G, int b, int cx, int cy, int cz) {

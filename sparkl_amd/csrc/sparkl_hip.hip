@@ -135,6 +135,7 @@ struct SparklPipeline {
     bool pb_order_valid = false;
     DevBuf<unsigned char> split_flags;
     int pb_bnd = 0, nb_bnd = 0;
+    bool split_ordered = false;   // split_pb was cut out of the fullest-first launch order (pb_order): [cut-adjacent, fullest first | interior, EMPTIEST first: read back to front]
     // Halo / compute overlap of the slab-group loop: -1 = automatic (on between RCCL ranks, where the exchange has a network latency to
     // hide; off for the members of one process on one device, where the cross-stream events cost more than they hide: 2 slabs of 10 M
     // on one MI355X 1.19 ms per substep in line, 1.23 overlapped), 0 / 1 = SPARKL_HIP_OVERLAP forces it
@@ -562,7 +563,7 @@ static int resort(SparklPipeline* p) {
                 // all the XCD mapping needs (speed only)
                 {
                     const int m = std::max(nb, npb);
-                    CHK(p->split_flags.reserve((size_t)2 * m));
+                    CHK(p->split_flags.reserve((size_t)3 * m));
                     CHK(p->split_pb.reserve(npb)); CHK(p->split_nb.reserve(nb));
                     hipLaunchKernelGGL(k_split_flags, dim3(grid_for(m, 256)), dim3(256), 0, st, p->pb_info.p, npb, p->blk_origin.p, nb, p->slab_axis, p->slab_lo, p->slab_hi,
                                        p->split_flags.p, p->split_flags.p + m);
@@ -570,6 +571,19 @@ static int resort(SparklPipeline* p) {
                     size_t tb = 0;
                     HIPCHK(hipcub::DevicePartition::Flagged(nullptr, tb, iota, p->split_flags.p, p->split_pb.p, p->d_scalars.p + 6, m, st));
                     CHK(cub_reserve(p, tb));
+                    // Particle blocks: the subsets keep the FULLEST-FIRST launch order of the whole list where there is one (k_order_keys: a grid of
+                    // unequal workgroups ends with whatever comes last; -1.6 ... -6.9 % on one GPU, round 4 experiment 14 -- round 4 left the slab
+                    // subsets in Morton order).  The rejected (interior) items come out back to front: that subset is read backwards (pb_plain = 2).
+                    p->split_ordered = p->pb_order_valid;
+                    if (p->split_ordered) {
+                        CHK(p->split_flags.reserve((size_t)3 * m));
+                        unsigned char* ford = p->split_flags.p + 2 * m;
+                        hipLaunchKernelGGL(k_gather_flags, dim3(grid_for(npb, 256)), dim3(256), 0, st, (const uint32_t*)p->pb_order.p, (const unsigned char*)p->split_flags.p, npb, ford);
+                        size_t tbo = 0;
+                        HIPCHK(hipcub::DevicePartition::Flagged(nullptr, tbo, reinterpret_cast<const int*>(p->pb_order.p), ford, p->split_pb.p, p->d_scalars.p + 6, npb, st));
+                        CHK(cub_reserve(p, std::max(tb, tbo)));
+                        HIPCHK(hipcub::DevicePartition::Flagged(p->cub_temp.p, tbo, reinterpret_cast<const int*>(p->pb_order.p), ford, p->split_pb.p, p->d_scalars.p + 6, npb, st));
+                    } else
                     HIPCHK(hipcub::DevicePartition::Flagged(p->cub_temp.p, tb, iota, p->split_flags.p, p->split_pb.p, p->d_scalars.p + 6, npb, st));
                     HIPCHK(hipcub::DevicePartition::Flagged(p->cub_temp.p, tb, iota, p->split_flags.p + m, p->split_nb.p, p->d_scalars.p + 7, nb, st));
                     HIPCHK(hipMemcpyAsync(&p->pb_bnd, p->d_scalars.p + 6, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -2646,7 +2660,7 @@ static int launch_subset(SparklPipeline* p, int which, bool fuse_next, bool prim
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, false>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);
         return SPARKL_OK;
     }
-    G.pb_plain = 0;
+    G.pb_plain = p->split_ordered ? (bnd ? 1 : 2) : 0;
     G.pb_list = bnd ? p->split_pb.p : p->split_pb.p + p->pb_bnd;
     G.pb_count = bnd ? p->pb_bnd : p->num_pblocks - p->pb_bnd;
     G.primary = primary ? 1 : 0;

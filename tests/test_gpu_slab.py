@@ -196,7 +196,7 @@ def test_cube_through_sand_two_slabs_match_oracle(tmp_path):
     assert not bad, (bad, rep)
 
 
-@pytest.mark.parametrize("kind,nsteps,overlap", [("spin", 40, "0"), ("cube", 100, "0"), ("spin", 40, "1"), ("cube", 100, "1")])
+@pytest.mark.parametrize("kind,nsteps,overlap", [("spin", 40, "0"), ("cube", 100, "0"), ("spin", 40, "1"), ("cube", 100, "1"), ("cube", 100, "1+order")])
 def test_group_substeps_two_slabs_in_the_library(kind, nsteps, overlap, monkeypatch):
     """sparkl_hip_group_substeps: the whole slab loop (re-bin agreement, halo swap, migration) inside the C ABI, no Python in
     the exchange.  Two slabs share one GPU and one stream (device-copy transport of the same loop that uses RCCL between ranks);
@@ -205,6 +205,9 @@ def test_group_substeps_two_slabs_in_the_library(kind, nsteps, overlap, monkeypa
     from tests.parity import parity_verdict
     # SPARKL_HIP_OVERLAP (read when a pipeline is created): 1 forces the two-stream schedule the RCCL ranks use by default -- interior
     # blocks on the main stream while the halo chain and the cut-adjacent blocks run on the halo stream --, 0 the in-line schedule
+    if overlap.endswith("+order"):   # the interior / cut-adjacent subsets cut out of the fullest-first launch order (forced: the scene is small), read forwards / backwards
+        overlap = overlap.split("+")[0]
+        monkeypatch.setenv("SPARKL_HIP_BLOCK_ORDER", "1")
     monkeypatch.setenv("SPARKL_HIP_OVERLAP", overlap)
     world = 2
     sc, dt = _scene(kind)
