@@ -214,6 +214,18 @@ typedef struct {
     uint8_t _pad[2];
 } SparklTriMeshCollider;
 
+/* rapier `ColliderBuilder::polyline(vertices, None)` as CudaColliderSet::from_collider_set takes it (cuda_collider_set.rs:102-117,
+ * src_kernels/gpu_collider.rs:99-201): a CLOSED polygon, counter-clockwise in the collider's local x-y plane (vertex i is joined to vertex
+ * (i + 1) % n), extruded along local z; the inside of the polygon is solid.  The CPU path (parry's open Polyline) never reports is_inside;
+ * this is the GPU path's shape, the only one the reference defines for MPM boundaries. */
+typedef struct {
+    uint32_t num_vertices;
+    const float* vertices;        /* 3 * num_vertices, local frame */
+    float rotation[4];            /* (i, j, k, w) */
+    float translation[3];
+    float friction;
+} SparklPolylineCollider;
+
 /* `CudaColliderOptions` (src/cuda/cuda_collider_set.rs:22-38): what the reference's GPU path lets a caller choose PER COLLIDER, beside the
  * collider itself.  Given to sparkl_hip_colliders_set_*_options, one record per collider of that kind, in the order of the matching
  * sparkl_hip_colliders_set_* call (which resets every collider of its kind to the defaults).
@@ -360,6 +372,9 @@ int sparkl_hip_colliders_set_trimeshes(SparklPipeline* p, uint32_t n, const Spar
 int sparkl_hip_colliders_set_cuboid_options(SparklPipeline* p, uint32_t n, const SparklColliderOptions* options);
 int sparkl_hip_colliders_set_heightfield_options(SparklPipeline* p, uint32_t n, const SparklColliderOptions* options);
 int sparkl_hip_colliders_set_trimesh_options(SparklPipeline* p, uint32_t n, const SparklColliderOptions* options);
+/* CudaColliderSet::from_collider_set (polylines); applied after the triangle meshes.  Vertices are copied. */
+int sparkl_hip_colliders_set_polylines(SparklPipeline* p, uint32_t n, const SparklPolylineCollider* colliders);
+int sparkl_hip_colliders_set_polyline_options(SparklPipeline* p, uint32_t n, const SparklColliderOptions* options);
 
 /* MpmPipeline::step / CudaMpmPipeline::step
  * (src/pipelines/mpm_pipeline.rs:15-42, src/cuda/cuda_mpm_pipeline.rs:262-271):

@@ -125,15 +125,21 @@ class Oracle:
         self._keep.append(trimeshes)
         self.L.oracle_set_trimeshes(self.h, C.c_uint32(len(trimeshes)), arr)
 
+    def set_polylines(self, polylines):
+        arr = (abi.PolylineColliderC * max(len(polylines), 1))(*polylines)
+        self._keep.append(polylines)
+        self.L.oracle_set_polylines(self.h, C.c_uint32(len(polylines)), arr)
+
     def set_collider_options(self, kind, options):
         arr = (abi.ColliderOptionsC * max(len(options), 1))(*options)
-        self.L.oracle_set_collider_options(self.h, C.c_int({"cuboid": 0, "heightfield": 1, "trimesh": 2}[kind]), C.c_uint32(len(options)), arr)
+        self.L.oracle_set_collider_options(self.h, C.c_int({"cuboid": 0, "heightfield": 1, "trimesh": 2, "polyline": 3}[kind]), C.c_uint32(len(options)), arr)
 
     def load_scene(self, scene):
         self.set_models(scene.models)
         self.set_cuboids(scene.colliders)
         self.set_heightfields(getattr(scene, "heightfields", []))
         self.set_trimeshes(getattr(scene, "trimeshes", []))
+        self.set_polylines(getattr(scene, "polylines", []))
         for kind, opts in getattr(scene, "collider_options", {}).items():
             self.set_collider_options(kind, opts)
         self.set_particles(scene.particles)

@@ -112,6 +112,19 @@ void fill_trimesh(TriMesh<R>& m, const SparklTriMeshCollider& c) {
     if (m.oriented) m.compute_pseudo_normals();
 }
 template <class R>
+void set_polylines(Oracle<R>& o, uint32_t n, const SparklPolylineCollider* c) {
+    o.polylines.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        auto& pl = o.polylines[i];
+        pl.v.resize(c[i].num_vertices);
+        for (uint32_t k = 0; k < c[i].num_vertices; ++k) pl.v[k] = Vec3<R>{{(R)c[i].vertices[3 * k], (R)c[i].vertices[3 * k + 1], (R)c[i].vertices[3 * k + 2]}};
+        for (int a = 0; a < 4; ++a) pl.q[a] = c[i].rotation[a];
+        for (int a = 0; a < 3; ++a) pl.t[a] = c[i].translation[a];
+        pl.friction = c[i].friction;
+        pl.opts = ColliderOpts{};
+    }
+}
+template <class R>
 void set_trimeshes(Oracle<R>& o, uint32_t n, const SparklTriMeshCollider* c) {
     o.trimeshes.resize(n);
     for (uint32_t i = 0; i < n; ++i) fill_trimesh(o.trimeshes[i], c[i]);
@@ -175,6 +188,7 @@ void set_options(Oracle<R>& o, int kind, uint32_t n, const SparklColliderOptions
     if (kind == 0) for (uint32_t i = 0; i < n && i < o.cuboids.size(); ++i) put(o.cuboids[i].opts, opt[i]);
     if (kind == 1) for (uint32_t i = 0; i < n && i < o.heightfields.size(); ++i) put(o.heightfields[i].opts, opt[i]);
     if (kind == 2) for (uint32_t i = 0; i < n && i < o.trimeshes.size(); ++i) { put(o.trimeshes[i].opts, opt[i]); o.trimeshes[i].flip_interior = opt[i].flip_interior != 0; }
+    if (kind == 3) for (uint32_t i = 0; i < n && i < o.polylines.size(); ++i) put(o.polylines[i].opts, opt[i]);
 }
 extern "C" {
 
@@ -217,6 +231,10 @@ void oracle_set_cuboids(void* hv, uint32_t n, const SparklCuboidCollider* c) {
 void oracle_set_heightfields(void* hv, uint32_t n, const SparklHeightFieldCollider* c) {
     Handle* h = (Handle*)hv;
     if (h->f64) set_heightfields(*h->od, n, c); else set_heightfields(*h->of, n, c);
+}
+void oracle_set_polylines(void* hv, uint32_t n, const SparklPolylineCollider* c) {
+    Handle* h = (Handle*)hv;
+    if (h->f64) set_polylines(*h->od, n, c); else set_polylines(*h->of, n, c);
 }
 void oracle_set_trimeshes(void* hv, uint32_t n, const SparklTriMeshCollider* c) {
     Handle* h = (Handle*)hv;

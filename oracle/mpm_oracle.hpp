@@ -774,6 +774,57 @@ template <class R> int triangle_feature(const Vec3<R>& p, const Vec3<R>& a, cons
     if (d3 * d6 - d5 * d4 <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) return 5;
     return 6;
 }
+// src_kernels/gpu_collider.rs:99-201 (`polyline_project_point`): a closed counter-clockwise polygon in the local x-y plane, extruded along z.
+// Closest segment in 3-D (brute force, as the reference), the projection keeps the point's local z; inside / outside from the segment's planar
+// normal (Segment::planar_normal(2) = (dir.y, -dir.x, 0) normalised), at a vertex from the adjacent segment's direction unless the two are
+// collinear within 1e-3.  Only the reference's GPU path has this shape (the CPU path's parry Polyline is open and never inside).  Deviation:
+// the reference dots (WORLD point - LOCAL projection) with the normal -- right for an identity pose only; the local point is used.
+template <class R> struct Polyline { std::vector<Vec3<R>> v; R q[4]; Vec3<R> t; R friction; ColliderOpts opts; };
+template <class R> Projection<R> polyline_project_point(const Polyline<R>& pl, const Vec3<R>& pt_world) {
+    Vec3<R> rel{{pt_world[0] - pl.t[0], pt_world[1] - pl.t[1], pt_world[2] - pl.t[2]}};
+    Vec3<R> lp = quat_rotate(pl.q, rel, true);
+    const size_t n = pl.v.size();
+    R best = std::numeric_limits<R>::max(), bt = 0;
+    Vec3<R> bp = lp;
+    size_t bi = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const Vec3<R>& A = pl.v[i];
+        const Vec3<R>& B = pl.v[(i + 1) % n];
+        Vec3<R> ab{{B[0] - A[0], B[1] - A[1], B[2] - A[2]}}, ap{{lp[0] - A[0], lp[1] - A[1], lp[2] - A[2]}};
+        R ab2 = dot(ab, ab);
+        R tt = ab2 > R(0) ? dot(ap, ab) / ab2 : R(0);
+        tt = std::min(std::max(tt, R(0)), R(1));
+        Vec3<R> c{{A[0] + tt * ab[0], A[1] + tt * ab[1], A[2] + tt * ab[2]}};
+        Vec3<R> dd{{c[0] - lp[0], c[1] - lp[1], c[2] - lp[2]}};
+        R d = norm(dd);
+        if (d < best) { best = d; bp = c; bt = tt; bi = i; }
+    }
+    bool inside = false;
+    {
+        const Vec3<R>& A = pl.v[bi];
+        const Vec3<R>& B = pl.v[(bi + 1) % n];
+        R dx = B[0] - A[0], dy = B[1] - A[1];
+        R nl = std::sqrt(dx * dx + dy * dy);
+        if (nl > R(0)) {
+            R n1[2] = {dy / nl, -dx / nl};
+            R side = (lp[0] - bp[0]) * n1[0] + (lp[1] - bp[1]) * n1[1];
+            if (bt > R(0) && bt < R(1)) inside = side <= R(0);
+            else {
+                Vec3<R> d2;
+                if (bt <= R(0)) { const Vec3<R>& P = pl.v[(bi + n - 1) % n]; d2 = Vec3<R>{{-(A[0] - P[0]), -(A[1] - P[1]), -(A[2] - P[2])}}; }
+                else { const Vec3<R>& Nn = pl.v[(bi + 2) % n]; d2 = Vec3<R>{{Nn[0] - B[0], Nn[1] - B[1], Nn[2] - B[2]}}; }
+                R dt = n1[0] * d2[0] + n1[1] * d2[1];
+                R thr = R(1.0e-3) * norm(d2);
+                inside = std::fabs(dt) > thr ? dt >= R(0) : side <= R(0);
+            }
+        }
+    }
+    bp[2] = lp[2];
+    if (pl.opts.flip_interior) inside = !inside;
+    Vec3<R> w = quat_rotate(pl.q, bp, false);
+    return Projection<R>{inside, Vec3<R>{{w[0] + pl.t[0], w[1] + pl.t[1], w[2] + pl.t[2]}}};
+}
+
 template <class R> Projection<R> trimesh_project_point(const TriMesh<R>& m, const Vec3<R>& pt_world) {
     Vec3<R> rel{{pt_world[0] - m.t[0], pt_world[1] - m.t[1], pt_world[2] - m.t[2]}};
     Vec3<R> lp = quat_rotate(m.q, rel, true);
@@ -816,6 +867,7 @@ struct Oracle {
     std::vector<Cuboid<R>> cuboids;
     std::vector<HeightField<R>> heightfields;
     std::vector<TriMesh<R>> trimeshes;
+    std::vector<Polyline<R>> polylines;
     int last_num_substeps = 0;
     std::vector<double> last_dts;
     int num_threads = 1;
@@ -1056,6 +1108,7 @@ struct Oracle {
                 for (const auto& col : cuboids) apply(cuboid_project_point(col, cell_pos), col.friction, col.opts);
                 for (const auto& hf : heightfields) apply(heightfield_project_point(hf, cell_pos), hf.friction, hf.opts);
                 for (const auto& tm : trimeshes) apply(trimesh_project_point(tm, cell_pos), tm.friction, tm.opts);
+                for (const auto& pl : polylines) apply(polyline_project_point(pl, cell_pos), pl.friction, pl.opts);
             }
         }
     }
@@ -1143,6 +1196,7 @@ struct Oracle {
                     for (const auto& col : cuboids) fix(cuboid_project_point(col, p.position));
                     for (const auto& hf : heightfields) fix(heightfield_project_point(hf, p.position));
                     for (const auto& tm : trimeshes) fix(trimesh_project_point(tm, p.position));
+                    for (const auto& pl : polylines) fix(polyline_project_point(pl, p.position));
                 }
                 // penalty force of colliders with a stiffness (particle_updater.rs:200-225, `if false` there: the intended rule): a particle
                 // inside feels f = (proj - x) k, and the momentum it scatters next is m v + f dt (g2p2g.rs:286-287) -- the kick on the
@@ -1158,6 +1212,7 @@ struct Oracle {
                     for (const auto& col : cuboids) if (col.opts.penalty > 0) push(cuboid_project_point(col, p.position), col.opts);
                     for (const auto& hf : heightfields) if (hf.opts.penalty > 0) push(heightfield_project_point(hf, p.position), hf.opts);
                     for (const auto& tm : trimeshes) if (tm.opts.penalty > 0) push(trimesh_project_point(tm, p.position), tm.opts);
+                    for (const auto& pl : polylines) if (pl.opts.penalty > 0) push(polyline_project_point(pl, p.position), pl.opts);
                     if (any) { const R k = dt * inv_exact(p.mass); for (int a = 0; a < 3; ++a) p.velocity[a] += f[a] * k; }
                 }
             }

@@ -136,6 +136,27 @@ class CuboidColliderC(C.Structure):
                 ("translation", C.c_float * 3), ("friction", C.c_float)]
 
 
+class PolylineColliderC(C.Structure):
+    _fields_ = [("num_vertices", C.c_uint32), ("vertices", C.POINTER(C.c_float)), ("rotation", C.c_float * 4), ("translation", C.c_float * 3), ("friction", C.c_float)]
+
+
+def polyline(vertices_xy, translation=(0.0, 0.0, 0.0), rotation=(0.0, 0.0, 0.0, 1.0), friction=0.5):
+    """`ColliderBuilder::polyline(vertices, None)` as the reference's GPU path reads it (gpu_collider.rs:99-201): a closed counter-clockwise polygon
+    in the local x-y plane, extruded along z.  `vertices_xy`: (n, 2) or (n, 3)."""
+    v = np.asarray(vertices_xy, dtype=np.float32)
+    if v.shape[1] == 2:
+        v = np.concatenate([v, np.zeros((len(v), 1), np.float32)], axis=1)
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    c = PolylineColliderC()
+    c.num_vertices = len(v)
+    c.vertices = v.ctypes.data_as(C.POINTER(C.c_float))
+    c._keep = v
+    c.rotation[:] = [float(x) for x in rotation]
+    c.translation[:] = [float(x) for x in translation]
+    c.friction = float(friction)
+    return c
+
+
 class ColliderOptionsC(C.Structure):
     """`CudaColliderOptions` (src/cuda/cuda_collider_set.rs:22-38) without the handle: one per collider of a kind, in set_* order."""
     _fields_ = [("grid_boundary_handling", C.c_int32), ("penalty_stiffness", C.c_float), ("flip_interior", C.c_uint8), ("_pad", C.c_uint8 * 3)]

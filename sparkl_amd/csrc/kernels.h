@@ -111,6 +111,7 @@ SPK_DEV uint32_t particle_id(const ParticleArrays& P, int i) { return reinterpre
 struct DevCuboid;
 struct DevHeightField;
 struct DevTriMesh;
+struct DevPolyline;
 struct GridArrays {
     const int4* blk_origin;    // cell coordinate of node (0,0,0) of the block, w = tile index or -1
     const int* blk_pfirst;
@@ -145,6 +146,8 @@ struct GridArrays {
     const DevCuboid* cuboids;  // the collider arrays, for enable_boundary_particle_projection (G2P tail)
     const DevHeightField* heightfields;
     const DevTriMesh* trimeshes;
+    const DevPolyline* polylines;
+    int num_polylines;
     int num_blocks;
     int num_pblocks;
 };
@@ -224,6 +227,19 @@ struct DevTriMesh {
     int oriented, flip_interior;
     int handling;
     float penalty;
+};
+
+// Polyline collider (src_kernels/gpu_collider.rs:99-201, cuda_collider_set.rs:102-117): a CLOSED counter-clockwise polygon in the local x-y plane,
+// extruded along local z; vertex i is joined to vertex (i + 1) % n.
+struct DevPolyline {
+    const float* verts;     // 3 floats per vertex (local frame)
+    int n;
+    float q[4];
+    float t[3];
+    float friction;
+    int handling;
+    float penalty;
+    int flip_interior;
 };
 
 SPK_DEV int xcd_remap(int bid, int n);
@@ -1126,6 +1142,61 @@ SPK_DEV bool trimesh_project(const DevTriMesh& tm, const float ptw[3], float rea
     return true;
 }
 
+// gpu_collider.rs:99-201 (`polyline_project_point`, restated): the closest of the polygon's segments in 3-D, brute force like the reference; the
+// projection keeps the point's own local z (the shape is the polygon extruded along z); inside / outside from the segment's planar normal
+// (dir.y, -dir.x, 0) -- a point ON the side the normal points away from is inside a counter-clockwise polygon --, at a vertex from the adjacent
+// segment's direction (reentrant vertex = inside) unless the two are collinear within 1e-3.  (The reference dots the WORLD point minus the LOCAL
+// projection with the normal, which is only right for an identity pose; the local point is used here.)
+SPK_DEV bool polyline_project(const DevPolyline& pl, const float ptw[3], float projw[3], bool& inside) {
+    if (pl.n < 2) return false;
+    float rel[3] = {ptw[0] - pl.t[0], ptw[1] - pl.t[1], ptw[2] - pl.t[2]};
+    float lp[3];
+    quat_rot(pl.q, rel, -1.f, lp);
+    float best = 3.402823466e+38f, bp[3] = {0.f, 0.f, 0.f}, bt = 0.f;
+    int bi = 0;
+    for (int i = 0; i < pl.n; ++i) {
+        const float* A = pl.verts + 3 * i;
+        const float* B = pl.verts + 3 * ((i + 1) % pl.n);
+        const float ab[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, ap[3] = {lp[0] - A[0], lp[1] - A[1], lp[2] - A[2]};
+        const float ab2 = ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2];
+        float tt = ab2 > 0.f ? (ap[0] * ab[0] + ap[1] * ab[1] + ap[2] * ab[2]) / ab2 : 0.f;
+        tt = fminf(fmaxf(tt, 0.f), 1.f);
+        const float c[3] = {A[0] + tt * ab[0], A[1] + tt * ab[1], A[2] + tt * ab[2]};
+        const float d = sqrtf((c[0] - lp[0]) * (c[0] - lp[0]) + (c[1] - lp[1]) * (c[1] - lp[1]) + (c[2] - lp[2]) * (c[2] - lp[2]));
+        if (d < best) { best = d; bp[0] = c[0]; bp[1] = c[1]; bp[2] = c[2]; bt = tt; bi = i; }
+    }
+    inside = false;
+    {
+        const float* A = pl.verts + 3 * bi;
+        const float* B = pl.verts + 3 * ((bi + 1) % pl.n);
+        const float dx = B[0] - A[0], dy = B[1] - A[1];
+        const float nl = sqrtf(dx * dx + dy * dy);
+        if (nl > 0.f) {   // Segment::planar_normal(2)
+            const float n1[2] = {dy / nl, -dx / nl};
+            const float side = (lp[0] - bp[0]) * n1[0] + (lp[1] - bp[1]) * n1[1];
+            if (bt > 0.f && bt < 1.f) inside = side <= 0.f;                 // SegmentPointLocation::OnEdge
+            else {                                                          // OnVertex(0 | 1): the adjacent segment decides
+                float d2[3];
+                if (bt <= 0.f) {
+                    const float* P = pl.verts + 3 * ((bi + pl.n - 1) % pl.n);
+                    d2[0] = -(A[0] - P[0]); d2[1] = -(A[1] - P[1]); d2[2] = -(A[2] - P[2]);
+                } else {
+                    const float* Nn = pl.verts + 3 * ((bi + 2) % pl.n);
+                    d2[0] = Nn[0] - B[0]; d2[1] = Nn[1] - B[1]; d2[2] = Nn[2] - B[2];
+                }
+                const float dot = n1[0] * d2[0] + n1[1] * d2[1];
+                const float thr = 1.0e-3f * sqrtf(d2[0] * d2[0] + d2[1] * d2[1] + d2[2] * d2[2]);
+                inside = fabsf(dot) > thr ? dot >= 0.f : side <= 0.f;
+            }
+        }
+    }
+    bp[2] = lp[2];
+    if (pl.flip_interior) inside = !inside;
+    quat_rot(pl.q, bp, 1.f, projw);
+    projw[0] += pl.t[0]; projw[1] += pl.t[1]; projw[2] += pl.t[2];
+    return true;
+}
+
 // Closest point of a heightfield to a world point, searching only the cells within `reach` (world units) of the point
 // horizontally: the boundary rule never needs a projection farther than a couple of cells (grid_update.rs:103-127).
 // Returns false when no triangle is in reach.  The CPU reference brute-forces every triangle (parry HeightField::
@@ -1283,7 +1354,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
     if (S.dofs & 1u) { px = 0.f; v[0] = 0.f; }
     if (S.dofs & 2u) { py = 0.f; v[1] = 0.f; }
     if (S.dofs & 4u) { pz = 0.f; v[2] = 0.f; }
-    if ((S.num_cuboids > 0 || HEIGHTFIELDS) && (S.boundary_handling != SPARKL_BOUNDARY_NONE || S.collider_handling)) {
+    if ((S.num_cuboids > 0 || HEIGHTFIELDS) && (S.boundary_handling != SPARKL_BOUNDARY_NONE || S.collider_handling)) {   // (HEIGHTFIELDS: some collider that is not a cuboid)
         const int4 org = G.blk_origin[b];
         const float cpos[3] = {(float)(org.x + cx) * S.h, (float)(org.y + cy) * S.h, (float)(org.z + cz) * S.h};
         for (int ci = 0; ci < S.num_cuboids; ++ci) {
@@ -1328,6 +1399,11 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
             const DevTriMesh& tm = trimeshes[ti];
             if (tm.handling == SPARKL_BOUNDARY_NONE || (tm.handling < 0 && S.boundary_handling == SPARKL_BOUNDARY_NONE)) continue;
             cached(S.num_heightfields + ti, [&](float proj[3], bool& inside) { return trimesh_project(tm, cpos, 4.0f * S.h, proj, inside); }, tm.friction, tm.handling);
+        }
+        if (HEIGHTFIELDS) for (int pi = 0; pi < G.num_polylines; ++pi) {
+            const DevPolyline& pl = G.polylines[pi];
+            if (pl.handling == SPARKL_BOUNDARY_NONE || (pl.handling < 0 && S.boundary_handling == SPARKL_BOUNDARY_NONE)) continue;
+            cached(S.num_heightfields + S.num_trimeshes + pi, [&](float proj[3], bool& inside) { return polyline_project(pl, cpos, proj, inside); }, pl.friction, pl.handling);
         }
     }
     G.node_vel[(size_t)b * 64 + lane] = make_float4(v[0], v[1], v[2], m);
@@ -1501,6 +1577,15 @@ SPK_DEV void project_particle_on_colliders(const GridArrays& G, const StepParams
             for (int a = 0; a < 3; ++a) { vel[a] += (proj[a] - px[a]) * inv_dt; px[a] = proj[a]; }
         }
     }
+    for (int pi = 0; pi < G.num_polylines; ++pi) {
+        float proj[3];
+        bool inside = false;
+        if (polyline_project(G.polylines[pi], px, proj, inside) && inside) {
+            moved = true;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { vel[a] += (proj[a] - px[a]) * inv_dt; px[a] = proj[a]; }
+        }
+    }
     if (moved) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) u[a] = rel_from_world(px[a], orgv[a], S.h);
@@ -1531,6 +1616,12 @@ SPK_DEV void penalty_kick(const GridArrays& G, const StepParams& S, const int or
         bool inside = false;
         if (G.trimeshes[ti].penalty > 0.f && trimesh_project(G.trimeshes[ti], px, reach, proj, inside) && inside)
             for (int a = 0; a < 3; ++a) f[a] += (proj[a] - px[a]) * G.trimeshes[ti].penalty;
+    }
+    for (int pi = 0; pi < G.num_polylines; ++pi) {
+        float proj[3];
+        bool inside = false;
+        if (G.polylines[pi].penalty > 0.f && polyline_project(G.polylines[pi], px, proj, inside) && inside)
+            for (int a = 0; a < 3; ++a) f[a] += (proj[a] - px[a]) * G.polylines[pi].penalty;
     }
     vel[0] += f[0] * k; vel[1] += f[1] * k; vel[2] += f[2] * k;
 }

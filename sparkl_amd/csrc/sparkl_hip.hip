@@ -184,6 +184,10 @@ struct SparklPipeline {
     std::vector<DevCuboid> h_cuboids;
     std::vector<DevHeightField> h_heightfields;
     std::vector<DevTriMesh> h_trimeshes;
+    std::vector<DevPolyline> h_polylines;
+    DevBuf<DevPolyline> d_polylines;
+    std::vector<float*> d_poly_verts;
+    int num_polylines = 0;
     bool collider_handling = false, collider_penalty = false, rare_by_models = false;
     DevBuf<float4> node_proj;        // GridArrays::node_proj: [heightfields + trimeshes][num_blocks][64]
     DevBuf<int> node_proj_blk;       // GridArrays::node_proj_blk: [heightfields + trimeshes][num_blocks]
@@ -368,6 +372,7 @@ static GridArrays grid_arrays(const SparklPipeline* p) {
     GridArrays g;
     g.blk_origin = p->blk_origin.p; g.blk_pfirst = p->blk_pfirst.p; g.blk_pcount = p->blk_pcount.p; g.blk_nbr = p->blk_nbr.p; g.blk_tnbr = p->blk_tnbr.p; g.dt_partial = p->dt_partial.p;
     g.cuboids = p->d_cuboids.p; g.heightfields = p->d_heightfields.p; g.trimeshes = p->d_trimeshes.p;
+    g.polylines = p->d_polylines.p; g.num_polylines = p->num_polylines;
     g.node_proj = nullptr; g.node_proj_blk = nullptr;   // only launch_grid_update hands the cache out (it also sizes and clears it, in stream order)
     g.pblk = p->pblk.p; g.pb_info = p->pb_info.p; g.tile_mode = p->tile_mode.p; g.pb_heads = p->pb_heads.p; g.tiles = p->tiles.p; g.node_vel = p->node_vel.p; g.node_mom = p->capture_mom ? p->node_mom.p : nullptr;
     g.halo_in = (p->slab_on && p->num_blocks) ? p->halo_in.p : nullptr;
@@ -634,7 +639,7 @@ static StepParams make_params(const SparklPipeline* p, const SparklSolverParams*
 
 // the projection cache of the grid update: sized for the current node blocks, zeroed (= "not computed") when they or the colliders changed
 static void prepare_proj_cache(SparklPipeline* p, hipStream_t st) {
-    const size_t slots = (size_t)(p->num_heightfields + p->num_trimeshes);
+    const size_t slots = (size_t)(p->num_heightfields + p->num_trimeshes + p->num_polylines);
     if (!p->proj_cache_on || slots == 0 || p->num_blocks == 0) return;
     const size_t need = slots * (size_t)p->num_blocks * 64, need_blk = slots * (size_t)p->num_blocks;
     if (need > p->node_proj.cap || need_blk > p->node_proj_blk.cap) {
@@ -646,13 +651,13 @@ static void prepare_proj_cache(SparklPipeline* p, hipStream_t st) {
 }
 static void launch_grid_update(SparklPipeline* p, const GridArrays& G_in, const StepParams& S, hipStream_t st) {
     GridArrays G = G_in;
-    if (p->num_heightfields + p->num_trimeshes > 0) {
+    if (p->num_heightfields + p->num_trimeshes + p->num_polylines > 0) {
         prepare_proj_cache(p, st);
         G.node_proj = (p->proj_cache_on && p->node_proj.p && p->node_proj_blk.p && !p->proj_cache_clear) ? p->node_proj.p : nullptr;
         G.node_proj_blk = p->node_proj_blk.p;
     }
     const dim3 grid((p->num_blocks + 3) / 4), block(BLK_THREADS);
-    if (p->num_heightfields > 0 || p->num_trimeshes > 0)
+    if (p->num_heightfields > 0 || p->num_trimeshes > 0 || p->num_polylines > 0)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, true>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, false>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);
@@ -1021,7 +1026,8 @@ void sparkl_hip_pipeline_destroy(SparklPipeline* p) {
     p->d_models.release(); p->d_cuboids.release(); p->d_heightfields.release();
     for (float* d : p->d_heights) (void)hipFree(d);
     for (void* d : p->d_mesh_bufs) (void)hipFree(d);
-    p->d_trimeshes.release();
+    for (float* d : p->d_poly_verts) (void)hipFree(d);
+    p->d_trimeshes.release(); p->d_polylines.release();
     p->blk_origin.release(); p->blk_pfirst.release(); p->blk_pcount.release(); p->blk_nbr.release(); p->blk_tnbr.release(); p->pblk.release(); p->pb_info.release(); p->tile_mode.release(); p->pb_heads.release(); p->blk_keys.release();
     p->tiles.release(); p->node_vel.release(); p->node_mom.release(); p->hash_keys.release(); p->hash_vals.release();
     p->keys_a.release(); p->keys_b.release(); p->pb_keys.release(); p->bkeys.release(); p->idx_a.release(); p->idx_b.release();
@@ -1167,6 +1173,7 @@ static void collider_options_changed(SparklPipeline* p) {
     for (const auto& c : p->h_cuboids) { p->collider_handling |= c.handling >= 0; p->collider_penalty |= c.penalty > 0.f; }
     for (const auto& c : p->h_heightfields) { p->collider_handling |= c.handling >= 0; p->collider_penalty |= c.penalty > 0.f; }
     for (const auto& c : p->h_trimeshes) { p->collider_handling |= c.handling >= 0; p->collider_penalty |= c.penalty > 0.f; }
+    for (const auto& c : p->h_polylines) { p->collider_handling |= c.handling >= 0; p->collider_penalty |= c.penalty > 0.f; }
     p->rare_models = p->rare_by_models || p->collider_penalty;   // the penalty force lives in the RARE instantiations of the G2P kernels
     p->proj_cache_clear = true;
     p->carry_valid = false;
@@ -1212,6 +1219,44 @@ int sparkl_hip_colliders_set_trimesh_options(SparklPipeline* p, uint32_t n, cons
         p->h_trimeshes[i].handling = o[i].grid_boundary_handling; p->h_trimeshes[i].penalty = o[i].penalty_stiffness; p->h_trimeshes[i].flip_interior = o[i].flip_interior ? 1 : 0;
     }
     if (n) HIPCHK(hipMemcpy(p->d_trimeshes.p, p->h_trimeshes.data(), n * sizeof(DevTriMesh), hipMemcpyHostToDevice));
+    collider_options_changed(p);
+    return SPARKL_OK;
+}
+int sparkl_hip_colliders_set_polylines(SparklPipeline* p, uint32_t n, const SparklPolylineCollider* c) {
+    if (!p || (n && !c)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null argument");
+    for (uint32_t i = 0; i < n; ++i)
+        if (c[i].num_vertices < 3 || !c[i].vertices) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "polyline %u: a closed polygon needs >= 3 vertices", i);
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    for (float* d : p->d_poly_verts) (void)hipFree(d);
+    p->d_poly_verts.clear();
+    std::vector<DevPolyline> dp(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        float* d = nullptr;
+        HIPCHK(hipMalloc((void**)&d, (size_t)c[i].num_vertices * 3 * sizeof(float)));
+        p->d_poly_verts.push_back(d);
+        HIPCHK(hipMemcpy(d, c[i].vertices, (size_t)c[i].num_vertices * 3 * sizeof(float), hipMemcpyHostToDevice));
+        dp[i].verts = d; dp[i].n = (int)c[i].num_vertices;
+        for (int a = 0; a < 4; ++a) dp[i].q[a] = c[i].rotation[a];
+        for (int a = 0; a < 3; ++a) dp[i].t[a] = c[i].translation[a];
+        dp[i].friction = c[i].friction; dp[i].handling = SPARKL_COLLIDER_HANDLING_FROM_PARAMS; dp[i].penalty = 0.f; dp[i].flip_interior = 0;
+    }
+    CHK(p->d_polylines.reserve(std::max<uint32_t>(n, 1)));
+    if (n) HIPCHK(hipMemcpy(p->d_polylines.p, dp.data(), n * sizeof(DevPolyline), hipMemcpyHostToDevice));
+    p->num_polylines = (int)n;
+    p->h_polylines = dp;
+    collider_options_changed(p);
+    return SPARKL_OK;
+}
+int sparkl_hip_colliders_set_polyline_options(SparklPipeline* p, uint32_t n, const SparklColliderOptions* o) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    CHK(check_options(n, o, p->h_polylines.size(), "polyline"));
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    for (uint32_t i = 0; i < n; ++i) {
+        p->h_polylines[i].handling = o[i].grid_boundary_handling; p->h_polylines[i].penalty = o[i].penalty_stiffness; p->h_polylines[i].flip_interior = o[i].flip_interior ? 1 : 0;
+    }
+    if (n) HIPCHK(hipMemcpy(p->d_polylines.p, p->h_polylines.data(), n * sizeof(DevPolyline), hipMemcpyHostToDevice));
     collider_options_changed(p);
     return SPARKL_OK;
 }
@@ -2654,7 +2699,7 @@ static int launch_subset(SparklPipeline* p, int which, bool fuse_next, bool prim
         if (G.nb_count == 0) return SPARKL_OK;
         const dim3 grid((G.nb_count + 3) / 4), block(BLK_THREADS);
         G.node_proj = nullptr;   // (two streams: the projection cache is only handed out by the single-stream launch_grid_update)
-        if (p->num_heightfields > 0 || p->num_trimeshes > 0)
+        if (p->num_heightfields > 0 || p->num_trimeshes > 0 || p->num_polylines > 0)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, true>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, false>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);

@@ -159,11 +159,16 @@ class MpmPipeline:
         arr = (abi.TriMeshColliderC * max(len(trimeshes), 1))(*trimeshes)
         check(self.L.sparkl_hip_colliders_set_trimeshes(self.h, C.c_uint32(len(trimeshes)), arr))
 
+    def set_polylines(self, polylines):
+        """`CudaColliderSet::from_collider_set` for polyline colliders (abi.polyline(..)); applied after the triangle meshes."""
+        arr = (abi.PolylineColliderC * max(len(polylines), 1))(*polylines)
+        check(self.L.sparkl_hip_colliders_set_polylines(self.h, C.c_uint32(len(polylines)), arr))
+
     def set_collider_options(self, kind, options):
         """`CudaColliderSet::from_collider_set(.., options)`: one abi.collider_options(..) per collider of `kind` ("cuboid", "heightfield",
-        "trimesh"), in the order of the matching set_* call (which resets the options of its kind to the defaults)."""
+        "trimesh", "polyline"), in the order of the matching set_* call (which resets the options of its kind to the defaults)."""
         fn = {"cuboid": self.L.sparkl_hip_colliders_set_cuboid_options, "heightfield": self.L.sparkl_hip_colliders_set_heightfield_options,
-              "trimesh": self.L.sparkl_hip_colliders_set_trimesh_options}[kind]
+              "trimesh": self.L.sparkl_hip_colliders_set_trimesh_options, "polyline": self.L.sparkl_hip_colliders_set_polyline_options}[kind]
         arr = (abi.ColliderOptionsC * max(len(options), 1))(*options)
         check(fn(self.h, C.c_uint32(len(options)), arr))
 
@@ -294,6 +299,7 @@ class MpmPipeline:
         self.set_colliders(scene.colliders)
         self.set_heightfields(getattr(scene, "heightfields", []))
         self.set_trimeshes(getattr(scene, "trimeshes", []))
+        self.set_polylines(getattr(scene, "polylines", []))
         for kind, opts in getattr(scene, "collider_options", {}).items():
             self.set_collider_options(kind, opts)
         self.upload_particles(scene.particles)

@@ -74,6 +74,7 @@ class Scene:
         self.domain_log2_bytes = domain_log2_bytes
         self.heightfields = []
         self.trimeshes = []
+        self.polylines = []
         self.collider_options = {}     # kind ("cuboid" | "heightfield" | "trimesh") -> [abi.collider_options(..)] (CudaColliderOptions)
 
 

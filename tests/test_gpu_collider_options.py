@@ -167,3 +167,55 @@ def test_projection_cache_is_bit_identical_and_survives_rebins(Pipeline, kind, m
     assert rebins >= 2
     for k in ("position", "velocity", "volume", "velocity_gradient"):
         assert getattr(on, k).tobytes() == getattr(off, k).tobytes(), k
+
+
+def _sand_over_polyline():
+    """A sand block over a V-shaped ground given as a closed counter-clockwise polygon in the x-y plane (extruded along z): the polyline collider of
+    the reference's GPU path (gpu_collider.rs:99-201), rotated a little about z so that the pose is exercised."""
+    sc = scenes.sand_column(12, 6, 10, with_block=False)
+    sc.colliders = []
+    sc.particles.velocity["vector"][:, 1] = -2.0
+    sc.particles.velocity["vector"][:, 0] = 0.8
+    verts = np.array([[-5.0, -1.0], [8.0, -1.0], [8.0, 1.2], [1.4, 0.75], [-5.0, 1.2]], dtype=np.float32)
+    ang = 0.02
+    sc.polylines = [abi.polyline(verts, translation=(0.0, 0.0, 0.3), rotation=(0.0, 0.0, np.sin(ang / 2), np.cos(ang / 2)), friction=0.4)]
+    return sc
+
+
+def test_polyline_collider_parity(Pipeline):
+    sc = _sand_over_polyline()
+    dt, n = 2.5e-4, 160
+    got = _hip(Pipeline, sc, n, dt)
+    r32, r64 = _oracles(sc, n, dt)
+    rep, bad = parity_verdict(got, r32, r64, sc.cell_width)
+    free_vy = -2.0 + sc.gravity[1] * dt * n
+    touched = int((np.abs(r64.velocity["vector"][:, 1] - free_vy) > 0.05).sum())
+    print("polyline ground: vs f64", rep["vs_f64"]["eps_x"], rep["vs_f64"]["eps_v"], "| particles the ground has slowed:", touched)
+    assert touched > 100, "the scene must reach the collider"
+    assert not bad, (bad, rep)
+
+
+def test_polyline_inside_test_matches_the_oracle_node_by_node(Pipeline):
+    """Stick handling makes is_inside visible on the grid: node velocities after one substep against the oracle's, including the nodes next to
+    the reentrant vertex of the V (where the inside test takes the adjacent segment's direction)."""
+    from oracle import Oracle
+    from tests.parity import node_errors
+    sc = _sand_over_polyline()
+    sc.params = copy.copy(sc.params)
+    sc.params.boundary_handling = abi.BOUNDARY_STICK
+    sc.particles.position["point"][:, 1] -= np.float32(0.4 * sc.cell_width)     # the lowest particles scatter onto nodes inside the ground
+    dt = 2.5e-4
+    o = Oracle(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes, threads=_threads())
+    o.load_scene(sc)
+    o.sort(); o.p2g(dt, sc.gravity); o.grid_update(dt, sc.params.boundary_handling, 0)
+    ref = o.nodes()
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.grid_debug_capture(True)
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, dt, 1)
+        e = node_errors(p.read_grid_nodes(), ref)
+    stuck = int((np.abs(ref["velocity"]).max(axis=1) == 0.0).sum())
+    print("polyline stick: node errors", e, "| nodes stopped inside the ground:", stuck)
+    assert e["n_got"] == e["n_ref"] == e["n_common"]
+    assert stuck > 20
+    assert e["velocity_rel"] < 2e-5
