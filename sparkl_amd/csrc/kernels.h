@@ -879,13 +879,6 @@ SPK_DEV void tile_write(double (*tile)[ACC_N], const GridArrays& G, int pb, int 
     if (tid == 0) G.tile_mode[pb] = mode;
 }
 // (mass, momentum) partial of tile `t` at tile coordinate (tx, ty, tz) in [0, 8)^3
-SPK_DEV float4 tile_read(const GridArrays& G, int t, int tx, int ty, int tz) {
-    const int mode = G.tile_mode[t];
-    if (mode == TILE_MODE_MASS) return make_float4(((const float*)(G.tiles + (size_t)t * TILE_N))[tx + TILE_W * ty + TILE_W * TILE_W * tz], 0.f, 0.f, 0.f);
-    const int i = tile_box_index(mode, tx, ty, tz);
-    if (i < 0) return make_float4(0.f, 0.f, 0.f, 0.f);
-    return G.tiles[(size_t)t * TILE_N + i];
-}
 
 // One thread per launch: account for the heads of the previous scatter (index `prev`), arm the counter, maybe abort.
 // `parity` is the launch's substep parity: like a margin violation, the abort takes effect from the next substep.
@@ -1299,9 +1292,12 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
     const int nb_total = G.nb_list ? G.nb_count : G.num_blocks;
     const int bi = xcd_remap(blockIdx.x, (nb_total + 3) / 4) * 4 + (threadIdx.x >> 6);
     if (bi >= nb_total) return;
-    const int b = G.nb_list ? G.nb_list[bi] : bi;
+    // (one node block per wave: b is wave-uniform, and as a scalar it turns the block's origin into a scalar load issued HERE, beside the table
+    // read, instead of one more dependent round trip behind the tile reads where the collider loop first needs it)
+    const int b = __builtin_amdgcn_readfirstlane(G.nb_list ? G.nb_list[bi] : bi);
     const int lane = threadIdx.x & 63;
     const int cx = lane & 3, cy = (lane >> 2) & 3, cz = lane >> 4;
+    const int4 org = G.blk_origin[b];
     const int dx0 = cx <= 2 ? -1 : 0, dy0 = cy <= 2 ? -1 : 0, dz0 = cz <= 2 ? -1 : 0;
     // The 27 neighbour tiles of the block and their storage modes are the same for the whole wave (one node block per wave): lanes 0..26
     // load one table entry and one mode each -- two coalesced loads instead of sixteen 4-byte gathers per lane, a third of the kernel's
@@ -1319,24 +1315,39 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
         tl[i] = __builtin_amdgcn_ds_bpermute(src, my_t);
         mode[i] = MASS_ONLY ? 0 : __builtin_amdgcn_ds_bpermute(src, my_mode);
     }
+    // The eight tile reads of a node are issued back to back, without a branch around any of them: a read that has nothing to fetch (no such tile, or a
+    // node outside the box the tile stored) goes to element 0 of tile 0 and is replaced by zeros -- x + 0 is x, so the sums are those of the guarded
+    // loop bit for bit.  With a branch per read the compiler waited for each one inside its branch: eight dependent round trips to memory per wave
+    // behind the three of the tables (2.7 TB/s at 10 M particles; profiles/r05_kernel_experiments.txt, 10).
     float m = 0.f, px = 0.f, py = 0.f, pz = 0.f;
+    if (MASS_ONLY) {   // every tile was written by a mass pass (TILE_MODE_MASS)
+        float tm[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int dx = dx0 + (i & 1), dy = dy0 + ((i >> 1) & 1), dz = dz0 + (i >> 2);
-        const int tx = cx - 4 * dx + 1, ty = cy - 4 * dy + 1, tz = cz - 4 * dz + 1;
-        if (MASS_ONLY) {   // every tile was written by a mass pass (TILE_MODE_MASS)
-            if (tl[i] >= 0) m += ((const float*)(G.tiles + (size_t)tl[i] * TILE_N))[tx + TILE_W * ty + TILE_W * TILE_W * tz];
-            continue;
+        for (int i = 0; i < 8; ++i) {
+            const int dx = dx0 + (i & 1), dy = dy0 + ((i >> 1) & 1), dz = dz0 + (i >> 2);
+            const int tx = cx - 4 * dx + 1, ty = cy - 4 * dy + 1, tz = cz - 4 * dz + 1;
+            tm[i] = ((const float*)(G.tiles + (size_t)max(tl[i], 0) * TILE_N))[tx + TILE_W * ty + TILE_W * TILE_W * tz];
         }
-        const int off = tile_box_index(mode[i], tx, ty, tz);   // -1: outside what the tile stored
-        if ((tl[i] >= 0) & (off >= 0)) {
-            const float4 v = G.tiles[(size_t)tl[i] * TILE_N + off];
-            m += v.x; px += v.y; py += v.z; pz += v.w;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m += tl[i] >= 0 ? tm[i] : 0.f;
+    } else {
+        float4 tv[8];
+        bool ok[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int dx = dx0 + (i & 1), dy = dy0 + ((i >> 1) & 1), dz = dz0 + (i >> 2);
+            const int tx = cx - 4 * dx + 1, ty = cy - 4 * dy + 1, tz = cz - 4 * dz + 1;
+            const int off = tile_box_index(mode[i], tx, ty, tz);   // -1: outside what the tile stored
+            ok[i] = (tl[i] >= 0) & (off >= 0);
+            tv[i] = G.tiles[ok[i] ? (size_t)tl[i] * TILE_N + off : (size_t)0];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            m += ok[i] ? tv[i].x : 0.f; px += ok[i] ? tv[i].y : 0.f; py += ok[i] ? tv[i].z : 0.f; pz += ok[i] ? tv[i].w : 0.f;
         }
     }
     if (G.halo_in) {  // partial sums of the neighbour slab(s): a + b is bit-identical on both sides of a cut
-        const int4 ob = G.blk_origin[b];
-        const int bp = (G.halo_axis == 0 ? ob.x : (G.halo_axis == 1 ? ob.y : ob.z)) >> 2;
+        const int bp = (G.halo_axis == 0 ? org.x : (G.halo_axis == 1 ? org.y : org.z)) >> 2;
         if (bp == G.halo_lo || bp == G.halo_hi || bp + 1 == G.halo_lo || bp + 1 == G.halo_hi) {   // wave-uniform: one block per wave
             const float4 hv = G.halo_in[(size_t)b * 64 + lane];
             m += hv.x; px += hv.y; py += hv.z; pz += hv.w;
@@ -1355,7 +1366,6 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
     if (S.dofs & 2u) { py = 0.f; v[1] = 0.f; }
     if (S.dofs & 4u) { pz = 0.f; v[2] = 0.f; }
     if ((S.num_cuboids > 0 || HEIGHTFIELDS) && (S.boundary_handling != SPARKL_BOUNDARY_NONE || S.collider_handling)) {   // (HEIGHTFIELDS: some collider that is not a cuboid)
-        const int4 org = G.blk_origin[b];
         const float cpos[3] = {(float)(org.x + cx) * S.h, (float)(org.y + cy) * S.h, (float)(org.z + cz) * S.h};
         for (int ci = 0; ci < S.num_cuboids; ++ci) {
             const DevCuboid col = cuboids[ci];
@@ -3172,25 +3182,44 @@ __global__ void k_gather_flags(const uint32_t* __restrict__ order, const unsigne
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = flag[order[i]];
 }
-// this slab's partial (mass, momentum) of node (cx, cy, cz) of block b, gathered from its own tiles
+// this slab's partial (mass, momentum) of node (cx, cy, cz) of block b, gathered from its own tiles.
+// Three dependent round trips -- the eight tile-neighbour entries, their storage modes, the eight node records, each set issued back to back without a
+// branch (a missing tile reads element 0 and is replaced by zeros: the sums are those of a guarded loop bit for bit) -- where the loop
+// blk_nbr -> blk_origin.w -> tile_mode -> tile per neighbour made thirty-two, on the critical path of every substep of a slab group.
 SPK_DEV float4 halo_node_sum(const GridArrays& G, int b, int cx, int cy, int cz) {
     const int dx0 = cx <= 2 ? -1 : 0, dy0 = cy <= 2 ? -1 : 0, dz0 = cz <= 2 ? -1 : 0;
+    int t[8], mode[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int dx = dx0 + (k & 1), dy = dy0 + ((k >> 1) & 1), dz = dz0 + (k >> 2);
+        t[k] = G.blk_tnbr[b * 27 + (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mode[k] = G.tile_mode[max(t[k], 0)];
+    float4 v[8];
+    bool ok[8], mass_tile[8], any_mass = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int dx = dx0 + (k & 1), dy = dy0 + ((k >> 1) & 1), dz = dz0 + (k >> 2);
+        const int tx = cx - 4 * dx + 1, ty = cy - 4 * dy + 1, tz = cz - 4 * dz + 1;
+        mass_tile[k] = (t[k] >= 0) & (mode[k] == TILE_MODE_MASS);
+        any_mass |= mass_tile[k];
+        const int i = tile_box_index(mode[k], tx, ty, tz);
+        ok[k] = (t[k] >= 0) & !mass_tile[k] & (i >= 0);
+        v[k] = G.tiles[ok[k] ? (size_t)t[k] * TILE_N + i : (size_t)0];
+    }
+    if (__any(any_mass)) {   // tiles of a fluid mass pass: one float per node, all 8^3 of them
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int dx = dx0 + (k & 1), dy = dy0 + ((k >> 1) & 1), dz = dz0 + (k >> 2);
+            const int tx = cx - 4 * dx + 1, ty = cy - 4 * dy + 1, tz = cz - 4 * dz + 1;
+            const float f = ((const float*)(G.tiles + (size_t)max(t[k], 0) * TILE_N))[tx + TILE_W * ty + TILE_W * TILE_W * tz];
+            if (mass_tile[k]) { v[k] = make_float4(f, 0.f, 0.f, 0.f); ok[k] = true; }
+        }
+    }
     float m = 0.f, px = 0.f, py = 0.f, pz = 0.f;
 #pragma unroll
-    for (int iz = 0; iz < 2; ++iz)
-#pragma unroll
-        for (int iy = 0; iy < 2; ++iy)
-#pragma unroll
-            for (int ix = 0; ix < 2; ++ix) {
-                const int dx = dx0 + ix, dy = dy0 + iy, dz = dz0 + iz;
-                const int nb = G.blk_nbr[b * 27 + (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1)];
-                if (nb < 0) continue;
-                const int t = G.blk_origin[nb].w;
-                if (t < 0) continue;
-                const int tx = cx - 4 * dx + 1, ty = cy - 4 * dy + 1, tz = cz - 4 * dz + 1;
-                const float4 v = tile_read(G, t, tx, ty, tz);
-                m += v.x; px += v.y; py += v.z; pz += v.w;
-            }
+    for (int k = 0; k < 8; ++k) { m += ok[k] ? v[k].x : 0.f; px += ok[k] ? v[k].y : 0.f; py += ok[k] ? v[k].z : 0.f; pz += ok[k] ? v[k].w : 0.f; }
     return make_float4(m, px, py, pz);
 }
 // one wave per listed column
@@ -3259,15 +3288,21 @@ struct HaloSides {
 // (psi_mass, psi_momentum) partial of node (cx, cy, cz) of block b from this slab's psi tiles (DamageModel::ModifiedEigenerosion)
 SPK_DEV float4 halo_node_sum_psi(const GridArrays& G, const float2* __restrict__ psi_tiles, int b, int cx, int cy, int cz) {
     const int dx0 = cx <= 2 ? -1 : 0, dy0 = cy <= 2 ? -1 : 0, dz0 = cz <= 2 ? -1 : 0;
-    float m = 0.f, pm = 0.f;
+    int t[8];
+    float2 v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int dx = dx0 + (k & 1), dy = dy0 + ((k >> 1) & 1), dz = dz0 + (k >> 2);
-        const int t = G.blk_tnbr[b * 27 + (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1)];
-        if (t < 0) continue;
-        const float2 v = psi_tiles[(size_t)t * TILE_N + (cx - 4 * dx + 1) + TILE_W * (cy - 4 * dy + 1) + TILE_W * TILE_W * (cz - 4 * dz + 1)];
-        m += v.x; pm += v.y;
+        t[k] = G.blk_tnbr[b * 27 + (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1)];
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {   // (branch-free like halo_node_sum: two round trips instead of sixteen)
+        const int dx = dx0 + (k & 1), dy = dy0 + ((k >> 1) & 1), dz = dz0 + (k >> 2);
+        v[k] = psi_tiles[(size_t)max(t[k], 0) * TILE_N + (cx - 4 * dx + 1) + TILE_W * (cy - 4 * dy + 1) + TILE_W * TILE_W * (cz - 4 * dz + 1)];
+    }
+    float m = 0.f, pm = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { m += t[k] >= 0 ? v[k].x : 0.f; pm += t[k] >= 0 ? v[k].y : 0.f; }
     return make_float4(m, pm, 0.f, 0.f);
 }
 // `psi_tiles` != NULL: the records carry (psi_mass, psi_momentum, 0, 0) of the psi sweep instead of (mass, momentum)
