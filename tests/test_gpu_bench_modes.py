@@ -16,8 +16,10 @@ VIOLATIONS = ("bad_particle_ids", "blocks_not_in_hash", "particles_outside_their
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench_two_ranks(extra, port):
+def _bench_two_ranks(extra, port, env_extra=None):
     env = dict(os.environ, SPARKL_BENCH_BACKEND="gloo", SPARKL_BENCH_ONE_DEVICE="1")
+    if env_extra is not None:   # replaces the gloo hook: e.g. the library's own group loop over the host-staged transport
+        env = dict(os.environ, SPARKL_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-copy-peak", "--clock-wake-ms", "0"] + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
@@ -47,6 +49,20 @@ def test_bench_two_ranks_strong_sand_keeps_the_total():
     w = _bench_two_ranks(["--particles", "1e5"], 29545)          # default: weak, one configured column per rank
     assert w["scaling"] == "weak" and w["config"]["particles_total"] == 2 * w["config"]["particles_per_gpu"]
     assert w["metric"].startswith("particle-steps/sec (whole node) + achieved HBM GB/s, 3D sand 10M particles")
+
+
+def test_bench_two_ranks_default_path_is_the_library_group_loop():
+    """The DEFAULT N > 1 path of bench.py -- comm mode "rccl": sparkl_hip_comm_init from a broadcast unique id, then sparkl_hip_group_substeps, the C++
+    loop with the flag all-reduce, the halo send / recv and the schedule calibration -- launched exactly as the driver launches it (torch.distributed.run,
+    one process per rank), with the one substitution a one-GPU box needs: the host-staged transport behind the same function table
+    (SPARKL_HIP_TRANSPORT=host; RCCL refuses two ranks on one device)."""
+    o = _bench_two_ranks(["--particles", "4e5"], 29547, env_extra={"SPARKL_HIP_TRANSPORT": "host"})
+    assert o["n_gpus"] == 2 and o["ranks"] == 2 and o["scaling"] == "weak"
+    cfg = o["config"]
+    assert cfg["particles_total"] == 2 * cfg["particles_per_gpu"]
+    assert o["value"] == pytest.approx(cfg["particles_total"] / (o["ms_per_step"] * 1e-3), rel=1e-6)
+    assert o["roofline"]["frac"] > 0.0 and o["halo_ms_per_step"] >= 0.0
+    assert o.get("comm") == "rccl" or "overlap" in o, sorted(o)
 
 
 def test_config5_80M_as_eight_slabs_of_one_device():
