@@ -173,8 +173,8 @@ struct StepParams {
     int want_dt;      // G2P also reduces the next substep's dt bound into ctl->dt_bits (adaptive stepping)
     int num_models;   // entries of the model table (<= MAX_LDS_MODELS: the particle kernels stage it in LDS)
     float dt_next;    // k_g2p2g: the step length the fused scatter (P2G of the NEXT substep) is built for; = dt for fixed-dt batches
-    // k_g2p2g inside a fixed-dt batch: the next fused launch takes v and C from the grid, never from the particle, so C.m[1..8]
-    // (32 of the 112 B the kernel writes per particle) are only stored by the launch that ends the batch.  If the batch is cut
+    // k_g2p2g inside a fixed-dt batch: the next fused launch takes v and C from the grid, never from the particle, so v and C
+    // (q[3..5]: 48 of the 112 B the kernel writes per particle) are only stored by the launch that ends the batch.  If the batch is cut
     // short (re-bin request), k_regather_c rebuilds them from the node velocities of the last substep that ran.
     int defer_c;
     // standalone P2G kernels (DPP scatter: their heads are lane-GROUP heads, another measure than the fused run-task scatter's distinct cells):
@@ -1852,15 +1852,15 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const MO& mo
     o.eh = eh; o.phase = phase;
     return o;
 }
-// `defer_c`: q[4], q[5] (C.m[1..8]) are not written; k_regather_c recomputes them if anything but the next fused launch needs
+// `defer_c`: q[3], q[4], q[5] (v and C) are not written; k_regather_c recomputes them if anything but the next fused launch needs
 // them (see StepParams::defer_c)
 SPK_DEV void g2p_store(const ParticleArrays& P, int i, const Advected& o, int defer_c = 0) {
     P.q[0][i] = make_float4(o.px[0], o.px[1], o.px[2], o.Fe.m[0]);
     P.q[1][i] = make_float4(o.Fe.m[1], o.Fe.m[2], o.Fe.m[3], o.Fe.m[4]);
     P.q[2][i] = make_float4(o.Fe.m[5], o.Fe.m[6], o.Fe.m[7], o.Fe.m[8]);
-    P.q[3][i] = make_float4(o.vel[0], o.vel[1], o.vel[2], o.C.m[0]);
-    // a particle that just left the domain is never touched again (k_regather_c included): its last C is stored now
+    // a particle that just left the domain is never touched again (k_regather_c included): its last v and C are stored now
     if (!defer_c || (o.flags & FLAG_INVALID)) {
+        P.q[3][i] = make_float4(o.vel[0], o.vel[1], o.vel[2], o.C.m[0]);
         P.q[4][i] = make_float4(o.C.m[1], o.C.m[2], o.C.m[3], o.C.m[4]);
         P.q[5][i] = make_float4(o.C.m[5], o.C.m[6], o.C.m[7], o.C.m[8]);
     }
@@ -1878,8 +1878,8 @@ SPK_DEV void g2p_store_at(const ParticleArrays& Pb, unsigned off, const Advected
     *at_off(Pb.q[0], off) = make_float4(o.px[0], o.px[1], o.px[2], o.Fe.m[0]);
     *at_off(Pb.q[1], off) = make_float4(o.Fe.m[1], o.Fe.m[2], o.Fe.m[3], o.Fe.m[4]);
     *at_off(Pb.q[2], off) = make_float4(o.Fe.m[5], o.Fe.m[6], o.Fe.m[7], o.Fe.m[8]);
-    *at_off(Pb.q[3], off) = make_float4(o.vel[0], o.vel[1], o.vel[2], o.C.m[0]);
     if (!defer_c || (o.flags & FLAG_INVALID)) {
+        *at_off(Pb.q[3], off) = make_float4(o.vel[0], o.vel[1], o.vel[2], o.C.m[0]);
         *at_off(Pb.q[4], off) = make_float4(o.C.m[1], o.C.m[2], o.C.m[3], o.C.m[4]);
         *at_off(Pb.q[5], off) = make_float4(o.C.m[5], o.C.m[6], o.C.m[7], o.C.m[8]);
     }
@@ -2102,10 +2102,14 @@ __global__ __launch_bounds__(BLK_THREADS, (RARE ? SPK_RARE_MIN_BLOCKS : SPK_G2P2
     }
 }
 
-// Rebuilds C.m[1..8] (q[4], q[5]) after a fixed-dt batch was cut short behind a fused launch that deferred them
-// (StepParams::defer_c).  The node velocities of the last substep that ran are still in place (every later grid update was
-// a no-op), v is stored, so the position the gather was evaluated at is x - v dt (to one rounding of x: C comes back to
-// ~1e-6 relative, v and C.m[0] are the stored bits).  Static and failed particles carry C = 0 (grid_to_particle.rs:104-121).
+// Rebuilds v and C (q[3], q[4], q[5]) after a fixed-dt batch was cut short behind a fused launch that deferred them (StepParams::defer_c).
+// The node velocities of the last substep that ran are still in place (every later grid update was a no-op) and the stored position is the
+// ADVECTED one, x' = x + v(x) dt with v(x) the APIC gather at x (grid_to_particle.rs:47-86): v is the fixed point of  v = gather(x' - v dt),
+// a contraction by |grad v| dt per round (1e-3 .. 1e-2 under any stable step), started from the gather at x' and iterated until two rounds
+// agree to 2^-22 of the velocity (three or four gathers; at most eight).  What comes back: v and C to ~1e-6 relative (x' carries one
+// rounding of the sum), the same order as the f32 gather's own rounding.  Kinematic particles take their prescribed velocity (exactly the
+// kernel's override), static ones v = 0, C = 0, failed ones C = 0 (grid_to_particle.rs:82-121).  Only launches of the non-RARE kernels defer
+// (no particle projection, no penalty kick on v).
 __global__ __launch_bounds__(BLK_THREADS) void k_regather_c(ParticleArrays P, GridArrays G, StepParams S) {
     const int tid = threadIdx.x;
     __shared__ VelTile vt;
@@ -2116,15 +2120,35 @@ __global__ __launch_bounds__(BLK_THREADS) void k_regather_c(ParticleArrays P, Gr
     __syncthreads();
     for (int li = tid; li < pcount; li += BLK_THREADS) {
         const int i = pfirst + li;
-        const float4 q0 = P.q[0][i], q3 = P.q[3][i];
+        const float4 q0 = P.q[0][i];
         const uint32_t flags = __float_as_uint(P.k[i].w);
         if (flags & FLAG_INVALID) continue;
         M3 C = m3_zero();
-        if (!(flags & (FLAG_STATIC | FLAG_FAILED))) {
-            const float u[3] = {q0.x - q3.x * S.dt_h, q0.y - q3.y * S.dt_h, q0.z - q3.z * S.dt_h};
-            float vel[3];
-            apic_gather<true>(vt, u, S, vel, C);
+        float v[3] = {0.f, 0.f, 0.f};
+        if (!(flags & FLAG_STATIC)) {
+            const float x1[3] = {q0.x, q0.y, q0.z};
+            if (flags & FLAG_KINEMATIC) {
+                const float4 kv = P.kinvel[i];
+                v[0] = kv.x; v[1] = kv.y; v[2] = kv.z;
+                const float u[3] = {x1[0] - v[0] * S.dt_h, x1[1] - v[1] * S.dt_h, x1[2] - v[2] * S.dt_h};
+                float vg[3];
+                apic_gather<true>(vt, u, S, vg, C);
+            } else {
+                apic_gather<true>(vt, x1, S, v, C);
+#pragma unroll 1
+                for (int round = 0; round < 8; ++round) {
+                    const float u[3] = {x1[0] - v[0] * S.dt_h, x1[1] - v[1] * S.dt_h, x1[2] - v[2] * S.dt_h};
+                    float vn[3];
+                    apic_gather<true>(vt, u, S, vn, C);
+                    const float d = fmaxf(fmaxf(fabsf(vn[0] - v[0]), fabsf(vn[1] - v[1])), fabsf(vn[2] - v[2]));
+                    const float s = fmaxf(fmaxf(fabsf(vn[0]), fabsf(vn[1])), fabsf(vn[2]));
+                    v[0] = vn[0]; v[1] = vn[1]; v[2] = vn[2];
+                    if (!(d > 2.4e-7f * s)) break;   // (also leaves on NaN)
+                }
+            }
+            if (flags & FLAG_FAILED) C = m3_zero();
         }
+        P.q[3][i] = make_float4(v[0], v[1], v[2], C.m[0]);
         P.q[4][i] = make_float4(C.m[1], C.m[2], C.m[3], C.m[4]);
         P.q[5][i] = make_float4(C.m[5], C.m[6], C.m[7], C.m[8]);
     }
