@@ -105,6 +105,11 @@ struct ParticleArrays {
     float4* kinvel;   // (kx, ky, kz, -)
     float4* aux;      // (phase, radius0, nacc_alpha, bits of the particle's caller/global id): cold, only moved by re-bins
     float4* frac;     // (crack_propagation_factor, crack_threshold, -, -): ParticleFracture, NULL unless the caller uploaded it
+    // Mirror of the flags words (k[i].w) as a dense 4-byte stream, or NULL.  Built by the re-bin (k_permute) when every binned particle carries the
+    // same (mass, volume0, elastic hardening) -- a lattice-sampled body, the benchmark's column -- and the models are the fused kernel's Drucker-Prager
+    // view: that kernel (MSET = 4) then reads 4 bytes per particle where the k stream costs 16, the three constants travel in StepParams.  Kept in
+    // step by everything that touches a binned particle's flags between two re-bins: the G2P stores (newly failed) and the in-place block reorder.
+    uint32_t* fl;
 };
 SPK_DEV uint32_t particle_id(const ParticleArrays& P, int i) { return reinterpret_cast<const uint32_t*>(&P.aux[i])[3]; }
 
@@ -169,6 +174,7 @@ struct StepParams {
     int project_particles;   // SolverParameters::enable_boundary_particle_projection
     int collider_handling;   // some collider carries its own grid_boundary_handling (SparklColliderOptions): the grid update may not skip on boundary_handling == None
     int penalty;             // some collider has a penalty_stiffness: the RARE G2P kernels apply the force
+    float ku_mass, ku_vol0, ku_eh;   // the (mass, volume0, elastic hardening) every binned particle shares when the launch runs on ParticleArrays::fl
     int jp_one;              // every particle was uploaded with plastic_deformation_gradient_det == 1 and every model is a plain fluid (nothing changes it): k_vol_p2g does not read it
     int want_dt;      // G2P also reduces the next substep's dt bound into ctl->dt_bits (adaptive stepping)
     int num_models;   // entries of the model table (<= MAX_LDS_MODELS: the particle kernels stage it in LDS)
@@ -1865,7 +1871,7 @@ SPK_DEV void g2p_store(const ParticleArrays& P, int i, const Advected& o, int de
         P.q[5][i] = make_float4(o.C.m[5], o.C.m[6], o.C.m[7], o.C.m[8]);
     }
     P.d[i] = make_float4(o.q, o.lvg, o.Jp, o.psi);
-    if (o.newly_failed) reinterpret_cast<uint32_t*>(&P.k[i])[3] = o.flags;
+    if (o.newly_failed) { reinterpret_cast<uint32_t*>(&P.k[i])[3] = o.flags; if (P.fl) P.fl[i] = o.flags; }
     if (o.store_k) reinterpret_cast<float*>(&P.k[i])[2] = o.eh;
     if (o.store_aux) { float* a = reinterpret_cast<float*>(&P.aux[i]); a[0] = o.phase; a[2] = o.alpha; }
 }
@@ -1884,7 +1890,7 @@ SPK_DEV void g2p_store_at(const ParticleArrays& Pb, unsigned off, const Advected
         *at_off(Pb.q[5], off) = make_float4(o.C.m[5], o.C.m[6], o.C.m[7], o.C.m[8]);
     }
     *at_off(Pb.d, off) = make_float4(o.q, o.lvg, o.Jp, o.psi);
-    if (o.newly_failed) reinterpret_cast<uint32_t*>(at_off(Pb.k, off))[3] = o.flags;
+    if (o.newly_failed) { reinterpret_cast<uint32_t*>(at_off(Pb.k, off))[3] = o.flags; if (Pb.fl) *at_off(Pb.fl, off >> 2) = o.flags; }
     if (o.store_k) reinterpret_cast<float*>(at_off(Pb.k, off))[2] = o.eh;
     if (o.store_aux) { float* a = reinterpret_cast<float*>(at_off(Pb.aux, off)); a[0] = o.phase; a[2] = o.alpha; }
 }
@@ -1955,7 +1961,8 @@ __global__ __launch_bounds__(BLK_THREADS, (RARE ? SPK_RARE_MIN_BLOCKS_G2P : 4)) 
 #endif
 
 // REDUCE_STEPS >= 0: DPP pre-reduction over groups of 2^REDUCE_STEPS lanes (p2g_scatter); -1: run tasks (p2g_scatter_runs).
-// MSET: 0 = any model table; 1 = every model is a corotated solid with Drucker-Prager plasticity (DpSandModel: no model dispatch);
+// MSET: 0 = any model table; 1 = every model is a corotated solid with Drucker-Prager plasticity (DpSandModel: no model dispatch); 4 = the same view on
+// the flags mirror (ParticleArrays::fl: mass, volume0 and elastic hardening are the same for every binned particle and come from StepParams);
 // 3 = every model is a neo-Hookean solid without plasticity (NeoHookeanOnlyModel)
 #ifndef SPK_RARE_MIN_BLOCKS
 #define SPK_RARE_MIN_BLOCKS 3   // three workgroups per CU (168 VGPRs) instead of four with 244 B/lane of scratch: 1 M snow block k_g2p2g 0.121 -> 0.095 ms (two: 0.115), profiles/r05_kernel_experiments.txt
@@ -1983,6 +1990,12 @@ __global__ __launch_bounds__(BLK_THREADS, (RARE ? SPK_RARE_MIN_BLOCKS : SPK_G2P2
 #pragma unroll
     for (int sidx = 0; sidx < 6; ++sidx) Pb.q[sidx] = P.q[sidx] + pfirst;
     Pb.d = P.d + pfirst; Pb.k = P.k + pfirst; Pb.kinvel = P.kinvel + pfirst; Pb.aux = P.aux + pfirst;
+    constexpr bool KU = MSET == 4;   // flags from the 4-byte mirror, the rest of the k record from StepParams
+    if (P.fl) Pb.fl = P.fl + pfirst;
+    auto load_k = [&](unsigned o16) -> float4 {
+        if constexpr (KU) return make_float4(S.ku_mass, S.ku_vol0, S.ku_eh, __uint_as_float(*at_off(Pb.fl, o16 >> 2)));
+        else return *at_off(Pb.k, o16);
+    };
     // the small loads of the prologue go out AHEAD of the particle loads (vector loads return in order): the neighbour table of the velocity
     // tile (load_vel_tile) and the model table (stage_models_load); what used to be four dependent round trips before the first barrier is one
     const int my_nb = G.blk_nbr[b * 27 + min(tid & 63, 26)];
@@ -1991,11 +2004,12 @@ __global__ __launch_bounds__(BLK_THREADS, (RARE ? SPK_RARE_MIN_BLOCKS : SPK_G2P2
     // The plastic scalars (D stream): prefetched an iteration ahead like the rest where the update reads them early (PREFETCH_D: the
     // neo-Hookean view -- no return map in front of their first use, so a load issued at the top of the iteration is waited for in full:
     // +15 % on the 1 M cube), loaded at the top of the iteration that uses them where the return map sits in front (see the loop).
+    // (MSET = 4 frees three of the four registers of the k prefetch and could carry the D prefetch without a spill: measured, no gain)
     constexpr bool PREFETCH_D = MSET == 3;
     float4 n0, n1, n2, nk, nd = make_float4(0.f, 0.f, 0.f, 0.f);
     {
         const unsigned o0 = (unsigned)min(tid, pcount - 1) << 4;
-        n0 = *at_off(Pb.q[0], o0); n1 = *at_off(Pb.q[1], o0); n2 = *at_off(Pb.q[2], o0); nk = *at_off(Pb.k, o0);
+        n0 = *at_off(Pb.q[0], o0); n1 = *at_off(Pb.q[1], o0); n2 = *at_off(Pb.q[2], o0); nk = load_k(o0);
         if (PREFETCH_D) nd = *at_off(Pb.d, o0);
     }
     if (aborted) {   // sticky abort: keep every later substep a no-op until the host re-bins
@@ -2032,7 +2046,7 @@ __global__ __launch_bounds__(BLK_THREADS, (RARE ? SPK_RARE_MIN_BLOCKS : SPK_G2P2
         const float4 dd = PREFETCH_D ? nd : *at_off(Pb.d, off);
         if (it + 1 < niter) {
             const unsigned on = (unsigned)min(li + BLK_THREADS, pcount - 1) << 4;
-            n0 = *at_off(Pb.q[0], on); n1 = *at_off(Pb.q[1], on); n2 = *at_off(Pb.q[2], on); nk = *at_off(Pb.k, on);
+            n0 = *at_off(Pb.q[0], on); n1 = *at_off(Pb.q[1], on); n2 = *at_off(Pb.q[2], on); nk = load_k(on);
             if (PREFETCH_D) nd = *at_off(Pb.d, on);
         }
         const uint32_t flags = __float_as_uint(kk.w);
@@ -2081,7 +2095,7 @@ __global__ __launch_bounds__(BLK_THREADS, (RARE ? SPK_RARE_MIN_BLOCKS : SPK_G2P2
         };
         if (live) {
             const DevModel& mo_t = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
-            if constexpr (MSET == 1) particle(DpSandModel(mo_t));
+            if constexpr (MSET == 1 || MSET == 4) particle(DpSandModel(mo_t));
             else if constexpr (MSET == 3) particle(NeoHookeanOnlyModel(mo_t));
             else particle(mo_t);
         }
@@ -2240,6 +2254,12 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_block_reorder(ParticleArrays
             __syncthreads();
             if (ok0) { P.q[5][d0] = a1; P.d[d0] = a2; P.k[d0] = a3; P.kinvel[d0] = a4; P.aux[d0] = a5; }
             if (ok1) { P.q[5][d1] = b1; P.d[d1] = b2; P.k[d1] = b3; P.kinvel[d1] = b4; P.aux[d1] = b5; }
+        }
+        if (P.fl) {   // kernel-uniform: the flags mirror follows its particles
+            const uint32_t a1 = P.fl[s0], b1 = P.fl[s1];
+            __syncthreads();
+            if (ok0) P.fl[d0] = a1;
+            if (ok1) P.fl[d1] = b1;
         }
         if (P.frac) {   // kernel-uniform
             const float4 a1 = P.frac[s0], b1 = P.frac[s1];
@@ -2886,7 +2906,8 @@ __global__ void k_shift_keys(const KeyT* __restrict__ keys, uint64_t* bkeys, int
 // coordinate of a particle that stays in its block bit for bit alone, or from world coordinates with one rounding --; a particle that lands
 // in the tail goes back to world coordinates.
 template <class KeyT>
-__global__ void k_permute(ParticleArrays src, ParticleArrays dst, const uint32_t* __restrict__ perm, const KeyT* __restrict__ keys_sorted, const uint32_t* __restrict__ oorg, int n, float h) {
+__global__ void k_permute(ParticleArrays src, ParticleArrays dst, const uint32_t* __restrict__ perm, const KeyT* __restrict__ keys_sorted, const uint32_t* __restrict__ oorg, int n, float h,
+                          uint32_t* __restrict__ fl, uint32_t* __restrict__ k_not_uniform) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t s = perm[i];
@@ -2906,7 +2927,15 @@ __global__ void k_permute(ParticleArrays src, ParticleArrays dst, const uint32_t
 #pragma unroll
     for (int a = 1; a < 6; ++a) dst.q[a][i] = src.q[a][s];
     dst.d[i] = src.d[s];
-    dst.k[i] = src.k[s];
+    const float4 kr = src.k[s];
+    dst.k[i] = kr;
+    if (fl) {   // flags mirror (ParticleArrays::fl) + do all binned particles share the record of the first one?
+        fl[i] = __float_as_uint(kr.w);
+        const float4 k0 = src.k[perm[0]];
+        const bool differs = key < TailKeys<KeyT>::EMIG_LO &&
+                             (__float_as_uint(kr.x) != __float_as_uint(k0.x) || __float_as_uint(kr.y) != __float_as_uint(k0.y) || __float_as_uint(kr.z) != __float_as_uint(k0.z));
+        if (__any(differs) && (threadIdx.x & 63) == __builtin_ctzll(__ballot(differs))) atomicOr(k_not_uniform, 1u);
+    }
     dst.kinvel[i] = src.kinvel[s];
     dst.aux[i] = src.aux[s];
     if (src.frac) dst.frac[i] = src.frac[s];

@@ -173,6 +173,11 @@ struct SparklPipeline {
     int heads_kind = -1;            // which scatter's measure the disorder books hold (note_heads_kind)
     bool all_plain_fluid = false;   // every model is a fluid without plastic / failure model: the FLUID_ONLY kernels apply
     bool all_neo_elastic = false;   // every model is a neo-Hookean solid without plasticity / failure: k_g2p2g<.., MSET = 3>
+    // flags mirror (ParticleArrays::fl): built by every re-bin; ku_ok = every binned particle shares ku[] = (mass, volume0, elastic hardening) and nothing
+    // has touched a flags word behind the mirror's back since (the fluid and psi sweeps do: they clear it until the next re-bin).  SPARKL_HIP_KUNIFORM=0: off
+    DevBuf<uint32_t> fl;
+    bool ku_on = true, ku_ok = false;
+    float ku[3] = {0.f, 0.f, 0.f};
     bool all_dp_sand = false;       // every model is a corotated solid with (always active) Drucker-Prager plasticity: k_g2p2g<.., MSET = 1>
     bool mass_tiles_ready = false;  // k_g2p_mass of the previous substep already scattered the next volume sweep's masses
     bool fluid_bound_valid = false; // adaptive step with the volume sweep: the last dt bound seen (predicts the next step length)
@@ -400,11 +405,12 @@ static int upload_policy(SparklPipeline* p) {
     return SPARKL_OK;
 }
 // every REORDER_PERIOD substeps: the in-place block reorder, which returns at once unless the policy asked for it
+static ParticleArrays with_mirror(const SparklPipeline* p, const ParticleArrays& P0);
 static int maybe_reorder(SparklPipeline* p, int parity) {
     if (p->num_pblocks == 0 || (p->substep_index % REORDER_PERIOD) != 0 || !(effective_reorder_limit(p) > 0.f)) return SPARKL_OK;
     size_t tok = 0;
     CHK(clock_begin(p, SPAN_REORDER, &tok));
-    hipLaunchKernelGGL(k_block_reorder, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, p->stream, p->cur.arrays(), grid_arrays(p), p->d_ctl, p->h, parity);
+    hipLaunchKernelGGL(k_block_reorder, dim3(p->num_pblocks), dim3(BLK_THREADS), 0, p->stream, with_mirror(p, p->cur.arrays()), grid_arrays(p), p->d_ctl, p->h, parity);
     hipLaunchKernelGGL(k_reorder_done, dim3(1), dim3(1), 0, p->stream, p->d_ctl, parity);
     CHK(clock_end(p, tok));
     return SPARKL_OK;
@@ -430,13 +436,14 @@ static int resort(SparklPipeline* p) {
     const int old_npb = p->num_pblocks, old_binned = (int)std::min<uint64_t>(p->n_binned, p->n);
     p->num_blocks = p->num_pblocks = 0;
     p->pb_order_valid = false;
+    p->ku_ok = false;
     if (n > 0) {
         CHK(p->keys_a.reserve(n)); CHK(p->keys_b.reserve(n)); CHK(p->idx_a.reserve(n)); CHK(p->idx_b.reserve(n)); CHK(p->oorg.reserve(n));
         CHK(p->bkeys.reserve(n)); CHK(p->pb_keys.reserve(n)); CHK(p->pb_counts.reserve(n)); CHK(p->pb_first.reserve(n));
         CHK(p->d_scalars.reserve(8));
         p->alt.has_frac = p->cur.has_frac;
         CHK(p->alt.reserve(p->cur.q[0].cap));
-        CHK(p->d_tail.reserve(4));
+        CHK(p->d_tail.reserve(8));
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&p->d_ctl->dead_dt_bits, 0x7f7fffff, 1, st));   // rebuilt from the particles that are outside the domain now
         // key bits actually in use: Morton code of the block coordinate biased by +1 (3 x block_bits) + 6 cell bits; the tail
         // classes (emigrants, out of domain, removed) are all-ones words, so ONE more bit keeps them behind every valid key and
@@ -461,8 +468,10 @@ static int resort(SparklPipeline* p) {
             HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, ka, kb, p->idx_a.p, p->idx_b.p, n, 0, end_bit, st));
             CHK(cub_reserve(p, tb));
             HIPCHK(hipcub::DeviceRadixSort::SortPairs(p->cub_temp.p, tb, ka, kb, p->idx_a.p, p->idx_b.p, n, 0, end_bit, st));
+            // (d_tail[4]: "some binned particle's (mass, volume0, hardening) differs from the first one's", see ParticleArrays::fl)
+            if (p->ku_on) { CHK(p->fl.reserve(p->cur.q[0].cap)); HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(p->d_tail.p + 4), 0, 1, st)); }
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_permute<KeyT>), dim3(grid_for(n, 256)), dim3(256), 0, st, p->cur.arrays(), p->alt.arrays(), p->idx_b.p, (const KeyT*)kb,
-                               (const uint32_t*)p->oorg.p, n, p->h);
+                               (const uint32_t*)p->oorg.p, n, p->h, p->ku_on ? p->fl.p : nullptr, reinterpret_cast<uint32_t*>(p->d_tail.p + 4));
             // block keys of the sorted particles (run-length encoded below) and the tail classes
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shift_keys<KeyT>), dim3(grid_for(n, 256)), dim3(256), 0, st, (const KeyT*)kb, p->bkeys.p, n);
             HIPCHK(hipMemsetD32Async((hipDeviceptr_t)p->d_tail.p, n, 4, st));   // no host staging buffer to outlive
@@ -476,9 +485,14 @@ static int resort(SparklPipeline* p) {
         CHK(cub_reserve(p, tb2));
         HIPCHK(hipcub::DeviceRunLengthEncode::Encode(p->cub_temp.p, tb2, p->bkeys.p, p->pb_keys.p, p->pb_counts.p, p->d_scalars.p, n, st));
         // tail classes (removed | emigrants low | emigrants high | out of domain) sit after the valid keys
-        int h_runs = 0, tail[4] = {n, n, n, n};
+        int h_runs = 0, tail[4] = {n, n, n, n}, k_differs = 1;
+        float4 k_first = make_float4(0.f, 0.f, 0.f, 0.f);
         HIPCHK(hipMemcpyAsync(&h_runs, p->d_scalars.p, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(tail, p->d_tail.p, sizeof(tail), hipMemcpyDeviceToHost, st));
+        if (p->ku_on) {
+            HIPCHK(hipMemcpyAsync(&k_differs, p->d_tail.p + 4, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(&k_first, p->cur.k.p, sizeof(float4), hipMemcpyDeviceToHost, st));   // slot 0 of the new order
+        }
         HIPCHK(hipStreamSynchronize(st));
         // tail[k] = first index with class >= k; a missing class keeps the bound of the next one
         for (int k = 2; k >= 0; --k) tail[k] = std::min(tail[k], tail[k + 1]);
@@ -488,6 +502,7 @@ static int resort(SparklPipeline* p) {
         p->emig_first[1] = tail[1]; p->n_emig[1] = tail[2] - tail[1];
         p->n = (uint64_t)tail[3];   // particles already handed to a neighbour slab are dropped here
         p->n_binned = (uint64_t)tail[0];   // k_permute left block-relative positions in front of the tail classes, world coordinates behind
+        if (p->ku_on && tail[0] > 0 && k_differs == 0) { p->ku_ok = true; p->ku[0] = k_first.x; p->ku[1] = k_first.y; p->ku[2] = k_first.z; }
         const int npb = h_runs;
         if (npb > 0) {
             size_t tb3 = 0;
@@ -625,6 +640,7 @@ static StepParams make_params(const SparklPipeline* p, const SparklSolverParams*
     S.project_particles = sp->enable_boundary_particle_projection ? 1 : 0;
     S.collider_handling = p->collider_handling ? 1 : 0;
     S.penalty = p->collider_penalty ? 1 : 0;
+    S.ku_mass = p->ku[0]; S.ku_vol0 = p->ku[1]; S.ku_eh = p->ku[2];
     S.jp_one = (p->all_jp_one && p->all_plain_fluid && !p->slab_on) ? 1 : 0;   // (slabs receive immigrants whose value the host has not seen)
     S.dt_next = dt;
     S.count_heads = 1;
@@ -694,18 +710,30 @@ static void launch_p2g(SparklPipeline* p, const ParticleArrays& P, const GridArr
     else if (pair_steps == 0) SPK_LAUNCH_MODELS(k_p2g, SPK_P2G_REDUCE_STEPS);
     else SPK_LAUNCH_MODELS(k_p2g_pair, 3);
 }
-static void launch_g2p(SparklPipeline* p, const ParticleArrays& P, const GridArrays& G, const StepParams& S, hipStream_t st) {
+// the flags mirror travels with every launch that may change a binned particle's flags while it is valid (ParticleArrays::fl)
+static ParticleArrays with_mirror(const SparklPipeline* p, const ParticleArrays& P0) {
+    ParticleArrays P = P0;
+    // (all_dp_sand: no fluid model, so none of the fluid-sweep kernels -- which store flags without the mirror -- ever runs on these particles;
+    // has_frac: the psi sweep's crack test sets FLAG_PHASE_NOT_ONE behind the mirror's back)
+    P.fl = (p->ku_ok && p->all_dp_sand && !p->cur.has_frac) ? p->fl.p : nullptr;
+    return P;
+}
+static void launch_g2p(SparklPipeline* p, const ParticleArrays& P0, const GridArrays& G, const StepParams& S, hipStream_t st) {
+    const ParticleArrays P = with_mirror(p, P0);
     const dim3 grid(p->num_pblocks), block(BLK_THREADS);
     if (p->rare_models || S.project_particles) SPK_LAUNCH_MODELS(k_g2p, true);
     else SPK_LAUNCH_MODELS(k_g2p, false);
 }
-static void launch_g2p2g(SparklPipeline* p, const ParticleArrays& P, const GridArrays& G, const StepParams& S, hipStream_t st) {
+static void launch_g2p2g(SparklPipeline* p, const ParticleArrays& P0, const GridArrays& G, const StepParams& S, hipStream_t st) {
+    const ParticleArrays P = with_mirror(p, P0);
     const dim3 grid(G.pb_list ? G.pb_count : p->num_pblocks), block(BLK_THREADS);   // the whole list or the launch's subset (slab groups)
     note_heads_kind(p, (getenv("SPARKL_HIP_SCATTER") && !strcmp(getenv("SPARKL_HIP_SCATTER"), "dpp")) ? 0 : 1, st);
     // SPARKL_HIP_SCATTER=dpp selects the DPP pre-reduction scatter (A/B); the default is the run-task scatter
     static const bool dpp = getenv("SPARKL_HIP_SCATTER") && !strcmp(getenv("SPARKL_HIP_SCATTER"), "dpp");
     if (p->rare_models || S.project_particles) SPK_LAUNCH_MODELS(k_g2p2g, -1, true);
     else if (dpp) SPK_LAUNCH_MODELS(k_g2p2g, SPK_P2G_REDUCE_STEPS, false);
+    else if (p->all_dp_sand && S.num_models <= MAX_LDS_MODELS && P.fl)   // the same view on the 4-byte flags mirror (every binned particle shares mass, volume0, hardening)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<-1, false, true, 4>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
     else if (p->all_dp_sand && S.num_models <= MAX_LDS_MODELS)   // SPARKL_HIP_MSET=0 keeps the generic kernel (A/B)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<-1, false, true, 1>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
     else if (p->all_neo_elastic && S.num_models <= MAX_LDS_MODELS)
@@ -983,6 +1011,7 @@ int sparkl_hip_pipeline_create(const SparklPipelineDesc* desc, SparklPipeline** 
     SparklPipeline* p = new SparklPipeline;
     p->fuse_fixed_dt = getenv("SPARKL_HIP_NO_FUSE") == nullptr;
     p->defer_c = !(getenv("SPARKL_HIP_DEFER_C") && !strcmp(getenv("SPARKL_HIP_DEFER_C"), "0"));
+    p->ku_on = !(getenv("SPARKL_HIP_KUNIFORM") && !strcmp(getenv("SPARKL_HIP_KUNIFORM"), "0"));
     if (const char* e = getenv("SPARKL_HIP_CARRY")) p->carry_on = atoi(e) != 0;
     if (const char* e = getenv("SPARKL_HIP_PROJ_CACHE")) p->proj_cache_on = atoi(e) != 0;
     if (const char* e = getenv("SPARKL_HIP_OVERLAP")) p->overlap_mode = !strcmp(e, "cal") ? -2 : (atoi(e) != 0 ? 1 : 0);   // "cal": calibrate even on one device (tests)
@@ -1033,7 +1062,7 @@ void sparkl_hip_pipeline_destroy(SparklPipeline* p) {
     p->keys_a.release(); p->keys_b.release(); p->pb_keys.release(); p->bkeys.release(); p->idx_a.release(); p->idx_b.release();
     p->pb_counts.release(); p->pb_first.release(); p->cand_a.release(); p->cand_b.release(); p->cub_temp.release(); p->d_scalars.release();
     p->staging.release(); p->node_staging.release(); p->d_count.release(); p->dt_partial.release(); p->psi_tiles.release(); p->node_psi.release();
-    p->oorg.release(); p->node_proj.release(); p->node_proj_blk.release(); p->pb_order.release(); p->order_keys.release(); p->order_keys_out.release(); p->order_vals.release();
+    p->oorg.release(); p->node_proj.release(); p->node_proj_blk.release(); p->pb_order.release(); p->fl.release(); p->order_keys.release(); p->order_keys_out.release(); p->order_vals.release();
     p->split_pb.release(); p->split_nb.release(); p->split_flags.release(); p->bal_dev.release();
     p->halo_list[0].release(); p->halo_list[1].release(); p->halo_in.release(); p->d_tail.release();
     for (int k = 0; k < 2; ++k) { p->x_send[k].release(); p->x_recv[k].release(); p->x_mig_send[k].release(); p->x_mig_recv[k].release(); }
@@ -3268,4 +3297,10 @@ extern "C" int sparkl_hip_debug_run_stats(SparklPipeline* p, unsigned long long*
     HIPCHK(hipMemcpyAsync(out, p->d_count.p, sizeof(unsigned long long) * RS_HISTS * RS_BINS, hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     return SPARKL_OK;
+}
+
+// (tests) 1 while the fused kernel of this pipeline would run on the flags mirror (ParticleArrays::fl), else 0
+extern "C" int sparkl_hip_debug_flags_mirror(const SparklPipeline* p) {
+    if (!p) return -1;
+    return (p->ku_ok && p->all_dp_sand && !p->cur.has_frac && !p->rare_models) ? 1 : 0;
 }
