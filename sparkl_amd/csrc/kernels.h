@@ -2429,7 +2429,8 @@ SPK_DEV void mass_scatter(double* mtile, const float u[3], float mass, bool live
 }
 
 // G2P of substep s + mass-only scatter of the advected particles (= the first half of substep s+1's volume sweep).
-template <bool FLUID_ONLY, bool LDS_MODELS>
+// KU: the k record comes from the flags mirror + StepParams (ParticleArrays::fl): a plain fluid reads 20 instead of 32 bytes per particle here.
+template <bool FLUID_ONLY, bool LDS_MODELS, bool KU = false>
 __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
     const int tid = threadIdx.x;
     if (ctl->abort_flag[S.parity]) {
@@ -2444,9 +2445,13 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
     const int b = org.w, pfirst = rng.x, pcount = rng.y;
     const int niter = (pcount + BLK_THREADS - 1) / BLK_THREADS;
     float4 n0, n1, n2, nd, nk;
+    auto load_k = [&](int i) -> float4 {
+        if constexpr (KU) return make_float4(S.ku_mass, S.ku_vol0, S.ku_eh, __uint_as_float(P.fl[i]));
+        else return P.k[i];
+    };
     {
         const int i0 = pfirst + min(tid, pcount - 1);
-        n0 = P.q[0][i0]; nk = P.k[i0];
+        n0 = P.q[0][i0]; nk = load_k(i0);
         if (!FLUID_ONLY) { n1 = P.q[1][i0]; n2 = P.q[2][i0]; nd = P.d[i0]; }
     }
     for (int n = tid; n < TILE_N; n += BLK_THREADS) mtile[n] = 0.0;
@@ -2468,7 +2473,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
         const float4 dd = FLUID_ONLY ? make_float4(1.f, 0.f, 1.f, 0.f) : nd;
         if (it + 1 < niter) {
             const int inx = pfirst + min(li + BLK_THREADS, pcount - 1);
-            n0 = P.q[0][inx]; nk = P.k[inx];
+            n0 = P.q[0][inx]; nk = load_k(inx);
             if (!FLUID_ONLY) { n1 = P.q[1][inx]; n2 = P.q[2][inx]; nd = P.d[inx]; }
         }
         const uint32_t flags = __float_as_uint(kk.w);
@@ -2483,7 +2488,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
                 P.q[3][i] = make_float4(o.vel[0], o.vel[1], o.vel[2], o.C.m[0]);
                 P.q[4][i] = make_float4(o.C.m[1], o.C.m[2], o.C.m[3], o.C.m[4]);
                 P.q[5][i] = make_float4(o.C.m[5], o.C.m[6], o.C.m[7], o.C.m[8]);
-                if (o.newly_failed) reinterpret_cast<uint32_t*>(&P.k[i])[3] = o.flags;
+                if (o.newly_failed) { reinterpret_cast<uint32_t*>(&P.k[i])[3] = o.flags; if (P.fl) P.fl[i] = o.flags; }
             } else {
                 g2p_store(P, i, o);
             }
@@ -2520,7 +2525,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
 #ifndef SPK_VOLP2G_STEPS
 #define SPK_VOLP2G_STEPS 4   // 16-lane groups: 64 particles per cell in the fluid configs (0.88 -> 0.73 ms at 20M against 8-lane groups)
 #endif
-template <bool FLUID_ONLY, bool LDS_MODELS>
+template <bool FLUID_ONLY, bool LDS_MODELS, bool KU = false>
 __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* __restrict__ ctl, StepParams S) {
     if (ctl->abort_flag[S.parity]) return;
     __shared__ double tile[4][ACC_N];
@@ -2569,7 +2574,11 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
         const int wbase = base + wv * 128;                                   // first record of this wave's 128 (block-relative)
         const int eA = pfirst + min(wbase + lane, pcount - 1), eB = pfirst + min(wbase + 64 + lane, pcount - 1);
         // every load of the batch is issued here; the velocity / affine streams are only waited for behind the volume gather
-        const float4 a0 = P.q[0][eA], b0 = P.q[0][eB], ak = P.k[eA], bk = P.k[eB];
+        // (KU: the flags words of the mirror travel through the 4-byte hand-over buffer, the rest of the k record is in StepParams: ParticleArrays::fl)
+        const float4 a0 = P.q[0][eA], b0 = P.q[0][eB];
+        float4 ak = make_float4(0.f, 0.f, 0.f, 0.f), bk = ak;
+        uint32_t afl = 0u, bfl = 0u;
+        if constexpr (KU) { afl = P.fl[eA]; bfl = P.fl[eB]; } else { ak = P.k[eA]; bk = P.k[eB]; }
         // plastic_deformation_gradient_det, the "fluid J" of the stress (eos_monaghan_sph.rs glue).  Nothing ever changes it for a plain fluid, and
         // every particle generator leaves it at 1: when the host saw only ones at upload (StepParams::jp_one) the D stream -- 16 B per particle of
         // which 4 are used: the 12 % of this kernel's HBM traffic beyond its algorithmic bytes, r04 PMC -- is not read at all
@@ -2583,7 +2592,13 @@ __global__ __launch_bounds__(BLK_THREADS) void k_vol_p2g(ParticleArrays P, GridA
         float jp_stored[2], cfx[2][3];
         int clc[2][3];
         hand_over(a0, b0, q0);
-        hand_over(ak, bk, kk);
+        if constexpr (KU) {
+            float* xj = s_xj[wv];
+            xj[sA] = __uint_as_float(afl); xj[sB] = __uint_as_float(bfl);
+            __builtin_amdgcn_wave_barrier();
+            kk[0] = make_float4(S.ku_mass, S.ku_vol0, S.ku_eh, xj[lane]); kk[1] = make_float4(S.ku_mass, S.ku_vol0, S.ku_eh, xj[72 + lane]);
+            __builtin_amdgcn_wave_barrier();
+        } else hand_over(ak, bk, kk);
         jp_stored[0] = jp_stored[1] = 1.f;
         if (!(FLUID_ONLY && S.jp_one)) {
             float* xj = s_xj[wv];

@@ -715,7 +715,8 @@ static ParticleArrays with_mirror(const SparklPipeline* p, const ParticleArrays&
     ParticleArrays P = P0;
     // (all_dp_sand: no fluid model, so none of the fluid-sweep kernels -- which store flags without the mirror -- ever runs on these particles;
     // has_frac: the psi sweep's crack test sets FLAG_PHASE_NOT_ONE behind the mirror's back)
-    P.fl = (p->ku_ok && p->all_dp_sand && !p->cur.has_frac) ? p->fl.p : nullptr;
+    // (all_plain_fluid: the fused sweep's kernels keep the mirror themselves, k_vol_p2g / k_g2p_mass<.., KU>)
+    P.fl = (p->ku_ok && (p->all_dp_sand || p->all_plain_fluid) && !p->cur.has_frac) ? p->fl.p : nullptr;
     return P;
 }
 static void launch_g2p(SparklPipeline* p, const ParticleArrays& P0, const GridArrays& G, const StepParams& S, hipStream_t st) {
@@ -911,11 +912,12 @@ static int enqueue_fluid_batch(SparklPipeline* p, const SparklSolverParams* sp, 
     if (p->num_pblocks == 0) { p->substep_index += n; return SPARKL_OK; }
     hipStream_t st = p->stream;
     GridArrays G = grid_arrays(p);
-    const ParticleArrays P = p->cur.arrays();
+    const ParticleArrays P = with_mirror(p, p->cur.arrays());
     const bool was_on = p->clock_on;
     const dim3 grid(p->num_pblocks), block(BLK_THREADS), ggrid((p->num_blocks + 3) / 4);
     size_t tk = 0;
     const bool fluid_only = p->all_plain_fluid && !sp->enable_boundary_particle_projection;
+    const bool ku = fluid_only && P.fl != nullptr && p->h_models.size() <= (size_t)MAX_LDS_MODELS;   // the k record from the flags mirror + StepParams (ParticleArrays::fl)
     note_heads_kind(p, 0, st);   // k_vol_p2g counts lane-group heads like the standalone P2G: one measure in the books at a time
     if (!p->mass_tiles_ready) {
         const StepParams S = make_params(p, sp, g, dt);
@@ -935,7 +937,8 @@ static int enqueue_fluid_batch(SparklPipeline* p, const SparklSolverParams* sp, 
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<true>), ggrid, block, 0, st, Gm, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);
         CHK(clock_end(p, tk));
         CHK(clock_begin(p, SPAN_P2G, &tk));
-        if (fluid_only) SPK_LAUNCH_MODELS(k_vol_p2g, true); else SPK_LAUNCH_MODELS(k_vol_p2g, false);
+        if (ku) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vol_p2g<true, true, true>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
+        else if (fluid_only) SPK_LAUNCH_MODELS(k_vol_p2g, true); else SPK_LAUNCH_MODELS(k_vol_p2g, false);
         CHK(clock_end(p, tk));
         if (check) {
             uint32_t dt_bits;
@@ -955,7 +958,8 @@ static int enqueue_fluid_batch(SparklPipeline* p, const SparklSolverParams* sp, 
         }
         CHK(clock_end(p, tk));
         CHK(clock_begin(p, SPAN_G2P, &tk));
-        if (fluid_only) SPK_LAUNCH_MODELS(k_g2p_mass, true); else SPK_LAUNCH_MODELS(k_g2p_mass, false);
+        if (ku) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p_mass<true, true, true>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
+        else if (fluid_only) SPK_LAUNCH_MODELS(k_g2p_mass, true); else SPK_LAUNCH_MODELS(k_g2p_mass, false);
         CHK(clock_end(p, tk));
         p->clock_on = was_on;
         p->substep_index++;
@@ -2739,7 +2743,7 @@ static int launch_subset(SparklPipeline* p, int which, bool fuse_next, bool prim
     G.pb_count = bnd ? p->pb_bnd : p->num_pblocks - p->pb_bnd;
     G.primary = primary ? 1 : 0;
     if (G.pb_count == 0) return SPARKL_OK;
-    const ParticleArrays P = p->cur.arrays();
+    const ParticleArrays P = with_mirror(p, p->cur.arrays());   // (k_g2p below stores flags too)
     const dim3 grid(G.pb_count), block(BLK_THREADS);
     if (fuse_next && p->fuse_fixed_dt) {
         S.defer_c = (defer && p->defer_c && !p->rare_models && !S.project_particles) ? 1 : 0;
@@ -3302,5 +3306,5 @@ extern "C" int sparkl_hip_debug_run_stats(SparklPipeline* p, unsigned long long*
 // (tests) 1 while the fused kernel of this pipeline would run on the flags mirror (ParticleArrays::fl), else 0
 extern "C" int sparkl_hip_debug_flags_mirror(const SparklPipeline* p) {
     if (!p) return -1;
-    return (p->ku_ok && p->all_dp_sand && !p->cur.has_frac && !p->rare_models) ? 1 : 0;
+    return (p->ku_ok && (p->all_dp_sand || p->all_plain_fluid) && !p->cur.has_frac && !p->rare_models) ? 1 : 0;
 }
