@@ -713,10 +713,9 @@ static void launch_p2g(SparklPipeline* p, const ParticleArrays& P, const GridArr
 // the flags mirror travels with every launch that may change a binned particle's flags while it is valid (ParticleArrays::fl)
 static ParticleArrays with_mirror(const SparklPipeline* p, const ParticleArrays& P0) {
     ParticleArrays P = P0;
-    // (all_dp_sand: no fluid model, so none of the fluid-sweep kernels -- which store flags without the mirror -- ever runs on these particles;
-    // has_frac: the psi sweep's crack test sets FLAG_PHASE_NOT_ONE behind the mirror's back)
-    // (all_plain_fluid: the fused sweep's kernels keep the mirror themselves, k_vol_p2g / k_g2p_mass<.., KU>)
-    P.fl = (p->ku_ok && (p->all_dp_sand || p->all_plain_fluid) && !p->cur.has_frac) ? p->fl.p : nullptr;
+    // Handed out whatever the models are, so that every G2P store keeps it in step (which KERNEL reads it is the launchers' choice: the Drucker-Prager
+    // view of k_g2p2g, the plain-fluid sweep); has_frac: the psi sweep's crack test sets FLAG_PHASE_NOT_ONE behind the mirror's back.
+    P.fl = (p->ku_ok && !p->cur.has_frac) ? p->fl.p : nullptr;
     return P;
 }
 static void launch_g2p(SparklPipeline* p, const ParticleArrays& P0, const GridArrays& G, const StepParams& S, hipStream_t st) {

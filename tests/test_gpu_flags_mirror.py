@@ -113,3 +113,38 @@ def test_fluid_sweep_on_the_mirror_matches_the_k_record_kernels(Pipeline, monkey
     print("fluid, mirror vs k record:", e)
     # (the weakly compressible EOS amplifies the summation-order noise of the mass grid: two runs of one kernel differ by this much)
     assert e["eps_x"] <= 1e-5 and e["eps_v"] <= 1e-4 and e["failed_mismatch"] == 0, e
+
+
+def test_mirror_stays_in_step_while_another_kernel_stores_the_flags(Pipeline, monkeypatch):
+    """The mirror is handed to every G2P store whatever kernel runs: here the model table gets a second (unused) neo-Hookean entry for 120 substeps --
+    the generic fused kernel takes over and particles die on its watch -- and loses it again: the Drucker-Prager view comes back on a mirror that must have
+    followed.  Same sequence with the mirror off as the reference."""
+    import copy
+    sc = _flowing_column()
+    dt = sc.fixed_dt
+    two = copy.deepcopy(sc.models)
+    two.insert(scenes.elastic_cube(2).models.get(0))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SPARKL_HIP_KUNIFORM", mode)
+        with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+            p.load_scene(sc)
+            p.substeps(sc.params, sc.gravity, dt, 140)
+            dead0 = int((p.read_statuses()["failed"] == 1).sum())
+            p.set_models(two)
+            p.substeps(sc.params, sc.gravity, dt, 120)        # k_g2p2g<.., MSET = 0>: flags stored by the generic kernel
+            dead1 = int((p.read_statuses()["failed"] == 1).sum())
+            p.set_models(sc.models)
+            p.substeps(sc.params, sc.gravity, dt, 60)
+            assert _mirror_active(p) == int(mode)
+            out[mode] = p.read_particles()
+            assert dead1 > dead0, (dead0, dead1)               # flags changed while the other kernel ran
+    a, b = out["1"], out["0"]
+    h = sc.cell_width
+    near = (np.abs(a.position["point"][:, 0] / h - 0.5) < 1e-4) | (np.abs(b.position["point"][:, 0] / h - 0.5) < 1e-4)
+    assert near.sum() <= 8 and (a.status[~near].tobytes() == b.status[~near].tobytes())
+    for comps in (a, b):
+        comps.position["point"][near] = 0.0; comps.velocity["vector"][near] = 0.0; comps.status["failed"][near] = 0
+        comps.volume["deformation_gradient"][near] = 0.0; comps.velocity_gradient["m"][near] = 0.0
+    e = particle_errors(a, b, h)
+    assert e["eps_x"] <= 1e-5 and e["eps_v"] <= 1e-5 and e["failed_mismatch"] == 0, e
