@@ -232,12 +232,17 @@ typedef struct {
  *   grid_boundary_handling  SPARKL_BOUNDARY_* for this collider, or SPARKL_COLLIDER_HANDLING_FROM_PARAMS (-1, the default): whatever
  *                           SolverParameters::boundary_handling says -- the CPU path's single switch (grid_update.rs:84-128), which is what
  *                           every collider did until round 5.  SPARKL_BOUNDARY_NONE takes the collider out of the grid update.
- *                           SPARKL_BOUNDARY_FRICTION_Z_UP given HERE follows the GPU rule (src_kernels/cuda/grid_update.rs:166-170: friction only
- *                           where the normal has z >= 0, nothing elsewhere), with the CPU path's normal (direction of the projection); given
- *                           through SolverParameters it is the CPU path's, i.e. the same as SPARKL_BOUNDARY_FRICTION.
- *   penalty_stiffness       force (proj - x) * stiffness on a particle found inside the collider (src_kernels/cuda/particle_updater.rs:200-225;
- *                           compiled out there -- `if false` -- so this is the INTENDED rule): enters the momentum the particle scatters
- *                           next, m v + f dt (src_kernels/cuda/g2p2g.rs:286-287).  0 (default) = none.
+ *                           As soon as ONE collider of the set carries a handling of its own, the whole set follows the reference's GPU grid
+ *                           update (src_kernels/cuda/grid_update.rs:97-190), the only place these options exist: of all colliders whose rule is
+ *                           not NONE only the one whose projection of the node is CLOSEST acts, and the collision normal is the normalised
+ *                           central-difference gradient of the signed distance to all of them (grid_update.rs:54-95), not the direction of the
+ *                           projection; SPARKL_BOUNDARY_FRICTION_Z_UP applies friction only where that normal has z >= 0.  Without any such
+ *                           option the CPU path's rule stands: every collider acts in turn (grid_update.rs:84-128).
+ *   penalty_stiffness       force (proj - x) * stiffness on a particle found inside the collider (src_kernels/cuda/particle_updater.rs:200-225).
+ *                           The reference compiles this force OUT (`if false`, particle_updater.rs:204): the value is stored and changes nothing,
+ *                           and that is the default here too.  sparkl_hip_colliders_enable_penalty_force(p, 1) (or SPARKL_HIP_PENALTY_FORCE=1 in
+ *                           the environment at create) applies the intended rule: the force enters the momentum the particle scatters next,
+ *                           m v + f dt (src_kernels/cuda/g2p2g.rs:286-287).
  *   flip_interior           heightfields (with below_is_solid) and oriented triangle meshes: swaps inside and outside
  *                           (src_kernels/gpu_collider.rs:58-92).  For a triangle mesh it overrides SparklTriMeshCollider::flip_interior. */
 enum { SPARKL_COLLIDER_HANDLING_FROM_PARAMS = -1 };
@@ -375,6 +380,9 @@ int sparkl_hip_colliders_set_trimesh_options(SparklPipeline* p, uint32_t n, cons
 /* CudaColliderSet::from_collider_set (polylines); applied after the triangle meshes.  Vertices are copied. */
 int sparkl_hip_colliders_set_polylines(SparklPipeline* p, uint32_t n, const SparklPolylineCollider* colliders);
 int sparkl_hip_colliders_set_polyline_options(SparklPipeline* p, uint32_t n, const SparklColliderOptions* options);
+/* SparklColliderOptions::penalty_stiffness acts only behind this switch: the reference has the force under `if false`
+ * (src_kernels/cuda/particle_updater.rs:203-221), so by default (enable = 0) a stiffness is stored and ignored, as there. */
+int sparkl_hip_colliders_enable_penalty_force(SparklPipeline* p, int enable);
 
 /* MpmPipeline::step / CudaMpmPipeline::step
  * (src/pipelines/mpm_pipeline.rs:15-42, src/cuda/cuda_mpm_pipeline.rs:262-271):

@@ -293,6 +293,7 @@ public:
     void set_heightfield_options(const std::vector<SparklColliderOptions>& o) { check(sparkl_hip_colliders_set_heightfield_options(h_, (uint32_t)o.size(), o.data())); }
     void set_polylines(const std::vector<SparklPolylineCollider>& pl) { check(sparkl_hip_colliders_set_polylines(h_, (uint32_t)pl.size(), pl.data())); }
     void set_polyline_options(const std::vector<SparklColliderOptions>& o) { check(sparkl_hip_colliders_set_polyline_options(h_, (uint32_t)o.size(), o.data())); }
+    void enable_penalty_force(bool on) { check(sparkl_hip_colliders_enable_penalty_force(h_, on ? 1 : 0)); }   // off = the reference (`if false`)
     void set_trimesh_options(const std::vector<SparklColliderOptions>& o) { check(sparkl_hip_colliders_set_trimesh_options(h_, (uint32_t)o.size(), o.data())); }
     // per-frame render readback (testbed_plugin.rs:533-588): pinned buffers, copies overlapped with the next step
     template <class T> static T* host_alloc(size_t count) { void* ptr = nullptr; check(sparkl_hip_host_alloc(&ptr, count * sizeof(T))); return (T*)ptr; }

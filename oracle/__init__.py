@@ -55,7 +55,7 @@ def _g(g):
 class Oracle:
     """One CPU solver instance (f32 by default; f64=True for the double-precision variant)."""
 
-    def __init__(self, cell_width, f64=False, domain_log2_bytes=30, threads=1):
+    def __init__(self, cell_width, f64=False, domain_log2_bytes=30, threads=1, penalty_force=False):
         self.L = lib()
         self.f64 = bool(f64)
         self.h = self.L.oracle_create(int(f64), C.c_float(cell_width), domain_log2_bytes)
@@ -63,6 +63,8 @@ class Oracle:
             raise MemoryError("oracle mmap failed")
         self.h = C.c_void_p(self.h)
         self.L.oracle_set_num_threads(self.h, int(threads))
+        # the reference has the collider penalty force under `if false` (particle_updater.rs:204): off unless a test asks for the intended rule
+        self.L.oracle_set_penalty_force(self.h, int(bool(penalty_force)))
         self._keep = []
 
     def close(self):

@@ -201,6 +201,7 @@ void* oracle_create(int use_f64, float cell_width, uint32_t domain_log2_bytes) {
     return h;
 }
 void oracle_destroy(void* hv) { Handle* h = (Handle*)hv; if (!h) return; delete h->of; delete h->od; delete h; }
+void oracle_set_penalty_force(void* hv, int on) { Handle* h = (Handle*)hv; if (h->f64) h->od->penalty_force = on != 0; else h->of->penalty_force = on != 0; }
 void oracle_set_num_threads(void* hv, int n) { Handle* h = (Handle*)hv; if (h->f64) h->od->num_threads = n; else h->of->num_threads = n; }
 
 void oracle_set_particles(void* hv, uint64_t n, const SparklParticleStatus* st, const SparklParticlePosition* pos,

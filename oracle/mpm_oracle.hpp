@@ -1061,8 +1061,102 @@ struct Oracle {
         }
     }
 
-    // ---- grid_update.rs:43-132
+    // ---- the reference's GPU grid update (src_kernels/cuda/grid_update.rs:54-190), the only place where colliders carry options of their own
+    // (CudaColliderOptions): ONE collider acts on a node -- the one whose projection of the node is closest -- and the collision normal is the
+    // normalised central-difference gradient of the signed distance to ALL colliders, not the direction of that projection.
+    // project_point_with_max_dist (src_kernels/gpu_collider.rs:31-92): cuboids and polylines always answer, triangle meshes too (the
+    // max_dist argument is commented out there: Real::MAX), heightfields only within max_dist = 2 h.
+    template <class F> void for_each_projection(const Vec3<R>& q, int params_handling, F&& f) const {
+        auto handling_of = [&](const ColliderOpts& o) { return o.handling >= 0 ? o.handling : params_handling; };
+        const R max_dist = R(2) * h;
+        for (const auto& col : cuboids) if (handling_of(col.opts) != SPARKL_BOUNDARY_NONE) f(cuboid_project_point(col, q), col.friction, handling_of(col.opts));
+        for (const auto& hf : heightfields) if (handling_of(hf.opts) != SPARKL_BOUNDARY_NONE) {
+            const Projection<R> pr = heightfield_project_point(hf, q);
+            Vec3<R> d{{pr.point[0] - q[0], pr.point[1] - q[1], pr.point[2] - q[2]}};
+            if (norm(d) <= max_dist) f(pr, hf.friction, handling_of(hf.opts));
+        }
+        for (const auto& tm : trimeshes) if (handling_of(tm.opts) != SPARKL_BOUNDARY_NONE && !tm.idx.empty()) f(trimesh_project_point(tm, q), tm.friction, handling_of(tm.opts));
+        for (const auto& pl : polylines) if (handling_of(pl.opts) != SPARKL_BOUNDARY_NONE && pl.v.size() >= 2) f(polyline_project_point(pl, q), pl.friction, handling_of(pl.opts));
+    }
+    // grid_update.rs:54-70
+    bool sdf(const Vec3<R>& q, int params_handling, R& out) const {
+        bool any = false;
+        R best = 0;
+        for_each_projection(q, params_handling, [&](const Projection<R>& pr, R, int) {
+            Vec3<R> d{{pr.point[0] - q[0], pr.point[1] - q[1], pr.point[2] - q[2]}};
+            const R sd = norm(d) * (pr.is_inside ? R(-1) : R(1));
+            if (!any || sd < best) { best = sd; any = true; }
+        });
+        out = best;
+        return any;
+    }
+    // grid_update.rs:72-95
+    Vec3<R> sdf_gradient(const Vec3<R>& q, int params_handling) const {
+        const R FACTOR = R(0.1);
+        Vec3<R> g{{0, 0, 0}};
+        for (int a = 0; a < 3; ++a) {
+            Vec3<R> qp = q, qn = q;
+            qp[a] += h * FACTOR; qn[a] -= h * FACTOR;
+            R sp, sn;
+            if (sdf(qp, params_handling, sp) && sdf(qn, params_handling, sn)) g[a] = (sp - sn) / h / FACTOR / R(2);
+        }
+        const R n = norm(g);
+        if (!(n > R(1.0e-5))) return Vec3<R>{{0, 0, 0}};   // try_normalize(1.0e-5).unwrap_or(zeros)
+        return Vec3<R>{{g[0] / n, g[1] / n, g[2] / n}};
+    }
+    bool any_collider_options() const {
+        for (const auto& c : cuboids) if (c.opts.handling >= 0) return true;
+        for (const auto& c : heightfields) if (c.opts.handling >= 0) return true;
+        for (const auto& c : trimeshes) if (c.opts.handling >= 0) return true;
+        for (const auto& c : polylines) if (c.opts.handling >= 0) return true;
+        return false;
+    }
+    // grid_update.rs:97-190 (update_single_cell) on a node whose velocity already holds (momentum + m g dt) / m
+    void gpu_rule_cell(GridNode<R>& cell, const Vec3<R>& cell_pos, R dt, int params_handling) {
+        bool have = false, inside = false;
+        Vec3<R> scaled_dir{{0, 0, 0}};
+        R best_dist = std::numeric_limits<R>::max(), friction = 0;
+        int handling = SPARKL_BOUNDARY_NONE;
+        for_each_projection(cell_pos, params_handling, [&](const Projection<R>& pr, R fr, int hd) {
+            Vec3<R> d{{cell_pos[0] - pr.point[0], cell_pos[1] - pr.point[1], cell_pos[2] - pr.point[2]}};
+            const R dist = norm(d);
+            if (dist < best_dist) { best_dist = dist; scaled_dir = d; inside = pr.is_inside; friction = fr; handling = hd; have = true; }
+        });
+        if (!have) return;
+        if (inside) cell.flags |= 2u;
+        if (handling == SPARKL_BOUNDARY_STICK) {
+            if (inside) cell.velocity[0] = cell.velocity[1] = cell.velocity[2] = 0;
+            return;
+        }
+        if (handling != SPARKL_BOUNDARY_FRICTION && handling != SPARKL_BOUNDARY_FRICTION_Z_UP) return;
+        const Vec3<R> normal = sdf_gradient(cell_pos, params_handling);
+        if (normal[0] == R(0) && normal[1] == R(0) && normal[2] == R(0)) return;
+        const R dist = norm(scaled_dir);
+        if (handling == SPARKL_BOUNDARY_FRICTION_Z_UP && !(normal[2] >= R(0))) return;
+        Vec3<R> vel{{cell.velocity[0], cell.velocity[1], cell.velocity[2]}};
+        const R normal_vel = dot(vel, normal);
+        if (normal_vel < R(0)) {
+            const R dist_with_margin = dist - h;
+            if (inside || dist_with_margin <= R(0)) {
+                Vec3<R> tv{{vel[0] - normal_vel * normal[0], vel[1] - normal_vel * normal[1], vel[2] - normal_vel * normal[2]}};
+                const R tvn = norm(tv);
+                for (int a = 0; a < 3; ++a) cell.velocity[a] = tv[a];
+                if (tvn > R(1.0e-10)) {
+                    const R f = std::max(tvn + normal_vel * friction, R(0));
+                    for (int a = 0; a < 3; ++a) cell.velocity[a] = tv[a] / tvn * f;
+                }
+            } else if (-normal_vel * dt > dist_with_margin) {
+                const R k = dist_with_margin / dt + normal_vel;
+                for (int a = 0; a < 3; ++a) cell.velocity[a] -= k * normal[a];
+            }
+        }
+    }
+
+    // ---- grid_update.rs:43-132 (the CPU path: every collider in turn, SolverParameters::boundary_handling for all of them).  As soon as ONE
+    // collider carries a boundary handling of its own -- an option only the reference's GPU path has -- that path's rule applies to the whole
+    // collider set (gpu_rule_cell above).
     void grid_update(R dt, int boundary_handling, uint32_t dofs) {
+        const bool gpu_rule = any_collider_options();
 #pragma omp parallel for schedule(static) num_threads(num_threads)
         for (size_t r = 0; r < regions.size(); ++r) {
             for (uint64_t i = 0; i < 64; ++i) {
@@ -1071,11 +1165,9 @@ struct Oracle {
                 GridNode<R>& cell = node(cell_id);
                 for (int a = 0; a < 3; ++a)
                     if (dofs & (1u << a)) { cell.momentum[a] = 0; cell.velocity[a] = 0; }
-                const int params_handling = boundary_handling;
-                auto apply = [&](const Projection<R>& proj, R friction, const ColliderOpts& opts) {
+                if (gpu_rule) { gpu_rule_cell(cell, cell_pos, dt, boundary_handling); continue; }
+                auto apply = [&](const Projection<R>& proj, R friction) {
                     if (!(cell.flags & 2u) && proj.is_inside) cell.flags |= 2u;
-                    // the collider's own switch where one was given (CudaColliderOptions::grid_boundary_handling, src_kernels/cuda/grid_update.rs:150-170)
-                    const int boundary_handling = opts.handling >= 0 ? opts.handling : params_handling;
                     if (boundary_handling == SPARKL_BOUNDARY_NONE) return;
                     if (boundary_handling == SPARKL_BOUNDARY_STICK) {
                         if (proj.is_inside) cell.velocity[0] = cell.velocity[1] = cell.velocity[2] = 0;
@@ -1086,7 +1178,6 @@ struct Oracle {
                     if (!(dist > R(1.0e-5))) return;  // Unit::try_new_and_get(.., 1e-5)
                     Vec3<R> normal{{dv[0] / dist, dv[1] / dist, dv[2] / dist}};
                     if (proj.is_inside) for (int a = 0; a < 3; ++a) normal[a] = -normal[a];
-                    if (opts.handling == SPARKL_BOUNDARY_FRICTION_Z_UP && !(normal[2] >= R(0))) return;   // GPU rule (grid_update.rs:166-170), per collider only
                     Vec3<R> vel{{cell.velocity[0], cell.velocity[1], cell.velocity[2]}};
                     R normal_vel = dot(vel, normal);
                     if (normal_vel < R(0)) {
@@ -1105,10 +1196,10 @@ struct Oracle {
                         }
                     }
                 };
-                for (const auto& col : cuboids) apply(cuboid_project_point(col, cell_pos), col.friction, col.opts);
-                for (const auto& hf : heightfields) apply(heightfield_project_point(hf, cell_pos), hf.friction, hf.opts);
-                for (const auto& tm : trimeshes) apply(trimesh_project_point(tm, cell_pos), tm.friction, tm.opts);
-                for (const auto& pl : polylines) apply(polyline_project_point(pl, cell_pos), pl.friction, pl.opts);
+                for (const auto& col : cuboids) apply(cuboid_project_point(col, cell_pos), col.friction);
+                for (const auto& hf : heightfields) apply(heightfield_project_point(hf, cell_pos), hf.friction);
+                for (const auto& tm : trimeshes) apply(trimesh_project_point(tm, cell_pos), tm.friction);
+                for (const auto& pl : polylines) apply(polyline_project_point(pl, cell_pos), pl.friction);
             }
         }
     }
@@ -1117,6 +1208,7 @@ struct Oracle {
     // other two (CdMpm, Eigenerosion) are separate passes of mls_solver.rs:68-83 that this restatement does not hold.
     int damage_model = SPARKL_DAMAGE_NONE;
     bool project_particles = false;   // SolverParameters::enable_boundary_particle_projection (set by substep / oracle_g2p_project)
+    bool penalty_force = false;       // opt-in: apply the penalty force the reference has under `if false` (see g2p)
     void g2p(R dt) {
         R invd = inv_d(h);
         uint64_t pshift[27];
@@ -1198,10 +1290,12 @@ struct Oracle {
                     for (const auto& tm : trimeshes) fix(trimesh_project_point(tm, p.position));
                     for (const auto& pl : polylines) fix(polyline_project_point(pl, p.position));
                 }
-                // penalty force of colliders with a stiffness (particle_updater.rs:200-225, `if false` there: the intended rule): a particle
-                // inside feels f = (proj - x) k, and the momentum it scatters next is m v + f dt (g2p2g.rs:286-287) -- the kick on the
-                // stored velocity, which nothing but the next scatter and the dt estimate reads before G2P overwrites it
-                {
+                // penalty force of colliders with a stiffness (particle_updater.rs:200-225).  The reference compiles it OUT (`if false`,
+                // particle_updater.rs:204): a collider's penalty_stiffness changes nothing there, and nothing here unless `penalty_force` is
+                // switched on (the intended rule: a particle inside feels f = (proj - x) k, and the momentum it scatters next is
+                // m v + f dt, g2p2g.rs:286-287 -- the kick on the stored velocity, which nothing but the next scatter and the dt estimate
+                // reads before G2P overwrites it)
+                if (penalty_force) {
                     Vec3<R> f{{0, 0, 0}};
                     bool any = false;
                     auto push = [&](const Projection<R>& proj, const ColliderOpts& o) {

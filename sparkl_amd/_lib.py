@@ -18,7 +18,7 @@ SYMBOLS = [
     "sparkl_hip_particles_read_velocity_gradients", "sparkl_hip_particles_set_fracture", "sparkl_hip_particles_read_fracture", "sparkl_hip_particles_read_sorted_ids", "sparkl_hip_host_alloc", "sparkl_hip_host_free",
     "sparkl_hip_readback_begin", "sparkl_hip_readback_wait", "sparkl_hip_reorder_policy_set", "sparkl_hip_reorder_policy_stats", "sparkl_hip_pipeline_step_stats", "sparkl_hip_grid_check", "sparkl_hip_models_set",
     "sparkl_hip_colliders_set_cuboids", "sparkl_hip_colliders_set_heightfields", "sparkl_hip_colliders_set_trimeshes", "sparkl_hip_colliders_set_cuboid_options", "sparkl_hip_colliders_set_heightfield_options",
-    "sparkl_hip_colliders_set_trimesh_options", "sparkl_hip_colliders_set_polylines", "sparkl_hip_colliders_set_polyline_options", "sparkl_hip_pipeline_step_substep_timings", "sparkl_hip_pipeline_step", "sparkl_hip_pipeline_substeps", "sparkl_hip_pipeline_sync",
+    "sparkl_hip_colliders_set_trimesh_options", "sparkl_hip_colliders_set_polylines", "sparkl_hip_colliders_set_polyline_options", "sparkl_hip_colliders_enable_penalty_force", "sparkl_hip_pipeline_step_substep_timings", "sparkl_hip_pipeline_step", "sparkl_hip_pipeline_substeps", "sparkl_hip_pipeline_sync",
     "sparkl_hip_pipeline_clock_enable", "sparkl_hip_pipeline_clock_read", "sparkl_hip_grid_num_active_blocks",
     "sparkl_hip_grid_num_particle_blocks", "sparkl_hip_grid_debug_capture", "sparkl_hip_grid_read_nodes",
     "sparkl_hip_last_error_string", "sparkl_hip_version",
@@ -33,7 +33,7 @@ SYMBOLS = [
 def build(force=False, extra=""):
     """hipcc --offload-arch=gfx950 build of the library (cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("sparkl_hip.hip", "kernels.h", "device_math.h", "probes.h", "probe_hooks.h")] + [os.path.join(_HERE, "..", "include", "sparkl_hip.h")]
+    srcs = [os.path.join(src_dir, f) for f in ("sparkl_hip.hip", "kernels.h", "device_math.h", "probes.h", "probe_hooks.h", "host_transport.h", "Makefile")] + [os.path.join(_HERE, "..", "include", "sparkl_hip.h")]
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
         cmd = ["make", "-C", src_dir, "-s"] + (["-B"] if force else []) + ([f"EXTRA={extra}"] if extra else [])

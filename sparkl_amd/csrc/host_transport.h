@@ -110,6 +110,7 @@ struct Op {
     hipStream_t stream;
     std::vector<unsigned char> host;
     size_t off = 0;
+    uint64_t seq = 0;   // all-reduce: its number on the communicator, taken when it is posted
     bool posted = false, done = false;
 };
 inline thread_local int g_depth = 0;
@@ -162,9 +163,16 @@ inline ncclResult_t run_ops(std::vector<Op>& ops) {
     Deadline dl;
     for (;;) {
         bool all = true, moved = false;
-        for (Op& o : ops) {
+        for (size_t oi = 0; oi < ops.size(); ++oi) {
+            Op& o = ops[oi];
             if (o.done) continue;
             Comm* c = o.comm;
+            // issue order per (communicator, peer, kind), as ncclSend / ncclRecv match and as the two-buffer all-reduce needs: an operation
+            // does not start before every earlier one of its kind to the same peer has finished (a skipped Send must not be overtaken by a
+            // later one, a multi-chunk message must not interleave with the next, a second all-reduce must not post before the first has reduced)
+            bool blocked = false;
+            for (size_t e = 0; e < oi && !blocked; ++e) blocked = !ops[e].done && ops[e].comm == c && ops[e].kind == o.kind && ops[e].peer == o.peer;
+            if (blocked) { all = false; continue; }
             if (o.kind == 0) {
                 Mailbox* b = c->box(c->rank, o.peer);
                 if (load(&b->read) == c->sent[o.peer]) {   // the previous chunk was consumed
@@ -189,13 +197,13 @@ inline ncclResult_t run_ops(std::vector<Op>& ops) {
                 }
             } else {
                 if (!o.posted) {
-                    const uint64_t k = ++c->reduce_seq;
-                    memcpy(c->slot(c->rank)->data[k & 1], o.host.data(), o.bytes);
-                    store(&c->slot(c->rank)->seq, k);
+                    o.seq = ++c->reduce_seq;
+                    memcpy(c->slot(c->rank)->data[o.seq & 1], o.host.data(), o.bytes);
+                    store(&c->slot(c->rank)->seq, o.seq);
                     o.posted = true;
                     moved = true;
                 }
-                const uint64_t k = c->reduce_seq;
+                const uint64_t k = o.seq;
                 bool ready = true;
                 for (int r = 0; r < c->world; ++r) ready = ready && load(&c->slot(r)->seq) >= k;
                 if (ready) {
@@ -216,13 +224,18 @@ inline ncclResult_t run_ops(std::vector<Op>& ops) {
         if (o.kind != 0 && o.bytes && hipMemcpy(o.dst, o.host.data(), o.bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
     return ncclSuccess;
 }
+// an error anywhere between GroupStart and GroupEnd (or CommAbort) leaves no half-open group behind on this thread: later groups would
+// otherwise be queued and never executed
+inline void reset_group_state() { g_depth = 0; g_ops.clear(); g_new_comms.clear(); }
 inline ncclResult_t submit(Op&& o) {
-    if (!o.comm || o.comm->aborted) return ncclInvalidUsage;
+    if (!o.comm || o.comm->aborted) { reset_group_state(); return ncclInvalidUsage; }
     g_ops.push_back(std::move(o));
     if (g_depth > 0) return ncclSuccess;
     std::vector<Op> ops;
     ops.swap(g_ops);
-    return run_ops(ops);
+    const ncclResult_t r = run_ops(ops);
+    if (r != ncclSuccess) reset_group_state();
+    return r;
 }
 
 // every rank has attached: rank 0 removes the name (every rank holds its mapping: nothing is left behind in /dev/shm whatever happens next)
@@ -276,29 +289,31 @@ inline ncclResult_t GroupEnd() {
     {
         std::vector<Comm*> fresh;
         fresh.swap(g_new_comms);
-        for (Comm* c : fresh) { const ncclResult_t r = rendezvous(c); if (r != ncclSuccess) return r; }
+        for (Comm* c : fresh) { const ncclResult_t r = rendezvous(c); if (r != ncclSuccess) { reset_group_state(); return r; } }
     }
     std::vector<Op> ops;
     ops.swap(g_ops);
     if (ops.empty()) return ncclSuccess;
-    return run_ops(ops);
+    const ncclResult_t r = run_ops(ops);
+    if (r != ncclSuccess) reset_group_state();
+    return r;
 }
 inline ncclResult_t Send(const void* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t st) {
     Op o{};
     o.kind = 0; o.comm = reinterpret_cast<Comm*>(comm); o.src = buf; o.dst = nullptr; o.bytes = count * type_bytes(t); o.peer = peer; o.type = t; o.red = ncclSum; o.stream = st;
-    if (!o.comm || peer < 0 || peer >= o.comm->world || peer == o.comm->rank) return ncclInvalidArgument;
+    if (!o.comm || peer < 0 || peer >= o.comm->world || peer == o.comm->rank) { reset_group_state(); return ncclInvalidArgument; }
     return submit(std::move(o));
 }
 inline ncclResult_t Recv(void* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t st) {
     Op o{};
     o.kind = 1; o.comm = reinterpret_cast<Comm*>(comm); o.src = nullptr; o.dst = buf; o.bytes = count * type_bytes(t); o.peer = peer; o.type = t; o.red = ncclSum; o.stream = st;
-    if (!o.comm || peer < 0 || peer >= o.comm->world || peer == o.comm->rank) return ncclInvalidArgument;
+    if (!o.comm || peer < 0 || peer >= o.comm->world || peer == o.comm->rank) { reset_group_state(); return ncclInvalidArgument; }
     return submit(std::move(o));
 }
 inline ncclResult_t AllReduce(const void* src, void* dst, size_t count, ncclDataType_t t, ncclRedOp_t red, ncclComm_t comm, hipStream_t st) {
     Op o{};
     o.kind = 2; o.comm = reinterpret_cast<Comm*>(comm); o.src = src; o.dst = dst; o.bytes = count * type_bytes(t); o.peer = -1; o.type = t; o.red = red; o.stream = st;
-    if (!o.comm || type_bytes(t) == 0) return ncclInvalidArgument;
+    if (!o.comm || type_bytes(t) == 0) { reset_group_state(); return ncclInvalidArgument; }
     return submit(std::move(o));
 }
 inline const char* GetErrorString(ncclResult_t r) {
@@ -315,6 +330,7 @@ inline ncclResult_t CommAbort(ncclComm_t comm) {
     Comm* c = reinterpret_cast<Comm*>(comm);
     if (!c) return ncclSuccess;
     c->aborted = true;
+    reset_group_state();
     if (c->base) store(&c->hdr()->abort_flag, 1);   // (unlike ncclCommAbort this also wakes the peers; a KILLED rank cannot do it, they time out)
     return CommDestroy(comm);
 }

@@ -1253,11 +1253,9 @@ SPK_DEV bool heightfield_project(const DevHeightField& hf, const float ptw[3], f
     return true;
 }
 
-// grid_update.rs:84-128 for one collider: `proj` = projection of the node position, `inside` = proj.is_inside.
-// `own_handling` (SparklColliderOptions::grid_boundary_handling, -1 = none given): the collider's own switch as the reference's GPU path has it
-// (src_kernels/cuda/grid_update.rs:150-170): None takes it out, FrictionZUp applies the friction rule only where the normal has z >= 0.
-SPK_DEV void boundary_rule(float v[3], const float cpos[3], const float proj[3], bool inside, float friction, int boundary_handling, int own_handling, float h, float dt) {
-    if (own_handling >= 0) boundary_handling = own_handling;
+// grid_update.rs:84-128 (the CPU path) for one collider: `proj` = projection of the node position, `inside` = proj.is_inside.  Every collider
+// acts in turn under SolverParameters::boundary_handling; a set with per-collider options runs gpu_boundary_rule instead.
+SPK_DEV void boundary_rule(float v[3], const float cpos[3], const float proj[3], bool inside, float friction, int boundary_handling, float h, float dt) {
     if (boundary_handling == SPARKL_BOUNDARY_NONE) return;
     if (boundary_handling == SPARKL_BOUNDARY_STICK) {
         if (inside) { v[0] = v[1] = v[2] = 0.f; }
@@ -1268,7 +1266,6 @@ SPK_DEV void boundary_rule(float v[3], const float cpos[3], const float proj[3],
     if (!(dist > 1.0e-5f)) return;
     float nrm[3] = {dv[0] / dist, dv[1] / dist, dv[2] / dist};
     if (inside) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
-    if (own_handling == SPARKL_BOUNDARY_FRICTION_Z_UP && !(nrm[2] >= 0.f)) return;
     const float nv = v[0] * nrm[0] + v[1] * nrm[1] + v[2] * nrm[2];
     if (nv < 0.f) {
         const float dwm = dist - h;
@@ -1287,9 +1284,113 @@ SPK_DEV void boundary_rule(float v[3], const float cpos[3], const float proj[3],
     }
 }
 
+// ---- the reference's GPU grid update (src_kernels/cuda/grid_update.rs:54-190): the rule of a collider set in which some collider carries a
+// boundary handling of its own (SparklColliderOptions::grid_boundary_handling, an option only that path has).  ONE collider acts on a node,
+// the one whose projection of the node is closest, and the collision normal is the normalised central-difference gradient of the signed
+// distance to ALL colliders (grid_update.rs:54-95), not the direction of that projection.  project_point_with_max_dist
+// (src_kernels/gpu_collider.rs:31-92): cuboids and polylines always answer, heightfields within 2 h; triangle meshes without limit there --
+// here within the reach of the mesh's uniform grid (4 h), beyond which no rule but Stick-inside could act anyway.
+struct ColliderScan {
+    bool any;          // some collider answered
+    float sdf;         // min over the colliders of +-distance (grid_update.rs:54-70)
+    float dist;        // the closest projection (grid_update.rs:110-128): its distance, direction node - projection, side, and the collider's own rule
+    float dir[3];
+    bool inside;
+    float friction;
+    int handling;
+};
+template <bool HEIGHTFIELDS>
+SPK_DEV void collider_scan(const GridArrays& G, const DevCuboid* __restrict__ cuboids, const DevHeightField* __restrict__ heightfields, const DevTriMesh* __restrict__ trimeshes,
+                           const StepParams& S, const float q[3], ColliderScan& out) {
+    out.any = false; out.sdf = 0.f; out.dist = 3.402823466e+38f; out.dir[0] = out.dir[1] = out.dir[2] = 0.f; out.inside = false; out.friction = 0.f; out.handling = SPARKL_BOUNDARY_NONE;
+    bool have_best = false;
+    auto take = [&](const float proj[3], bool inside, float friction, int handling) {
+        const float d[3] = {q[0] - proj[0], q[1] - proj[1], q[2] - proj[2]};
+        const float dist = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        const float sd = inside ? -dist : dist;
+        if (!out.any || sd < out.sdf) out.sdf = sd;
+        out.any = true;
+        if (!have_best || dist < out.dist) { have_best = true; out.dist = dist; out.dir[0] = d[0]; out.dir[1] = d[1]; out.dir[2] = d[2]; out.inside = inside; out.friction = friction; out.handling = handling; }
+    };
+    auto rule_of = [&](int own) { return own >= 0 ? own : S.boundary_handling; };
+    for (int ci = 0; ci < S.num_cuboids; ++ci) {
+        const DevCuboid col = cuboids[ci];
+        if (rule_of(col.handling) == SPARKL_BOUNDARY_NONE) continue;
+        float proj[3];
+        const bool inside = cuboid_project(col, q, proj);
+        take(proj, inside, col.friction, rule_of(col.handling));
+    }
+    if (HEIGHTFIELDS) {
+        for (int hi = 0; hi < S.num_heightfields; ++hi) {
+            const DevHeightField& hf = heightfields[hi];
+            if (rule_of(hf.handling) == SPARKL_BOUNDARY_NONE) continue;
+            float proj[3]; bool inside = false;
+            if (heightfield_project(hf, q, 2.0f * S.h, proj, inside)) take(proj, inside, hf.friction, rule_of(hf.handling));
+        }
+        for (int ti = 0; ti < S.num_trimeshes; ++ti) {
+            const DevTriMesh& tm = trimeshes[ti];
+            if (rule_of(tm.handling) == SPARKL_BOUNDARY_NONE) continue;
+            float proj[3]; bool inside = false;
+            if (trimesh_project(tm, q, 4.0f * S.h, proj, inside)) take(proj, inside, tm.friction, rule_of(tm.handling));
+        }
+        for (int pi = 0; pi < G.num_polylines; ++pi) {
+            const DevPolyline& pl = G.polylines[pi];
+            if (rule_of(pl.handling) == SPARKL_BOUNDARY_NONE) continue;
+            float proj[3]; bool inside = false;
+            if (polyline_project(pl, q, proj, inside)) take(proj, inside, pl.friction, rule_of(pl.handling));
+        }
+    }
+}
+// grid_update.rs:97-190 (update_single_cell) on the velocity (momentum + m g dt) / m of the node at cpos
+template <bool HEIGHTFIELDS>
+SPK_DEV void gpu_boundary_rule(float v[3], const float cpos[3], const GridArrays& G, const DevCuboid* __restrict__ cuboids, const DevHeightField* __restrict__ heightfields,
+                               const DevTriMesh* __restrict__ trimeshes, const StepParams& S) {
+    ColliderScan best;
+    collider_scan<HEIGHTFIELDS>(G, cuboids, heightfields, trimeshes, S, cpos, best);
+    if (!best.any) return;
+    if (best.handling == SPARKL_BOUNDARY_STICK) {
+        if (best.inside) { v[0] = v[1] = v[2] = 0.f; }
+        return;
+    }
+    if (best.handling != SPARKL_BOUNDARY_FRICTION && best.handling != SPARKL_BOUNDARY_FRICTION_Z_UP) return;
+    // collision normal: central differences of the signed distance at +-0.1 h (grid_update.rs:72-95); a side with no collider in reach gives 0
+    float g[3] = {0.f, 0.f, 0.f};
+    const float step = S.h * 0.1f;
+    for (int a = 0; a < 3; ++a) {
+        float qp[3] = {cpos[0], cpos[1], cpos[2]}, qn[3] = {cpos[0], cpos[1], cpos[2]};
+        qp[a] += step; qn[a] -= step;
+        ColliderScan sp, sn;
+        collider_scan<HEIGHTFIELDS>(G, cuboids, heightfields, trimeshes, S, qp, sp);
+        collider_scan<HEIGHTFIELDS>(G, cuboids, heightfields, trimeshes, S, qn, sn);
+        if (sp.any && sn.any) g[a] = (sp.sdf - sn.sdf) / S.h / 0.1f / 2.f;
+    }
+    const float gn = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    if (!(gn > 1.0e-5f)) return;
+    const float nrm[3] = {g[0] / gn, g[1] / gn, g[2] / gn};
+    if (best.handling == SPARKL_BOUNDARY_FRICTION_Z_UP && !(nrm[2] >= 0.f)) return;
+    const float dist = sqrtf(best.dir[0] * best.dir[0] + best.dir[1] * best.dir[1] + best.dir[2] * best.dir[2]);
+    const float nv = v[0] * nrm[0] + v[1] * nrm[1] + v[2] * nrm[2];
+    if (nv < 0.f) {
+        const float dwm = dist - S.h;
+        if (best.inside || dwm <= 0.f) {
+            const float tv[3] = {v[0] - nv * nrm[0], v[1] - nv * nrm[1], v[2] - nv * nrm[2]};
+            const float tvn = sqrtf(tv[0] * tv[0] + tv[1] * tv[1] + tv[2] * tv[2]);
+            v[0] = tv[0]; v[1] = tv[1]; v[2] = tv[2];
+            if (tvn > 1.0e-10f) {
+                const float f = fmaxf(tvn + nv * best.friction, 0.f);
+                v[0] = tv[0] / tvn * f; v[1] = tv[1] / tvn * f; v[2] = tv[2] / tvn * f;
+            }
+        } else if (-nv * S.dt > dwm) {
+            const float kq = dwm / S.dt + nv;
+            v[0] -= kq * nrm[0]; v[1] -= kq * nrm[1]; v[2] -= kq * nrm[2];
+        }
+    }
+}
+
 // One wave per node block, 4 blocks per workgroup.  MASS_ONLY: fluid volume recompute (fluids_volume.rs).
 // HEIGHTFIELDS keeps the triangle search out of the kernel every scene without a heightfield runs.
-template <bool MASS_ONLY, bool HEIGHTFIELDS = false>
+// GPU_RULE: some collider carries its own boundary handling: the reference's GPU rule for the whole set (gpu_boundary_rule), no projection cache.
+template <bool MASS_ONLY, bool HEIGHTFIELDS = false, bool GPU_RULE = false>
 __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const DevCuboid* __restrict__ cuboids, const DevHeightField* __restrict__ heightfields, const DevTriMesh* __restrict__ trimeshes,
                                                              const Ctl* __restrict__ ctl, StepParams S) {
     // The abort flag is read first but only consulted behind the first table loads: the topology arrays stay valid (stale) after an
@@ -1371,19 +1472,22 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
     if (S.dofs & 1u) { px = 0.f; v[0] = 0.f; }
     if (S.dofs & 2u) { py = 0.f; v[1] = 0.f; }
     if (S.dofs & 4u) { pz = 0.f; v[2] = 0.f; }
-    if ((S.num_cuboids > 0 || HEIGHTFIELDS) && (S.boundary_handling != SPARKL_BOUNDARY_NONE || S.collider_handling)) {   // (HEIGHTFIELDS: some collider that is not a cuboid)
+    if (GPU_RULE) {
+        const float cpos[3] = {(float)(org.x + cx) * S.h, (float)(org.y + cy) * S.h, (float)(org.z + cz) * S.h};
+        gpu_boundary_rule<HEIGHTFIELDS>(v, cpos, G, cuboids, heightfields, trimeshes, S);
+    } else if ((S.num_cuboids > 0 || HEIGHTFIELDS) && S.boundary_handling != SPARKL_BOUNDARY_NONE) {   // (HEIGHTFIELDS: some collider that is not a cuboid)
         const float cpos[3] = {(float)(org.x + cx) * S.h, (float)(org.y + cy) * S.h, (float)(org.z + cz) * S.h};
         for (int ci = 0; ci < S.num_cuboids; ++ci) {
             const DevCuboid col = cuboids[ci];
             float proj[3];
             const bool inside = cuboid_project(col, cpos, proj);
-            boundary_rule(v, cpos, proj, inside, col.friction, S.boundary_handling, col.handling, S.h, S.dt);
+            boundary_rule(v, cpos, proj, inside, col.friction, S.boundary_handling, S.h, S.dt);
         }
         // Heightfields and triangle meshes search triangles: the projection of a node on a static collider is computed once per binning and
         // kept (GridArrays::node_proj); a cached record replays the very floats the search returned, so the velocities are bit for bit those
         // of the uncached kernel.  Colliders of both kinds in the order of the uncached loop.
         const size_t cache_stride = (size_t)G.num_blocks * 64;
-        auto cached = [&](int slot, auto&& search, float friction, int own_handling) {
+        auto cached = [&](int slot, auto&& search, float friction) {
             float proj[3] = {0.f, 0.f, 0.f};
             bool inside = false, hit;
             // one word per node block first (wave-uniform: one node block per wave): most blocks of a scene are nowhere near the collider
@@ -1404,22 +1508,19 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
                     if (lane == 0) *blk_rec = any_hit ? 2 : 1;
                 }
             }
-            if (hit) boundary_rule(v, cpos, proj, inside, friction, S.boundary_handling, own_handling, S.h, S.dt);
+            if (hit) boundary_rule(v, cpos, proj, inside, friction, S.boundary_handling, S.h, S.dt);
         };
         if (HEIGHTFIELDS) for (int hi = 0; hi < S.num_heightfields; ++hi) {
             const DevHeightField& hf = heightfields[hi];
-            if (hf.handling == SPARKL_BOUNDARY_NONE || (hf.handling < 0 && S.boundary_handling == SPARKL_BOUNDARY_NONE)) continue;
-            cached(hi, [&](float proj[3], bool& inside) { return heightfield_project(hf, cpos, 4.0f * S.h, proj, inside); }, hf.friction, hf.handling);
+            cached(hi, [&](float proj[3], bool& inside) { return heightfield_project(hf, cpos, 4.0f * S.h, proj, inside); }, hf.friction);
         }
         if (HEIGHTFIELDS) for (int ti = 0; ti < S.num_trimeshes; ++ti) {
             const DevTriMesh& tm = trimeshes[ti];
-            if (tm.handling == SPARKL_BOUNDARY_NONE || (tm.handling < 0 && S.boundary_handling == SPARKL_BOUNDARY_NONE)) continue;
-            cached(S.num_heightfields + ti, [&](float proj[3], bool& inside) { return trimesh_project(tm, cpos, 4.0f * S.h, proj, inside); }, tm.friction, tm.handling);
+            cached(S.num_heightfields + ti, [&](float proj[3], bool& inside) { return trimesh_project(tm, cpos, 4.0f * S.h, proj, inside); }, tm.friction);
         }
         if (HEIGHTFIELDS) for (int pi = 0; pi < G.num_polylines; ++pi) {
             const DevPolyline& pl = G.polylines[pi];
-            if (pl.handling == SPARKL_BOUNDARY_NONE || (pl.handling < 0 && S.boundary_handling == SPARKL_BOUNDARY_NONE)) continue;
-            cached(S.num_heightfields + S.num_trimeshes + pi, [&](float proj[3], bool& inside) { return polyline_project(pl, cpos, proj, inside); }, pl.friction, pl.handling);
+            cached(S.num_heightfields + S.num_trimeshes + pi, [&](float proj[3], bool& inside) { return polyline_project(pl, cpos, proj, inside); }, pl.friction);
         }
     }
     G.node_vel[(size_t)b * 64 + lane] = make_float4(v[0], v[1], v[2], m);

@@ -107,7 +107,10 @@ struct SparklPipeline {
     uint64_t n_binned = 0;
     ParticleStore cur, alt;
     uint32_t max_model_index = 0;
-    bool all_jp_one = true;   // every particle uploaded so far carries plastic_deformation_gradient_det == 1 (StepParams::jp_one)
+    // every particle uploaded so far carries plastic_deformation_gradient_det == 1 (StepParams::jp_one) AND nothing that may change the value has
+    // been stepped since: a model table that is not all plain fluid clears it for good (a later switch to plain fluids must read the device
+    // values again) -- only a fresh upload sets it back
+    bool all_jp_one = true;
     // slab decomposition (multi-GPU): owned home blocks along `slab_axis` are [slab_lo, slab_hi)
     bool slab_on = false;
     int slab_axis = 0, slab_lo = INT32_MIN, slab_hi = INT32_MAX;
@@ -194,6 +197,9 @@ struct SparklPipeline {
     std::vector<float*> d_poly_verts;
     int num_polylines = 0;
     bool collider_handling = false, collider_penalty = false, rare_by_models = false;
+    // The reference compiles its collider penalty force out (`if false`, src_kernels/cuda/particle_updater.rs:203-221): a penalty_stiffness is stored and
+    // changes nothing.  Same here unless the caller opts in (sparkl_hip_colliders_enable_penalty_force, or SPARKL_HIP_PENALTY_FORCE=1 at create).
+    bool penalty_force_on = false;
     DevBuf<float4> node_proj;        // GridArrays::node_proj: [heightfields + trimeshes][num_blocks][64]
     DevBuf<int> node_proj_blk;       // GridArrays::node_proj_blk: [heightfields + trimeshes][num_blocks]
     bool proj_cache_on = true;       // SPARKL_HIP_PROJ_CACHE=0: off (A/B, tests)
@@ -665,18 +671,24 @@ static void prepare_proj_cache(SparklPipeline* p, hipStream_t st) {
     // only the per-block words are cleared: a node record is never read before its block's word says "computed"
     if (p->proj_cache_clear) { (void)hipMemsetAsync(p->node_proj_blk.p, 0, need_blk * sizeof(int), st); p->proj_cache_clear = false; }
 }
+// the instantiation of k_grid_update a collider set needs: triangle-searching shapes or not, and the reference's GPU rule (closest collider,
+// signed-distance normal: kernels.h gpu_boundary_rule) as soon as one collider carries a boundary handling of its own
+static void launch_grid_kernel(SparklPipeline* p, const GridArrays& G, const StepParams& S, dim3 grid, hipStream_t st) {
+    const dim3 block(BLK_THREADS);
+    const bool shapes = p->num_heightfields > 0 || p->num_trimeshes > 0 || p->num_polylines > 0;
+#define SPK_GU(HF, GR) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, HF, GR>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S)
+    if (p->collider_handling) { if (shapes) SPK_GU(true, true); else SPK_GU(false, true); }
+    else { if (shapes) SPK_GU(true, false); else SPK_GU(false, false); }
+#undef SPK_GU
+}
 static void launch_grid_update(SparklPipeline* p, const GridArrays& G_in, const StepParams& S, hipStream_t st) {
     GridArrays G = G_in;
-    if (p->num_heightfields + p->num_trimeshes + p->num_polylines > 0) {
+    if (p->num_heightfields + p->num_trimeshes + p->num_polylines > 0 && !p->collider_handling) {   // (the GPU rule keeps no cache)
         prepare_proj_cache(p, st);
         G.node_proj = (p->proj_cache_on && p->node_proj.p && p->node_proj_blk.p && !p->proj_cache_clear) ? p->node_proj.p : nullptr;
         G.node_proj_blk = p->node_proj_blk.p;
     }
-    const dim3 grid((p->num_blocks + 3) / 4), block(BLK_THREADS);
-    if (p->num_heightfields > 0 || p->num_trimeshes > 0 || p->num_polylines > 0)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, true>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, false>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);
+    launch_grid_kernel(p, G, S, dim3((p->num_blocks + 3) / 4), st);
 }
 
 // Particle kernels stage the model table in LDS when it fits (see stage_models); longer tables are read from global memory.
@@ -802,6 +814,7 @@ static int enqueue_substep(SparklPipeline* p, const SparklSolverParams* sp, cons
     CHK(clock_end(p, t2));
     p->clock_on = was_on;
     p->substep_index++;
+    p->enq_steps++;
     return SPARKL_OK;
 }
 
@@ -845,6 +858,7 @@ static int enqueue_adaptive_substep(SparklPipeline* p, const SparklSolverParams*
     hipLaunchKernelGGL(k_dt_reduce, dim3(1), dim3(1024), 0, st, p->dt_partial.p, p->num_pblocks, p->d_ctl, expect_bound_bits, (S.parity + 1) & 1);
     p->clock_on = was_on;
     p->substep_index++;
+    p->enq_steps++;
     return SPARKL_OK;
 }
 
@@ -927,6 +941,8 @@ static int enqueue_fluid_batch(SparklPipeline* p, const SparklSolverParams* sp, 
         p->clock_on = was_on;
     }
     for (uint32_t j = 0; j < n; ++j) {
+        // the same bounded enqueue-ahead as the fused sand batch (a re-bin request is up: the caller reads the control block and re-bins)
+        if (j > 0 && !may_enqueue_next(p)) { p->mass_tiles_ready = false; return SPARKL_OK; }
         const StepParams S = make_params(p, sp, g, dt);
         if (was_on && (p->substep_index % p->clock_stride) != 0) p->clock_on = false;
         if (p->clock_on) p->clock_sampled++;
@@ -962,6 +978,7 @@ static int enqueue_fluid_batch(SparklPipeline* p, const SparklSolverParams* sp, 
         CHK(clock_end(p, tk));
         p->clock_on = was_on;
         p->substep_index++;
+        p->enq_steps++;
     }
     p->mass_tiles_ready = true;
     return SPARKL_OK;
@@ -1016,6 +1033,7 @@ int sparkl_hip_pipeline_create(const SparklPipelineDesc* desc, SparklPipeline** 
     p->defer_c = !(getenv("SPARKL_HIP_DEFER_C") && !strcmp(getenv("SPARKL_HIP_DEFER_C"), "0"));
     p->ku_on = !(getenv("SPARKL_HIP_KUNIFORM") && !strcmp(getenv("SPARKL_HIP_KUNIFORM"), "0"));
     if (const char* e = getenv("SPARKL_HIP_CARRY")) p->carry_on = atoi(e) != 0;
+    if (const char* e = getenv("SPARKL_HIP_PENALTY_FORCE")) p->penalty_force_on = atoi(e) != 0;
     if (const char* e = getenv("SPARKL_HIP_PROJ_CACHE")) p->proj_cache_on = atoi(e) != 0;
     if (const char* e = getenv("SPARKL_HIP_OVERLAP")) p->overlap_mode = !strcmp(e, "cal") ? -2 : (atoi(e) != 0 ? 1 : 0);   // "cal": calibrate even on one device (tests)
     p->lookahead = !(getenv("SPARKL_HIP_LOOKAHEAD") && !strcmp(getenv("SPARKL_HIP_LOOKAHEAD"), "0"));
@@ -1206,6 +1224,7 @@ static void collider_options_changed(SparklPipeline* p) {
     for (const auto& c : p->h_heightfields) { p->collider_handling |= c.handling >= 0; p->collider_penalty |= c.penalty > 0.f; }
     for (const auto& c : p->h_trimeshes) { p->collider_handling |= c.handling >= 0; p->collider_penalty |= c.penalty > 0.f; }
     for (const auto& c : p->h_polylines) { p->collider_handling |= c.handling >= 0; p->collider_penalty |= c.penalty > 0.f; }
+    p->collider_penalty = p->collider_penalty && p->penalty_force_on;   // stored, not applied, unless opted in (see penalty_force_on)
     p->rare_models = p->rare_by_models || p->collider_penalty;   // the penalty force lives in the RARE instantiations of the G2P kernels
     p->proj_cache_clear = true;
     p->carry_valid = false;
@@ -1218,6 +1237,14 @@ static int check_options(uint32_t n, const SparklColliderOptions* o, size_t have
             return set_error(SPARKL_ERR_INVALID_ARGUMENT, "%s collider %u: grid_boundary_handling %d", kind, i, (int)o[i].grid_boundary_handling);
         if (!(o[i].penalty_stiffness >= 0.f)) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "%s collider %u: penalty_stiffness must be >= 0", kind, i);
     }
+    return SPARKL_OK;
+}
+int sparkl_hip_colliders_enable_penalty_force(SparklPipeline* p, int enable) {
+    if (!p) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "null pipeline");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    p->penalty_force_on = enable != 0;
+    collider_options_changed(p);
     return SPARKL_OK;
 }
 int sparkl_hip_colliders_set_cuboid_options(SparklPipeline* p, uint32_t n, const SparklColliderOptions* o) {
@@ -1763,6 +1790,7 @@ static int unsupported_damage_model(const SparklSolverParams* params) {
 static int ensure_ready(SparklPipeline* p) {
     HIPCHK(hipSetDevice(p->device));
     CHK(validate_models(p));
+    if (!p->all_plain_fluid) p->all_jp_one = false;   // about to step under models that may move det Fp (see all_jp_one)
     if (!p->sorted) CHK(resort(p));
     return SPARKL_OK;
 }
@@ -1905,6 +1933,7 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
             }
             // wrong prediction (or a NaN bound): clear the chain, take this substep in the reference's order
             p->fluid_fused_mismatches++;
+            if (p->h_words) p->h_words[0] = 0u;   // (the stream is idle behind read_ctl: nothing in flight can raise it again)
             HIPCHK(hipMemsetAsync(p->d_ctl, 0, 2 * sizeof(uint32_t), p->stream));
             HIPCHK(hipMemsetAsync(&p->d_ctl->dt_mismatch, 0, sizeof(uint32_t), p->stream));
             HIPCHK(hipMemsetAsync(&p->d_ctl->dt_nan, 0, sizeof(uint32_t), p->stream));
@@ -1996,6 +2025,9 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
                     p->substep_index = base_index + executed;   // parity continues as if the no-op substeps had not been enqueued
                     if (p->h_ctl->dt_mismatch) {
                         p->lookahead_mismatches++;
+                        // the abort word in pinned host memory goes down with the device flags (only resort() used to clear it: the next
+                        // fixed-dt batch then stopped enqueueing behind its first substep and re-binned for nothing)
+                        if (p->h_words) p->h_words[0] = 0u;
                         HIPCHK(hipMemsetAsync(p->d_ctl, 0, 2 * sizeof(uint32_t), p->stream));
                         HIPCHK(hipMemsetAsync(&p->d_ctl->dt_mismatch, 0, sizeof(uint32_t), p->stream));
                         p->h_ctl->abort_flag[0] = p->h_ctl->abort_flag[1] = 0;
@@ -2729,12 +2761,8 @@ static int launch_subset(SparklPipeline* p, int which, bool fuse_next, bool prim
         G.nb_list = bnd ? p->split_nb.p : p->split_nb.p + p->nb_bnd;
         G.nb_count = bnd ? p->nb_bnd : p->num_blocks - p->nb_bnd;
         if (G.nb_count == 0) return SPARKL_OK;
-        const dim3 grid((G.nb_count + 3) / 4), block(BLK_THREADS);
         G.node_proj = nullptr;   // (two streams: the projection cache is only handed out by the single-stream launch_grid_update)
-        if (p->num_heightfields > 0 || p->num_trimeshes > 0 || p->num_polylines > 0)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, true>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, false>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S);
+        launch_grid_kernel(p, G, S, dim3((G.nb_count + 3) / 4), st);
         return SPARKL_OK;
     }
     G.pb_plain = p->split_ordered ? (bnd ? 1 : 2) : 0;

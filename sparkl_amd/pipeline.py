@@ -172,6 +172,10 @@ class MpmPipeline:
         arr = (abi.ColliderOptionsC * max(len(options), 1))(*options)
         check(fn(self.h, C.c_uint32(len(options)), arr))
 
+    def enable_penalty_force(self, on=True):
+        """`penalty_stiffness` acts only behind this switch: the reference has the force under `if false` (particle_updater.rs:203-221)."""
+        check(self.L.sparkl_hip_colliders_enable_penalty_force(self.h, C.c_int(1 if on else 0)))
+
     # ---- CudaParticleSet
     def _args(self, c):
         return (C.c_uint64(len(c)), abi.ptr(c.status, abi.STATUS_DTYPE), abi.ptr(c.position, abi.POSITION_DTYPE),

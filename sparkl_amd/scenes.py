@@ -85,17 +85,22 @@ def _domain_bits_for(max_cell):
     raise ValueError("scene does not fit the largest virtual grid")
 
 
-def sand_column(nx, ny, nz, h=0.2, with_block=False, jitter=True, name=None, x_slab=(0, 1)):
+def sand_column(nx, ny, nz, h=0.2, with_block=False, jitter=True, name=None, x_slab=(0, 1), stock_lattice=False):
     """Configs 1/3: Drucker-Prager sand (corotated, E=1e7, nu=0.2, rho=2700) on a friction floor.
 
     with_block=True stacks the sand on an elastic block of the same size (config 1, examples3d/sand3.rs:39-78).
     x_slab=(k, K): generate only the k-th of K x-slabs of a column K*nx particles long (multi-GPU weak scaling).
+    stock_lattice=True: the reference examples' own sampling (examples3d/helper.rs:28-33 with randomize = false, sand3.rs:49-71): no jitter and
+    the lattice origin on a multiple of the cell width, so that every other particle of a row sits ON a half-cell tie of
+    `round(x / h)` (sp_grid.rs:216-226) -- the scenes above sample a quarter cell off, where no tie can occur.
     """
     E, NU = 1.0e7, 0.2
     models = ParticleModelSet()
     sand = models.insert(ParticleModel.with_plasticity(CorotatedLinearElasticity(E, NU), DruckerPragerPlasticity(E, NU)))
     r = h / 4.0
-    origin = np.array([4 * h, 4 * h, 4 * h], dtype=f32) + f32(r)  # >= 2 cells inside the domain (SURVEY F5)
+    origin = np.array([4 * h, 4 * h, 4 * h], dtype=f32) + (f32(0.0) if stock_lattice else f32(r))  # >= 2 cells inside the domain (SURVEY F5)
+    if stock_lattice:
+        jitter = False
     origin[0] += f32(x_slab[0] * nx) * f32(2 * r)
     parts = []
     y0 = origin[1]
@@ -114,13 +119,13 @@ def sand_column(nx, ny, nz, h=0.2, with_block=False, jitter=True, name=None, x_s
                  _domain_bits_for(max_cell))
 
 
-def elastic_cube(n, h=0.2, jitter=True, name=None):
+def elastic_cube(n, h=0.2, jitter=True, name=None, stock_lattice=False):
     """Config 2: neo-Hookean cube n^3 (E=1e6, nu=0.3, rho=1000), no gravity/collider, spinning + expanding."""
     models = ParticleModelSet()
     mid = models.insert(ParticleModel.new(NeoHookeanElasticity(1.0e6, 0.3)))
     r = h / 4.0
-    origin = np.array([4 * h, 4 * h, 4 * h], dtype=f32) + f32(r)
-    pos = cube_positions(origin, n, n, n, r, jitter)
+    origin = np.array([4 * h, 4 * h, 4 * h], dtype=f32) + (f32(0.0) if stock_lattice else f32(r))
+    pos = cube_positions(origin, n, n, n, r, jitter and not stock_lattice)
     comps = new_particles(mid, pos, r, 1000.0)
     c = pos.mean(axis=0, dtype=np.float64).astype(f32)
     d = pos - c
@@ -153,12 +158,14 @@ def block_on_floor(n, constitutive, plasticity=None, failure=None, density=1000.
     return Scene(f"{name}_{n}", h, models, comps, [floor], params, gravity, dt, _domain_bits_for(max_cell))
 
 
-def fluid_dam(nx, ny, nz, h=0.8, r=0.1, jitter=True, name=None):
-    """Config 4: fluids3-like dam break (examples3d/fluids3.rs:17-43), 64 particles per cell."""
+def fluid_dam(nx, ny, nz, h=0.8, r=0.1, jitter=True, name=None, stock_lattice=False):
+    """Config 4: fluids3-like dam break (examples3d/fluids3.rs:17-43), 64 particles per cell.
+    stock_lattice=True: fluids3's own sampling -- origin on a multiple of the cell width (it uses 2 h), no jitter: every fourth particle of a row
+    sits on a half-cell tie (see sand_column)."""
     models = ParticleModelSet()
     mid = models.insert(ParticleModel.new(MonaghanSphEos(1.0e6, 7, 1.01e-3)))
-    origin = np.array([4 * h, 4 * h, 4 * h], dtype=f32) + f32(r)
-    pos = cube_positions(origin, nx, ny, nz, r, jitter)
+    origin = np.array([4 * h, 4 * h, 4 * h], dtype=f32) + (f32(0.0) if stock_lattice else f32(r))
+    pos = cube_positions(origin, nx, ny, nz, r, jitter and not stock_lattice)
     comps = new_particles(mid, pos, r, 1000.0)
     floor = floor_cuboid(top_y=4 * h - 0.5 * h, friction=0.0)
     params = abi.SolverParameters()

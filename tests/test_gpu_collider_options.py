@@ -111,9 +111,28 @@ def test_heightfield_flip_interior(Pipeline, flip):
         assert vy.mean() < -0.2                        # falls (and is being stopped by the ground it has reached by now)
 
 
-def test_penalty_stiffness_pushes_particles_out(Pipeline):
-    """particle_updater.rs:200-225 (intended rule): a block that starts half inside a cuboid with a penalty stiffness and NO grid boundary
-    handling is pushed out by f = (proj - x) k; without the stiffness it falls through.  HIP vs oracle under the gate."""
+def test_penalty_stiffness_is_stored_and_ignored_like_the_reference(Pipeline):
+    """src_kernels/cuda/particle_updater.rs:203-221 has the penalty force under `if false`: a collider's penalty_stiffness changes nothing in
+    the reference, so by default it changes nothing here either -- same bits as without the option, and no detour through the RARE kernels."""
+    sc = scenes.sand_column(8, 6, 8, with_block=False)
+    sc.params = copy.copy(sc.params)
+    sc.params.boundary_handling = abi.BOUNDARY_NONE
+    sc.particles.position["point"][:, 1] -= np.float32(1.25 * sc.cell_width)
+    dt, n = 2.5e-4, 80
+    free = _hip(Pipeline, sc, n, dt)
+    sc.collider_options = {"cuboid": [abi.collider_options(penalty_stiffness=2.0e5)]}
+    got = _hip(Pipeline, sc, n, dt)
+    for k in ("position", "velocity", "volume", "velocity_gradient"):
+        assert getattr(got, k).tobytes() == getattr(free, k).tobytes(), k
+    r32, r64 = _oracles(sc, n, dt)          # the oracle's default is the reference's too
+    rep, bad = parity_verdict(got, r32, r64, sc.cell_width)
+    assert not bad, (bad, rep)
+
+
+def test_penalty_stiffness_pushes_particles_out_when_opted_in(Pipeline):
+    """The INTENDED rule behind sparkl_hip_colliders_enable_penalty_force: a block that starts half inside a cuboid with a penalty stiffness and
+    NO grid boundary handling is pushed out by f = (proj - x) k; without the stiffness it falls through.  HIP vs oracle (same switch) under the gate."""
+    from oracle import Oracle
     sc = scenes.sand_column(8, 6, 8, with_block=False)
     sc.params = copy.copy(sc.params)
     sc.params.boundary_handling = abi.BOUNDARY_NONE
@@ -121,13 +140,74 @@ def test_penalty_stiffness_pushes_particles_out(Pipeline):
     dt, n = 2.5e-4, 80
     free = _hip(Pipeline, sc, n, dt)
     sc.collider_options = {"cuboid": [abi.collider_options(penalty_stiffness=2.0e5)]}
-    got = _hip(Pipeline, sc, n, dt)
-    r32, r64 = _oracles(sc, n, dt)
-    rep, bad = parity_verdict(got, r32, r64, sc.cell_width)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.enable_penalty_force(True)
+        p.substeps(sc.params, sc.gravity, dt, n)
+        got = p.read_particles()
+    refs = []
+    for f64 in (False, True):
+        o = Oracle(sc.cell_width, f64=f64, domain_log2_bytes=sc.domain_log2_bytes, threads=_threads(), penalty_force=True)
+        o.load_scene(sc)
+        for _ in range(n):
+            o.substep_fixed(sc.params, sc.gravity, dt)
+        refs.append(o.get_particles())
+        o.close()
+    rep, bad = parity_verdict(got, refs[0], refs[1], sc.cell_width)
     dy = float((got.position["point"][:, 1] - free.position["point"][:, 1]).mean()) / sc.cell_width
     print("penalty force: vs f64", rep["vs_f64"]["eps_x"], rep["vs_f64"]["eps_v"], "| mean lift over the free fall", dy, "h")
     assert not bad, (bad, rep)
     assert dy > 0.02, dy
+
+
+def _two_floors(near, far):
+    """Falling sand over TWO overlapping floor cuboids: `far`'s top lies 0.3 h below `near`'s, so for every node above the ground the projection on
+    `near` is the closer one -- under the reference's GPU rule (src_kernels/cuda/grid_update.rs:110-146) only `near`'s handling may act."""
+    sc = _falling_sand()
+    lo = scenes.floor_cuboid(top_y=4 * sc.cell_width - 0.5 * sc.cell_width - 0.3 * sc.cell_width, friction=0.5)
+    sc.colliders = [sc.colliders[0], lo]
+    sc.collider_options = {"cuboid": [abi.collider_options(grid_boundary_handling=near), abi.collider_options(grid_boundary_handling=far)]}
+    return sc
+
+
+@pytest.mark.parametrize("near,far", [(abi.BOUNDARY_FRICTION, abi.BOUNDARY_STICK), (abi.BOUNDARY_NONE, abi.BOUNDARY_STICK), (abi.BOUNDARY_STICK, abi.BOUNDARY_FRICTION)])
+def test_mixed_options_only_the_closest_collider_acts(Pipeline, near, far):
+    """with per-collider options the reference picks the SINGLE closest projection over all colliders whose rule is not None and applies
+    that collider's rule only (grid_update.rs:110-190); rounds 1 - 5 let every collider act in turn.  Two stacked floors with different rules:
+    HIP vs oracle (which restates the GPU rule) under the gate, and the result must be the nearer floor's rule, not a mix."""
+    sc = _two_floors(near, far)
+    dt, n = 2.5e-4, 100
+    got = _hip(Pipeline, sc, n, dt)
+    r32, r64 = _oracles(sc, n, dt)
+    rep, bad = parity_verdict(got, r32, r64, sc.cell_width)
+    assert not bad, (bad, rep)
+    print("mixed options", near, far, "vs f64", rep["vs_f64"]["eps_x"], rep["vs_f64"]["eps_v"])
+    if near == abi.BOUNDARY_NONE:
+        # a collider whose rule is None is not a candidate at all (grid_update.rs:112-114): the far floor alone gives the same bits
+        one = _falling_sand()
+        one.colliders = [sc.colliders[1]]
+        one.collider_options = {"cuboid": [abi.collider_options(grid_boundary_handling=far)]}
+        alone = _hip(Pipeline, one, n, dt)
+        assert np.abs(got.position["point"] - alone.position["point"]).max() / sc.cell_width < 1e-6
+
+
+def test_gpu_rule_normal_is_the_sdf_gradient_on_a_heightfield(Pipeline):
+    """With an option on the heightfield the collision normal is the central-difference gradient of the signed distance (grid_update.rs:72-95), which
+    on a sinusoidal ground differs from the direction of the projection the CPU rule uses: HIP vs the oracle's GPU rule, and the two rules must
+    really end apart."""
+    sc = scenes.sand_on_heightfield(16, 6, 12, below_is_solid=True)
+    sc.particles.velocity["vector"][:, 1] = -3.0
+    sc.particles.velocity["vector"][:, 0] = 2.0
+    dt, n = 2.5e-4, 120
+    cpu_rule = _hip(Pipeline, sc, n, dt)
+    sc.collider_options = {"heightfield": [abi.collider_options(grid_boundary_handling=abi.BOUNDARY_FRICTION)]}
+    got = _hip(Pipeline, sc, n, dt)
+    r32, r64 = _oracles(sc, n, dt)
+    rep, bad = parity_verdict(got, r32, r64, sc.cell_width)
+    apart = np.abs(got.position["point"] - cpu_rule.position["point"]).max() / sc.cell_width
+    print("gpu rule on a heightfield: vs f64", rep["vs_f64"]["eps_x"], rep["vs_f64"]["eps_v"], "| differs from the CPU rule by", apart, "h")
+    assert not bad, (bad, rep)
+    assert apart > 1e-4, apart
 
 
 def test_options_are_validated_and_reset(Pipeline):

@@ -116,6 +116,47 @@ def test_particle_state_parity_100_substeps(Pipeline, name, builder, dt):
             assert np.isfinite(got.position["point"]).all()
 
 
+@pytest.mark.parametrize("name,builder", [
+    ("sand3_stock", lambda: scenes.sand_column(24, 12, 16, with_block=True, stock_lattice=True)),
+    ("neo_stock", lambda: scenes.elastic_cube(24, stock_lattice=True)),
+    ("fluids3_stock", lambda: scenes.fluid_dam(32, 24, 16, stock_lattice=True)),
+])
+def test_stock_unjittered_lattice_parity(Pipeline, name, builder):
+    """The reference's examples sample their bodies with `randomize = false` (examples3d/helper.rs:28-33) from an origin that is a multiple of
+    the cell width: half of sand3's particles (a quarter of fluids3's) start EXACTLY on a half-cell tie of `round(x / h)`
+    (sp_grid.rs:216-226), where f32::round goes away from zero and this path's rintf (kernels.h, cell_frac) goes to even, and where the
+    double-precision re-basing to block-relative coordinates may land a hair on either side.  The B-spline weights are continuous across the
+    tie, so the result may only differ at rounding level: 100 fixed substeps + one adaptive frame under the full gate, and the scene must
+    really hold ties."""
+    sc = builder()
+    q = sc.particles.position["point"].astype(np.float32) / np.float32(sc.cell_width)
+    ties = int((np.abs(q - np.floor(q) - 0.5) < 1e-6).any(axis=1).sum())
+    assert ties > len(sc.particles) // 5, ties
+    dt = sc.fixed_dt
+    o32, o64 = _oracle(sc), _oracle(sc, f64=True)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        done = 0
+        for k in (1, 100):
+            for _ in range(k - done):
+                o32.substep_fixed(sc.params, sc.gravity, dt)
+                o64.substep_fixed(sc.params, sc.gravity, dt)
+            p.substeps(sc.params, sc.gravity, dt, k - done)
+            done = k
+            rep, bad = parity_verdict(p.read_particles(), o32.get_particles(), o64.get_particles(), sc.cell_width)
+            _report(f"stock_lattice_{name}_k{k}", {**rep, "particles_on_a_tie": ties})
+            assert not bad, (k, bad, rep)
+        t_ref = o32.step(sc.params, sc.gravity)
+        o64.step(sc.params, sc.gravity)
+        t_got, tim = p.step(sc.params, sc.gravity, timings=True)
+        assert t_got == pytest.approx(t_ref, rel=1e-7) and tim.num_substeps == len(o32.last_dts())
+        rep, bad = parity_verdict(p.read_particles(), o32.get_particles(), o64.get_particles(), sc.cell_width)
+        _report(f"stock_lattice_{name}_frame", rep)
+        assert not bad, (bad, rep)
+        chk = p.grid_check()
+    assert chk["particles_outside_their_block"] == 0 and chk["coverage_errors"] == 0, chk
+
+
 def test_sheared_sand_crosses_every_return_map_path(Pipeline):
     """Drucker-Prager sand with a shear rate that grows along x: within 60 substeps the column holds waves on the quartic series path
     (|S| < 0.03), on its second tier (< 0.1) and on the eigenbasis path (>= 0.1) of the return map -- asserted from the library's
