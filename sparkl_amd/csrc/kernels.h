@@ -75,6 +75,9 @@ struct Ctl {
     // them in the set with their last v and C, so `adaptive_timestep_length` (timestep_estimator.rs:25-35) still sees them, while no
     // kernel here visits them any more.  Rebuilt at every re-bin, extended by G2P when a particle dies; k_dt_reduce folds it in.
     uint32_t dead_dt_bits;
+    // peer-direct halo exchange (PeerBox below): a kernel gave up waiting for a peer's mail or halo records (1 = mail, 2 = halo): the peer is gone.
+    // The abort chain is raised with it, the host turns it into an error (sparkl_hip_group_substeps)
+    uint32_t direct_error;
     // Two words of PINNED HOST memory the device can write (hipHostMalloc, mapped): [0] is set to 1 by whatever RAISES the abort chain (margin
     // violation, disorder policy, dt mismatch), [1] mirrors steps_done.  The host enqueues a fixed-dt batch ahead of the GPU; with these it
     // stays only a few substeps ahead (polling [1], no events, no synchronisation) and stops enqueueing the moment [0] is raised -- the rest
@@ -98,6 +101,81 @@ SPK_DEV void note_step(Ctl* ctl) {
     if (hw) hw[1] = v;
 }
 
+// ---- peer-direct halo exchange (round 6) -------------------------------------------------------------------------------------------------
+// The group loop of rounds 3 - 5 spent, per slab and substep, one 4-byte all-reduce (or a single-thread kernel), a pack kernel, two copies (or an
+// ncclSend / Recv pair) and a merge kernel in series in front of the grid update: 28 - 60 us of launch latencies for ~1 MB.  When every rank can
+// map its neighbours' memory -- members of one process (the same device, or peer access between devices: the reference's own shape,
+// cuda_mpm_pipeline.rs:458-472), or hipIpc mappings between the processes of one node -- the exchange is ONE kernel per slab and substep:
+//   k_halo_push   (behind the particle kernel of substep s - 1)  posts this member's re-bin flag of substep s into EVERY member's mailbox, packs the
+//                 partial sums of the shared node planes and stores them straight into the neighbours' halo buffers of parity s & 1, at the node-block
+//                 slots negotiated at the re-bin (k_halo_keys / k_halo_slots); the last workgroup publishes "all records of epoch e have landed";
+//   k_grid_update (direct)  waits for the mail of all members (the MAX of the flags is the agreed flag of the substep: every member skips the same
+//                 substeps, what the all-reduce was for) and for the neighbours' epoch words, then reads the halo like before.
+// Everything a peer writes lives in one fine-grained allocation per member (the "arena": PeerBox + two halo buffers).  Mail and epoch words are
+// double-buffered by epoch parity: a fast peer is at most one substep ahead (its push of epoch e + 1 sits behind its grid update of epoch e, which
+// waited for THIS member's mail of epoch e), never two.  Payload: plain stores, per wave s_waitcnt vmcnt(0), workgroup barrier, one lane's system-scope
+// release, then the arrival counter; flag words: relaxed system-scope atomics; the reader polls relaxed, then ONE system-scope acquire
+// (MI355X_MICROARCH.md, inter-workgroup visibility -- the same recipe across devices needs system scope and fine-grained memory).
+// A peer that never answers: the wait gives up after `timeout_ticks` of the 100 MHz wall clock, raises the abort chain and Ctl::direct_error.
+constexpr int MAX_DIRECT = 64;
+struct PeerBox {
+    unsigned long long mail[2][MAX_DIRECT];   // [epoch & 1][writer]: (epoch << 32) | re-bin flag of that member for that substep
+    unsigned int halo_epoch[2][2];            // [epoch & 1][side]: written by the neighbour on `side` once all of its records of that epoch have landed
+    unsigned int arrive;                      // arrival counter of this member's own k_halo_push workgroups (local)
+    unsigned int pad[11];
+};
+typedef __attribute__((address_space(1))) unsigned long long* global_u64p;
+struct DirectWait {
+    const PeerBox* box;        // this member's box, NULL = not a direct launch
+    int n_mail;                // members in the job
+    unsigned int epoch;
+    int wait_side[2];          // a neighbour on that side pushes records
+    unsigned long long timeout_ticks;
+};
+struct DirectPush {
+    const int* list[2];        // halo columns of each cut (k_halo_list)
+    const int2* dst[2];        // per column: node-block slot of the UPPER block (.x) and of the LOWER block (.y) in the neighbour's block list, -1 = not there
+    int n[2];
+    float4* remote_halo[2];    // the neighbour's halo buffer of this epoch's parity
+    unsigned int* remote_epoch[2];   // &neighbour_box->halo_epoch[epoch & 1][its side that faces this member]
+    unsigned long long* mail[MAX_DIRECT];   // &box_of_member_k->mail[epoch & 1][this member's index], k < n_mail
+    int n_mail;
+    unsigned int epoch;
+    unsigned int* arrive;      // &own_box->arrive
+};
+#define SPK_RLX_SYS __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
+// the agreed re-bin flag of the substep: MAX over the mail of all members; false = timed out
+SPK_DEV bool direct_wait_mail(const DirectWait& W, int lane, bool& aborted) {
+    const unsigned long long t0 = wall_clock64();
+    const int par = W.epoch & 1u;
+    unsigned long long v = (unsigned long long)W.epoch << 32;
+    for (unsigned spin = 0;; ++spin) {
+        if (lane < W.n_mail) v = __hip_atomic_load((global_u64p)&W.box->mail[par][lane], SPK_RLX_SYS);
+        if (__all((unsigned int)(v >> 32) == W.epoch)) break;
+        if ((spin & 63u) == 63u && wall_clock64() - t0 > W.timeout_ticks) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    aborted = __any((unsigned int)v != 0u);
+    return true;
+}
+SPK_DEV bool direct_wait_halo(const DirectWait& W, int lane) {
+    const unsigned long long t0 = wall_clock64();
+    const int par = W.epoch & 1u;
+    for (unsigned spin = 0;; ++spin) {
+        unsigned int e = W.epoch;
+        if (lane < 2 && W.wait_side[lane]) e = __hip_atomic_load((global_u32p)&W.box->halo_epoch[par][lane], SPK_RLX_SYS);
+        if (__all(e == W.epoch)) break;
+        if ((spin & 63u) == 63u && wall_clock64() - t0 > W.timeout_ticks) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // ONE system-scope acquire behind the match; plain loads from here
+    return true;
+}
+SPK_DEV void direct_give_up(Ctl* ctl, int parity, unsigned int code) {
+    ctl->direct_error = code;
+    raise_abort(ctl, parity);
+    raise_abort(ctl, (parity + 1) & 1);
+}
 struct ParticleArrays {
     float4* q[6];
     float4* d;
@@ -1392,10 +1470,10 @@ SPK_DEV void gpu_boundary_rule(float v[3], const float cpos[3], const GridArrays
 // GPU_RULE: some collider carries its own boundary handling: the reference's GPU rule for the whole set (gpu_boundary_rule), no projection cache.
 template <bool MASS_ONLY, bool HEIGHTFIELDS = false, bool GPU_RULE = false>
 __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const DevCuboid* __restrict__ cuboids, const DevHeightField* __restrict__ heightfields, const DevTriMesh* __restrict__ trimeshes,
-                                                             const Ctl* __restrict__ ctl, StepParams S) {
+                                                             Ctl* ctl, StepParams S, DirectWait W = DirectWait{nullptr, 0, 0u, {0, 0}, 0ull}) {
     // The abort flag is read first but only consulted behind the first table loads: the topology arrays stay valid (stale) after an
     // abort, and the dependent-load chain stays at  blk_tnbr -> tile_mode -> tile  (3 hops; it used to be 5).
-    const int aborted = ctl->abort_flag[S.parity];
+    int aborted = ctl->abort_flag[S.parity];
     const int nb_total = G.nb_list ? G.nb_count : G.num_blocks;
     const int bi = xcd_remap(blockIdx.x, (nb_total + 3) / 4) * 4 + (threadIdx.x >> 6);
     if (bi >= nb_total) return;
@@ -1410,6 +1488,16 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
     // load one table entry and one mode each -- two coalesced loads instead of sixteen 4-byte gathers per lane, a third of the kernel's
     // vector-memory instructions -- and every lane picks its eight through the LDS crossbar (ds_bpermute).
     const int my_t = G.blk_tnbr[b * 27 + min(lane, 26)];
+    if (W.box) {
+        // peer-direct exchange: the flag of the substep is the MAX over the mail of ALL members (every wave derives it for itself; the first wave of
+        // the launch leaves it in the control block for the particle kernel behind), then the neighbours' records must have landed
+        bool any = false;
+        const bool first = blockIdx.x == 0 && threadIdx.x == 0;
+        if (!direct_wait_mail(W, lane, any)) { if (first) direct_give_up(ctl, S.parity, 1u); return; }
+        if (any) { if (first) raise_abort(ctl, S.parity); return; }
+        if (!direct_wait_halo(W, lane)) { if (first) direct_give_up(ctl, S.parity, 2u); return; }
+        aborted = 0;
+    }
     // the flag (a scalar load issued first) has arrived long before the table entry: an aborted launch leaves here, 34 -> ~8 us
     // at 10M particles (a batch cut by a re-bin request leaves up to 127 of them behind)
     if (aborted) return;
@@ -3526,6 +3614,71 @@ __global__ __launch_bounds__(BLK_THREADS) void k_halo_merge2(HaloSides hs, int a
     const int c = lo_part ? 3 : (lane - 16) >> 4, uv = lo_part ? lane : (lane - 16) & 15;
     halo_in[(size_t)b * 64 + plane_node(axis, c, uv & 3, uv >> 2)] = in[r].nodes[lane];
 }
+// record keys of the halo columns of one cut, in list order: what the neighbour resolves to its own node-block slots (k_halo_slots)
+__global__ void k_halo_keys(GridArrays G, const uint32_t* __restrict__ blk_keys, const int* __restrict__ list, int n, int axis, uint32_t* out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int e = list[r];
+    if (!(e & 1)) { out[r] = blk_keys[e >> 1]; return; }
+    const int4 o = G.blk_origin[e >> 1];
+    int bc[3] = {o.x >> 2, o.y >> 2, o.z >> 2};
+    bc[axis] += 1;
+    out[r] = block_key(bc[0], bc[1], bc[2]);
+}
+// (.x, .y) = slot of the block of that key and of the block below it along the axis in THIS member's block list (what k_halo_merge2 looked up every substep)
+__global__ void k_halo_slots(const uint32_t* __restrict__ keys, int n, int axis, HashTable H, int2* out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t key = keys[r];
+    int bc[3] = {(int)compact10(key) - 1, (int)compact10(key >> 1) - 1, (int)compact10(key >> 2) - 1};
+    bc[axis] -= 1;
+    out[r] = make_int2(hash_lookup(H, (uint64_t)key), bc[axis] >= -1 ? hash_lookup(H, (uint64_t)block_key(bc[0], bc[1], bc[2])) : -1);
+}
+// one wave per halo column, both cuts in one launch (waves [0, n0) serve the low cut); at least one workgroup even without columns: the mail
+__global__ __launch_bounds__(BLK_THREADS) void k_halo_push(GridArrays G, DirectPush D, int axis, Ctl* ctl, int parity) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned int aborted = ctl->abort_flag[parity];   // this member's own flag for the substep: final, the particle kernel in front has finished
+    if (blockIdx.x == 0 && tid < D.n_mail)
+        __hip_atomic_store((global_u64p)D.mail[tid], ((unsigned long long)D.epoch << 32) | (aborted ? 1ull : 0ull), SPK_RLX_SYS);
+    if (aborted) return;   // (every member's grid update will read the flag in the mail and skip the substep without waiting for records)
+    int r = blockIdx.x * 4 + (tid >> 6);
+    const int side = r >= D.n[0] ? 1 : 0;
+    if (side) r -= D.n[0];
+    if (r < D.n[side]) {
+        const int e = D.list[side][r];
+        const int2 dst = D.dst[side][r];
+        int upper = (e & 1) ? -1 : (e >> 1), lower = (e & 1) ? (e >> 1) : G.blk_nbr[(e >> 1) * 27 + nbr_slot(axis, -1)];
+        const bool lo_part = lane < 16;
+        const int b = lo_part ? lower : upper;
+        const int c = lo_part ? 3 : (lane - 16) >> 4, uv = lo_part ? lane : (lane - 16) & 15;
+        const int node = plane_node(axis, c, uv & 3, uv >> 2);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b >= 0) v = halo_node_sum(G, b, node & 3, (node >> 2) & 3, node >> 4);
+        const int slot = lo_part ? dst.y : dst.x;
+        if (slot >= 0) D.remote_halo[side][(size_t)slot * 64 + node] = v;
+    }
+    // every record of this launch has landed before the neighbours are told so
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int old = __hip_atomic_fetch_add((global_u32p)D.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == gridDim.x) {
+            __hip_atomic_store((global_u32p)D.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch is a later kernel
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");   // the other workgroups' releases happened before their increments, which this one has read
+            for (int sd = 0; sd < 2; ++sd)
+                if (D.remote_epoch[sd]) __hip_atomic_store((global_u32p)D.remote_epoch[sd], D.epoch, SPK_RLX_SYS);
+        }
+    }
+}
+// a member without particle blocks: the agreed flag goes into its control block in front of k_bump_steps (its push has posted the mail)
+__global__ void k_direct_agree(DirectWait W, Ctl* ctl, int parity) {
+    bool aborted = false;
+    if (!direct_wait_mail(W, threadIdx.x & 63, aborted)) { if (threadIdx.x == 0) direct_give_up(ctl, parity, 1u); return; }
+    if (aborted && threadIdx.x == 0) raise_abort(ctl, parity);
+}
+
 // MAX of the members' abort flags of the upcoming substep, written back to all of them (members of one process on one stream)
 struct CtlList { Ctl* c[16]; int n; };
 __global__ void k_flags_max(CtlList L, int parity) {

@@ -170,6 +170,24 @@ struct SparklPipeline {
     DevBuf<long long> x_dev;          // small device staging area for counts / flags
     long long* x_host = nullptr;     // pinned
     uint64_t group_rebins = 0, cut_moves = 0;
+    // Peer-direct halo exchange (kernels.h, PeerBox): the arena peers write into, this member's view of theirs, and the epoch counter.
+    struct Direct {
+        bool ready = false;              // arena mapped everywhere, slots negotiated for the current binning (agreed by every rank)
+        bool failed = false;             // a setup step failed on some rank: the job stays on the RCCL / copy exchange
+        void* arena = nullptr;           // [PeerBox | halo buffer parity 0 | halo buffer parity 1], fine-grained device memory
+        size_t arena_bytes = 0, cap_blocks = 0;
+        uint64_t arena_serial = 0;       // bumped by every (re)allocation
+        int index = 0, n = 1;            // this member's mailbox slot and the number of members in the job
+        uint32_t epoch = 0;              // group substeps enqueued so far (the same on every member of the job)
+        DevBuf<int2> dst[2];             // per halo column of each cut: the neighbour's node-block slots (k_halo_slots)
+        void* peer_arena[MAX_DIRECT] = {nullptr};   // every member's arena in THIS process' address space ([index] = own)
+        void* peer_ipc[MAX_DIRECT] = {nullptr};     // the ones opened with hipIpcOpenMemHandle (closed when replaced / at destroy)
+        uint64_t peer_serial[MAX_DIRECT] = {0};
+        uint64_t peer_pid[MAX_DIRECT] = {0};
+        size_t peer_cap[MAX_DIRECT] = {0};          // cap_blocks of the peer's arena (where its second halo buffer starts)
+        PeerBox* box() const { return reinterpret_cast<PeerBox*>(arena); }
+    } direct;
+    DirectWait dw{nullptr, 0, 0u, {0, 0}, 0ull};   // handed to the grid update of the substep in flight (group loop, direct exchange), else box == NULL
     DevBuf<long long> bal_dev;       // plane histogram + cut list of the slab re-balancing (group_rebalance)
     long long* bal_host = nullptr; int bal_host_words = 0;
     bool slab_balance = true;        // sparkl_hip_slab_balance
@@ -284,6 +302,7 @@ struct SparklPipeline {
 };
 
 static void comm_destroy(SparklPipeline* p);
+static void direct_release(SparklPipeline* p);
 enum { SPAN_P2G = 0, SPAN_GRID = 1, SPAN_G2P = 2, SPAN_SORT = 3, SPAN_DT = 4, SPAN_HALO = 5, SPAN_FUSED = 6, SPAN_REORDER = 7, SPAN_P2G_MASS = 8, SPAN_GRID_MASS = 9, SPAN_G2P_VOLUME = 10 };
 
 static int clock_begin(SparklPipeline* p, int kind, size_t* tok, hipStream_t st = nullptr) {
@@ -673,10 +692,16 @@ static void prepare_proj_cache(SparklPipeline* p, hipStream_t st) {
 }
 // the instantiation of k_grid_update a collider set needs: triangle-searching shapes or not, and the reference's GPU rule (closest collider,
 // signed-distance normal: kernels.h gpu_boundary_rule) as soon as one collider carries a boundary handling of its own
-static void launch_grid_kernel(SparklPipeline* p, const GridArrays& G, const StepParams& S, dim3 grid, hipStream_t st) {
+static float4* direct_halo(const SparklPipeline* p, const void* arena, size_t cap_blocks, int parity) {
+    (void)p;
+    return reinterpret_cast<float4*>((char*)arena + sizeof(PeerBox)) + (size_t)parity * cap_blocks * 64;
+}
+static void launch_grid_kernel(SparklPipeline* p, const GridArrays& G_in, const StepParams& S, dim3 grid, hipStream_t st) {
     const dim3 block(BLK_THREADS);
+    GridArrays G = G_in;
+    if (p->dw.box) G.halo_in = p->num_blocks ? direct_halo(p, p->direct.arena, p->direct.cap_blocks, (int)(p->dw.epoch & 1u)) : nullptr;   // what the neighbours' k_halo_push wrote for this epoch
     const bool shapes = p->num_heightfields > 0 || p->num_trimeshes > 0 || p->num_polylines > 0;
-#define SPK_GU(HF, GR) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, HF, GR>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S)
+#define SPK_GU(HF, GR) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_update<false, HF, GR>), grid, block, 0, st, G, p->d_cuboids.p, p->d_heightfields.p, p->d_trimeshes.p, p->d_ctl, S, p->dw)
     if (p->collider_handling) { if (shapes) SPK_GU(true, true); else SPK_GU(false, true); }
     else { if (shapes) SPK_GU(true, false); else SPK_GU(false, false); }
 #undef SPK_GU
@@ -1088,6 +1113,7 @@ void sparkl_hip_pipeline_destroy(SparklPipeline* p) {
     p->halo_list[0].release(); p->halo_list[1].release(); p->halo_in.release(); p->d_tail.release();
     for (int k = 0; k < 2; ++k) { p->x_send[k].release(); p->x_recv[k].release(); p->x_mig_send[k].release(); p->x_mig_recv[k].release(); }
     p->x_dev.release();
+    direct_release(p);
     if (p->x_host) (void)hipHostFree(p->x_host);
     if (p->bal_host) (void)hipHostFree(p->bal_host);
     comm_destroy(p);
@@ -2283,6 +2309,7 @@ static int substep_finish_impl(SparklPipeline* p, bool fuse_next, bool defer_c =
     if (part & 2) { p->in_substep = false; p->tiles_ready = false; }
     if (p->num_pblocks == 0) {
         if (!(part & 2)) return SPARKL_OK;
+        if (p->dw.box) hipLaunchKernelGGL(k_direct_agree, dim3(1), dim3(64), 0, p->stream, p->dw, p->d_ctl, p->pending.parity);   // the agreed flag first
         hipLaunchKernelGGL(k_bump_steps, dim3(1), dim3(1), 0, p->stream, p->d_ctl, p->pending.parity);
         p->clock_on = p->pending_clock_saved;
         p->substep_index++;
@@ -2292,10 +2319,12 @@ static int substep_finish_impl(SparklPipeline* p, bool fuse_next, bool defer_c =
     const GridArrays G = grid_arrays(p);
     size_t t1 = 0, t2 = 0;
     if (part & 1) {
-        CHK(maybe_reorder(p, p->pending.parity));
+        // (direct exchange: the grid update is where the substep's flag is agreed; the reorder, which reads it, goes behind)
+        if (!p->dw.box) CHK(maybe_reorder(p, p->pending.parity));
         CHK(clock_begin(p, SPAN_GRID, &t1));
         launch_grid_update(p, G, p->pending, st);
         CHK(clock_end(p, t1));
+        if (p->dw.box) CHK(maybe_reorder(p, p->pending.parity));
     }
     if (!(part & 2)) return SPARKL_OK;
     p->last_finish_fused = fuse_next && p->fuse_fixed_dt;
@@ -2690,6 +2719,7 @@ static int group_rebalance(const Group& G) {
     return SPARKL_OK;
 }
 
+static int group_direct_setup(Group& G);
 // `balance`: agreed by every rank (balance_veto through group_max); needs the block list of an earlier re-bin
 static int group_rebin(const Group& G, bool balance) {
     const uint64_t mig_bytes = MIG_F4 * sizeof(float4), halo_bytes = sizeof(HaloRecord);
@@ -2739,10 +2769,204 @@ static int group_rebin(const Group& G, bool balance) {
             CHK(p->x_recv[side].reserve(std::max<uint64_t>(n_in[i][side] * halo_bytes, 16)));
         }
         p->group_rebins++;
+        p->direct.ready = false;   // the binning is new: slots and buffers are rebuilt below
+    }
+    {
+        Group Gd = G;
+        CHK(group_direct_setup(Gd));
+    }
+    return SPARKL_OK;
+}
+
+// ---------------------------------------------------------------- peer-direct halo exchange: setup (see kernels.h, PeerBox)
+// What every member publishes about its arena: one 128-byte record per member of the job, gathered over the communicator.
+struct ArenaRecord {
+    uint64_t pid, token;          // process identity (pid + a per-process random word: members of one process exchange raw pointers)
+    uint64_t ptr, bytes, cap_blocks, serial;
+    int32_t device, valid;
+    unsigned char handle[64];     // hipIpcMemHandle_t
+    unsigned char pad[8];
+};
+static_assert(sizeof(ArenaRecord) == 128 && sizeof(hipIpcMemHandle_t) == 64, "");
+static uint64_t process_token() {
+    static const uint64_t t = [] {
+        uint64_t r = 0;
+        if (FILE* f = fopen("/dev/urandom", "rb")) { if (fread(&r, sizeof(r), 1, f) != 1) r = 0; fclose(f); }
+        return r ^ ((uint64_t)getpid() << 32);
+    }();
+    return t;
+}
+static bool direct_wanted() { return !(getenv("SPARKL_HIP_DIRECT") && !strcmp(getenv("SPARKL_HIP_DIRECT"), "0")); }   // (read at every collective re-bin)
+// the arena of one member, sized for its current node blocks (grows by half: a reallocation means new mappings on every peer)
+static int direct_arena(SparklPipeline* p) {
+    const size_t need_blocks = std::max<size_t>((size_t)p->num_blocks, 64);
+    SparklPipeline::Direct& D = p->direct;
+    if (D.arena && need_blocks <= D.cap_blocks) return SPARKL_OK;
+    const size_t cap = need_blocks + need_blocks / 2;
+    const size_t bytes = sizeof(PeerBox) + 2 * cap * 64 * sizeof(float4);
+    void* a = nullptr;
+    // fine-grained: peers store into it while kernels of this device poll and read it (system-scope release / acquire needs coherent memory)
+    hipError_t e = hipExtMallocWithFlags(&a, bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&a, bytes); }   // (one device, one process: plain device memory does)
+    if (e != hipSuccess) return set_error(SPARKL_ERR_OUT_OF_MEMORY, "direct exchange arena: %s", hipGetErrorString(e));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    if (D.arena) {
+        HIPCHK(hipMemcpy(a, D.arena, sizeof(PeerBox), hipMemcpyDeviceToDevice));   // (the mail of past epochs: harmless either way)
+        (void)hipFree(D.arena);
+    } else HIPCHK(hipMemset(a, 0, sizeof(PeerBox)));
+    D.arena = a; D.arena_bytes = bytes; D.cap_blocks = cap; D.arena_serial++;
+    return SPARKL_OK;
+}
+// Behind a collective re-bin: arenas sized and zeroed, every member's arena mapped into every other member's address space, the halo columns
+// of each cut resolved to the neighbour's node-block slots.  A step that fails on ANY rank (no peer access, hipIpc refused, more than MAX_DIRECT
+// members) is agreed through one more group_max and the whole job stays on the RCCL / copy exchange -- never a mix.
+static int group_direct_setup(Group& G) {
+    const int world = G.rccl ? G.m[0]->comm_world : G.n;
+    bool ok = direct_wanted() && world <= MAX_DIRECT && world >= 1;
+    // (a schedule forced or calibrated through SPARKL_HIP_OVERLAP is a request for the RCCL / copy exchange, whose two-stream variant it selects)
+    for (int i = 0; i < G.n; ++i) ok = ok && !G.m[i]->direct.failed && (G.m[i]->overlap_mode == -1 || G.m[i]->overlap_mode == 0);
+    auto index_of = [&](int i) { return G.rccl ? G.m[i]->comm_rank : i; };
+    std::vector<ArenaRecord> table((size_t)world);
+    memset(table.data(), 0, table.size() * sizeof(ArenaRecord));
+    if (ok)
+        for (int i = 0; i < G.n && ok; ++i) {
+            SparklPipeline* p = G.m[i];
+            HIPCHK(hipSetDevice(p->device));
+            if (direct_arena(p) != SPARKL_OK) { ok = false; break; }
+            p->direct.index = index_of(i); p->direct.n = world;
+            ArenaRecord& r = table[(size_t)index_of(i)];
+            r.pid = (uint64_t)getpid(); r.token = process_token(); r.ptr = (uint64_t)(uintptr_t)p->direct.arena; r.bytes = p->direct.arena_bytes;
+            r.cap_blocks = p->direct.cap_blocks; r.serial = p->direct.arena_serial; r.device = p->device; r.valid = 1;
+            if (G.rccl && world > G.n) {   // some member lives in another process: it needs a handle
+                hipIpcMemHandle_t h;
+                if (hipIpcGetMemHandle(&h, p->direct.arena) != hipSuccess) { (void)hipGetLastError(); r.valid = 0; ok = false; }
+                else memcpy(r.handle, &h, 64);
+            }
+        }
+    if (G.rccl && world > 1) {
+        // all-gather as a byte-wise SUM over zero-filled tables (every rank fills its own records): one collective RCCL and the test transport both have
+        const size_t bytes = table.size() * sizeof(ArenaRecord);
+        for (int i = 0; i < G.n; ++i) {
+            SparklPipeline* p = G.m[i];
+            HIPCHK(hipSetDevice(p->device));
+            CHK(p->x_mig_send[0].reserve(std::max<size_t>(bytes, 16)));
+            std::vector<ArenaRecord> mine((size_t)world);
+            memset(mine.data(), 0, bytes);
+            if (ok) mine[(size_t)index_of(i)] = table[(size_t)index_of(i)];
+            HIPCHK(hipMemcpyAsync(p->x_mig_send[0].p, mine.data(), bytes, hipMemcpyHostToDevice, p->stream));
+            HIPCHK(hipStreamSynchronize(p->stream));
+        }
+        NCCLCHK(g_rccl.GroupStart());
+        for (int i = 0; i < G.n; ++i) NCCLCHK(g_rccl.AllReduce(G.m[i]->x_mig_send[0].p, G.m[i]->x_mig_send[0].p, bytes, ncclUint8, ncclSum, G.m[i]->comm, G.m[i]->stream));
+        NCCLCHK(g_rccl.GroupEnd());
+        for (int i = 0; i < G.n; ++i) {
+            SparklPipeline* p = G.m[i];
+            HIPCHK(hipSetDevice(p->device));
+            HIPCHK(hipMemcpyAsync(table.data(), p->x_mig_send[0].p, bytes, hipMemcpyDeviceToHost, p->stream));
+            CHK(comm_wait(p, p->stream));
+        }
+        for (int q = 0; q < world; ++q) ok = ok && table[(size_t)q].valid == 1;
+    }
+    // map
+    if (ok)
+        for (int i = 0; i < G.n && ok; ++i) {
+            SparklPipeline* p = G.m[i];
+            SparklPipeline::Direct& D = p->direct;
+            HIPCHK(hipSetDevice(p->device));
+            for (int q = 0; q < world && ok; ++q) {
+                const ArenaRecord& r = table[(size_t)q];
+                if (D.peer_arena[q] && D.peer_serial[q] == r.serial && D.peer_pid[q] == r.token) continue;   // still the mapping of the last setup
+                if (D.peer_ipc[q]) { (void)hipIpcCloseMemHandle(D.peer_ipc[q]); D.peer_ipc[q] = nullptr; }
+                D.peer_arena[q] = nullptr;
+                if (r.pid == (uint64_t)getpid() && r.token == process_token()) {
+                    if (r.device != p->device) {   // another device of this process (sparkl_hip_comm_init_all): peer access, both ways (the peer's loop turn does the other)
+                        int can = 0;
+                        if (hipDeviceCanAccessPeer(&can, p->device, r.device) != hipSuccess || !can) { (void)hipGetLastError(); ok = false; break; }
+                        const hipError_t e = hipDeviceEnablePeerAccess(r.device, 0);
+                        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); ok = false; break; }
+                        (void)hipGetLastError();
+                    }
+                    D.peer_arena[q] = (void*)(uintptr_t)r.ptr;
+                } else {
+                    hipIpcMemHandle_t h;
+                    memcpy(&h, r.handle, 64);
+                    void* mapped = nullptr;
+                    if (hipIpcOpenMemHandle(&mapped, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+                    D.peer_ipc[q] = mapped; D.peer_arena[q] = mapped;
+                }
+                D.peer_serial[q] = r.serial; D.peer_pid[q] = r.token; D.peer_cap[q] = (size_t)r.cap_blocks;
+            }
+            for (int q = 0; q < world; ++q) D.peer_cap[q] = (size_t)table[(size_t)q].cap_blocks;
+        }
+    {   // every rank takes the same branch
+        std::vector<long long> v(G.n, ok ? 0 : 1);
+        long long any_bad = 0;
+        CHK(group_max(G, v.data(), &any_bad));
+        if (any_bad) {
+            for (int i = 0; i < G.n; ++i) { G.m[i]->direct.ready = false; G.m[i]->direct.failed = true; }
+            if (getenv("SPARKL_HIP_DEBUG")) fprintf(stderr, "[sparkl_hip] direct halo exchange not available (local setup %s): staying on the RCCL / copy exchange\n", ok ? "ok" : "failed");
+            return SPARKL_OK;
+        }
+    }
+    // slots: my column keys -> neighbour -> its node-block slots -> back (two exchanges per re-bin, on the main streams, like the migration)
+    std::vector<std::array<uint64_t, 2>> b_out(G.n), b_in(G.n);
+    Group Gm = G;
+    Gm.overlap = false;
+    for (int i = 0; i < G.n; ++i) {
+        SparklPipeline* p = G.m[i];
+        HIPCHK(hipSetDevice(p->device));
+        for (int side = 0; side < 2; ++side) {
+            const uint64_t ns = G.nbr(i, side) != -2 ? p->x_nsend[side] : 0, nr = G.nbr(i, side) != -2 ? p->x_nrecv[side] : 0;
+            b_out[i][side] = ns * sizeof(uint32_t); b_in[i][side] = nr * sizeof(uint32_t);
+            CHK(p->x_mig_send[side].reserve(std::max<uint64_t>(std::max(ns, nr) * sizeof(int2), 16)));
+            CHK(p->x_mig_recv[side].reserve(std::max<uint64_t>(std::max(ns, nr) * sizeof(int2), 16)));
+            if (ns) hipLaunchKernelGGL(k_halo_keys, dim3(grid_for(ns, 256)), dim3(256), 0, p->stream, grid_arrays(p), p->blk_keys.p, p->halo_list[side].p, (int)ns, p->slab_axis, (uint32_t*)p->x_mig_send[side].p);
+        }
+    }
+    CHK(group_exchange(Gm, &SparklPipeline::x_mig_send, &SparklPipeline::x_mig_recv, (const uint64_t(*)[2])b_out.data(), (const uint64_t(*)[2])b_in.data()));
+    for (int i = 0; i < G.n; ++i) {
+        SparklPipeline* p = G.m[i];
+        HIPCHK(hipSetDevice(p->device));
+        HashTable H{p->hash_keys.p, p->hash_vals.p, p->hash_mask};
+        for (int side = 0; side < 2; ++side) {
+            const uint64_t nr = b_in[i][side] / sizeof(uint32_t);
+            if (nr && p->num_blocks) hipLaunchKernelGGL(k_halo_slots, dim3(grid_for(nr, 256)), dim3(256), 0, p->stream, (const uint32_t*)p->x_mig_recv[side].p, (int)nr, p->slab_axis, H, (int2*)p->x_mig_send[side].p);
+            else if (nr) HIPCHK(hipMemsetAsync(p->x_mig_send[side].p, 0xFF, nr * sizeof(int2), p->stream));   // no block at all here: every slot -1
+            const uint64_t ns = b_out[i][side] / sizeof(uint32_t);
+            b_out[i][side] = nr * sizeof(int2); b_in[i][side] = ns * sizeof(int2);
+        }
+    }
+    CHK(group_exchange(Gm, &SparklPipeline::x_mig_send, &SparklPipeline::x_mig_recv, (const uint64_t(*)[2])b_out.data(), (const uint64_t(*)[2])b_in.data()));
+    for (int i = 0; i < G.n; ++i) {
+        SparklPipeline* p = G.m[i];
+        HIPCHK(hipSetDevice(p->device));
+        for (int side = 0; side < 2; ++side) {
+            const uint64_t ns = b_in[i][side] / sizeof(int2);
+            CHK(p->direct.dst[side].reserve(std::max<uint64_t>(ns, 1)));
+            if (ns) HIPCHK(hipMemcpyAsync(p->direct.dst[side].p, p->x_mig_recv[side].p, ns * sizeof(int2), hipMemcpyDeviceToDevice, p->stream));
+        }
+        // both halo buffers start from zero: a node of a cut plane no record covers reads 0, like the halo_in of the copy exchange
+        HIPCHK(hipMemsetAsync((char*)p->direct.arena + sizeof(PeerBox), 0, 2 * p->direct.cap_blocks * 64 * sizeof(float4), p->stream));
+        CHK(comm_wait(p, p->stream));
+        p->direct.ready = true;
+    }
+    // nobody may push into a buffer its owner is still clearing: one more agreement (host-synchronous, like everything around a re-bin)
+    {
+        std::vector<long long> v(G.n, 0);
+        long long dummy = 0;
+        CHK(group_max(G, v.data(), &dummy));
     }
     return SPARKL_OK;
 }
 }  // namespace
+static void direct_release(SparklPipeline* p) {
+    SparklPipeline::Direct& D = p->direct;
+    for (int k = 0; k < MAX_DIRECT; ++k) { if (D.peer_ipc[k]) (void)hipIpcCloseMemHandle(D.peer_ipc[k]); D.peer_ipc[k] = nullptr; D.peer_arena[k] = nullptr; D.peer_serial[k] = 0; }
+    if (D.arena) (void)hipFree(D.arena);
+    D.arena = nullptr; D.arena_bytes = 0; D.cap_blocks = 0;
+    D.dst[0].release(); D.dst[1].release();
+    D.ready = false;
+}
 
 // halo stream and fork / join events of a member (created on first use)
 static int overlap_resources(SparklPipeline* p) {
@@ -2945,7 +3169,10 @@ static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, con
     std::vector<std::array<uint64_t, 2>> bs(G.n), br(G.n);
     while (done < nsubsteps) {
         const uint32_t batch = std::min<uint32_t>(16, nsubsteps - done);
-        G.overlap = schedule_of_batch();
+        // peer-direct exchange (kernels.h, PeerBox): set up by the last collective re-bin on every rank or on none
+        bool direct = !fluid_sweep && !psi_sweep;
+        for (int i = 0; i < G.n; ++i) direct = direct && members[i]->direct.ready;
+        G.overlap = !direct && schedule_of_batch();
         if (G.overlap) for (int i = 0; i < G.n; ++i) CHK(overlap_resources(members[i]));
         const auto batch_t0 = std::chrono::steady_clock::now();
         for (uint32_t j = 0; j < batch; ++j) {
@@ -2957,7 +3184,9 @@ static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, con
                     HIPCHK(hipEventRecord(members[i]->ev_main, members[i]->stream));
                     HIPCHK(hipStreamWaitEvent(G.xs(i), members[i]->ev_main, 0));
                 }
-            if (G.rccl) {
+            if (direct) {
+                // nothing here: every member's k_halo_push mails its flag to all members and their grid updates take the MAX
+            } else if (G.rccl) {
                 NCCLCHK(g_rccl.GroupStart());
                 for (int i = 0; i < G.n; ++i) {
                     uint32_t* flag = &members[i]->d_ctl->abort_flag[members[i]->substep_index & 1u];
@@ -3097,6 +3326,42 @@ static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, con
                 HIPCHK(hipGetLastError());
                 continue;
             }
+            if (direct) {
+                // ONE kernel per member in front of the grid update: flag mail to everybody, records straight into the neighbours' halo buffers
+                static const double tmo_s = std::min(20.0, comm_timeout_s() > 0.0 ? comm_timeout_s() : 20.0);   // (a kernel may not spin for minutes: the driver's compute watchdog)
+                for (int i = 0; i < G.n; ++i) {
+                    SparklPipeline* p = members[i];
+                    SparklPipeline::Direct& Dp = p->direct;
+                    HIPCHK(hipSetDevice(p->device));
+                    const uint32_t epoch = ++Dp.epoch;
+                    const int par = (int)(epoch & 1u);
+                    DirectPush D;
+                    memset(&D, 0, sizeof(D));
+                    D.n_mail = Dp.n; D.epoch = epoch; D.arrive = &Dp.box()->arrive;
+                    for (int k = 0; k < Dp.n; ++k) D.mail[k] = &reinterpret_cast<PeerBox*>(Dp.peer_arena[k])->mail[par][Dp.index];
+                    p->dw.box = Dp.box(); p->dw.n_mail = Dp.n; p->dw.epoch = epoch; p->dw.timeout_ticks = (unsigned long long)(tmo_s * 1.0e8);
+                    for (int side = 0; side < 2; ++side) {
+                        const bool has = G.nbr(i, side) != -2;
+                        p->dw.wait_side[side] = has ? 1 : 0;
+                        if (!has) continue;
+                        const int q = Dp.index + (side == 0 ? -1 : 1);
+                        D.list[side] = p->halo_list[side].p; D.dst[side] = Dp.dst[side].p; D.n[side] = p->num_pblocks ? (int)p->x_nsend[side] : 0;
+                        D.remote_halo[side] = direct_halo(p, Dp.peer_arena[q], Dp.peer_cap[q], par);
+                        D.remote_epoch[side] = &reinterpret_cast<PeerBox*>(Dp.peer_arena[q])->halo_epoch[par][1 - side];
+                    }
+                    size_t tok = 0;
+                    CHK(clock_begin(p, SPAN_HALO, &tok));
+                    hipLaunchKernelGGL(k_halo_push, dim3(std::max(1, (D.n[0] + D.n[1] + 3) / 4)), dim3(BLK_THREADS), 0, p->stream, grid_arrays(p), D, p->slab_axis, p->d_ctl, p->pending.parity);
+                    CHK(clock_end(p, tok));
+                }
+                for (int i = 0; i < G.n; ++i) {
+                    const int rc = substep_finish_impl(members[i], fuse_next, defer);
+                    members[i]->dw.box = nullptr;
+                    CHK(rc);
+                }
+                HIPCHK(hipGetLastError());
+                continue;
+            }
             CHK(halo_round(false));
             if (psi_sweep) {
                 // DamageModel::ModifiedEigenerosion across the cuts: the psi_mass / psi_momentum planes travel like the momentum planes,
@@ -3135,6 +3400,8 @@ static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, con
             HIPCHK(hipSetDevice(members[i]->device));
             CHK(read_ctl(members[i]));
             if (members[i]->clock_on) CHK(clock_collect(members[i]));
+            if (members[i]->h_ctl->direct_error)
+                return set_error(SPARKL_ERR_HIP, "member %d: a kernel gave up waiting for a peer's %s (direct halo exchange; the peer is gone?)", i, members[i]->h_ctl->direct_error == 1 ? "re-bin flag" : "halo records");
             const uint32_t r = members[i]->h_ctl->steps_done - base[i];
             // cut short behind a fused launch that deferred C.m[1..8] (the last launch of a whole batch stores C, fused or not)
             if (r > done && r < done + batch && !fluid_sweep && !psi_sweep && members[i]->fuse_fixed_dt && members[i]->defer_c && !members[i]->rare_models &&
@@ -3328,6 +3595,14 @@ extern "C" int sparkl_hip_debug_run_stats(SparklPipeline* p, unsigned long long*
     HIPCHK(hipMemcpyAsync(out, p->d_count.p, sizeof(unsigned long long) * RS_HISTS * RS_BINS, hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     return SPARKL_OK;
+}
+
+// (tests, bench) out[0] = 1 while the group loop of this pipeline exchanges its halo peer-direct (kernels.h, PeerBox), out[1] = substeps it has pushed so far,
+// out[2] = 1 when a setup attempt failed and the job fell back to the RCCL / copy exchange, out[3] = members of the job
+extern "C" int sparkl_hip_debug_direct(const SparklPipeline* p, unsigned long long out[4]) {
+    if (!p || !out) return -1;
+    out[0] = p->direct.ready ? 1 : 0; out[1] = p->direct.epoch; out[2] = p->direct.failed ? 1 : 0; out[3] = (unsigned long long)p->direct.n;
+    return 0;
 }
 
 // (tests) 1 while the fused kernel of this pipeline would run on the flags mirror (ParticleArrays::fl), else 0

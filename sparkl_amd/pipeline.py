@@ -117,6 +117,12 @@ class MpmPipeline:
         check(members[0].L.sparkl_hip_group_step(arr, C.c_uint32(len(members)), C.byref(params), g, C.byref(sim), C.byref(nsub)))
         return sim.value, int(nsub.value)
 
+    def direct_info(self):
+        """Peer-direct halo exchange of the group loop (kernels.h, PeerBox): {"ready", "epochs", "failed", "members"}."""
+        out = (C.c_ulonglong * 4)()
+        self.L.sparkl_hip_debug_direct(self.h, out)
+        return {"ready": bool(out[0]), "epochs": int(out[1]), "failed": bool(out[2]), "members": int(out[3])}
+
     def slab_balance(self, enable=True):
         check(self.L.sparkl_hip_slab_balance(self.h, int(bool(enable))))
 

@@ -62,6 +62,17 @@ void devmath_corotated(const float* mp, float eh, const float* E_in, float* tau9
     const float s[3] = {0.f, 0.f, 0.f};
     *psi = model_pos_energy(mo, 1.f, eh, F, E, s, false, det_minus_one(E));
 }
+// neo-Hookean positive energy of F = I + E (column-major) at phase = 1: mp[0] = lambda, mp[1] = mu
+float devmath_neo_hookean_energy(const float* mp, float eh, const float* E_in) {
+    DevModel mo = make_model(mp);
+    mo.ctag = SPARKL_CONSTITUTIVE_NEO_HOOKEAN;
+    M3 E;
+    for (int i = 0; i < 9; ++i) E.m[i] = E_in[i];
+    M3 F = E;
+    F.m[0] += 1.f; F.m[4] += 1.f; F.m[8] += 1.f;
+    const float s[3] = {0.f, 0.f, 0.f};
+    return model_pos_energy(mo, 1.f, eh, F, E, s, false, det_minus_one(E));
+}
 void devmath_sym_eigvals(const float* a6, float* e3) { sym_eigvals(a6, e3); }
 float devmath_series_max(void) { return SPK_SERIES_MAX; }
 float devmath_series_max2(void) { return SPK_SERIES_MAX2; }

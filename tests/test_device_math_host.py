@@ -206,3 +206,33 @@ def test_closed_form_eigenvalues(libs):
             gaps = np.diff(ref)
             if gaps.min() > 0.05 * nrm:
                 assert np.abs(got - ref).max() < 3e-6 * nrm
+
+
+@pytest.mark.parametrize("scale", [1e-5, 1e-3, 3e-2, 0.3])
+def test_neo_hookean_positive_energy_keeps_the_strain_precision(libs, scale):
+    """elasticity_neo_hookean.rs:118-141 forms psi_pos as differences of O(1) numbers (tr(F F^T) J^(-2/3) - 3, (J^2 - 1)/2 - ln J): in f32 that is
+    3e-7 mu of absolute error on a value of mu * strain^2.  The device form (device_math.h, model_pos_energy) cancels the first order analytically:
+    against the f64 formula on random stretches behind a rotation of the order of the strain (E = F - I is O(rotation): a particle that has turned far
+    carries the F-form's precision again), to 1e-4 of the value at every strain scale (the reference's f32 form: tens of per cent
+    at strains of 1e-3)."""
+    L = libs["series"]
+    L.devmath_neo_hookean_energy.restype = C.c_float
+    rng = np.random.default_rng(5)
+    lam, mu = 5.77e5, 3.85e5
+    mp = _MP.copy(); mp[0], mp[1] = lam, mu
+    worst = 0.0
+    for t in range(200):
+        A = rng.normal(size=(3, 3))
+        F = _rot(rng.normal(size=3), 3.0 * scale * rng.normal()) @ (np.eye(3) + 0.5 * (A + A.T) * scale)
+        E32 = (F - np.eye(3)).astype(f32)
+        F64 = np.eye(3) + E32.astype(np.float64)
+        j = np.linalg.det(F64)
+        if j <= 0.2:
+            continue
+        k = 2.0 / 3.0 * mu + lam
+        dev = mu / 2.0 * (np.trace(F64 @ F64.T) * j ** (-2.0 / 3.0) - 3.0)
+        vol = k / 2.0 * ((j * j - 1.0) / 2.0 - math.log(j))
+        want = dev if j < 1.0 else dev + vol
+        got = float(L.devmath_neo_hookean_energy(_p(mp), C.c_float(1.0), _p(np.ascontiguousarray(E32.T.reshape(9)))))
+        worst = max(worst, abs(got - want) / max(abs(want), 1e-300))
+    assert worst < 1e-4, worst

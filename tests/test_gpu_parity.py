@@ -433,7 +433,10 @@ def test_rare_material_models_parity(Pipeline, name):
             o64.substep_fixed(sc.params, sc.gravity, dt)
         p.substeps(sc.params, sc.gravity, dt, 100)
         got, r32, r64 = p.read_particles(), o32.get_particles(), o64.get_particles()
-    rep, bad = parity_verdict(got, r32, r64, sc.cell_width)
+    # snow and NACC run the reference's own F-form f32 arithmetic here too (RARE kernels, no strain form) and their yield surfaces snap: the
+    # reference's f32 trajectory itself sits 1e-3 (snow: psi_pos) .. 6e-3 (NACC: F) from its f64 one, see parity_verdict(spread=)
+    spread = {"snow": ("eps_psi",), "nacc": ("eps_F", "eps_C", "eps_psi", "eps_nacc")}.get(name, ())
+    rep, bad = parity_verdict(got, r32, r64, sc.cell_width, spread=spread)
     n = len(sc.particles)
     acted = {
         "snow": int((r32.volume["plastic_deformation_gradient_det"] < 0.999).sum()),

@@ -83,9 +83,10 @@ def _worker(rank, world, port, kind, nsteps, out_dir):
         got = pipe.read_particles()
         local_ids = pipe.read_sorted_particle_ids()
     # slab pipelines read back in device order; the ids travel with the particles through migrations
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pos=got.position["point"], vel=got.velocity["vector"], F=got.volume["deformation_gradient"],
-             C=got.velocity_gradient["m"], failed=got.status["failed"], caller=id_to_caller[local_ids],
-             mass=got.volume["mass"], rebins=st.num_rebins, n0=len(gids), n1=len(got), dts=np.array(dts))
+    from tests.parity import save_components
+    save_components(os.path.join(out_dir, f"rank{rank}.npz"), got, pos=got.position["point"], vel=got.velocity["vector"], F=got.volume["deformation_gradient"],
+                    C=got.velocity_gradient["m"], failed=got.status["failed"], caller=id_to_caller[local_ids],
+                    mass=got.volume["mass"], rebins=st.num_rebins, n0=len(gids), n1=len(got), dts=np.array(dts))
     pipe.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -178,13 +179,8 @@ def test_cube_through_sand_two_slabs_match_oracle(tmp_path):
     parts = [np.load(os.path.join(tmp_path, f"rank{k}.npz")) for k in range(world)]
     caller = np.concatenate([q["caller"] for q in parts])
     assert np.array_equal(np.sort(caller), np.arange(len(sc.particles))), "particles lost or duplicated across slabs"
-    got = ParticleComponents(len(sc.particles))
-    inv = np.argsort(caller)
-    got.position["point"] = np.concatenate([q["pos"] for q in parts])[inv]
-    got.velocity["vector"] = np.concatenate([q["vel"] for q in parts])[inv]
-    got.volume["deformation_gradient"] = np.concatenate([q["F"] for q in parts])[inv]
-    got.velocity_gradient["m"] = np.concatenate([q["C"] for q in parts])[inv]
-    got.status["failed"] = np.concatenate([q["failed"] for q in parts])[inv]
+    from tests.parity import union_components
+    got = union_components(parts, caller)
     rep, bad = parity_verdict(got, refs[0], refs[1], sc.cell_width)
     kin = sc.particles.status["kinematic_vel_enabled"] == 1
     _, gids = _ownership(sc, world)
@@ -196,7 +192,8 @@ def test_cube_through_sand_two_slabs_match_oracle(tmp_path):
     assert not bad, (bad, rep)
 
 
-@pytest.mark.parametrize("kind,nsteps,overlap", [("spin", 40, "0"), ("cube", 100, "0"), ("spin", 40, "1"), ("cube", 100, "1"), ("cube", 100, "1+order")])
+@pytest.mark.parametrize("kind,nsteps,overlap", [("spin", 40, "0"), ("cube", 100, "0"), ("spin", 40, "1"), ("cube", 100, "1"), ("cube", 100, "1+order"),
+                                                 ("spin", 40, "0+staged"), ("cube", 100, "0+staged")])
 def test_group_substeps_two_slabs_in_the_library(kind, nsteps, overlap, monkeypatch):
     """sparkl_hip_group_substeps: the whole slab loop (re-bin agreement, halo swap, migration) inside the C ABI, no Python in
     the exchange.  Two slabs share one GPU and one stream (device-copy transport of the same loop that uses RCCL between ranks);
@@ -205,6 +202,12 @@ def test_group_substeps_two_slabs_in_the_library(kind, nsteps, overlap, monkeypa
     from tests.parity import parity_verdict
     # SPARKL_HIP_OVERLAP (read when a pipeline is created): 1 forces the two-stream schedule the RCCL ranks use by default -- interior
     # blocks on the main stream while the halo chain and the cut-adjacent blocks run on the halo stream --, 0 the in-line schedule
+    # "0" runs the peer-direct exchange (round 6: k_halo_push stores into the neighbour's arena, the grid update agrees on the re-bin flag); "+staged"
+    # (SPARKL_HIP_DIRECT=0) and the forced two-stream schedule "1" run the flag reduce / pack / copy / merge chain of the RCCL call pattern
+    want_direct = overlap == "0"
+    if overlap.endswith("+staged"):
+        overlap = overlap.split("+")[0]
+        monkeypatch.setenv("SPARKL_HIP_DIRECT", "0")
     if overlap.endswith("+order"):   # the interior / cut-adjacent subsets cut out of the fullest-first launch order (forced: the scene is small), read forwards / backwards
         overlap = overlap.split("+")[0]
         monkeypatch.setenv("SPARKL_HIP_BLOCK_ORDER", "1")
@@ -228,6 +231,8 @@ def test_group_substeps_two_slabs_in_the_library(kind, nsteps, overlap, monkeypa
     MpmPipeline.group_substeps(pipes, sc.params, sc.gravity, dt, nsteps)
     parts = [(p.read_particles(), id_to_caller[p.read_sorted_particle_ids()]) for p in pipes]
     rebins = [p.group_rebins() for p in pipes]
+    direct = [p.direct_info() for p in pipes]
+    assert all(d["ready"] == want_direct for d in direct) and all((d["epochs"] >= nsteps) == want_direct for d in direct), direct
     regathers = [int(p.step_stats()["c_regathers"]) for p in pipes]
     n_after = [len(p) for p in pipes]
     for p in pipes:

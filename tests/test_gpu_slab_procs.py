@@ -45,24 +45,22 @@ def _union(tmp_path, sc, world):
     parts = [np.load(os.path.join(tmp_path, f"rank{k}.npz")) for k in range(world)]
     caller = np.concatenate([q["caller"] for q in parts])
     assert np.array_equal(np.sort(caller), np.arange(len(sc.particles))), "particles lost or duplicated across the ranks"
-    got = ParticleComponents(len(sc.particles))
-    inv = np.argsort(caller)
-    got.position["point"] = np.concatenate([q["pos"] for q in parts])[inv]
-    got.velocity["vector"] = np.concatenate([q["vel"] for q in parts])[inv]
-    got.volume["deformation_gradient"] = np.concatenate([q["F"] for q in parts])[inv]
-    got.velocity_gradient["m"] = np.concatenate([q["C"] for q in parts])[inv]
-    got.status["failed"] = np.concatenate([q["failed"] for q in parts])[inv]
-    return got, parts, caller
+    from tests.parity import union_components
+    return union_components(parts, caller), parts, caller
 
 
-def test_two_processes_run_the_group_loop_and_match_pipeline_and_oracle(tmp_path):
+@pytest.mark.parametrize("exchange", ["direct", "staged"])
+def test_two_processes_run_the_group_loop_and_match_pipeline_and_oracle(tmp_path, exchange):
     """cube_through_sand in small, the kinematic cube crossing the cut within the 100 substeps: the union of the two PROCESSES equals the
-    single pipeline (to rounding: the halo sums are formed in another order) and passes the oracle gate."""
+    single pipeline (to rounding: the halo sums are formed in another order) and passes the oracle gate.
+    "direct" (round 6, the default): each process maps the other's exchange arena with hipIpcOpenMemHandle; k_halo_push stores the records and
+    the re-bin flag mail straight into it and the peer's grid update waits for them inside the kernel -- no per-substep collective at all.
+    "staged": the RCCL call pattern (flag all-reduce, pack, send / recv, merge) over the host transport, with the overlap calibration."""
     from oracle import Oracle
     from sparkl_amd.pipeline import MpmPipeline
     from tests.parity import parity_verdict
     world, nsteps = 2, 100
-    res, el = _run_ranks(tmp_path, "cube", nsteps, world, env_extra={"SPARKL_HIP_OVERLAP": "cal"})
+    res, el = _run_ranks(tmp_path, "cube", nsteps, world, env_extra={"SPARKL_HIP_OVERLAP": "cal"} if exchange == "staged" else {"SPARKL_HIP_COMM_TIMEOUT_S": "20"})
     assert all(rc == 0 for rc, _, _ in res), res
     sc, dt = _scene("cube")
     got, parts, caller = _union(tmp_path, sc, world)
@@ -91,7 +89,13 @@ def test_two_processes_run_the_group_loop_and_match_pipeline_and_oracle(tmp_path
           "| cuts moved:", [int(q["cut_moves"]) for q in parts])
     assert crossed > 20, "the kinematic cube must cross the cut (migration between the processes)"
     assert all(int(q["rebins"]) >= 2 for q in parts) and int(parts[0]["rebins"]) == int(parts[1]["rebins"])
-    assert overlap[0] == overlap[1] and overlap[0][0] in (0.0, 1.0) and overlap[0][1] > 0 and overlap[0][2] > 0, overlap   # both schedules timed, MAX over the ranks agreed
+    direct = [tuple(int(x) for x in q["direct"]) for q in parts]
+    print("direct exchange (ready, substeps pushed):", direct)
+    if exchange == "staged":
+        assert overlap[0] == overlap[1] and overlap[0][0] in (0.0, 1.0) and overlap[0][1] > 0 and overlap[0][2] > 0, overlap   # both schedules timed, MAX over the ranks agreed
+        assert all(d[1] == 0 for d in direct), direct
+    else:
+        assert all(d[0] == 1 and d[1] >= nsteps for d in direct) and direct[0][1] == direct[1][1], direct   # every substep went through the mapped arenas, the same count on both
     assert int(parts[0]["cut_hi"]) == int(parts[1]["cut_lo"])                                                                # the ranks agree on the (possibly moved) cut
     assert ex < 5e-5 and ev < 5e-4
     assert not bad, (bad, rep)

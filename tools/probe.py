@@ -8,10 +8,12 @@ findings are in profiles/HISTORY.md and profiles/r0N_*.txt).  Library variants: 
   soak   [--config ...] [--chunks 8] [--chunk 500] [--step FRAME_DT]
          long run in chunks: throughput, kernel spans, re-bins, reorders, C rebuilds per chunk; validator + sanity check at the end;
          --step drives it through MpmPipeline::step (adaptive frames of FRAME_DT) instead of fixed-dt batches
-  slabs  [--world 4] [--scene column|cube] [--per-slab 10e6] [--substeps 1000] [--report 200] [--drift V] [--single]
+  slabs  [--world 4] [--scene column|cube] [--per-slab 10e6] [--substeps 1000] [--report 200] [--drift V] [--single] [--strong]
          K x-slabs of ONE device through sparkl_hip_group_substeps (device-copy transport of the loop that uses RCCL between ranks):
          per-slab counts, cuts, collective re-bins, validator, id completeness; --single also times one pipeline holding the whole
-         column (the fixed cost of the slab loop); SPARKL_HIP_OVERLAP=0/1/cal picks the schedule
+         column (the fixed cost of the slab loop: printed per slab-substep); --strong cuts the benchmark's own 10 M column --world ways instead
+         of scaling it (the geometry of strong scaling: thin slabs, full cross-section); SPARKL_HIP_OVERLAP=0/1/cal picks the schedule,
+         SPARKL_HIP_DIRECT=0 the staged exchange (flag reduce, pack, copies, merge) instead of the peer-direct one
   step   [--frames 60] [--frame-dt 0.0166667]
          MpmPipeline::step against the fixed-dt batch at the same step length and the same phase of the 10M collapse"""
 import argparse
@@ -159,6 +161,9 @@ def cmd_slabs(a):
     else:
         f = (a.per_slab / 10e6) ** (1 / 3)
         nx, ny, nz = max(8, int(round(200 * f / 8)) * 8), int(round(250 * f)), int(round(200 * f))
+        if a.strong:   # the 10 M column itself, cut along x at block boundaries (8 particles): 200 = 8 x 25 -> slabs of 24 or 32 particles are not equal; use 192 = 8 x 24
+            nx, ny, nz = max(8, (192 // world) // 8 * 8), 250, 200
+        single_ms = None
         if a.single:
             sc = scenes.sand_column(world * nx, ny, nz)
             with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes, stream=stream.cuda_stream) as p:
@@ -168,7 +173,8 @@ def cmd_slabs(a):
                 t0 = time.perf_counter()
                 p.substeps(sc.params, sc.gravity, sc.fixed_dt, a.report)
                 p.sync()
-                print(f"one pipeline, {len(sc.particles)} particles: {1e3 * (time.perf_counter() - t0) / a.report:.4f} ms per substep", flush=True)
+                single_ms = 1e3 * (time.perf_counter() - t0) / a.report
+                print(f"one pipeline, {len(sc.particles)} particles: {single_ms:.4f} ms per substep", flush=True)
             del sc
         total = 0
         for r in range(world):
@@ -183,6 +189,8 @@ def cmd_slabs(a):
             total += len(s.particles)
             params, gravity, dt = s.params, s.gravity, s.fixed_dt
     print(total, "particles on", world, "slabs:", [len(p) for p in pipes], flush=True)
+    if a.scene == "cube":
+        single_ms = None
     pipes[0].clock_enable(True, 4)
     for block in range(a.substeps // a.report):
         pipes[0].clock_read(True)
@@ -197,7 +205,8 @@ def cmd_slabs(a):
         k = pipes[0].clock_read(True)
         print(f"substeps {a.report * block:4d}..: {ms:.4f} ms per substep ({total / ms / 1e6:.2f} G particle-substeps/s), per slab {n} max/mean {max(n) * world / sum(n):.3f}, "
               f"re-bins {[p.group_rebins() for p in pipes]}, cuts {[p.slab_get()[1:3] for p in pipes]}, overlap {pipes[0].overlap_info()}, "
-              f"member 0 halo {k.halo_ms / max(k.sampled_substeps, 1):.4f} ms per substep, validator violations {bad}", flush=True)
+              f"member 0 halo {k.halo_ms / max(k.sampled_substeps, 1):.4f} ms per substep, validator violations {bad}, direct {pipes[0].direct_info()}"
+              + (f", FIXED COST {1e3 * (ms - single_ms) / world:.1f} us per slab-substep over the single pipeline" if single_ms else ""), flush=True)
     ids = np.concatenate([p.read_sorted_particle_ids() for p in pipes])
     print("ids unique and complete:", bool(np.array_equal(np.sort(ids), np.arange(total))))
     for p in pipes:
@@ -254,6 +263,7 @@ def main():
     s.add_argument("--report", type=int, default=200)
     s.add_argument("--drift", type=float, default=0.0)
     s.add_argument("--single", action="store_true")
+    s.add_argument("--strong", action="store_true")
     s.set_defaults(fn=cmd_slabs)
     s = sub.add_parser("step")
     s.add_argument("--frames", type=int, default=60)
