@@ -9,9 +9,14 @@ synthetic, HBM-resident particles.  Prints ONE JSON line.
 --config sand10m (default) is BASELINE.json's metric: the 10 M-particle Drucker-Prager column (configs[2]);
 neo1m = configs[1] (1 M neo-Hookean cube), fluid20m = configs[3] (20 M fluid particles, volume recompute sweep),
 cube80m = configs[4] (cube_through_sand3, ONE 80 M-particle scene: on N GPUs it is cut into N x-slabs -- strong scaling);
-snow1m is no BASELINE configuration: a 1 M-particle snow block, the one scene that times the RARE kernel instantiations.
---scaling weak (default for sand10m): every rank owns a 10 M column of an N x longer scene, so N = 1 is the headline line;
---scaling strong: the configured size is the whole job (sand10m: 192 x 260 x 200 = 9.98 M whatever N).
+snow1m is no BASELINE configuration: a 1 M-particle snow block, the one scene that times the RARE kernel instantiations;
+sandblock10m is configs[0]'s scene (sand3.rs: Drucker-Prager sand ON an elastic block) at 10 M particles: TWO materials, so the one-material
+specialisations of the sand column (compile-time model view, 4-byte flags mirror) stand down -- the generic fused kernel, measured.
+--scaling strong (default since round 6): the configured size is the WHOLE job whatever N -- BASELINE.json's metric is the 10 M column on the whole
+node with ">= 6x strong scaling at 8 GPUs" -- sand10m at N > 1: 192 x 260 x 200 = 9.98 M cut into N x-slabs (N = 1: the 200 x 250 x 200 column as ever);
+the weak-scaling figure (a 10 M column PER RANK) rides along as `weak_scaling` in the same line (--no-weak-figure: skip it).
+--scaling weak: every rank owns a column of the configured size, the job grows with N (`value` is then that figure).
+N = 1 also carries `strong_projection`: the 8-slab group loop of the same job on the ONE device, per slab -- a projection, not a scaling measurement.
 --gpus N > 1 with no WORLD_SIZE in the environment starts N ranks by itself (one process per GPU, RCCL); under
 torch.distributed.run the ranks come from the environment.  See DESIGN.md "Multi-GPU".
 """
@@ -58,17 +63,20 @@ def parse_args(argv=None):
     ap.add_argument("--no-cold-window", dest="cold_window", action="store_false",
                     help="skip the cold window: the same W + K substeps timed from an idle GPU BEFORE the clock wake-up (reported beside the headline, never as `value`)")
     ap.add_argument("--no-copy-peak", action="store_true", help="skip the 1 GiB device-to-device copy that measures the stream peak")
-    ap.add_argument("--config", choices=("sand10m", "neo1m", "fluid20m", "cube80m", "snow1m"), default="sand10m")
+    ap.add_argument("--config", choices=("sand10m", "neo1m", "fluid20m", "cube80m", "snow1m", "sandblock10m"), default="sand10m")
     ap.add_argument("--particles", type=float, default=None, help="particles per GPU with --scaling weak, in the whole job with --scaling strong (default: the configuration's own size)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
                     help="weak (default for sand10m): every rank owns a column of the configured size, the job grows with N; strong (default and only mode of cube80m): "
                          "the whole job is the configured size -- 80 M for cube80m, 10 M for sand10m -- cut into N x-slabs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-weak-figure", dest="weak_figure", action="store_false", help="N > 1, strong scaling: do not also time the weak-scaling job (a 10 M column per rank)")
+    ap.add_argument("--no-strong-projection", dest="strong_projection", action="store_false", help="N = 1, sand10m: skip the 8-slab group loop on the one device (`strong_projection`)")
     ap.add_argument("--no-kernel-clock", action="store_true", help="skip the per-kernel hipEvent spans")
     ap.add_argument("--no-late-phase", dest="late_phase", action="store_false", help="skip the flowing-phase measurements (late_collapse, deep_collapse of sand10m; late_collapse = the moving dam of fluid20m; N = 1)")
     args = ap.parse_args(argv)
     if args.scaling is None:
-        args.scaling = "strong" if args.config == "cube80m" else "weak"
+        # the job the metric names is fixed: the series N = 1, 2, 4, 8 the driver measures is a STRONG-scaling series (round 6; rounds 1 - 5 grew the job with N)
+        args.scaling = "strong" if args.config in ("cube80m", "sand10m") else "weak"
     if args.config == "cube80m" and args.scaling != "strong":
         ap.error("cube80m is BASELINE configs[4]: ONE 80 M-particle scene cut into slabs (--scaling strong)")
     if args.scaling == "strong" and args.config not in ("cube80m", "sand10m"):
@@ -138,7 +146,7 @@ def build_scene(args, rank, world, mode):
         desc = (f"cube_through_sand3: Drucker-Prager sand bed {nx}x{ny}x{nz} = {nx * ny * nz} particles + kinematic cube {cube_n}^3 at (10,0,0) m/s "
                 f"(8 ppc, h=0.2, E=1e7 nu=0.2 rho=2700, cuboid friction floor), fixed dt={sc.fixed_dt}; {len(sc.particles)} particles on this rank")
         return sc, "sand", desc, nx // slab[1]
-    if args.config == "sand10m" and args.scaling == "strong":
+    if args.config == "sand10m" and args.scaling == "strong" and world > 1:
         nx, ny, nz = strong_dims(args.particles or 10.0e6, world)
         sc = scenes.sand_column(nx // slab[1], ny, nz, name="config3_drucker_prager_column", x_slab=slab)
         desc = (f"3D Drucker-Prager sand column collapse, {nx}x{ny}x{nz} = {nx * ny * nz} particles in the whole job, {len(sc.particles)} on this rank (8 ppc, h=0.2, "
@@ -154,6 +162,16 @@ def build_scene(args, rank, world, mode):
         return sc, "sand", desc, nx
     if mode == "slabs":
         raise SystemExit("--gpus > 1 runs the slab decomposition of the sand scenes only (sand10m = BASELINE configs[2], cube80m = configs[4])")
+    if args.config == "sandblock10m":
+        # configs[0]'s scene at size (examples3d/sand3.rs:39-78: a Drucker-Prager sand layer on a corotated elastic block of the same footprint): two models in
+        # the table, so k_g2p2g runs its GENERIC instantiation (model dispatch per particle, the 16-byte k record) -- what the column's one-material
+        # specialisations (MSET = 1 / 4) are worth is the difference to the sand10m line
+        f = ((args.particles or 10.0e6) / 10.0e6) ** (1.0 / 3.0)
+        nx, ny, nz = max(8, int(round(200 * f))), max(4, int(round(125 * f))), max(8, int(round(200 * f)))
+        sc = scenes.sand_column(nx, ny, nz, with_block=True, name="config1_sand3_at_10m")
+        desc = (f"sand3.rs at size: Drucker-Prager sand {nx}x{ny}x{nz} on a corotated elastic block {nx}x{ny}x{nz} = {len(sc.particles)} particles (8 ppc, h=0.2, E=1e7 nu=0.2 "
+                f"rho=2700 both, cuboid friction floor), fixed dt={sc.fixed_dt}: two models -> the generic fused kernel; not BASELINE.json's headline configuration")
+        return sc, "sand", desc, nx
     if args.config == "snow1m":
         # not a BASELINE config: the RARE instantiations of the particle kernels (snow / Rankine / NACC plasticity, failure model, particle
         # projection, penalty force) measured on one scene of their own -- a 1 M-particle snow block dropped on the floor
@@ -184,14 +202,16 @@ def cpu_baseline(max_threads, sc=None, desc=None):
     BASELINE.md section 2 lists them) after one untimed substep (first touch of the mmap'd grid).
 
     Like the reference (serial region loop, particle_set.rs:171-253) the port stops scaling early: the thread count is probed
-    on one substep of a 400 k-particle column each (~1 s in all) and the best one is used and reported as `cores`."""
+    on one substep of a 2.5 M-particle column each (round 6; a 400 k column until round 5, small enough to sit in the last-level caches of one
+    socket and to pick 16 threads for a 10 M scene that wants more), every probe on an oracle of its own, so that particles AND grid pages are
+    first touched by the thread team that then works on them (the grid in the untimed substep); the best count is used and reported as `cores`."""
     from sparkl_amd import scenes
     from oracle import Oracle
-    nx, ny, nz = column_dims(400_000)
+    nx, ny, nz = column_dims(2_500_000)
     probe = scenes.sand_column(nx, ny, nz, name="cpu_thread_probe")
     n = len(probe.particles)
     best_t, best_rate, rates = 1, 0.0, {}
-    for t in (8, 16, 32, 64, 128):
+    for t in (8, 16, 32, 64, 96, 128, 192, 256):
         if t > max_threads:
             break
         o = Oracle(probe.cell_width, domain_log2_bytes=probe.domain_log2_bytes, threads=t)
@@ -227,7 +247,7 @@ def cpu_baseline(max_threads, sc=None, desc=None):
             "ms_per_substep": 1e3 * t / nsub, "phase_ms_per_substep": {k: 1e3 * v / nsub for k, v in phases.items()},
             "thread_probe_particle_steps_per_s": {str(k): v for k, v in rates.items()},
             "sample": f"{nsub} substeps (after one untimed) of the benchmark's own configuration: {desc}; f32 oracle (oracle/mpm_oracle.hpp: restated sparkl CPU "
-                      f"path), OpenMP with {best_t} threads = the best of 8/16/32/64/128 probed on a {len(probe.particles)}-particle column, on a {max_threads}-thread host"}
+                      f"path), OpenMP with {best_t} threads = the best of 8/16/32/64/96/128/192/256 probed on a {len(probe.particles)}-particle column (one substep each, first touch by the probing team), on a {max_threads}-thread host"}
 
 
 def recorded_traffic(kernel, n_particles, config):
@@ -289,6 +309,48 @@ def roofline_of(clock, kb, n_particles, config, kernel=None):
     return {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": kb[dom], "avg_launch_ms": avg_ms[dom],
             "launches_sampled": int(spans[dom][1])}, avg_ms
+
+
+def scenes_mod():
+    from sparkl_amd import scenes
+    return scenes
+
+
+def strong_projection(args, stream, device_id, single_ms, slabs=8, steps=96, warmup=32):
+    """The strong-scaling job (192 x 260 x 200 = 9.98 M, bench.py --gpus 8) as 8 slab pipelines of THIS device stepped by sparkl_hip_group_substeps."""
+    import torch
+    from sparkl_amd.pipeline import MpmPipeline
+    from sparkl_amd.slab import INT32_MAX, INT32_MIN
+    nx, ny, nz = strong_dims(10.0e6, slabs)
+    pipes, total = [], 0
+    for r in range(slabs):
+        s = scenes_mod().sand_column(nx // slabs, ny, nz, x_slab=(r, slabs))
+        p = MpmPipeline(s.cell_width, device_id=device_id, domain_log2_bytes=s.domain_log2_bytes, stream=stream.cuda_stream)
+        blocks = (nx // slabs) // 8
+        p.set_slab(0, INT32_MIN if r == 0 else 1 + r * blocks, INT32_MAX if r == slabs - 1 else 1 + (r + 1) * blocks, id_offset=r * len(s.particles))
+        p.load_scene(s)
+        pipes.append(p)
+        total += len(s.particles)
+        params, gravity, dt = s.params, s.gravity, s.fixed_dt
+    try:
+        MpmPipeline.group_substeps(pipes, params, gravity, dt, warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        MpmPipeline.group_substeps(pipes, params, gravity, dt, steps)
+        torch.cuda.synchronize()
+        group_ms = 1e3 * (time.perf_counter() - t0) / steps
+        info = pipes[0].direct_info()
+        rebins = [int(p.group_rebins()) for p in pipes]
+    finally:
+        for p in pipes:
+            p.close()
+    per_slab_ms = group_ms / slabs
+    return {"what": f"PROJECTION, not a measurement of scaling: the strong-scaling job ({nx}x{ny}x{nz} = {total} particles) as {slabs} x-slabs on ONE device, "
+                    f"{steps} substeps through sparkl_hip_group_substeps (one stream: the slabs run one after the other), against this run's single pipeline",
+            "slabs": slabs, "particles_per_slab": total // slabs, "group_ms_per_substep_one_device": group_ms, "per_slab_ms_per_substep": per_slab_ms,
+            "single_pipeline_ms_per_substep": single_ms, "fixed_cost_us_per_slab_substep": 1e3 * (group_ms - single_ms) / slabs,
+            "projected_speedup_at_8_gpus": single_ms / per_slab_ms, "direct_exchange": info, "collective_rebins": rebins,
+            "not_included": "the xGMI hop of the halo stores and of the flag mail (a few us per substep), clock effects of 8 GPUs running at a 12 % duty cycle each, load imbalance as the column collapses"}
 
 
 # ------------------------------------------------------------------------------------------ one rank
@@ -501,7 +563,7 @@ def main(args):
     # timed region and never part of `value`, but measured the same way -- wall clock over 128 substeps and the dominant
     # kernel's hipEvent spans -> `roofline_late` (see profiles/r01_reorder_policy.txt)
     late, deep = None, None
-    if world == 1 and args.late_phase and args.config in ("sand10m", "fluid20m") and args.scaling == "weak":
+    if world == 1 and args.late_phase and args.config in ("sand10m", "fluid20m"):
         substeps_run = [args.steps + args.warmup]
 
         def phase(start):
@@ -538,6 +600,59 @@ def main(args):
         else:
             late = phase(2000)     # the 20 M dam 0.2 s after release (dt = 1e-4): the front runs, cells hold odd counts, re-bins and reorders happen
 
+    # N > 1, strong scaling of the 10 M column (the default): the weak-scaling job -- a 10 M column PER RANK, what rounds 1 - 5 reported as `value` --
+    # timed the same way on a second set of pipelines, reported as `weak_scaling` beside the headline
+    weak = None
+    if world > 1 and mode == "slabs" and args.config == "sand10m" and args.scaling == "strong" and args.weak_figure:
+        wnx, wny, wnz = column_dims(args.particles or 10.0e6)
+        wnx = max(8, int(round(wnx / 8.0)) * 8)
+        wsc = scenes_mod().sand_column(wnx, wny, wnz, name="config3_drucker_prager_column_weak", x_slab=(rank, world))
+        wpipe = MpmPipeline(wsc.cell_width, device_id=device_id, domain_log2_bytes=wsc.domain_log2_bytes, stream=stream.cuda_stream)
+        wpipe.set_slab(0, INT32_MIN if rank == 0 else 1 + rank * (wnx // 8), INT32_MAX if rank == world - 1 else 1 + (rank + 1) * (wnx // 8), id_offset=rank * len(wsc.particles))
+        wpipe.load_scene(wsc)
+        wstep = None
+        if in_library:
+            wid = [MpmPipeline.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(wid, src=0)
+            sys.stdout.flush(); saved = os.dup(1); os.dup2(2, 1)
+            try:
+                wpipe.comm_init(wid[0], rank, world)
+            finally:
+                sys.stdout.flush(); os.dup2(saved, 1); os.close(saved)
+        else:
+            wstep = SlabStepper(HipSlabBackend(wpipe, torch.device("cuda", device_id)), rank, world, group=group, chunk=16)
+
+        def wrun(n):
+            if in_library:
+                MpmPipeline.group_substeps([wpipe], wsc.params, wsc.gravity, wsc.fixed_dt, n)
+            else:
+                wstep.substeps(wsc.params, wsc.gravity, wsc.fixed_dt, n)
+        wrun(args.warmup)
+        dist.barrier(); torch.cuda.synchronize(); wpipe.sync()
+        tw = time.perf_counter()
+        wrun(args.steps)
+        dist.barrier(); torch.cuda.synchronize(); wpipe.sync()
+        welapsed = time.perf_counter() - tw
+        tt = torch.tensor([welapsed], device="cpu" if default_pg_is_cpu else "cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wtotal = torch.tensor([len(wsc.particles)], device="cpu" if default_pg_is_cpu else "cuda", dtype=torch.int64)
+        dist.all_reduce(wtotal)
+        weak = {"scaling": "weak", "particles_total": int(wtotal.item()), "particles_per_gpu": len(wsc.particles), "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": 1e3 * float(tt.item()) / args.steps, "value": int(wtotal.item()) * args.steps / float(tt.item()), "unit": "particle-steps/s",
+                "direct_exchange": wpipe.direct_info(),
+                "note": "one 10 M column per rank (the job grows with N): what `value` was in rounds 1 - 5; never the headline"}
+        wpipe.close()
+
+    # N = 1: what the SAME 10 M job costs per slab when it is cut 8 ways -- the 8-member group loop of the library on this ONE device (peer-direct
+    # exchange: k_halo_push, flag mail, grid update), one stream.  A PROJECTION of 8-GPU strong scaling from two measured numbers, not a measurement of it:
+    # no xGMI hop, no second GPU has run.
+    projection = None
+    if world == 1 and args.config == "sand10m" and args.strong_projection and not args.particles:
+        try:
+            projection = strong_projection(args, stream, device_id, 1e3 * elapsed / args.steps)
+        except Exception as e:   # a convenience figure: never at the price of the headline
+            print(f"bench.py: strong_projection skipped ({e})", file=sys.stderr)
+
     # the achieved rate is also reported against a MEASURED stream peak, not only the 8 TB/s of the
     # data sheet: a device-to-device copy of 1 GiB (read + write = 2 GiB of traffic per copy), hipEvent-timed, after the run
     copy_gbs = None
@@ -558,7 +673,7 @@ def main(args):
 
     if rank == 0:
         value = total_particles * args.steps / elapsed
-        headline = args.config == "sand10m" and (args.scaling == "weak" or world == 1)
+        headline = args.config == "sand10m" and (args.scaling == "strong" or world == 1)
         metric = "particle-steps/sec (whole node) + achieved HBM GB/s, 3D sand 10M particles" if headline else \
             f"particle-steps/sec (whole node) + achieved HBM GB/s, {args.config} {args.scaling} scaling (not BASELINE.json's headline metric)"
         out = {
@@ -571,8 +686,8 @@ def main(args):
                        "active_node_blocks": n_blocks, "particle_blocks": n_pblocks,
                        "parallelism": "single GPU" if world == 1 else (
                            f"{world} x-slabs of one {world * nx}-particle-long scene ({'fixed total, strong scaling' if args.scaling == 'strong' else 'one configured column per rank, weak scaling'}), the four shared node planes of every cut swapped with both neighbours every substep "
-                           f"({'RCCL send/recv inside libsparkl_hip.so (sparkl_hip_group_substeps)' if in_library else backend + ' send/recv from the Python SlabStepper'}), "
-                           f"re-bin flag all-reduce" if mode == "slabs" else f"{world} independent replicas")},
+                           f"({('peer-direct inside libsparkl_hip.so: k_halo_push stores into the hipIpc-mapped arenas of the neighbours, the re-bin flag travels as mail to every rank and is agreed in the grid update -- no per-substep collective' if pipe.direct_info()['ready'] else 'RCCL send/recv inside libsparkl_hip.so (sparkl_hip_group_substeps), re-bin flag all-reduce') if in_library else backend + ' send/recv from the Python SlabStepper, re-bin flag all-reduce'})"
+                           if mode == "slabs" else f"{world} independent replicas")},
             "step_gbs": step_bytes * (total_particles / n_particles) / (elapsed / args.steps) / 1e9,
             "step_frac_of_hbm_peak": step_bytes * (total_particles / n_particles) / world / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
             "setup_s": {"generate": gen_s, "upload_and_pack": upload_s},
@@ -605,6 +720,12 @@ def main(args):
                 chosen, us_inline, us_overlap = pipe.overlap_info()
                 out["overlap"] = {"chosen": chosen, "in_line_us_per_substep": us_inline, "overlapped_us_per_substep": us_overlap,
                                   "note": "schedule of the halo chain between RCCL ranks, chosen on the MAX over the ranks of one 16-substep batch per schedule (-1: not decided / forced by SPARKL_HIP_OVERLAP)"}
+        if mode == "slabs":
+            out["direct_exchange"] = pipe.direct_info()
+        if weak is not None:
+            out["weak_scaling"] = weak
+        if projection is not None:
+            out["strong_projection"] = projection
         if cold is not None:
             out["cold_window"] = cold
         if late is not None:

@@ -114,15 +114,15 @@ SPK_DEV void note_step(Ctl* ctl) {
 // Everything a peer writes lives in one fine-grained allocation per member (the "arena": PeerBox + two halo buffers).  Mail and epoch words are
 // double-buffered by epoch parity: a fast peer is at most one substep ahead (its push of epoch e + 1 sits behind its grid update of epoch e, which
 // waited for THIS member's mail of epoch e), never two.  Payload: plain stores, per wave s_waitcnt vmcnt(0), workgroup barrier, one lane's system-scope
-// release, then the arrival counter; flag words: relaxed system-scope atomics; the reader polls relaxed, then ONE system-scope acquire
-// (MI355X_MICROARCH.md, inter-workgroup visibility -- the same recipe across devices needs system scope and fine-grained memory).
+// (write-through, system scope: halo_store_wt), per wave s_waitcnt vmcnt(0), workgroup barrier, then the arrival counter; flag words: relaxed
+// system-scope atomics; the reader polls relaxed and reads the records past the caches (halo_load_wt) -- the "sc1 payload + drained flag / sc1
+// loads" form of MI355X_MICROARCH.md (inter-workgroup visibility), at system scope and on fine-grained memory because the writer is another device.
 // A peer that never answers: the wait gives up after `timeout_ticks` of the 100 MHz wall clock, raises the abort chain and Ctl::direct_error.
 constexpr int MAX_DIRECT = 64;
 struct PeerBox {
     unsigned long long mail[2][MAX_DIRECT];   // [epoch & 1][writer]: (epoch << 32) | re-bin flag of that member for that substep
     unsigned int halo_epoch[2][2];            // [epoch & 1][side]: written by the neighbour on `side` once all of its records of that epoch have landed
-    unsigned int arrive;                      // arrival counter of this member's own k_halo_push workgroups (local)
-    unsigned int pad[11];
+    unsigned int pad[12];
 };
 typedef __attribute__((address_space(1))) unsigned long long* global_u64p;
 struct DirectWait {
@@ -141,7 +141,7 @@ struct DirectPush {
     unsigned long long* mail[MAX_DIRECT];   // &box_of_member_k->mail[epoch & 1][this member's index], k < n_mail
     int n_mail;
     unsigned int epoch;
-    unsigned int* arrive;      // &own_box->arrive
+    unsigned int* arrive;      // arrival counter of this launch's workgroups: plain device memory of this member (zero between launches)
 };
 #define SPK_RLX_SYS __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
 // the agreed re-bin flag of the substep: MAX over the mail of all members; false = timed out
@@ -168,8 +168,20 @@ SPK_DEV bool direct_wait_halo(const DirectWait& W, int lane) {
         if ((spin & 63u) == 63u && wall_clock64() - t0 > W.timeout_ticks) return false;
         __builtin_amdgcn_s_sleep(2);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // ONE system-scope acquire behind the match; plain loads from here
-    return true;
+    return true;   // the records are read with halo_load_wt: no fence
+}
+// The halo payload travels WRITE-THROUGH and is read past the caches: two 8-byte system-scope relaxed atomics per node record on either side
+// (global_store / global_load ... sc0 sc1).  No release fence in the sender (a buffer_wbl2 per workgroup) and, above all, no acquire fence in
+// the receiver: a buffer_inv per wave of the grid update serialised on the L2 and cost more than the whole staged exchange had (round 6, first cut).
+SPK_DEV void halo_store_wt(float4* p, const float4& v) {
+    const global_u64p q = (global_u64p)p;
+    __hip_atomic_store(q, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x), SPK_RLX_SYS);
+    __hip_atomic_store(q + 1, ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z), SPK_RLX_SYS);
+}
+SPK_DEV float4 halo_load_wt(const float4* p) {
+    const global_u64p q = (global_u64p)p;
+    const unsigned long long a = __hip_atomic_load(q, SPK_RLX_SYS), b = __hip_atomic_load(q + 1, SPK_RLX_SYS);
+    return make_float4(__uint_as_float((unsigned int)a), __uint_as_float((unsigned int)(a >> 32)), __uint_as_float((unsigned int)b), __uint_as_float((unsigned int)(b >> 32)));
 }
 SPK_DEV void direct_give_up(Ctl* ctl, int parity, unsigned int code) {
     ctl->direct_error = code;
@@ -1495,7 +1507,6 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
         const bool first = blockIdx.x == 0 && threadIdx.x == 0;
         if (!direct_wait_mail(W, lane, any)) { if (first) direct_give_up(ctl, S.parity, 1u); return; }
         if (any) { if (first) raise_abort(ctl, S.parity); return; }
-        if (!direct_wait_halo(W, lane)) { if (first) direct_give_up(ctl, S.parity, 2u); return; }
         aborted = 0;
     }
     // the flag (a scalar load issued first) has arrived long before the table entry: an aborted launch leaves here, 34 -> ~8 us
@@ -1544,7 +1555,11 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
     if (G.halo_in) {  // partial sums of the neighbour slab(s): a + b is bit-identical on both sides of a cut
         const int bp = (G.halo_axis == 0 ? org.x : (G.halo_axis == 1 ? org.y : org.z)) >> 2;
         if (bp == G.halo_lo || bp == G.halo_hi || bp + 1 == G.halo_lo || bp + 1 == G.halo_hi) {   // wave-uniform: one block per wave
-            const float4 hv = G.halo_in[(size_t)b * 64 + lane];
+            float4 hv;
+            if (W.box) {   // peer-direct: only the waves of the cut planes wait for the neighbours' records, and read them past the caches
+                if (!direct_wait_halo(W, lane)) { if (lane == 0) direct_give_up(ctl, S.parity, 2u); return; }
+                hv = halo_load_wt(&G.halo_in[(size_t)b * 64 + lane]);
+            } else hv = G.halo_in[(size_t)b * 64 + lane];
             m += hv.x; px += hv.y; py += hv.z; pz += hv.w;
         }
     }
@@ -3655,18 +3670,15 @@ __global__ __launch_bounds__(BLK_THREADS) void k_halo_push(GridArrays G, DirectP
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (b >= 0) v = halo_node_sum(G, b, node & 3, (node >> 2) & 3, node >> 4);
         const int slot = lo_part ? dst.y : dst.x;
-        if (slot >= 0) D.remote_halo[side][(size_t)slot * 64 + node] = v;
+        if (slot >= 0) halo_store_wt(&D.remote_halo[side][(size_t)slot * 64 + node], v);
     }
-    // every record of this launch has landed before the neighbours are told so
+    // every record of this launch has landed (write-through stores, drained by every wave) before the neighbours are told so
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned int old = __hip_atomic_fetch_add((global_u32p)D.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old + 1u == gridDim.x) {
             __hip_atomic_store((global_u32p)D.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch is a later kernel
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");   // the other workgroups' releases happened before their increments, which this one has read
             for (int sd = 0; sd < 2; ++sd)
                 if (D.remote_epoch[sd]) __hip_atomic_store((global_u32p)D.remote_epoch[sd], D.epoch, SPK_RLX_SYS);
         }

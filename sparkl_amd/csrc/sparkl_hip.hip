@@ -179,6 +179,7 @@ struct SparklPipeline {
         uint64_t arena_serial = 0;       // bumped by every (re)allocation
         int index = 0, n = 1;            // this member's mailbox slot and the number of members in the job
         uint32_t epoch = 0;              // group substeps enqueued so far (the same on every member of the job)
+        DevBuf<unsigned int> arrive;     // arrival counter of k_halo_push's workgroups (ordinary device memory: an RMW on the fine-grained arena is a trip to memory)
         DevBuf<int2> dst[2];             // per halo column of each cut: the neighbour's node-block slots (k_halo_slots)
         void* peer_arena[MAX_DIRECT] = {nullptr};   // every member's arena in THIS process' address space ([index] = own)
         void* peer_ipc[MAX_DIRECT] = {nullptr};     // the ones opened with hipIpcOpenMemHandle (closed when replaced / at destroy)
@@ -2945,6 +2946,7 @@ static int group_direct_setup(Group& G) {
             CHK(p->direct.dst[side].reserve(std::max<uint64_t>(ns, 1)));
             if (ns) HIPCHK(hipMemcpyAsync(p->direct.dst[side].p, p->x_mig_recv[side].p, ns * sizeof(int2), hipMemcpyDeviceToDevice, p->stream));
         }
+        if (!p->direct.arrive.p) { CHK(p->direct.arrive.reserve(16)); HIPCHK(hipMemsetAsync(p->direct.arrive.p, 0, 16 * sizeof(unsigned int), p->stream)); }
         // both halo buffers start from zero: a node of a cut plane no record covers reads 0, like the halo_in of the copy exchange
         HIPCHK(hipMemsetAsync((char*)p->direct.arena + sizeof(PeerBox), 0, 2 * p->direct.cap_blocks * 64 * sizeof(float4), p->stream));
         CHK(comm_wait(p, p->stream));
@@ -2964,7 +2966,7 @@ static void direct_release(SparklPipeline* p) {
     for (int k = 0; k < MAX_DIRECT; ++k) { if (D.peer_ipc[k]) (void)hipIpcCloseMemHandle(D.peer_ipc[k]); D.peer_ipc[k] = nullptr; D.peer_arena[k] = nullptr; D.peer_serial[k] = 0; }
     if (D.arena) (void)hipFree(D.arena);
     D.arena = nullptr; D.arena_bytes = 0; D.cap_blocks = 0;
-    D.dst[0].release(); D.dst[1].release();
+    D.dst[0].release(); D.dst[1].release(); D.arrive.release();
     D.ready = false;
 }
 
@@ -3337,7 +3339,7 @@ static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, con
                     const int par = (int)(epoch & 1u);
                     DirectPush D;
                     memset(&D, 0, sizeof(D));
-                    D.n_mail = Dp.n; D.epoch = epoch; D.arrive = &Dp.box()->arrive;
+                    D.n_mail = Dp.n; D.epoch = epoch; D.arrive = Dp.arrive.p;
                     for (int k = 0; k < Dp.n; ++k) D.mail[k] = &reinterpret_cast<PeerBox*>(Dp.peer_arena[k])->mail[par][Dp.index];
                     p->dw.box = Dp.box(); p->dw.n_mail = Dp.n; p->dw.epoch = epoch; p->dw.timeout_ticks = (unsigned long long)(tmo_s * 1.0e8);
                     for (int side = 0; side < 2; ++side) {
