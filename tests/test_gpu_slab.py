@@ -38,6 +38,12 @@ def _scene(kind):
         x = sc.particles.position["point"][:, 0]
         x[kin] += np.float32((4 * cut + 0.5) * h - 1.0 * h) - x[kin].min()
         return sc, 2.5e-4
+    if kind == "long":
+        # a bar of sand 16 node blocks long, thrown along x: four slabs of four block planes, particles migrating through every cut
+        sc = scenes.sand_column(128, 6, 8)
+        sc.particles.velocity["vector"][:, 0] = 9.0
+        sc.particles.velocity["vector"][:, 1] = -1.0
+        return sc, 2.5e-4
     sc = scenes.sand_column(24, 12, 16, with_block=True)
     return sc, 2.5e-4
 

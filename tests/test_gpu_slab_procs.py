@@ -101,6 +101,47 @@ def test_two_processes_run_the_group_loop_and_match_pipeline_and_oracle(tmp_path
     assert not bad, (bad, rep)
 
 
+def test_four_processes_exchange_peer_direct_through_every_cut(tmp_path):
+    """World = 4 in four OS processes on the one GPU: inner ranks push to BOTH neighbours, every rank's re-bin flag travels as mail to all four
+    and every grid update takes the MAX of four -- the all-to-all part of the peer-direct exchange that two ranks cannot show.  A bar of sand thrown
+    along x (particles migrate through all three cuts, collective re-bins): the union equals the single pipeline and passes the oracle gate."""
+    from oracle import Oracle
+    from sparkl_amd.pipeline import MpmPipeline
+    from tests.parity import parity_verdict
+    world, nsteps = 4, 120
+    res, el = _run_ranks(tmp_path, "long", nsteps, world, env_extra={"SPARKL_HIP_COMM_TIMEOUT_S": "20"})
+    assert all(rc == 0 for rc, _, _ in res), res
+    sc, dt = _scene("long")
+    got, parts, caller = _union(tmp_path, sc, world)
+    direct = [tuple(int(x) for x in q["direct"]) for q in parts]
+    assert all(d[0] == 1 and d[1] >= nsteps for d in direct) and len({d[1] for d in direct}) == 1, direct
+    assert len({int(q["rebins"]) for q in parts}) == 1 and int(parts[0]["rebins"]) >= 2
+    moved = [int(q["n1"]) - int(q["n0"]) for q in parts]
+    assert any(m != 0 for m in moved[1:-1]), moved          # the inner slabs exchanged particles
+    for r in range(world - 1):
+        assert int(parts[r]["cut_hi"]) == int(parts[r + 1]["cut_lo"])
+    with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        p.load_scene(sc)
+        p.substeps(sc.params, sc.gravity, dt, nsteps)
+        single = p.read_particles()
+    ex = np.abs(got.position["point"].astype(np.float64) - single.position["point"]).max() / sc.cell_width
+    ev = np.abs(got.velocity["vector"].astype(np.float64) - single.velocity["vector"]).max() / np.abs(single.velocity["vector"]).max()
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    refs = []
+    for f64 in (False, True):
+        o = Oracle(sc.cell_width, f64=f64, domain_log2_bytes=sc.domain_log2_bytes, threads=threads)
+        o.load_scene(sc)
+        for _ in range(nsteps):
+            o.substep_fixed(sc.params, sc.gravity, dt)
+        refs.append(o.get_particles())
+        o.close()
+    rep, bad = parity_verdict(got, refs[0], refs[1], sc.cell_width)
+    print(f"four processes, {el:.1f} s: vs single pipeline eps_x {ex:.2e} eps_v {ev:.2e}; vs f64 oracle", rep["vs_f64"]["eps_x"], rep["vs_f64"]["eps_v"], "| particles moved per slab:", moved,
+          "| collective re-bins:", int(parts[0]["rebins"]), "| epochs pushed:", direct[0][1])
+    assert ex < 5e-5 and ev < 5e-4
+    assert not bad, (bad, rep)
+
+
 def test_two_processes_adaptive_step_agrees_with_pipeline_step(tmp_path):
     """sparkl_hip_group_step across processes: the dt bound is the MIN over the ranks (one all-reduce per substep); substep count, simulated
     time and particles equal sparkl_hip_pipeline_step on the undivided scene."""
