@@ -1074,9 +1074,21 @@ SPK_DEV bool maximum_stress_failed(const DevModel& mo, const M3& t) {
         const double b00 = (a00 - qm) * ip, b11 = (a11 - qm) * ip, b22 = (a22 - qm) * ip, b01 = a01 * ip, b02 = a02 * ip, b12 = a12 * ip;
         double r = 0.5 * (b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02));
         r = fmin(fmax(r, -1.0), 1.0);
-        const double phi = acos(r) / 3.0;
-        mx = qm + 2.0 * pp * cos(phi);
-        mn = qm + 2.0 * pp * cos(phi + 2.0943951023931953);
+        // cos(acos(|r|) / 3) as Newton steps on 4 c^3 - 3 c = |r| from the chord (c in [cos(pi/6), 1]: a simple root, quadratic convergence from
+        // an error <= 1e-2: four steps reach double precision); r < 0 is the mirrored problem.  The libm acos / cos this replaces (round 6) are two
+        // dozen double-precision polynomial coefficients that the compiler hoisted out of the particle loop of the RARE kernels and SPILLED: the
+        // whole 104 B per lane of scratch of k_g2p2g<RARE> / k_g2p<RARE> (profiles/r06_kernel_experiments.txt, 3).
+        const double ar = fabs(r);
+        double c = (double)(0.8660254f + 0.1339746f * (float)ar);   // (the start in f32: a 64-bit literal here is hoisted out of the particle loop and spilled too)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const double c2 = c * c;
+            c -= ((4.0 * c2 - 3.0) * c - ar) / (12.0 * c2 - 3.0);
+        }
+        const double sn = sqrt(fmax(3.0 - 3.0 * (c * c), 0.0));   // sqrt(3) sin(phi')
+        // eigenvalues of the normalised deviator: r >= 0: {2 c, -c + sn, -c - sn};  r < 0: their negatives
+        mx = qm + pp * (r >= 0.0 ? 2.0 * c : c + sn);
+        mn = qm + pp * (r >= 0.0 ? -c - sn : -2.0 * c);
     }
     return mx > (double)mo.max_principal_stress || (mx - mn) * 0.5 > (double)mo.max_shear_stress;
 }

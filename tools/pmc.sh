@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/pmc_$TAG
 rm -rf $OUT; mkdir -p $OUT
 ( [ -n "$LIB" ] && export SPARKL_HIP_LIB=$R/$LIB
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT/pmc_a -- python3 $R/bench.py --steps 8 --warmup 8 --no-cpu-baseline --no-late-phase --no-kernel-clock --no-cold-window --clock-wake-ms 0 "$@" > /dev/null 2> $OUT/pmc_a.err ) || { echo "pmc.sh $TAG: rocprofv3 / bench.py FAILED (rc $?)"; tail -5 $OUT/pmc_a.err; exit 1; }
+timeout 300 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT/pmc_a -- python3 $R/bench.py --steps 8 --warmup 8 --no-cpu-baseline --no-late-phase --no-kernel-clock --no-cold-window --no-strong-projection --clock-wake-ms 0 "$@" > /dev/null 2> $OUT/pmc_a.err ) || { echo "pmc.sh $TAG: rocprofv3 / bench.py FAILED (rc $?)"; tail -5 $OUT/pmc_a.err; exit 1; }
 python3 $R/tools/pmc_summary.py $OUT > $OUT/summary.txt
 rm -rf $OUT/pmc_a
 echo "== $TAG"; cat $OUT/summary.txt
