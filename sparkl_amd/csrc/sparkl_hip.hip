@@ -2950,7 +2950,6 @@ static int group_direct_setup(Group& G) {
         // both halo buffers start from zero: a node of a cut plane no record covers reads 0, like the halo_in of the copy exchange
         HIPCHK(hipMemsetAsync((char*)p->direct.arena + sizeof(PeerBox), 0, 2 * p->direct.cap_blocks * 64 * sizeof(float4), p->stream));
         CHK(comm_wait(p, p->stream));
-        p->direct.ready = true;
     }
     // nobody may push into a buffer its owner is still clearing: one more agreement (host-synchronous, like everything around a re-bin)
     {
@@ -2958,6 +2957,49 @@ static int group_direct_setup(Group& G) {
         long long dummy = 0;
         CHK(group_max(G, v.data(), &dummy));
     }
+    // Handshake through the mapped arenas, once per setup: every member mails a reserved epoch to all members and waits (bounded) for everybody's.
+    // A mapping that opens but does not carry stores from one device into another device's polling kernel (a platform without working peer / IPC
+    // coherence for fine-grained memory) is found HERE, where the job can still agree on the staged exchange, not in the first real substep,
+    // where a timeout is fatal.
+    {
+        const uint32_t E0 = 0xFFFFFFFEu;   // never a real epoch (they count up from 1); parity 0
+        static const double hs_s = getenv("SPARKL_HIP_DIRECT_HANDSHAKE_S") ? atof(getenv("SPARKL_HIP_DIRECT_HANDSHAKE_S")) : 5.0;
+        for (int i = 0; i < G.n; ++i) {
+            SparklPipeline* p = G.m[i];
+            SparklPipeline::Direct& Dp = p->direct;
+            HIPCHK(hipSetDevice(p->device));
+            DirectPush D;
+            memset(&D, 0, sizeof(D));
+            D.n_mail = Dp.n; D.epoch = E0; D.arrive = Dp.arrive.p;
+            for (int k = 0; k < Dp.n; ++k) D.mail[k] = &reinterpret_cast<PeerBox*>(Dp.peer_arena[k])->mail[E0 & 1u][Dp.index];
+            hipLaunchKernelGGL(k_halo_push, dim3(1), dim3(BLK_THREADS), 0, p->stream, grid_arrays(p), D, p->slab_axis, p->d_ctl, (int)(p->substep_index & 1u));
+        }
+        std::vector<long long> bad(G.n, 0);
+        for (int i = 0; i < G.n; ++i) {
+            SparklPipeline* p = G.m[i];
+            HIPCHK(hipSetDevice(p->device));
+            DirectWait W{p->direct.box(), p->direct.n, E0, {0, 0}, (unsigned long long)(hs_s * 1.0e8)};
+            hipLaunchKernelGGL(k_direct_agree, dim3(1), dim3(64), 0, p->stream, W, p->d_ctl, (int)(p->substep_index & 1u));
+            CHK(read_ctl(p));
+            if (p->h_ctl->direct_error) {   // undo what the give-up raised: this is a probe, not a substep
+                bad[i] = 1;
+                HIPCHK(hipMemsetAsync(p->d_ctl, 0, 2 * sizeof(uint32_t), p->stream));
+                HIPCHK(hipMemsetAsync(&p->d_ctl->direct_error, 0, sizeof(uint32_t), p->stream));
+                if (p->h_words) p->h_words[0] = 0u;
+                CHK(comm_wait(p, p->stream));
+            }
+        }
+        // (test hook: member 0 of the job reports a failed handshake -- the rank-asymmetric case the agreement below exists for)
+        if (getenv("SPARKL_HIP_DIRECT_TEST_FAIL")) for (int i = 0; i < G.n; ++i) if (G.m[i]->direct.index == 0) bad[i] = 1;
+        long long any_bad = 0;
+        CHK(group_max(G, bad.data(), &any_bad));
+        if (any_bad) {
+            for (int i = 0; i < G.n; ++i) { G.m[i]->direct.ready = false; G.m[i]->direct.failed = true; }
+            if (getenv("SPARKL_HIP_DEBUG")) fprintf(stderr, "[sparkl_hip] direct halo exchange: the handshake through the mapped arenas timed out: staying on the RCCL / copy exchange\n");
+            return SPARKL_OK;
+        }
+    }
+    for (int i = 0; i < G.n; ++i) G.m[i]->direct.ready = true;
     return SPARKL_OK;
 }
 }  // namespace

@@ -49,18 +49,21 @@ def _union(tmp_path, sc, world):
     return union_components(parts, caller), parts, caller
 
 
-@pytest.mark.parametrize("exchange", ["direct", "staged"])
+@pytest.mark.parametrize("exchange", ["direct", "staged", "handshake-fails"])
 def test_two_processes_run_the_group_loop_and_match_pipeline_and_oracle(tmp_path, exchange):
     """cube_through_sand in small, the kinematic cube crossing the cut within the 100 substeps: the union of the two PROCESSES equals the
     single pipeline (to rounding: the halo sums are formed in another order) and passes the oracle gate.
     "direct" (round 6, the default): each process maps the other's exchange arena with hipIpcOpenMemHandle; k_halo_push stores the records and
     the re-bin flag mail straight into it and the peer's grid update waits for them inside the kernel -- no per-substep collective at all.
-    "staged": the RCCL call pattern (flag all-reduce, pack, send / recv, merge) over the host transport, with the overlap calibration."""
+    "staged": the RCCL call pattern (flag all-reduce, pack, send / recv, merge) over the host transport, with the overlap calibration.
+    "handshake-fails": the arenas map, but ONE rank reports that the handshake through them failed (test hook): both ranks must agree on the staged
+    exchange -- the fallback a platform without working peer / IPC coherence would take -- and still produce the same result."""
     from oracle import Oracle
     from sparkl_amd.pipeline import MpmPipeline
     from tests.parity import parity_verdict
     world, nsteps = 2, 100
-    res, el = _run_ranks(tmp_path, "cube", nsteps, world, env_extra={"SPARKL_HIP_OVERLAP": "cal"} if exchange == "staged" else {"SPARKL_HIP_COMM_TIMEOUT_S": "20"})
+    env = {"staged": {"SPARKL_HIP_OVERLAP": "cal"}, "direct": {"SPARKL_HIP_COMM_TIMEOUT_S": "20"}, "handshake-fails": {"SPARKL_HIP_DIRECT_TEST_FAIL": "1"}}[exchange]
+    res, el = _run_ranks(tmp_path, "cube", nsteps, world, env_extra=env)
     assert all(rc == 0 for rc, _, _ in res), res
     sc, dt = _scene("cube")
     got, parts, caller = _union(tmp_path, sc, world)
@@ -94,6 +97,8 @@ def test_two_processes_run_the_group_loop_and_match_pipeline_and_oracle(tmp_path
     if exchange == "staged":
         assert overlap[0] == overlap[1] and overlap[0][0] in (0.0, 1.0) and overlap[0][1] > 0 and overlap[0][2] > 0, overlap   # both schedules timed, MAX over the ranks agreed
         assert all(d[1] == 0 for d in direct), direct
+    elif exchange == "handshake-fails":
+        assert all(d == (0, 0) for d in direct), direct        # no rank ever pushed: the agreement held on both
     else:
         assert all(d[0] == 1 and d[1] >= nsteps for d in direct) and direct[0][1] == direct[1][1], direct   # every substep went through the mapped arenas, the same count on both
     assert int(parts[0]["cut_hi"]) == int(parts[1]["cut_lo"])                                                                # the ranks agree on the (possibly moved) cut
