@@ -179,6 +179,7 @@ struct SparklPipeline {
         uint64_t arena_serial = 0;       // bumped by every (re)allocation
         int index = 0, n = 1;            // this member's mailbox slot and the number of members in the job
         uint32_t epoch = 0;              // group substeps enqueued so far (the same on every member of the job)
+        uint32_t handshakes = 0;         // handshakes through the mapped arenas so far (group_direct_setup)
         DevBuf<unsigned int> arrive;     // arrival counter of k_halo_push's workgroups (ordinary device memory: an RMW on the fine-grained arena is a trip to memory)
         DevBuf<int2> dst[2];             // per halo column of each cut: the neighbour's node-block slots (k_halo_slots)
         void* peer_arena[MAX_DIRECT] = {nullptr};   // every member's arena in THIS process' address space ([index] = own)
@@ -2811,10 +2812,8 @@ static int direct_arena(SparklPipeline* p) {
     if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&a, bytes); }   // (one device, one process: plain device memory does)
     if (e != hipSuccess) return set_error(SPARKL_ERR_OUT_OF_MEMORY, "direct exchange arena: %s", hipGetErrorString(e));
     HIPCHK(hipStreamSynchronize(p->stream));
-    if (D.arena) {
-        HIPCHK(hipMemcpy(a, D.arena, sizeof(PeerBox), hipMemcpyDeviceToDevice));   // (the mail of past epochs: harmless either way)
-        (void)hipFree(D.arena);
-    } else HIPCHK(hipMemset(a, 0, sizeof(PeerBox)));
+    HIPCHK(hipMemset(a, 0, sizeof(PeerBox)));   // a fresh box: no mail of past epochs (the job is quiescent around a re-bin: nothing in flight is lost)
+    if (D.arena) (void)hipFree(D.arena);
     D.arena = a; D.arena_bytes = bytes; D.cap_blocks = cap; D.arena_serial++;
     return SPARKL_OK;
 }
@@ -2868,7 +2867,9 @@ static int group_direct_setup(Group& G) {
         }
         for (int q = 0; q < world; ++q) ok = ok && table[(size_t)q].valid == 1;
     }
-    // map
+    // map (a mapping that is still the one of the last setup is kept: `remapped` says whether anything changed -- the same answer on every rank, they
+    // all read the same table -- and only then is the handshake below repeated)
+    bool remapped = false;
     if (ok)
         for (int i = 0; i < G.n && ok; ++i) {
             SparklPipeline* p = G.m[i];
@@ -2877,6 +2878,7 @@ static int group_direct_setup(Group& G) {
             for (int q = 0; q < world && ok; ++q) {
                 const ArenaRecord& r = table[(size_t)q];
                 if (D.peer_arena[q] && D.peer_serial[q] == r.serial && D.peer_pid[q] == r.token) continue;   // still the mapping of the last setup
+                remapped = true;
                 if (D.peer_ipc[q]) { (void)hipIpcCloseMemHandle(D.peer_ipc[q]); D.peer_ipc[q] = nullptr; }
                 D.peer_arena[q] = nullptr;
                 if (r.pid == (uint64_t)getpid() && r.token == process_token()) {
@@ -2951,18 +2953,23 @@ static int group_direct_setup(Group& G) {
         HIPCHK(hipMemsetAsync((char*)p->direct.arena + sizeof(PeerBox), 0, 2 * p->direct.cap_blocks * 64 * sizeof(float4), p->stream));
         CHK(comm_wait(p, p->stream));
     }
-    // nobody may push into a buffer its owner is still clearing: one more agreement (host-synchronous, like everything around a re-bin)
+    // Nobody may push into a buffer its owner is still clearing: one more agreement (host-synchronous, like everything around a re-bin).  It also
+    // carries `remapped`: a function of the gathered table and of what each member had mapped before -- members created at different times could
+    // disagree, so the decision to repeat the handshake is the MAX, like every other branch of this function.
+    long long hs_nonce = 0;   // (the epoch of this handshake: one more than the most any member has done, so that mail of an earlier one cannot answer it)
     {
         std::vector<long long> v(G.n, 0);
-        long long dummy = 0;
-        CHK(group_max(G, v.data(), &dummy));
+        for (int i = 0; i < G.n; ++i) v[i] = remapped ? (long long)G.m[i]->direct.handshakes + 1 : 0;
+        CHK(group_max(G, v.data(), &hs_nonce));
+        remapped = hs_nonce != 0;
     }
-    // Handshake through the mapped arenas, once per setup: every member mails a reserved epoch to all members and waits (bounded) for everybody's.
-    // A mapping that opens but does not carry stores from one device into another device's polling kernel (a platform without working peer / IPC
-    // coherence for fine-grained memory) is found HERE, where the job can still agree on the staged exchange, not in the first real substep,
-    // where a timeout is fatal.
-    {
-        const uint32_t E0 = 0xFFFFFFFEu;   // never a real epoch (they count up from 1); parity 0
+    // Handshake through the mapped arenas, whenever a mapping is new: every member mails a reserved epoch to all members and waits (bounded) for
+    // everybody's.  A mapping that opens but does not carry stores from one device into another device's polling kernel (a platform without working
+    // peer / IPC coherence for fine-grained memory) is found HERE, where the job can still agree on the staged exchange, not in the first real
+    // substep, where a timeout is fatal.
+    if (remapped) {
+        const uint32_t E0 = 0xFFFF0000u + (uint32_t)(hs_nonce & 0x7FFF);   // never a real epoch (they count up from 1)
+        for (int i = 0; i < G.n; ++i) G.m[i]->direct.handshakes = (uint32_t)hs_nonce;
         static const double hs_s = getenv("SPARKL_HIP_DIRECT_HANDSHAKE_S") ? atof(getenv("SPARKL_HIP_DIRECT_HANDSHAKE_S")) : 5.0;
         for (int i = 0; i < G.n; ++i) {
             SparklPipeline* p = G.m[i];

@@ -47,7 +47,11 @@ def test_bench_arguments():
     a = bench.parse_args(["--config", "cube80m", "--gpus", "8"])
     assert a.scaling == "strong"
     a = bench.parse_args(["--gpus", "8"])
-    assert a.scaling == "weak" and a.config == "sand10m"
+    # round 6: the default N > 1 job is the metric's own -- the 10 M column, fixed, cut N ways (BASELINE.json: ">= 6x strong scaling at 8 GPUs")
+    assert a.scaling == "strong" and a.config == "sand10m" and a.weak_figure and a.strong_projection
+    a = bench.parse_args(["--gpus", "8", "--scaling", "weak"])
+    assert a.scaling == "weak"
+    assert bench.parse_args(["--config", "fluid20m"]).scaling == "weak"
     with pytest.raises(SystemExit):
         bench.parse_args(["--config", "cube80m", "--scaling", "weak"])
     with pytest.raises(SystemExit):
