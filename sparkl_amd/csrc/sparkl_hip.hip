@@ -177,6 +177,7 @@ struct SparklPipeline {
         void* arena = nullptr;           // [PeerBox | halo buffer parity 0 | halo buffer parity 1], fine-grained device memory
         size_t arena_bytes = 0, cap_blocks = 0;
         uint64_t arena_serial = 0;       // bumped by every (re)allocation
+        bool arena_fine = false;         // hipDeviceMallocFinegrained was granted (else plain device memory: enough inside one device only)
         int index = 0, n = 1;            // this member's mailbox slot and the number of members in the job
         uint32_t epoch = 0;              // group substeps enqueued so far (the same on every member of the job)
         uint32_t handshakes = 0;         // handshakes through the mapped arenas so far (group_direct_setup)
@@ -2809,7 +2810,8 @@ static int direct_arena(SparklPipeline* p) {
     void* a = nullptr;
     // fine-grained: peers store into it while kernels of this device poll and read it (system-scope release / acquire needs coherent memory)
     hipError_t e = hipExtMallocWithFlags(&a, bytes, hipDeviceMallocFinegrained);
-    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&a, bytes); }   // (one device, one process: plain device memory does)
+    D.arena_fine = e == hipSuccess;
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&a, bytes); }   // (one device, one process: plain device memory does; across devices the handshake decides)
     if (e != hipSuccess) return set_error(SPARKL_ERR_OUT_OF_MEMORY, "direct exchange arena: %s", hipGetErrorString(e));
     HIPCHK(hipStreamSynchronize(p->stream));
     HIPCHK(hipMemset(a, 0, sizeof(PeerBox)));   // a fresh box: no mail of past epochs (the job is quiescent around a re-bin: nothing in flight is lost)
@@ -3649,10 +3651,12 @@ extern "C" int sparkl_hip_debug_run_stats(SparklPipeline* p, unsigned long long*
 }
 
 // (tests, bench) out[0] = 1 while the group loop of this pipeline exchanges its halo peer-direct (kernels.h, PeerBox), out[1] = substeps it has pushed so far,
-// out[2] = 1 when a setup attempt failed and the job fell back to the RCCL / copy exchange, out[3] = members of the job
+// out[2] = bit 0: a setup attempt failed and the job fell back to the RCCL / copy exchange, bit 1: the arena is fine-grained memory, bits 8..: handshakes done;
+// out[3] = members of the job
 extern "C" int sparkl_hip_debug_direct(const SparklPipeline* p, unsigned long long out[4]) {
     if (!p || !out) return -1;
-    out[0] = p->direct.ready ? 1 : 0; out[1] = p->direct.epoch; out[2] = p->direct.failed ? 1 : 0; out[3] = (unsigned long long)p->direct.n;
+    out[0] = p->direct.ready ? 1 : 0; out[1] = p->direct.epoch; out[2] = (p->direct.failed ? 1 : 0) | (p->direct.arena_fine ? 2 : 0) | ((unsigned long long)p->direct.handshakes << 8);
+    out[3] = (unsigned long long)p->direct.n;
     return 0;
 }
 

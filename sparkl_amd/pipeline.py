@@ -118,10 +118,10 @@ class MpmPipeline:
         return sim.value, int(nsub.value)
 
     def direct_info(self):
-        """Peer-direct halo exchange of the group loop (kernels.h, PeerBox): {"ready", "epochs", "failed", "members"}."""
+        """Peer-direct halo exchange of the group loop (kernels.h, PeerBox): {"ready", "epochs", "failed", "members", "arena_fine_grained", "handshakes"}."""
         out = (C.c_ulonglong * 4)()
         self.L.sparkl_hip_debug_direct(self.h, out)
-        return {"ready": bool(out[0]), "epochs": int(out[1]), "failed": bool(out[2]), "members": int(out[3])}
+        return {"ready": bool(out[0]), "epochs": int(out[1]), "failed": bool(out[2] & 1), "members": int(out[3]), "arena_fine_grained": bool(out[2] & 2), "handshakes": int(out[2] >> 8)}
 
     def slab_balance(self, enable=True):
         check(self.L.sparkl_hip_slab_balance(self.h, int(bool(enable))))

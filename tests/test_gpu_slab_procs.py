@@ -93,7 +93,7 @@ def test_two_processes_run_the_group_loop_and_match_pipeline_and_oracle(tmp_path
     assert crossed > 20, "the kinematic cube must cross the cut (migration between the processes)"
     assert all(int(q["rebins"]) >= 2 for q in parts) and int(parts[0]["rebins"]) == int(parts[1]["rebins"])
     direct = [tuple(int(x) for x in q["direct"]) for q in parts]
-    print("direct exchange (ready, substeps pushed):", direct)
+    print("direct exchange (ready, substeps pushed):", direct, "| arena fine-grained:", [int(q["direct_fine"]) for q in parts], "| handshakes:", [int(q["direct_handshakes"]) for q in parts])
     if exchange == "staged":
         assert overlap[0] == overlap[1] and overlap[0][0] in (0.0, 1.0) and overlap[0][1] > 0 and overlap[0][2] > 0, overlap   # both schedules timed, MAX over the ranks agreed
         assert all(d[1] == 0 for d in direct), direct
