@@ -361,11 +361,17 @@ def main(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    result_fd = None
     if world > 1:
         # a rank that waits forever in a collective (a peer died, a link is down) must not hold the node: dump the stacks
         # and exit after 15 minutes (a whole 8-rank run takes well under two)
         import faulthandler
         faulthandler.dump_traceback_later(900, exit=True)
+        # stdout carries ONE JSON line (rank 0's): gloo ("[Gloo] Rank 0 is connected to 7 peer ranks ...") and RCCL (its version banner) write
+        # there from C++ whenever they please, so everything but that line goes to stderr for the whole run
+        sys.stdout.flush()
+        result_fd = os.dup(1)
+        os.dup2(2, 1)
     # test hook: SPARKL_BENCH_BACKEND=gloo + SPARKL_BENCH_ONE_DEVICE=1 runs the N-rank slab path on a single GPU
     backend = os.environ.get("SPARKL_BENCH_BACKEND", "nccl")
     device_id = 0 if os.environ.get("SPARKL_BENCH_ONE_DEVICE") else local_rank
@@ -740,7 +746,11 @@ def main(args):
             threads = len(os.sched_getaffinity(0))
             # the port does 10 M particles in ~4 s per substep; an 80 M scene would take minutes: the thread-probe column stands in
             out["cpu_baseline"] = cpu_baseline(threads, sc, desc) if n_particles <= 12_000_000 else cpu_baseline(threads)
-        print(json.dumps(out), flush=True)
+        if result_fd is not None:
+            sys.stdout.flush()
+            os.write(result_fd, (json.dumps(out) + "\n").encode())
+        else:
+            print(json.dumps(out), flush=True)
     pipe.close()
     if world > 1:
         dist.barrier()

@@ -131,6 +131,12 @@ struct DirectWait {
     unsigned int epoch;
     int wait_side[2];          // a neighbour on that side pushes records
     unsigned long long timeout_ticks;
+    // 1: a one-wave k_direct_agree in front of this launch has already waited (mail AND records) and left the agreed flag in the control block: no
+    // wave of this launch spins.  Set when members of different processes share a physical device (test setups, partitioned GPUs): a grid update
+    // whose every wave polls fills the device with its own spinning waves, and the kernel of the OTHER process that would post the mail never gets a
+    // slot -- measured as a 20 s stall on the first substep of two 5 M-particle ranks on one MI355X.  With one rank per device the wait stays
+    // inside the grid update (one launch less per substep).
+    int pre_agreed;
 };
 struct DirectPush {
     const int* list[2];        // halo columns of each cut (k_halo_list)
@@ -1482,7 +1488,7 @@ SPK_DEV void gpu_boundary_rule(float v[3], const float cpos[3], const GridArrays
 // GPU_RULE: some collider carries its own boundary handling: the reference's GPU rule for the whole set (gpu_boundary_rule), no projection cache.
 template <bool MASS_ONLY, bool HEIGHTFIELDS = false, bool GPU_RULE = false>
 __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const DevCuboid* __restrict__ cuboids, const DevHeightField* __restrict__ heightfields, const DevTriMesh* __restrict__ trimeshes,
-                                                             Ctl* ctl, StepParams S, DirectWait W = DirectWait{nullptr, 0, 0u, {0, 0}, 0ull}) {
+                                                             Ctl* ctl, StepParams S, DirectWait W = DirectWait{nullptr, 0, 0u, {0, 0}, 0ull, 0}) {
     // The abort flag is read first but only consulted behind the first table loads: the topology arrays stay valid (stale) after an
     // abort, and the dependent-load chain stays at  blk_tnbr -> tile_mode -> tile  (3 hops; it used to be 5).
     int aborted = ctl->abort_flag[S.parity];
@@ -1500,7 +1506,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
     // load one table entry and one mode each -- two coalesced loads instead of sixteen 4-byte gathers per lane, a third of the kernel's
     // vector-memory instructions -- and every lane picks its eight through the LDS crossbar (ds_bpermute).
     const int my_t = G.blk_tnbr[b * 27 + min(lane, 26)];
-    if (W.box) {
+    if (W.box && !W.pre_agreed) {
         // peer-direct exchange: the flag of the substep is the MAX over the mail of ALL members (every wave derives it for itself; the first wave of
         // the launch leaves it in the control block for the particle kernel behind), then the neighbours' records must have landed
         bool any = false;
@@ -1557,7 +1563,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
         if (bp == G.halo_lo || bp == G.halo_hi || bp + 1 == G.halo_lo || bp + 1 == G.halo_hi) {   // wave-uniform: one block per wave
             float4 hv;
             if (W.box) {   // peer-direct: only the waves of the cut planes wait for the neighbours' records, and read them past the caches
-                if (!direct_wait_halo(W, lane)) { if (lane == 0) direct_give_up(ctl, S.parity, 2u); return; }
+                if (!W.pre_agreed && !direct_wait_halo(W, lane)) { if (lane == 0) direct_give_up(ctl, S.parity, 2u); return; }
                 hv = halo_load_wt(&G.halo_in[(size_t)b * 64 + lane]);
             } else hv = G.halo_in[(size_t)b * 64 + lane];
             m += hv.x; px += hv.y; py += hv.z; pz += hv.w;
@@ -3684,11 +3690,14 @@ __global__ __launch_bounds__(BLK_THREADS) void k_halo_push(GridArrays G, DirectP
         }
     }
 }
-// a member without particle blocks: the agreed flag goes into its control block in front of k_bump_steps (its push has posted the mail)
+// One wave: waits for the mail of all members, leaves the agreed flag in the control block and -- unless the substep is skipped -- waits for the
+// neighbours' records too.  In front of k_bump_steps for a member without particle blocks, and in front of the grid update when members of
+// different processes share a device (DirectWait::pre_agreed).
 __global__ void k_direct_agree(DirectWait W, Ctl* ctl, int parity) {
     bool aborted = false;
     if (!direct_wait_mail(W, threadIdx.x & 63, aborted)) { if (threadIdx.x == 0) direct_give_up(ctl, parity, 1u); return; }
-    if (aborted && threadIdx.x == 0) raise_abort(ctl, parity);
+    if (aborted) { if (threadIdx.x == 0) raise_abort(ctl, parity); return; }
+    if (!direct_wait_halo(W, threadIdx.x & 63)) { if (threadIdx.x == 0) direct_give_up(ctl, parity, 2u); }
 }
 
 // MAX of the members' abort flags of the upcoming substep, written back to all of them (members of one process on one stream)

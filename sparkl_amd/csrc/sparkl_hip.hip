@@ -177,6 +177,7 @@ struct SparklPipeline {
         void* arena = nullptr;           // [PeerBox | halo buffer parity 0 | halo buffer parity 1], fine-grained device memory
         size_t arena_bytes = 0, cap_blocks = 0;
         uint64_t arena_serial = 0;       // bumped by every (re)allocation
+        bool shared_device = false;      // members of different processes (or streams) sit on one physical device: no spinning grid update (DirectWait::pre_agreed)
         bool arena_fine = false;         // hipDeviceMallocFinegrained was granted (else plain device memory: enough inside one device only)
         int index = 0, n = 1;            // this member's mailbox slot and the number of members in the job
         uint32_t epoch = 0;              // group substeps enqueued so far (the same on every member of the job)
@@ -190,7 +191,7 @@ struct SparklPipeline {
         size_t peer_cap[MAX_DIRECT] = {0};          // cap_blocks of the peer's arena (where its second halo buffer starts)
         PeerBox* box() const { return reinterpret_cast<PeerBox*>(arena); }
     } direct;
-    DirectWait dw{nullptr, 0, 0u, {0, 0}, 0ull};   // handed to the grid update of the substep in flight (group loop, direct exchange), else box == NULL
+    DirectWait dw{nullptr, 0, 0u, {0, 0}, 0ull, 0};   // handed to the grid update of the substep in flight (group loop, direct exchange), else box == NULL
     DevBuf<long long> bal_dev;       // plane histogram + cut list of the slab re-balancing (group_rebalance)
     long long* bal_host = nullptr; int bal_host_words = 0;
     bool slab_balance = true;        // sparkl_hip_slab_balance
@@ -2788,9 +2789,10 @@ struct ArenaRecord {
     uint64_t ptr, bytes, cap_blocks, serial;
     int32_t device, valid;
     unsigned char handle[64];     // hipIpcMemHandle_t
-    unsigned char pad[8];
+    char bus_id[24];              // PCI bus id of the device ("0000:05:00.0"): which members share a physical device
+    unsigned char pad[16];
 };
-static_assert(sizeof(ArenaRecord) == 128 && sizeof(hipIpcMemHandle_t) == 64, "");
+static_assert(sizeof(ArenaRecord) == 160 && sizeof(hipIpcMemHandle_t) == 64, "");
 static uint64_t process_token() {
     static const uint64_t t = [] {
         uint64_t r = 0;
@@ -2839,6 +2841,7 @@ static int group_direct_setup(Group& G) {
             ArenaRecord& r = table[(size_t)index_of(i)];
             r.pid = (uint64_t)getpid(); r.token = process_token(); r.ptr = (uint64_t)(uintptr_t)p->direct.arena; r.bytes = p->direct.arena_bytes;
             r.cap_blocks = p->direct.cap_blocks; r.serial = p->direct.arena_serial; r.device = p->device; r.valid = 1;
+            if (hipDeviceGetPCIBusId(r.bus_id, (int)sizeof(r.bus_id) - 1, p->device) != hipSuccess) { (void)hipGetLastError(); snprintf(r.bus_id, sizeof(r.bus_id), "dev%d", p->device); }
             if (G.rccl && world > G.n) {   // some member lives in another process: it needs a handle
                 hipIpcMemHandle_t h;
                 if (hipIpcGetMemHandle(&h, p->direct.arena) != hipSuccess) { (void)hipGetLastError(); r.valid = 0; ok = false; }
@@ -2902,6 +2905,11 @@ static int group_direct_setup(Group& G) {
                 D.peer_serial[q] = r.serial; D.peer_pid[q] = r.token; D.peer_cap[q] = (size_t)r.cap_blocks;
             }
             for (int q = 0; q < world; ++q) D.peer_cap[q] = (size_t)table[(size_t)q].cap_blocks;
+            // two members on one physical device that do not share this member's process (their kernels sit in another queue): see DirectWait::pre_agreed
+            D.shared_device = false;
+            for (int a = 0; a < world; ++a)
+                for (int b = a + 1; b < world; ++b)
+                    if (!strncmp(table[(size_t)a].bus_id, table[(size_t)b].bus_id, sizeof(table[0].bus_id)) && table[(size_t)a].token != table[(size_t)b].token) D.shared_device = true;
         }
     {   // every rank takes the same branch
         std::vector<long long> v(G.n, ok ? 0 : 1);
@@ -2987,7 +2995,7 @@ static int group_direct_setup(Group& G) {
         for (int i = 0; i < G.n; ++i) {
             SparklPipeline* p = G.m[i];
             HIPCHK(hipSetDevice(p->device));
-            DirectWait W{p->direct.box(), p->direct.n, E0, {0, 0}, (unsigned long long)(hs_s * 1.0e8)};
+            DirectWait W{p->direct.box(), p->direct.n, E0, {0, 0}, (unsigned long long)(hs_s * 1.0e8), 0};
             hipLaunchKernelGGL(k_direct_agree, dim3(1), dim3(64), 0, p->stream, W, p->d_ctl, (int)(p->substep_index & 1u));
             CHK(read_ctl(p));
             if (p->h_ctl->direct_error) {   // undo what the give-up raised: this is a probe, not a substep
@@ -3393,6 +3401,7 @@ static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, con
                     D.n_mail = Dp.n; D.epoch = epoch; D.arrive = Dp.arrive.p;
                     for (int k = 0; k < Dp.n; ++k) D.mail[k] = &reinterpret_cast<PeerBox*>(Dp.peer_arena[k])->mail[par][Dp.index];
                     p->dw.box = Dp.box(); p->dw.n_mail = Dp.n; p->dw.epoch = epoch; p->dw.timeout_ticks = (unsigned long long)(tmo_s * 1.0e8);
+                    p->dw.pre_agreed = Dp.shared_device ? 1 : 0;
                     for (int side = 0; side < 2; ++side) {
                         const bool has = G.nbr(i, side) != -2;
                         p->dw.wait_side[side] = has ? 1 : 0;
@@ -3405,6 +3414,8 @@ static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, con
                     size_t tok = 0;
                     CHK(clock_begin(p, SPAN_HALO, &tok));
                     hipLaunchKernelGGL(k_halo_push, dim3(std::max(1, (D.n[0] + D.n[1] + 3) / 4)), dim3(BLK_THREADS), 0, p->stream, grid_arrays(p), D, p->slab_axis, p->d_ctl, p->pending.parity);
+                    // (ranks that share a device: one wave waits for everybody, the grid update behind it does not spin)
+                    if (p->dw.pre_agreed && p->num_pblocks) hipLaunchKernelGGL(k_direct_agree, dim3(1), dim3(64), 0, p->stream, p->dw, p->d_ctl, p->pending.parity);
                     CHK(clock_end(p, tok));
                 }
                 for (int i = 0; i < G.n; ++i) {
