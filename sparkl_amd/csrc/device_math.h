@@ -1053,6 +1053,31 @@ SPK_DEV void nacc_update(const DevModel& mo, M3& F, float& alpha) {
     for (int i = 0; i < 3; ++i) g[i] = d.s[i] == 0.f ? 0.f : ns[i] / d.s[i];
     F = svd_compose_scaled(d, g);
 }
+// Elastic predictor test (round 6): can the plastic model possibly act on F = I + E?  A bound from the strain metric S = F^T F - I alone, without the SVD
+// both models start with: every eigenvalue lambda_k = sigma_k^2 - 1 of S lies within +-|S|_F.
+//   snow (plasticity_snow.rs:27-49): nothing is clamped while every sigma_k is inside [1 - min_epsilon, 1 + max_epsilon]  <=  |S|_F below the nearer of
+//        1 - (1 - min_epsilon)^2 and (1 + max_epsilon)^2 - 1.  The reference still runs its SVD and recomposes the same F (to rounding) and multiplies
+//        Jp by 1; skipping leaves F as it is -- one rounding closer to the f64 trajectory.
+//   Rankine (plasticity_rankine.rs:34-47): returns at once when lambda tr(eps) + 2 mu eps_1 <= tensile strength left; eps_k = ln(1 + lambda_k) / 2
+//        <= |S|_F / 2 bounds the left side by (3 lambda + 2 mu) |S|_F / 2 for lambda, mu >= 0: the same early return, F untouched like there.
+// `false` = the model has nothing to do for this particle (no SVD).  A falling snow block is elastic everywhere but in the zone the impact has reached.
+SPK_DEV bool rare_plastic_may_act(const DevModel& mo, const M3& E, float q) {
+    if (mo.ptag != SPARKL_PLASTIC_SNOW && mo.ptag != SPARKL_PLASTIC_RANKINE) return true;
+    float S6[6];
+    strain_metric(E, S6);
+    const float n2 = S6[0] * S6[0] + S6[1] * S6[1] + S6[2] * S6[2] + 2.f * (S6[3] * S6[3] + S6[4] * S6[4] + S6[5] * S6[5]);
+    if (!(n2 == n2)) return true;
+    if (mo.ptag == SPARKL_PLASTIC_SNOW) {
+        const float lo = 1.f - (1.f - mo.x0) * (1.f - mo.x0), hi = (1.f + mo.x1) * (1.f + mo.x1) - 1.f;
+        const float r = 0.98f * fminf(lo, hi);
+        return !(r > 0.f && n2 < r * r);
+    }
+    const float mu = mo.x0, lambda = mo.x1, soft = mo.x2 - (q - 1.0f);
+    if (!(mu >= 0.f && lambda >= 0.f && soft > 0.f)) return true;
+    const float nS = sqrtf(n2);
+    if (nS > 0.5f) return true;                                   // (ln(1 + x) / 2 <= x / 2 only needs x > -1; keep well away from it)
+    return !(0.5f * 1.02f * (3.f * lambda + 2.f * mu) * nS <= soft);
+}
 // Snow / Rankine / NACC dispatch (only instantiated in the RARE kernels, see g2p_update)
 SPK_DEV void rare_plastic_update(const DevModel& mo, M3& F, float& Jp, float& q, float& eh, float& alpha) {
     if (mo.ptag == SPARKL_PLASTIC_SNOW) snow_update(mo, F, eh, Jp);

@@ -1991,7 +1991,7 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const MO& mo
     bool sv_valid = false;
     o.store_k = false; o.store_aux = false; o.alpha = 0.f;
     o.T.valid = false; o.T.jm1 = 0.f;
-    if constexpr (RARE) if (mo.ptag > SPARKL_PLASTIC_DRUCKER_PRAGER) {   // snow / Rankine / NACC (plastic_model.update_particle, :102-104)
+    if constexpr (RARE) if (mo.ptag > SPARKL_PLASTIC_DRUCKER_PRAGER && rare_plastic_may_act(mo, E, q)) {   // snow / Rankine / NACC (plastic_model.update_particle, :102-104), behind the elastic predictor test
         float alpha = mo.ptag == SPARKL_PLASTIC_NACC ? aux_i->z : 0.f;
         const float eh0 = eh, alpha0 = alpha;
         rare_plastic_update(mo, F, Jp, q, eh, alpha);

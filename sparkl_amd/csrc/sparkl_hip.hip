@@ -2444,6 +2444,14 @@ static void comm_destroy(SparklPipeline* p) {
     if (p->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(p->comm);
     p->comm = nullptr;
 }
+// a new communicator is a new job: other processes may sit behind the ranks now.  Mappings go, the mailbox starts empty (mail of the old job must
+// not answer an epoch of the new one), a failed setup may be tried again.
+static void direct_reset(SparklPipeline* p) {
+    SparklPipeline::Direct& D = p->direct;
+    for (int k = 0; k < MAX_DIRECT; ++k) { if (D.peer_ipc[k]) (void)hipIpcCloseMemHandle(D.peer_ipc[k]); D.peer_ipc[k] = nullptr; D.peer_arena[k] = nullptr; D.peer_serial[k] = 0; }
+    if (D.arena) { (void)hipStreamSynchronize(p->stream); (void)hipMemset(D.arena, 0, sizeof(PeerBox)); }
+    D.ready = false; D.failed = false; D.epoch = 0; D.handshakes = 0;
+}
 // RCCL failure path.  A rank that leaves the group loop on an error would leave its peers blocked in their next collective for ever, and a
 // rank whose peer has died would sit in hipStreamSynchronize behind an RCCL kernel that never completes.  So (1) every host wait of a
 // pipeline that holds a communicator polls the stream AND ncclCommGetAsyncError, with a deadline (SPARKL_HIP_COMM_TIMEOUT_S, default 300 s),
@@ -2968,10 +2976,14 @@ static int group_direct_setup(Group& G) {
     // disagree, so the decision to repeat the handshake is the MAX, like every other branch of this function.
     long long hs_nonce = 0;   // (the epoch of this handshake: one more than the most any member has done, so that mail of an earlier one cannot answer it)
     {
-        std::vector<long long> v(G.n, 0);
-        for (int i = 0; i < G.n; ++i) v[i] = remapped ? (long long)G.m[i]->direct.handshakes + 1 : 0;
-        CHK(group_max(G, v.data(), &hs_nonce));
+        // ... and the epoch counter: members that have stepped in other groups before (or not at all) continue from the largest count among them, so
+        // that everybody mails and expects the same number
+        std::vector<long long> v(G.n, 0), ep(G.n, 0);
+        for (int i = 0; i < G.n; ++i) { v[i] = remapped ? (long long)G.m[i]->direct.handshakes + 1 : 0; ep[i] = (long long)G.m[i]->direct.epoch; }
+        long long max_epoch = 0;
+        CHK(group_max(G, v.data(), &hs_nonce, ep.data(), &max_epoch));
         remapped = hs_nonce != 0;
+        for (int i = 0; i < G.n; ++i) G.m[i]->direct.epoch = (uint32_t)max_epoch;
     }
     // Handshake through the mapped arenas, whenever a mapping is new: every member mails a reserved epoch to all members and waits (bounded) for
     // everybody's.  A mapping that opens but does not carry stores from one device into another device's polling kernel (a platform without working
@@ -3082,6 +3094,7 @@ int sparkl_hip_comm_init(SparklPipeline* p, const void* unique_id_128_bytes, int
     CHK(rccl_load());
     HIPCHK(hipSetDevice(p->device));
     comm_destroy(p);
+    direct_reset(p);
     p->comm_aborted = false;
     ncclUniqueId id;
     memcpy(&id, unique_id_128_bytes, sizeof(id));
@@ -3103,7 +3116,7 @@ int sparkl_hip_comm_init_all(SparklPipeline** members, uint32_t n_members, const
     CHK(rccl_load());
     ncclUniqueId id;
     memcpy(&id, unique_id_128_bytes, sizeof(id));
-    for (uint32_t i = 0; i < n_members; ++i) { HIPCHK(hipSetDevice(members[i]->device)); comm_destroy(members[i]); members[i]->comm_aborted = false; }
+    for (uint32_t i = 0; i < n_members; ++i) { HIPCHK(hipSetDevice(members[i]->device)); comm_destroy(members[i]); direct_reset(members[i]); members[i]->comm_aborted = false; }
     NCCLCHK(g_rccl.GroupStart());
     for (uint32_t i = 0; i < n_members; ++i) {
         HIPCHK(hipSetDevice(members[i]->device));
