@@ -1438,17 +1438,27 @@ SPK_DEV void collider_scan(const GridArrays& G, const DevCuboid* __restrict__ cu
     }
 }
 // grid_update.rs:97-190 (update_single_cell) on the velocity (momentum + m g dt) / m of the node at cpos
+// What the reference keeps in a grid node between two grid allocations (GpuGridNode::projection_status / projection_scaled_dir / collision_normal,
+// src_kernels/cuda/grid_update.rs:110-146): the closest collider's projection of the node and the signed-distance normal.  Colliders are static between two
+// uploads and node blocks between two re-bins, so the record is computed once per binning and replayed (GridArrays::node_proj, two float4 per node:
+// (dir.xyz, status bits) and (normal.xyz, friction); node_proj_blk[b] says whether block b's records exist) -- the same floats, hence the same velocities.
+struct GpuProj {
+    float dir[3];      // node - projection
+    float nrm[3];      // zero: no usable gradient
+    float friction;
+    int handling;      // of the closest collider (never NONE when `any`)
+    bool any, inside;
+};
 template <bool HEIGHTFIELDS>
-SPK_DEV void gpu_boundary_rule(float v[3], const float cpos[3], const GridArrays& G, const DevCuboid* __restrict__ cuboids, const DevHeightField* __restrict__ heightfields,
+SPK_DEV GpuProj gpu_projection(const float cpos[3], const GridArrays& G, const DevCuboid* __restrict__ cuboids, const DevHeightField* __restrict__ heightfields,
                                const DevTriMesh* __restrict__ trimeshes, const StepParams& S) {
+    GpuProj P;
     ColliderScan best;
     collider_scan<HEIGHTFIELDS>(G, cuboids, heightfields, trimeshes, S, cpos, best);
-    if (!best.any) return;
-    if (best.handling == SPARKL_BOUNDARY_STICK) {
-        if (best.inside) { v[0] = v[1] = v[2] = 0.f; }
-        return;
-    }
-    if (best.handling != SPARKL_BOUNDARY_FRICTION && best.handling != SPARKL_BOUNDARY_FRICTION_Z_UP) return;
+    P.any = best.any; P.inside = best.inside; P.friction = best.friction; P.handling = best.handling;
+    P.dir[0] = best.dir[0]; P.dir[1] = best.dir[1]; P.dir[2] = best.dir[2];
+    P.nrm[0] = P.nrm[1] = P.nrm[2] = 0.f;
+    if (!best.any || (best.handling != SPARKL_BOUNDARY_FRICTION && best.handling != SPARKL_BOUNDARY_FRICTION_Z_UP)) return P;   // (Stick needs no normal)
     // collision normal: central differences of the signed distance at +-0.1 h (grid_update.rs:72-95); a side with no collider in reach gives 0
     float g[3] = {0.f, 0.f, 0.f};
     const float step = S.h * 0.1f;
@@ -1461,31 +1471,42 @@ SPK_DEV void gpu_boundary_rule(float v[3], const float cpos[3], const GridArrays
         if (sp.any && sn.any) g[a] = (sp.sdf - sn.sdf) / S.h / 0.1f / 2.f;
     }
     const float gn = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
-    if (!(gn > 1.0e-5f)) return;
-    const float nrm[3] = {g[0] / gn, g[1] / gn, g[2] / gn};
-    if (best.handling == SPARKL_BOUNDARY_FRICTION_Z_UP && !(nrm[2] >= 0.f)) return;
-    const float dist = sqrtf(best.dir[0] * best.dir[0] + best.dir[1] * best.dir[1] + best.dir[2] * best.dir[2]);
-    const float nv = v[0] * nrm[0] + v[1] * nrm[1] + v[2] * nrm[2];
+    if (gn > 1.0e-5f) { P.nrm[0] = g[0] / gn; P.nrm[1] = g[1] / gn; P.nrm[2] = g[2] / gn; }
+    return P;
+}
+// grid_update.rs:148-190 on the velocity (momentum + m g dt) / m of the node
+SPK_DEV void gpu_boundary_apply(float v[3], const GpuProj& P, const StepParams& S) {
+    if (!P.any) return;
+    if (P.handling == SPARKL_BOUNDARY_STICK) {
+        if (P.inside) { v[0] = v[1] = v[2] = 0.f; }
+        return;
+    }
+    if (P.handling != SPARKL_BOUNDARY_FRICTION && P.handling != SPARKL_BOUNDARY_FRICTION_Z_UP) return;
+    if (P.nrm[0] == 0.f && P.nrm[1] == 0.f && P.nrm[2] == 0.f) return;
+    if (P.handling == SPARKL_BOUNDARY_FRICTION_Z_UP && !(P.nrm[2] >= 0.f)) return;
+    const float dist = sqrtf(P.dir[0] * P.dir[0] + P.dir[1] * P.dir[1] + P.dir[2] * P.dir[2]);
+    const float nv = v[0] * P.nrm[0] + v[1] * P.nrm[1] + v[2] * P.nrm[2];
     if (nv < 0.f) {
         const float dwm = dist - S.h;
-        if (best.inside || dwm <= 0.f) {
-            const float tv[3] = {v[0] - nv * nrm[0], v[1] - nv * nrm[1], v[2] - nv * nrm[2]};
+        if (P.inside || dwm <= 0.f) {
+            const float tv[3] = {v[0] - nv * P.nrm[0], v[1] - nv * P.nrm[1], v[2] - nv * P.nrm[2]};
             const float tvn = sqrtf(tv[0] * tv[0] + tv[1] * tv[1] + tv[2] * tv[2]);
             v[0] = tv[0]; v[1] = tv[1]; v[2] = tv[2];
             if (tvn > 1.0e-10f) {
-                const float f = fmaxf(tvn + nv * best.friction, 0.f);
+                const float f = fmaxf(tvn + nv * P.friction, 0.f);
                 v[0] = tv[0] / tvn * f; v[1] = tv[1] / tvn * f; v[2] = tv[2] / tvn * f;
             }
         } else if (-nv * S.dt > dwm) {
             const float kq = dwm / S.dt + nv;
-            v[0] -= kq * nrm[0]; v[1] -= kq * nrm[1]; v[2] -= kq * nrm[2];
+            v[0] -= kq * P.nrm[0]; v[1] -= kq * P.nrm[1]; v[2] -= kq * P.nrm[2];
         }
     }
 }
 
 // One wave per node block, 4 blocks per workgroup.  MASS_ONLY: fluid volume recompute (fluids_volume.rs).
 // HEIGHTFIELDS keeps the triangle search out of the kernel every scene without a heightfield runs.
-// GPU_RULE: some collider carries its own boundary handling: the reference's GPU rule for the whole set (gpu_boundary_rule), no projection cache.
+// GPU_RULE: some collider carries its own boundary handling: the reference's GPU rule for the whole set (gpu_projection / gpu_boundary_apply), the node's
+// projection record cached like the reference caches it in the node.
 template <bool MASS_ONLY, bool HEIGHTFIELDS = false, bool GPU_RULE = false>
 __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const DevCuboid* __restrict__ cuboids, const DevHeightField* __restrict__ heightfields, const DevTriMesh* __restrict__ trimeshes,
                                                              Ctl* ctl, StepParams S, DirectWait W = DirectWait{nullptr, 0, 0u, {0, 0}, 0ull, 0}) {
@@ -1583,7 +1604,26 @@ __global__ __launch_bounds__(BLK_THREADS) void k_grid_update(GridArrays G, const
     if (S.dofs & 4u) { pz = 0.f; v[2] = 0.f; }
     if (GPU_RULE) {
         const float cpos[3] = {(float)(org.x + cx) * S.h, (float)(org.y + cy) * S.h, (float)(org.z + cz) * S.h};
-        gpu_boundary_rule<HEIGHTFIELDS>(v, cpos, G, cuboids, heightfields, trimeshes, S);
+        GpuProj P;
+        // one status word per node block (wave-uniform: one node block per wave): 2 = its 64 records are there
+        int* blk_rec = G.node_proj ? G.node_proj_blk + b : nullptr;
+        const int blk_status = blk_rec ? __builtin_amdgcn_readfirstlane(*blk_rec) : 0;
+        float4* rec = G.node_proj ? G.node_proj + (size_t)b * 64 + lane : nullptr;
+        const size_t rec_stride = (size_t)G.num_blocks * 64;
+        if (blk_status == 2) {
+            const float4 r0 = rec[0], r1 = rec[rec_stride];
+            const uint32_t bits = __float_as_uint(r0.w);
+            P.dir[0] = r0.x; P.dir[1] = r0.y; P.dir[2] = r0.z; P.nrm[0] = r1.x; P.nrm[1] = r1.y; P.nrm[2] = r1.z; P.friction = r1.w;
+            P.any = (bits & 1u) != 0u; P.inside = (bits & 2u) != 0u; P.handling = (int)(bits >> 2);
+        } else {
+            P = gpu_projection<HEIGHTFIELDS>(cpos, G, cuboids, heightfields, trimeshes, S);
+            if (rec) {
+                rec[0] = make_float4(P.dir[0], P.dir[1], P.dir[2], __uint_as_float((P.any ? 1u : 0u) | (P.inside ? 2u : 0u) | ((uint32_t)P.handling << 2)));
+                rec[rec_stride] = make_float4(P.nrm[0], P.nrm[1], P.nrm[2], P.friction);
+                if (lane == 0) *blk_rec = 2;
+            }
+        }
+        gpu_boundary_apply(v, P, S);
     } else if ((S.num_cuboids > 0 || HEIGHTFIELDS) && S.boundary_handling != SPARKL_BOUNDARY_NONE) {   // (HEIGHTFIELDS: some collider that is not a cuboid)
         const float cpos[3] = {(float)(org.x + cx) * S.h, (float)(org.y + cy) * S.h, (float)(org.z + cz) * S.h};
         for (int ci = 0; ci < S.num_cuboids; ++ci) {

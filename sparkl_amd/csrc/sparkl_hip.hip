@@ -684,7 +684,8 @@ static StepParams make_params(const SparklPipeline* p, const SparklSolverParams*
 
 // the projection cache of the grid update: sized for the current node blocks, zeroed (= "not computed") when they or the colliders changed
 static void prepare_proj_cache(SparklPipeline* p, hipStream_t st) {
-    const size_t slots = (size_t)(p->num_heightfields + p->num_trimeshes + p->num_polylines);
+    // (GPU rule: two records per node -- closest projection, signed-distance normal -- and one status word per block, whatever the collider kinds)
+    const size_t slots = p->collider_handling ? 2 : (size_t)(p->num_heightfields + p->num_trimeshes + p->num_polylines);
     if (!p->proj_cache_on || slots == 0 || p->num_blocks == 0) return;
     const size_t need = slots * (size_t)p->num_blocks * 64, need_blk = slots * (size_t)p->num_blocks;
     if (need > p->node_proj.cap || need_blk > p->node_proj_blk.cap) {
@@ -712,7 +713,7 @@ static void launch_grid_kernel(SparklPipeline* p, const GridArrays& G_in, const 
 }
 static void launch_grid_update(SparklPipeline* p, const GridArrays& G_in, const StepParams& S, hipStream_t st) {
     GridArrays G = G_in;
-    if (p->num_heightfields + p->num_trimeshes + p->num_polylines > 0 && !p->collider_handling) {   // (the GPU rule keeps no cache)
+    if (p->num_heightfields + p->num_trimeshes + p->num_polylines > 0 || p->collider_handling) {
         prepare_proj_cache(p, st);
         G.node_proj = (p->proj_cache_on && p->node_proj.p && p->node_proj_blk.p && !p->proj_cache_clear) ? p->node_proj.p : nullptr;
         G.node_proj_blk = p->node_proj_blk.p;

@@ -228,11 +228,18 @@ def test_options_are_validated_and_reset(Pipeline):
     np.testing.assert_array_equal(got.position["point"], base.position["point"])
 
 
-@pytest.mark.parametrize("kind", ["heightfield", "trimesh"])
+@pytest.mark.parametrize("kind", ["heightfield", "trimesh", "heightfield+gpu_rule", "trimesh+gpu_rule"])
 def test_projection_cache_is_bit_identical_and_survives_rebins(Pipeline, kind, monkeypatch):
     """The cache replays the floats the triangle search returned: with it on (default) and off (SPARKL_HIP_PROJ_CACHE=0) the particle
-    state after 240 substeps -- several re-bins, which rebuild the node blocks and clear the cache -- must be the same bits."""
+    state after 240 substeps -- several re-bins, which rebuild the node blocks and clear the cache -- must be the same bits.
+    "+gpu_rule" (round 6): the collider carries its own handling, so the grid update follows the reference's GPU rule and caches what the reference
+    caches in the node (closest projection + signed-distance normal, src_kernels/cuda/grid_update.rs:110-146): seven collider scans per node once per
+    binning instead of every substep."""
+    gpu_rule = kind.endswith("+gpu_rule")
+    kind = kind.split("+")[0]
     sc = scenes.sand_on_heightfield(16, 8, 12, below_is_solid=True) if kind == "heightfield" else scenes.sand_on_trimesh(16, 8, 12, oriented=True)
+    if gpu_rule:
+        sc.collider_options = {kind: [abi.collider_options(grid_boundary_handling=abi.BOUNDARY_FRICTION)]}
     sc.particles.velocity["vector"][:, 1] = -3.0
     sc.particles.velocity["vector"][:, 0] = 8.0
     dt, n = 2.5e-4, 240
