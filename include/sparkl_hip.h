@@ -544,7 +544,7 @@ int sparkl_hip_substep_finish_fused(SparklPipeline* p);
 /* synchronises; steps_done counts substeps whose G2P really ran, need_rebin != 0 when a re-bin is due */
 int sparkl_hip_substep_status(SparklPipeline* p, uint32_t* steps_done, uint32_t* need_rebin);
 
-/* ---- the exchange inside the library: slab groups over RCCL ----
+/* ---- the exchange inside the library: slab groups (RCCL for bootstrap, re-bins and as the fallback exchange) ----
  * `CudaMpmPipeline::step(.., &mut [SingleGpuMpmContext])` (cuda_mpm_pipeline.rs:262-271) drives every device from one host
  * thread and moves the halo itself (cuda_mpm_pipeline.rs:407-533).  sparkl_hip_group_substeps is that entry point for the slab
  * decomposition: `members` are the slab pipelines THIS process owns, ascending along the slab axis; each has been given its
@@ -553,9 +553,15 @@ int sparkl_hip_substep_status(SparklPipeline* p, uint32_t* steps_done, uint32_t*
  * ranks r - 1 and r + 1 (one process per GPU: one member per process; one process for all GPUs: one member and one
  * communicator per device).  The 128-byte id comes from sparkl_hip_comm_unique_id on one rank and travels to the others by
  * whatever bootstrap the host has (MPI, a file, torch.distributed).  Per substep the library runs, stream-ordered and without
- * host synchronisation: MAX all-reduce of the 4-byte re-bin request, P2G, halo pack, grouped ncclSend / ncclRecv of the
- * shared planes with both neighbours, halo merge, grid update, G2P (+ the next P2G); the host reads the control block once
- * per batch of 16 substeps; re-bins (with particle migration across the cuts) are collective.
+ * host synchronisation, ONE kernel beyond a single pipeline's two (round 6, "peer-direct"): at its first collective re-bin the job maps
+ * every member's exchange arena into every other member -- the pointer itself inside a process, with peer access between its devices as
+ * cuda_mpm_pipeline.rs:458-472 enables it between its contexts; hipIpcGetMemHandle / hipIpcOpenMemHandle between the processes of a node --
+ * and from then on the re-bin request and the shared node planes are STORED into the neighbours' memory by that kernel and awaited inside
+ * the grid update; no collective per substep.  A setup step that fails on any rank (no peer access, hipIpc refused, the handshake through
+ * the mapped arenas times out) is agreed collectively and the job runs the round-5 chain instead: MAX all-reduce of the 4-byte re-bin
+ * request, halo pack, grouped ncclSend / ncclRecv of the shared planes with both neighbours, halo merge (also: SPARKL_HIP_DIRECT=0, the
+ * fluid volume sweep and the eigenerosion psi sweep).  Either way the host reads the control block once per batch of 16 substeps and
+ * re-bins (with particle migration across the cuts) are collective, through RCCL.
  * Members WITHOUT a communicator must share one device and one stream and exchange by device copies: a single-GPU test mode
  * of the same loop.  Fixed-length substeps only (adaptive steps across ranks: sparkl_hip_dt_bound_export + a MIN all-reduce,
  * see sparkl_amd/slab.py).  librccl is loaded on first use (dlopen); SPARKL_ERR_UNSUPPORTED if it is absent. */
