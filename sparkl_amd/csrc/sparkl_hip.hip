@@ -2998,6 +2998,8 @@ static int group_direct_setup(Group& G) {
             SparklPipeline* p = G.m[i];
             SparklPipeline::Direct& Dp = p->direct;
             HIPCHK(hipSetDevice(p->device));
+            // (test hook, value 2: member 0 never mails, so every member's wait below really runs into its bound and the undo path is the one taken)
+            if (getenv("SPARKL_HIP_DIRECT_TEST_FAIL") && atoi(getenv("SPARKL_HIP_DIRECT_TEST_FAIL")) == 2 && Dp.index == 0) continue;
             DirectPush D;
             memset(&D, 0, sizeof(D));
             D.n_mail = Dp.n; D.epoch = E0; D.arrive = Dp.arrive.p;
@@ -3020,7 +3022,7 @@ static int group_direct_setup(Group& G) {
             }
         }
         // (test hook: member 0 of the job reports a failed handshake -- the rank-asymmetric case the agreement below exists for)
-        if (getenv("SPARKL_HIP_DIRECT_TEST_FAIL")) for (int i = 0; i < G.n; ++i) if (G.m[i]->direct.index == 0) bad[i] = 1;
+        if (getenv("SPARKL_HIP_DIRECT_TEST_FAIL") && atoi(getenv("SPARKL_HIP_DIRECT_TEST_FAIL")) == 1) for (int i = 0; i < G.n; ++i) if (G.m[i]->direct.index == 0) bad[i] = 1;
         long long any_bad = 0;
         CHK(group_max(G, bad.data(), &any_bad));
         if (any_bad) {

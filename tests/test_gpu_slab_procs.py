@@ -49,7 +49,7 @@ def _union(tmp_path, sc, world):
     return union_components(parts, caller), parts, caller
 
 
-@pytest.mark.parametrize("exchange", ["direct", "staged", "handshake-fails"])
+@pytest.mark.parametrize("exchange", ["direct", "staged", "handshake-fails", "handshake-times-out"])
 def test_two_processes_run_the_group_loop_and_match_pipeline_and_oracle(tmp_path, exchange):
     """cube_through_sand in small, the kinematic cube crossing the cut within the 100 substeps: the union of the two PROCESSES equals the
     single pipeline (to rounding: the halo sums are formed in another order) and passes the oracle gate.
@@ -57,12 +57,16 @@ def test_two_processes_run_the_group_loop_and_match_pipeline_and_oracle(tmp_path
     the re-bin flag mail straight into it and the peer's grid update waits for them inside the kernel -- no per-substep collective at all.
     "staged": the RCCL call pattern (flag all-reduce, pack, send / recv, merge) over the host transport, with the overlap calibration.
     "handshake-fails": the arenas map, but ONE rank reports that the handshake through them failed (test hook): both ranks must agree on the staged
-    exchange -- the fallback a platform without working peer / IPC coherence would take -- and still produce the same result."""
+    exchange -- the fallback a platform without working peer / IPC coherence would take -- and still produce the same result.
+    "handshake-times-out": rank 0 never mails its handshake (test hook), so the waiting kernels of BOTH ranks really run into their bound
+    (0.5 s here), raise the give-up, and the host undoes it (abort flags, error word) before the agreement: the same fallback, through the
+    path a dead mapping would take."""
     from oracle import Oracle
     from sparkl_amd.pipeline import MpmPipeline
     from tests.parity import parity_verdict
     world, nsteps = 2, 100
-    env = {"staged": {"SPARKL_HIP_OVERLAP": "cal"}, "direct": {"SPARKL_HIP_COMM_TIMEOUT_S": "20"}, "handshake-fails": {"SPARKL_HIP_DIRECT_TEST_FAIL": "1"}}[exchange]
+    env = {"staged": {"SPARKL_HIP_OVERLAP": "cal"}, "direct": {"SPARKL_HIP_COMM_TIMEOUT_S": "20"}, "handshake-fails": {"SPARKL_HIP_DIRECT_TEST_FAIL": "1"},
+           "handshake-times-out": {"SPARKL_HIP_DIRECT_TEST_FAIL": "2", "SPARKL_HIP_DIRECT_HANDSHAKE_S": "0.5"}}[exchange]
     res, el = _run_ranks(tmp_path, "cube", nsteps, world, env_extra=env)
     assert all(rc == 0 for rc, _, _ in res), res
     sc, dt = _scene("cube")
@@ -97,7 +101,7 @@ def test_two_processes_run_the_group_loop_and_match_pipeline_and_oracle(tmp_path
     if exchange == "staged":
         assert overlap[0] == overlap[1] and overlap[0][0] in (0.0, 1.0) and overlap[0][1] > 0 and overlap[0][2] > 0, overlap   # both schedules timed, MAX over the ranks agreed
         assert all(d[1] == 0 for d in direct), direct
-    elif exchange == "handshake-fails":
+    elif exchange in ("handshake-fails", "handshake-times-out"):
         assert all(d == (0, 0) for d in direct), direct        # no rank ever pushed: the agreement held on both
     else:
         assert all(d[0] == 1 and d[1] >= nsteps for d in direct) and direct[0][1] == direct[1][1], direct   # every substep went through the mapped arenas, the same count on both
