@@ -652,9 +652,19 @@ typedef volatile float* lds_fp;
 #else
 typedef volatile __attribute__((address_space(3))) float* lds_fp;
 #endif
+// The slot as the math functions take it: whether there is one is a fact of the CALL SITE (`on`, a constant after inlining), never a test of the
+// address -- LDS offset 0 is a valid address and compares equal to a null pointer of that address space: with the array the slots live in placed
+// first in the workgroup's LDS, lane 0 of wave 0 took "no slot", kept its stress in registers that the caller then ignored, and scattered what the
+// column held before (found with the 512-thread k_g2p2g, whose layout put the array there).
+struct ParkSlot {
+    lds_fp p;
+    bool on;
+    SPK_DEV ParkSlot() : p(nullptr), on(false) {}
+    SPK_DEV explicit ParkSlot(lds_fp q) : p(q), on(true) {}
+};
 // `jm1_known`: det(F) - 1 when the caller already holds it (the series return map: expm1 of the trace of the mapped Hencky strain).
 template <class MO>
-SPK_DEV SymStress corotated_tau_e(const MO& mo, float hardening, const M3& E, const float m6[6], lds_fp park = nullptr, const float* jm1_known = nullptr) {
+SPK_DEV SymStress corotated_tau_e(const MO& mo, float hardening, const M3& E, const float m6[6], ParkSlot park = ParkSlot(), const float* jm1_known = nullptr) {
     const M3 M = sym6_to_m3(m6);
     M3 A;                                // A = F M = M + E M, each entry one FMA chain started from M
 #pragma unroll
@@ -671,7 +681,7 @@ SPK_DEV SymStress corotated_tau_e(const MO& mo, float hardening, const M3& E, co
         const int a = ii[k], b = jj[k];
         // (A F^T)_ab = A_ab + sum_c A_ac E_bc
         const float t = k2 * (A.m[a + 3 * b] + (A.m[a] * E.m[b] + A.m[a + 3] * E.m[b + 3] + A.m[a + 6] * E.m[b + 6])) + (k < 3 ? sph : 0.f);
-        if (park != nullptr) { park[64 * k] = t; S.t[k] = 0.f; }
+        if (park.on) { park.p[64 * k] = t; S.t[k] = 0.f; }
         else S.t[k] = t;
     }
     S.jm1 = jm1;
@@ -696,7 +706,7 @@ SPK_DEV void strain_metric_left(const M3& E, float S[6]) {
 // (two 27-FMA products and one series product less than corotated_tau_e, and E is the only matrix live on entry).  The linear part is S_l / 2
 // itself, so the relative precision of the strain is kept as in the right-stretch form.
 template <class MO>
-SPK_DEV SymStress corotated_tau_left(const MO& mo, float hardening, const M3& E, bool hi, lds_fp park = nullptr, const float* jm1_known = nullptr) {
+SPK_DEV SymStress corotated_tau_left(const MO& mo, float hardening, const M3& E, bool hi, ParkSlot park = ParkSlot(), const float* jm1_known = nullptr) {
     float x[6], P2[6], V[6], U[6];
     strain_metric_left(E, x);
     sym_mul(x, x, P2);
@@ -721,7 +731,7 @@ SPK_DEV SymStress corotated_tau_left(const MO& mo, float hardening, const M3& E,
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         const float t = k2 * (U[k] + (0.5f * x[k] + 0.125f * P2[k])) + (k < 3 ? sph : 0.f);
-        if (park != nullptr) { park[64 * k] = t; S.t[k] = 0.f; }
+        if (park.on) { park.p[64 * k] = t; S.t[k] = 0.f; }
         else S.t[k] = t;
     }
     S.jm1 = jm1;
@@ -777,7 +787,7 @@ SPK_DEV M3 corotated_kirchhoff_e(const MO& mo, float hardening, const M3& F) {
 // exp(K) - I = expm1(c) I + e^c (D + D^2/2 + D^3/6).
 template <bool WANT_STRESS, class MO>
 SPK_DEV void dp_update_series(const MO& mo, float phase, float eh, const float S[6], M3& E, float& Jp, float& q, float& lvg, float sm1[3], bool& sv_valid,
-                              SymStress& T, lds_fp park = nullptr, bool hi = false) {
+                              SymStress& T, ParkSlot park = ParkSlot(), bool hi = false) {
     // (arguments of expm1_poly below: |S| < 0.1 => |eps| < 0.053, |tr eps| < 0.092; on the cone  -0.1 < lvg <= -tr eps  (dp_update_e's tier test), so
     // |tr eps + lvg| < 0.2 and |c| = |lvg| / 3 < 0.034; tensile: c = -tr eps / 3; eigenvalues of eps' < 0.12)
     float eps[6];
@@ -864,7 +874,7 @@ SPK_DEV void dp_update_series(const MO& mo, float phase, float eh, const float S
 
 template <bool WANT_STRESS, class MO>
 SPK_DEV void dp_update_e(const MO& mo, float phase, float eh, M3& E, float& Jp, float& q, float& lvg, float sm1[3], bool& sv_valid, SymStress& T,
-                         lds_fp park = nullptr) {
+                         ParkSlot park = ParkSlot()) {
     sv_valid = false;
     T.valid = false;
     if (mo.only_active_when_failed && phase != 0.f) return;

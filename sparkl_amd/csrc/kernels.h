@@ -1984,7 +1984,7 @@ SPK_DEV void apic_gather(const VelTile& vt, const float u[3], const StepParams& 
 template <bool RARE, bool WANT_STRESS = false, class MO = DevModel>
 SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const MO& mo, uint32_t flags, const float4& q0, const float4& q1, const float4& q2, const float4& dd,
                             const float4& kk, const float4* kinvel_i, const float4* aux_i, float phase, const int4& org, const TileRange tr_border, const StepParams& S,
-                            unsigned* num_invalid, lds_fp park = nullptr) {
+                            unsigned* num_invalid, ParkSlot park = ParkSlot()) {
     Advected o;
     const float h = S.h, dt = S.dt;
     float px[3] = {q0.x, q0.y, q0.z};   // block-relative, in cells
@@ -2311,7 +2311,7 @@ __global__ __launch_bounds__(BLK_THREADS, (RARE ? SPK_RARE_MIN_BLOCKS : SPK_G2P2
             sc.base = __builtin_nondeterministic_value(ui);
             sc.shell = 0;
         } else scatter_clear(sc);
-        const lds_fp park = (lds_fp)(&s_A[tid >> 6][0][tid & 63]);
+        const ParkSlot park((lds_fp)(&s_A[tid >> 6][0][tid & 63]));
         // behind the particle update: store, then the scatter descriptor of the advected particle
         auto finish = [&](const auto& mo, const Advected& o) {
             const bool t_valid = o.T.valid;   // the six components themselves sit in the LDS (see g2p_update's `park`)
@@ -2330,7 +2330,7 @@ __global__ __launch_bounds__(BLK_THREADS, (RARE ? SPK_RARE_MIN_BLOCKS : SPK_G2P2
                 SymStress T2;
                 T2.valid = t_valid; T2.jm1 = 0.f;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) T2.t[k] = park[64 * k];   // (unconditionally: whatever the columns hold is ignored unless T2.valid)
+                for (int k = 0; k < 6; ++k) T2.t[k] = park.p[64 * k];   // (unconditionally: whatever the columns hold is ignored unless T2.valid)
                 float fxn[3]; int lcn[3];
                 cell_frac_r(o.px, o.rnew, fxn, lcn);
                 sc = p2g_prepare(mo, o.flags, fxn, lcn, o.vel, o.C, o.Fe, kk.x, kk.y, o.eh, o.phase, o.Jp, h, S.inv_d, S.dt_next, &T2);
