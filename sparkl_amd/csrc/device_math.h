@@ -13,6 +13,7 @@
 // site only uses SVD-invariant combinations (U f(S) V^T), so sign/order conventions do not matter.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "../../include/sparkl_hip.h"
 
@@ -219,6 +220,24 @@ struct NeoHookeanOnlyModel {
     static constexpr int gamma = 0;
     const float &cfl_coeff, &lambda, &mu;
     __device__ __host__ __forceinline__ explicit NeoHookeanOnlyModel(const DevModel& m) : cfl_coeff(m.cfl_coeff), lambda(m.lambda), mu(m.mu) {}
+};
+
+// ... and of one whose every entry is a corotated-linear solid with snow plasticity and no failure model (the snow block of configs "snow1m"): the
+// kernels instantiated on it carry the snow return map behind its elastic predictor and nothing else of the rare code (no Rankine / NACC, no failure
+// test, no particle projection, no penalty kick: g2p_update<RARE = 2>).
+struct SnowOnlyModel {
+    static constexpr int ctag = SPARKL_CONSTITUTIVE_COROTATED_LINEAR;
+    static constexpr int ptag = SPARKL_PLASTIC_SNOW;
+    static constexpr int is_fluid = 0;
+    static constexpr int only_active_when_failed = 0;
+    static constexpr int has_failure = 0;
+    static constexpr float pressure0 = 0.f, viscosity = 0.f, max_neg_pressure = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, p_lambda = 0.f, p_mu = 0.f, volume_correction = 1.f, p_k = 0.f;
+    static constexpr float x3 = 0.f, x4 = 0.f;
+    static constexpr int gamma = 0, xi = 0;
+    const int& split_stress_on_failure;
+    const float &cfl_coeff, &lambda, &mu, &x0, &x1, &x2;
+    __device__ __host__ __forceinline__ explicit SnowOnlyModel(const DevModel& m)
+        : split_stress_on_failure(m.split_stress_on_failure), cfl_coeff(m.cfl_coeff), lambda(m.lambda), mu(m.mu), x0(m.x0), x1(m.x1), x2(m.x2) {}
 };
 
 // Compile-time view of a model table whose every entry is a plain fluid (Monaghan equation of state, no plastic or failure model:
@@ -971,7 +990,8 @@ SPK_DEV void dp_update_e(const MO& mo, float phase, float eh, M3& E, float& Jp, 
 }
 
 // SnowPlasticity::update_particle (plasticity_snow.rs:26-48)
-SPK_DEV void snow_update(const DevModel& mo, M3& F, float& eh, float& Jp) {
+template <class MO>
+SPK_DEV void snow_update(const MO& mo, M3& F, float& eh, float& Jp) {
     const Svd3 d = svd3<SPK_SVD_SWEEPS>(F);
     float g[3], prod_old = 1.f, prod_new = 1.f;
 #pragma unroll
@@ -1071,7 +1091,8 @@ SPK_DEV void nacc_update(const DevModel& mo, M3& F, float& alpha) {
 //   Rankine (plasticity_rankine.rs:34-47): returns at once when lambda tr(eps) + 2 mu eps_1 <= tensile strength left; eps_k = ln(1 + lambda_k) / 2
 //        <= |S|_F / 2 bounds the left side by (3 lambda + 2 mu) |S|_F / 2 for lambda, mu >= 0: the same early return, F untouched like there.
 // `false` = the model has nothing to do for this particle (no SVD).  A falling snow block is elastic everywhere but in the zone the impact has reached.
-SPK_DEV bool rare_plastic_may_act(const DevModel& mo, const M3& E, float q) {
+template <class MO>
+SPK_DEV bool rare_plastic_may_act(const MO& mo, const M3& E, float q) {
     if (mo.ptag != SPARKL_PLASTIC_SNOW && mo.ptag != SPARKL_PLASTIC_RANKINE) return true;
     float S6[6];
     strain_metric(E, S6);
@@ -1089,10 +1110,16 @@ SPK_DEV bool rare_plastic_may_act(const DevModel& mo, const M3& E, float q) {
     return !(0.5f * 1.02f * (3.f * lambda + 2.f * mu) * nS <= soft);
 }
 // Snow / Rankine / NACC dispatch (only instantiated in the RARE kernels, see g2p_update)
-SPK_DEV void rare_plastic_update(const DevModel& mo, M3& F, float& Jp, float& q, float& eh, float& alpha) {
-    if (mo.ptag == SPARKL_PLASTIC_SNOW) snow_update(mo, F, eh, Jp);
-    else if (mo.ptag == SPARKL_PLASTIC_RANKINE) rankine_update(mo, F, q);
-    else if (mo.ptag == SPARKL_PLASTIC_NACC) nacc_update(mo, F, alpha);
+template <class MO>
+SPK_DEV void rare_plastic_update(const MO& mo, M3& F, float& Jp, float& q, float& eh, float& alpha) {
+    if constexpr (std::is_same<MO, DevModel>::value) {
+        if (mo.ptag == SPARKL_PLASTIC_SNOW) snow_update(mo, F, eh, Jp);
+        else if (mo.ptag == SPARKL_PLASTIC_RANKINE) rankine_update(mo, F, q);
+        else if (mo.ptag == SPARKL_PLASTIC_NACC) nacc_update(mo, F, alpha);
+    } else {
+        static_assert(MO::ptag == SPARKL_PLASTIC_SNOW, "the only rare plastic model with a compile-time view");
+        snow_update(mo, F, eh, Jp);
+    }
 }
 // MaximumStressFailure::particle_failed (failure_maximum_stress.rs:20-28).  nalgebra's iterative symmetric eigensolver
 // (third party) -> closed-form eigenvalues of the symmetric 3x3 (trigonometric form), evaluated in double.

@@ -1981,7 +1981,8 @@ SPK_DEV void apic_gather(const VelTile& vt, const float u[3], const StepParams& 
 // RARE: the instantiation that also carries snow / Rankine / NACC plasticity and the failure model; launched only when a
 // model of the set needs it, so the elastic / Drucker-Prager kernels keep their register budget (inlining that code,
 // or calling it out of line, cost the hot kernel 35 %).
-template <bool RARE, bool WANT_STRESS = false, class MO = DevModel>
+// (as an int: 0 = none of it, 1 = all of it, 2 = the plastic models only -- no failure test, no particle projection, no penalty kick: the snow view)
+template <int RARE, bool WANT_STRESS = false, class MO = DevModel>
 SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const MO& mo, uint32_t flags, const float4& q0, const float4& q1, const float4& q2, const float4& dd,
                             const float4& kk, const float4* kinvel_i, const float4* aux_i, float phase, const int4& org, const TileRange tr_border, const StepParams& S,
                             unsigned* num_invalid, ParkSlot park = ParkSlot()) {
@@ -2031,7 +2032,7 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const MO& mo
     bool sv_valid = false;
     o.store_k = false; o.store_aux = false; o.alpha = 0.f;
     o.T.valid = false; o.T.jm1 = 0.f;
-    if constexpr (RARE) if (mo.ptag > SPARKL_PLASTIC_DRUCKER_PRAGER && rare_plastic_may_act(mo, E, q)) {   // snow / Rankine / NACC (plastic_model.update_particle, :102-104), behind the elastic predictor test
+    if constexpr (RARE != 0) if (mo.ptag > SPARKL_PLASTIC_DRUCKER_PRAGER && rare_plastic_may_act(mo, E, q)) {   // snow / Rankine / NACC (plastic_model.update_particle, :102-104), behind the elastic predictor test
         float alpha = mo.ptag == SPARKL_PLASTIC_NACC ? aux_i->z : 0.f;
         const float eh0 = eh, alpha0 = alpha;
         rare_plastic_update(mo, F, Jp, q, eh, alpha);
@@ -2071,14 +2072,14 @@ SPK_DEV Advected g2p_update(const GridArrays& G, const VelTile& vt, const MO& mo
     psi = fmaxf(psi, model_pos_energy(mo, phase, eh, F, E, sv, sv_valid, jm1));
     SPK_MARK("tile_checks");
     // failure model (:134-144): stress of the updated particle; a failed particle keeps phase = 0 from now on
-    if constexpr (RARE) if (mo.has_failure && phase != 0.f && failure_check(mo, phase, eh, F, kk.x, kk.y, Jp, C)) {
+    if constexpr (RARE == 1) if (mo.has_failure && phase != 0.f && failure_check(mo, phase, eh, F, kk.x, kk.y, Jp, C)) {
         phase = 0.f;
         if (!o.store_aux) o.alpha = aux_i->z;
         o.store_aux = true;
         if (!(flags & FLAG_PHASE_NOT_ONE)) { flags |= FLAG_PHASE_NOT_ONE; newly_failed = true; }   // the flags word must be stored
     }
-    if (RARE && S.project_particles) project_particle_on_colliders(G, S, orgv, px, vel);
-    if (RARE && S.penalty) penalty_kick(G, S, orgv, px, kk.x, vel);
+    if (RARE == 1 && S.project_particles) project_particle_on_colliders(G, S, orgv, px, vel);
+    if (RARE == 1 && S.penalty) penalty_kick(G, S, orgv, px, kk.x, vel);
     // does the particle still sit inside its home block's tile, and inside the domain?  One test against the block's box (TileRange: the
     // tile, cut by the domain where the block touches its border); a NaN coordinate fails it like the reference's range test does.
     o.rnew[0] = rintf(px[0]); o.rnew[1] = rintf(px[1]); o.rnew[2] = rintf(px[2]);
@@ -2184,7 +2185,7 @@ __global__ __launch_bounds__(BLK_THREADS, (RARE ? SPK_RARE_MIN_BLOCKS_G2P : 4)) 
         if (flags & FLAG_INVALID) continue;
         const DevModel& mo = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
         const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
-        const Advected o = g2p_update<RARE>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, tr, S, &ctl->num_invalid);
+        const Advected o = g2p_update<(RARE ? 1 : 0)>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, tr, S, &ctl->num_invalid);
         g2p_store(P, i, o);
         want_sort |= !o.in_tile && !(o.flags & FLAG_INVALID);   // a particle that left the DOMAIN is dead (skipped from now on): no re-bin for it
         if (S.want_dt) {  // the bound the next substep's estimator would compute from this state
@@ -2213,12 +2214,16 @@ __global__ __launch_bounds__(BLK_THREADS, (RARE ? SPK_RARE_MIN_BLOCKS_G2P : 4)) 
 // REDUCE_STEPS >= 0: DPP pre-reduction over groups of 2^REDUCE_STEPS lanes (p2g_scatter); -1: run tasks (p2g_scatter_runs).
 // MSET: 0 = any model table; 1 = every model is a corotated solid with Drucker-Prager plasticity (DpSandModel: no model dispatch); 4 = the same view on
 // the flags mirror (ParticleArrays::fl: mass, volume0 and elastic hardening are the same for every binned particle and come from StepParams);
-// 3 = every model is a neo-Hookean solid without plasticity (NeoHookeanOnlyModel)
+// 3 = every model is a neo-Hookean solid without plasticity (NeoHookeanOnlyModel); 5 = every model is a corotated solid with snow plasticity and no failure
+// model (SnowOnlyModel; launched with RARE = true for the register budget, runs g2p_update<2>)
 #ifndef SPK_RARE_MIN_BLOCKS
 #define SPK_RARE_MIN_BLOCKS 3   // three workgroups per CU (168 VGPRs) instead of four with 244 B/lane of scratch: 1 M snow block k_g2p2g 0.121 -> 0.095 ms (two: 0.115), profiles/r05_kernel_experiments.txt
 #endif
+#ifndef SPK_SNOW_MIN_BLOCKS
+#define SPK_SNOW_MIN_BLOCKS 4
+#endif
 template <int REDUCE_STEPS, bool RARE, bool LDS_MODELS = true, int MSET = 0>
-__global__ __launch_bounds__(BLK_THREADS, (RARE ? SPK_RARE_MIN_BLOCKS : SPK_G2P2G_MIN_BLOCKS)) void k_g2p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
+__global__ __launch_bounds__(BLK_THREADS, (MSET == 5 ? SPK_SNOW_MIN_BLOCKS : (RARE ? SPK_RARE_MIN_BLOCKS : SPK_G2P2G_MIN_BLOCKS))) void k_g2p2g(ParticleArrays P, GridArrays G, const DevModel* __restrict__ models, Ctl* ctl, StepParams S) {
     const int tid = threadIdx.x;
     __shared__ VelTile vt;
     __shared__ double tile[4][ACC_N];
@@ -2340,13 +2345,14 @@ __global__ __launch_bounds__(BLK_THREADS, (RARE ? SPK_RARE_MIN_BLOCKS : SPK_G2P2
         };
         auto particle = [&](const auto& mo) {
             const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &at_off(Pb.aux, off)->x, 1.f);
-            const Advected o = g2p_update<RARE, true>(G, vt, mo, flags, q0, q1, q2, dd, kk, at_off(Pb.kinvel, off), at_off(Pb.aux, off), phase, org, tr, S, &ctl->num_invalid, park);
+            const Advected o = g2p_update<(MSET == 5 ? 2 : (RARE ? 1 : 0)), true>(G, vt, mo, flags, q0, q1, q2, dd, kk, at_off(Pb.kinvel, off), at_off(Pb.aux, off), phase, org, tr, S, &ctl->num_invalid, park);
             finish(mo, o);
         };
         if (live) {
             const DevModel& mo_t = LDS_MODELS ? s_models[flags >> FLAG_MODEL_SHIFT] : models[flags >> FLAG_MODEL_SHIFT];
             if constexpr (MSET == 1 || MSET == 4) particle(DpSandModel(mo_t));
             else if constexpr (MSET == 3) particle(NeoHookeanOnlyModel(mo_t));
+            else if constexpr (MSET == 5) particle(SnowOnlyModel(mo_t));
             else particle(mo_t);
         }
         shell_used |= wave_or_i32(sc.shell);
@@ -2732,7 +2738,7 @@ __global__ __launch_bounds__(BLK_THREADS, 4) void k_g2p_mass(ParticleArrays P, G
         int nlc[3] = {0, 0, 0};
         auto particle = [&](const auto& mo) {
             const float phase = rare_load((flags & FLAG_PHASE_NOT_ONE) != 0, &P.aux[i].x, 1.f);
-            const Advected o = g2p_update<false>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, tr, S, &ctl->num_invalid);
+            const Advected o = g2p_update<0>(G, vt, mo, flags, q0, q1, q2, dd, kk, P.kinvel + i, P.aux + i, phase, org, tr, S, &ctl->num_invalid);
             if (FLUID_ONLY) {
                 P.q[0][i] = make_float4(o.px[0], o.px[1], o.px[2], o.Fe.m[0]);
                 P.q[3][i] = make_float4(o.vel[0], o.vel[1], o.vel[2], o.C.m[0]);

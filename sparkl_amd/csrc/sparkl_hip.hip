@@ -197,6 +197,7 @@ struct SparklPipeline {
     bool slab_balance = true;        // sparkl_hip_slab_balance
     int heads_kind = -1;            // which scatter's measure the disorder books hold (note_heads_kind)
     bool all_plain_fluid = false;   // every model is a fluid without plastic / failure model: the FLUID_ONLY kernels apply
+    bool all_snow = false;          // every model is a corotated solid with snow plasticity, no failure model: k_g2p2g<.., MSET = 5>
     bool all_neo_elastic = false;   // every model is a neo-Hookean solid without plasticity / failure: k_g2p2g<.., MSET = 3>
     // flags mirror (ParticleArrays::fl): built by every re-bin; ku_ok = every binned particle shares ku[] = (mass, volume0, elastic hardening) and nothing
     // has touched a flags word behind the mirror's back since (the fluid and psi sweeps do: they clear it until the next re-bin).  SPARKL_HIP_KUNIFORM=0: off
@@ -288,6 +289,10 @@ struct SparklPipeline {
     StepParams c_stale_S{};
     uint64_t c_regathers = 0;
     bool rare_models = false;      // some model needs the kernels that carry snow / Rankine / NACC / failure code
+    // ... and whether the FUSED launches really are the generic RARE instantiation: not for a table the snow view covers (k_g2p2g<.., MSET = 5>: no particle
+    // projection, no penalty kick, no failure test -- v and C are the plain gather, so the launch may defer them and its tiles may be carried over like the
+    // Drucker-Prager and elastic ones)
+    bool rare_fused() const { return rare_models && !(all_snow && !collider_penalty && h_models.size() <= (size_t)MAX_LDS_MODELS); }
     bool fuse_fixed_dt = true;     // SPARKL_HIP_NO_FUSE=1 in the environment turns the fused schedule off (A/B)
     bool clock_on = false;
     uint32_t clock_stride = 1;
@@ -772,7 +777,9 @@ static void launch_g2p2g(SparklPipeline* p, const ParticleArrays& P0, const Grid
     note_heads_kind(p, (getenv("SPARKL_HIP_SCATTER") && !strcmp(getenv("SPARKL_HIP_SCATTER"), "dpp")) ? 0 : 1, st);
     // SPARKL_HIP_SCATTER=dpp selects the DPP pre-reduction scatter (A/B); the default is the run-task scatter
     static const bool dpp = getenv("SPARKL_HIP_SCATTER") && !strcmp(getenv("SPARKL_HIP_SCATTER"), "dpp");
-    if (p->rare_models || S.project_particles) SPK_LAUNCH_MODELS(k_g2p2g, -1, true);
+    if (p->all_snow && !dpp && !S.project_particles && !S.penalty && S.num_models <= MAX_LDS_MODELS)   // (rare_models is set for it: in front of the generic RARE launch)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<-1, true, true, 5>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
+    else if (p->rare_models || S.project_particles) SPK_LAUNCH_MODELS(k_g2p2g, -1, true);
     else if (dpp) SPK_LAUNCH_MODELS(k_g2p2g, SPK_P2G_REDUCE_STEPS, false);
     else if (p->all_dp_sand && S.num_models <= MAX_LDS_MODELS && P.fl)   // the same view on the 4-byte flags mirror (every binned particle shares mass, volume0, hardening)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_g2p2g<-1, false, true, 4>), grid, block, 0, st, P, G, p->d_models.p, p->d_ctl, S);
@@ -875,7 +882,7 @@ static int enqueue_adaptive_substep(SparklPipeline* p, const SparklSolverParams*
     if (psi_sweep_on(p, sp)) CHK(enqueue_psi_sweep(p, S));
     if (dt_guess > 0.f) {
         S.dt_next = dt_guess;
-        S.defer_c = (defer_c && p->defer_c && !p->rare_models && !S.project_particles) ? 1 : 0;   // look-ahead plans only (the caller rebuilds C if the plan is cut)
+        S.defer_c = (defer_c && p->defer_c && !p->rare_fused() && !S.project_particles) ? 1 : 0;   // look-ahead plans only (the caller rebuilds C if the plan is cut)
         if (S.defer_c) p->c_stale_S = S;
         CHK(clock_begin(p, SPAN_FUSED, &t2));
         launch_g2p2g(p, P, G, S, st);
@@ -902,7 +909,7 @@ static int enqueue_fused_batch(SparklPipeline* p, const SparklSolverParams* sp, 
     const bool was_on = p->clock_on;
     size_t tk = 0;
     const bool carry_in = p->carry_on && p->carry_valid && p->carry_dt == dt && p->carry_index == p->substep_index;
-    const bool carry_out = p->carry_on && !p->rare_models && !sp->enable_boundary_particle_projection;
+    const bool carry_out = p->carry_on && !p->rare_fused() && !sp->enable_boundary_particle_projection;
     p->carry_valid = false;
     if (!carry_in) {
         const StepParams S = make_params(p, sp, g, dt);
@@ -923,7 +930,7 @@ static int enqueue_fused_batch(SparklPipeline* p, const SparklSolverParams* sp, 
         CHK(clock_end(p, tk));
         if (j + 1 < n) {
             StepParams Sf = S;
-            Sf.defer_c = (p->defer_c && !p->rare_models && !S.project_particles) ? 1 : 0;
+            Sf.defer_c = (p->defer_c && !p->rare_fused() && !S.project_particles) ? 1 : 0;
             if (Sf.defer_c) p->c_stale_S = S;   // what k_regather_c needs should the batch stop here
             CHK(clock_begin(p, SPAN_FUSED, &tk));
             launch_g2p2g(p, P, G, Sf, st);
@@ -1237,7 +1244,9 @@ int sparkl_hip_models_set(SparklPipeline* p, uint32_t n, const SparklParticleMod
     p->all_plain_fluid = n > 0;
     p->all_dp_sand = n > 0 && !(getenv("SPARKL_HIP_MSET") && !strcmp(getenv("SPARKL_HIP_MSET"), "0"));
     p->all_neo_elastic = p->all_dp_sand;
+    p->all_snow = p->all_dp_sand;
     for (const DevModel& d : dm) {
+        p->all_snow &= !d.is_fluid && d.ctag == SPARKL_CONSTITUTIVE_COROTATED_LINEAR && d.ptag == SPARKL_PLASTIC_SNOW && !d.only_active_when_failed && !d.has_failure;
         p->rare_by_models |= d.ptag > SPARKL_PLASTIC_DRUCKER_PRAGER || d.has_failure;
         p->all_plain_fluid &= d.is_fluid && d.ptag < 0 && !d.has_failure;
         p->all_neo_elastic &= !d.is_fluid && d.ctag == SPARKL_CONSTITUTIVE_NEO_HOOKEAN && d.ptag < 0 && !d.has_failure;
@@ -1863,7 +1872,7 @@ int sparkl_hip_pipeline_substeps(SparklPipeline* p, const SparklSolverParams* pa
         const bool aborted = now_done < done + batch;
         // cut short behind a fused launch that deferred C.m[1..8]: the last substep of a batch that runs to its end stores
         // everything (plain k_g2p, or k_g2p2g without the deferral when the tiles are carried over)
-        if (fuse && aborted && now_done > done && p->defer_c && !p->rare_models && !params->enable_boundary_particle_projection) p->c_stale = true;
+        if (fuse && aborted && now_done > done && p->defer_c && !p->rare_fused() && !params->enable_boundary_particle_projection) p->c_stale = true;
         done = now_done;
         if (aborted || p->h_ctl->abort_flag[0] || p->h_ctl->abort_flag[1]) {
             CHK(resort(p));  // a particle left its tile margin: re-bin, then carry on from `done`
@@ -2043,7 +2052,7 @@ int sparkl_hip_pipeline_step(SparklPipeline* p, const SparklSolverParams* params
                     memcpy(&spec_dt_bits, &g_last, 4);
                 } else {
                     // stopped early.  The tiles hold the scatter substep executed-1 built for plan[executed].
-                    if (executed > 0 && p->defer_c && !p->rare_models && !params->enable_boundary_particle_projection) {
+                    if (executed > 0 && p->defer_c && !p->rare_fused() && !params->enable_boundary_particle_projection) {
                         // ... and the last launch that ran had deferred C.m[1..8]: rebuilt from the node velocities it used
                         // (every grid update behind it was a no-op), before the next P2G or the re-bin reads them
                         StepParams Sr = p->c_stale_S;
@@ -2338,7 +2347,7 @@ static int substep_finish_impl(SparklPipeline* p, bool fuse_next, bool defer_c =
         // defer_c: only from sparkl_hip_group_substeps, which owns the batch and rebuilds C if it is cut (the public
         // substep_finish_fused leaves a complete particle state behind)
         StepParams Sf = p->pending;
-        Sf.defer_c = (defer_c && p->defer_c && !p->rare_models && !Sf.project_particles) ? 1 : 0;
+        Sf.defer_c = (defer_c && p->defer_c && !p->rare_fused() && !Sf.project_particles) ? 1 : 0;
         if (Sf.defer_c) p->c_stale_S = p->pending;
         CHK(clock_begin(p, SPAN_FUSED, &t2));
         launch_g2p2g(p, p->cur.arrays(), G, Sf, st);
@@ -3073,7 +3082,7 @@ static int launch_subset(SparklPipeline* p, int which, bool fuse_next, bool prim
     const ParticleArrays P = with_mirror(p, p->cur.arrays());   // (k_g2p below stores flags too)
     const dim3 grid(G.pb_count), block(BLK_THREADS);
     if (fuse_next && p->fuse_fixed_dt) {
-        S.defer_c = (defer && p->defer_c && !p->rare_models && !S.project_particles) ? 1 : 0;
+        S.defer_c = (defer && p->defer_c && !p->rare_fused() && !S.project_particles) ? 1 : 0;
         if (S.defer_c) p->c_stale_S = p->pending;
         launch_g2p2g(p, P, G, S, st);
     } else {
@@ -3484,7 +3493,7 @@ static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, con
                 return set_error(SPARKL_ERR_HIP, "member %d: a kernel gave up waiting for a peer's %s (direct halo exchange; the peer is gone?)", i, members[i]->h_ctl->direct_error == 1 ? "re-bin flag" : "halo records");
             const uint32_t r = members[i]->h_ctl->steps_done - base[i];
             // cut short behind a fused launch that deferred C.m[1..8] (the last launch of a whole batch stores C, fused or not)
-            if (r > done && r < done + batch && !fluid_sweep && !psi_sweep && members[i]->fuse_fixed_dt && members[i]->defer_c && !members[i]->rare_models &&
+            if (r > done && r < done + batch && !fluid_sweep && !psi_sweep && members[i]->fuse_fixed_dt && members[i]->defer_c && !members[i]->rare_fused() &&
                 !params->enable_boundary_particle_projection)
                 members[i]->c_stale = true;
             ran = i == 0 ? r : std::min(ran, r);

@@ -462,6 +462,42 @@ def test_rare_material_models_parity(Pipeline, name):
         assert extra["phase_mismatch"] <= max(2, acted // 100)
 
 
+def test_snow_view_defers_and_carries_like_the_generic_kernel(Pipeline, monkeypatch):
+    """A model table of snow only runs the fused substeps on the snow view (k_g2p2g<.., MSET = 5>: the snow return map behind its elastic predictor, none of
+    the other rare code, four workgroups per CU), which -- unlike the generic RARE kernel -- defers v and C inside a batch and carries its tiles from one call
+    to the next.  Stepped in chunks of 35 with a full read-back between them (every next chunk starts from carried tiles, the falling block re-bins inside
+    the batches, which leaves deferred v and C to rebuild): the same gate as the one-batch run, and the same particles as the generic kernel (SPARKL_HIP_MSET=0) to rounding."""
+    from sparkl_amd.models import CorotatedLinearElasticity, SnowPlasticity
+    sc = scenes.block_on_floor(16, CorotatedLinearElasticity(1.4e5, 0.2), SnowPlasticity(), density=400.0, v0=(14.0, -8.0, 6.0), dt=2.0e-4, name="snow")
+    dt = sc.fixed_dt
+    o32, o64 = _oracle(sc), _oracle(sc, f64=True)
+    for _ in range(105):
+        o32.substep_fixed(sc.params, sc.gravity, dt)
+        o64.substep_fixed(sc.params, sc.gravity, dt)
+    out = {}
+    for mset in ("1", "0"):
+        monkeypatch.setenv("SPARKL_HIP_MSET", mset)
+        with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+            p.load_scene(sc)
+            for _ in range(3):
+                p.substeps(sc.params, sc.gravity, dt, 35)
+                got = p.read_particles()
+            out[mset] = (got, p.step_stats())
+    monkeypatch.delenv("SPARKL_HIP_MSET")
+    got, stats = out["1"]
+    rep, bad = parity_verdict(got, o32.get_particles(), o64.get_particles(), sc.cell_width, spread=("eps_psi",))
+    _report("snow_view_chunks_of_35", {**rep, "c_regathers_view": int(stats["c_regathers"]), "c_regathers_generic": int(out["0"][1]["c_regathers"])})
+    # a batch cut by a re-bin leaves deferred v and C behind: the view rebuilds them (k_regather_c), the generic RARE kernel never defers
+    assert stats["c_regathers"] >= 1 and out["0"][1]["c_regathers"] == 0, (stats, out["0"][1])
+    assert (o32.get_particles().volume["plastic_deformation_gradient_det"] < 0.999).sum() > len(sc.particles) // 50
+    assert not bad, (bad, rep)
+    gen = out["0"][0]
+    h = sc.cell_width
+    assert np.abs(got.position["point"].astype(np.float64) - gen.position["point"]).max() / h < 2e-5
+    assert np.abs(got.velocity["vector"].astype(np.float64) - gen.velocity["vector"]).max() / np.abs(gen.velocity["vector"]).max() < 2e-5
+    assert np.abs(got.volume["plastic_deformation_gradient_det"].astype(np.float64) - gen.volume["plastic_deformation_gradient_det"]).max() < 2e-5
+
+
 def _edge_scenes():
     def kinematic():
         # config 5 in small: a kinematic cube ploughs through the sand bed (cube_through_sand3.rs:40-81)
