@@ -147,6 +147,14 @@ struct SparklPipeline {
     // each time is taken and the faster schedule kept on every rank (0 = nothing measured, 1 = in line measured, 2 = decided)
     int overlap_cal_state = 0, overlap_choice = -1;
     double overlap_cal_us[2] = {0.0, 0.0};   // per substep: [0] in line, [1] overlapped
+    // ... and the peer-direct exchange is a THIRD candidate there, not a foregone conclusion: what a store into a neighbour's memory costs is a property of
+    // the link between the two devices (one MI355X: nothing; xGMI: every record is a remote write), and the only honest way to know is to time it on the job's
+    // own hardware.  Between ranks of a communicator the loop times one undisturbed 16-substep batch on the direct exchange (after one it lets pass: the first
+    // batch of a job pays for cold caches and clocks), then the two staged schedules as before, takes the MAX over the ranks of each and keeps the fastest of
+    // the three on every rank.  SPARKL_HIP_DIRECT = 1: direct without asking, 0: never, cal: calibrate even inside one process (tests).
+    int direct_cal_state = 0;     // 0 = the batch to let pass, 1 = measuring next, 2 = measured
+    int direct_choice = -1;       // -1 undecided, 0 = staged (overlap_choice says which schedule), 1 = direct
+    double direct_cal_us = 0.0;
     hipStream_t halo_stream = nullptr;
     hipEvent_t ev_main = nullptr, ev_halo = nullptr, ev_flag = nullptr, ev_grid = nullptr, ev_xfer = nullptr;
     // Tile carry-over between fixed-dt batches and calls: the LAST substep of a fused batch also runs k_g2p2g (complete state stored), so
@@ -2820,6 +2828,9 @@ static uint64_t process_token() {
     return t;
 }
 static bool direct_wanted() { return !(getenv("SPARKL_HIP_DIRECT") && !strcmp(getenv("SPARKL_HIP_DIRECT"), "0")); }   // (read at every collective re-bin)
+// 1 = SPARKL_HIP_DIRECT=1 (use it whenever it is set up), 2 = "cal" (time it against the staged schedules whatever the group), 0 = unset: time it between the
+// ranks of a communicator, use it inside one process
+static int direct_policy() { const char* e = getenv("SPARKL_HIP_DIRECT"); return !e ? 0 : (!strcmp(e, "cal") ? 2 : (atoi(e) != 0 ? 1 : 0)); }
 // the arena of one member, sized for its current node blocks (grows by half: a reallocation means new mappings on every peer)
 static int direct_arena(SparklPipeline* p) {
     const size_t need_blocks = std::max<size_t>((size_t)p->num_blocks, 64);
@@ -2846,7 +2857,8 @@ static int group_direct_setup(Group& G) {
     const int world = G.rccl ? G.m[0]->comm_world : G.n;
     bool ok = direct_wanted() && world <= MAX_DIRECT && world >= 1;
     // (a schedule forced or calibrated through SPARKL_HIP_OVERLAP is a request for the RCCL / copy exchange, whose two-stream variant it selects)
-    for (int i = 0; i < G.n; ++i) ok = ok && !G.m[i]->direct.failed && (G.m[i]->overlap_mode == -1 || G.m[i]->overlap_mode == 0);
+    // (... and a job that has timed it and kept a staged schedule does not set it up again)
+    for (int i = 0; i < G.n; ++i) ok = ok && !G.m[i]->direct.failed && G.m[i]->direct_choice != 0 && (G.m[i]->overlap_mode == -1 || G.m[i]->overlap_mode == 0 || direct_policy() == 2);
     auto index_of = [&](int i) { return G.rccl ? G.m[i]->comm_rank : i; };
     std::vector<ArenaRecord> table((size_t)world);
     memset(table.data(), 0, table.size() * sizeof(ArenaRecord));
@@ -2934,7 +2946,7 @@ static int group_direct_setup(Group& G) {
         long long any_bad = 0;
         CHK(group_max(G, v.data(), &any_bad));
         if (any_bad) {
-            for (int i = 0; i < G.n; ++i) { G.m[i]->direct.ready = false; G.m[i]->direct.failed = true; }
+            for (int i = 0; i < G.n; ++i) { G.m[i]->direct.ready = false; G.m[i]->direct.failed = G.m[i]->direct_choice != 0; }   // (not a failure when the job timed it and kept a staged schedule)
             if (getenv("SPARKL_HIP_DEBUG")) fprintf(stderr, "[sparkl_hip] direct halo exchange not available (local setup %s): staying on the RCCL / copy exchange\n", ok ? "ok" : "failed");
             return SPARKL_OK;
         }
@@ -3059,6 +3071,15 @@ static int overlap_resources(SparklPipeline* p) {
     if (!p->halo_stream) HIPCHK(hipStreamCreateWithFlags(&p->halo_stream, hipStreamNonBlocking));
     for (hipEvent_t* e : {&p->ev_main, &p->ev_halo, &p->ev_flag, &p->ev_grid, &p->ev_xfer}) if (!*e) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     return SPARKL_OK;
+}
+// ... and back, once a job has settled on a schedule that does not use the second stream: an idle stream is still a hardware queue (eight processes of one
+// device with two queues each ran 12.8 ms per substep where the same eight with one queue each ran 0.69: the queues were time-sliced)
+static void overlap_release(SparklPipeline* p) {
+    if (!p->halo_stream) return;
+    (void)hipSetDevice(p->device);
+    (void)hipStreamSynchronize(p->halo_stream);
+    (void)hipStreamDestroy(p->halo_stream);
+    p->halo_stream = nullptr;
 }
 // The node / particle kernels of one substep over a subset of the blocks (GridArrays::pb_list / nb_list), on stream `st`.
 // which = 0: grid update of the interior node blocks, 1: of the cut-adjacent ones; 2 / 3: the particle kernel likewise.
@@ -3258,6 +3279,13 @@ static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, con
         // peer-direct exchange (kernels.h, PeerBox): set up by the last collective re-bin on every rank or on none
         bool direct = !fluid_sweep && !psi_sweep;
         for (int i = 0; i < G.n; ++i) direct = direct && members[i]->direct.ready;
+        // three-way calibration (see direct_cal_state): identical on every rank -- the states only advance on collectively agreed facts
+        const bool exchange_auto = direct && overlap_auto && (direct_policy() == 2 || (direct_policy() == 0 && G.rccl && members[0]->comm_world > 1));
+        if (exchange_auto) {
+            const SparklPipeline* m0 = members[0];
+            direct = m0->direct_choice == 1 || (m0->direct_choice < 0 && m0->direct_cal_state < 2);
+        }
+        const bool direct_cal_batch = exchange_auto && direct && members[0]->direct_choice < 0;
         G.overlap = !direct && schedule_of_batch();
         if (G.overlap) for (int i = 0; i < G.n; ++i) CHK(overlap_resources(members[i]));
         const auto batch_t0 = std::chrono::steady_clock::now();
@@ -3502,11 +3530,40 @@ static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, con
         std::vector<long long> veto(G.n, balance_veto(G));
         long long no_balance = 0;
         CHK(group_max(G, needs.data(), &need, veto.data(), &no_balance));
-        if (overlap_auto && members[0]->overlap_cal_state < 2 && batch == 16 && ran == done + batch && !need) {
+        if (direct_cal_batch && batch == 16 && ran == done + batch && !need) {
+            if (members[0]->direct_cal_state == 0) { for (int i = 0; i < G.n; ++i) members[i]->direct_cal_state = 1; }   // the batch that warms the job up
+            else {
+                const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - batch_t0).count() / batch;
+                std::vector<long long> a(G.n, (long long)(us * 1000.0));
+                long long amax = 0;
+                CHK(group_max(G, a.data(), &amax));
+                for (int i = 0; i < G.n; ++i) { members[i]->direct_cal_us = amax * 1e-3; members[i]->direct_cal_state = 2; }
+            }
+        }
+        if (exchange_auto && members[0]->direct_choice < 0 && members[0]->direct_cal_state == 2 && members[0]->overlap_cal_state == 2) {
+            // all three timed (every rank holds the same three maxima): the fastest stays
+            const double staged = members[0]->overlap_cal_us[1] > 0.0 ? std::min(members[0]->overlap_cal_us[0], members[0]->overlap_cal_us[1]) : members[0]->overlap_cal_us[0];
+            const int choice = members[0]->direct_cal_us <= staged ? 1 : 0;
+            for (int i = 0; i < G.n; ++i) members[i]->direct_choice = choice;
+            if (choice == 1 || members[0]->overlap_choice != 1) for (int i = 0; i < G.n; ++i) overlap_release(members[i]);
+            if (getenv("SPARKL_HIP_DEBUG"))
+                fprintf(stderr, "[sparkl_hip] halo exchange timed on this job: direct %.1f us per substep, staged in line %.1f, staged overlapped %.1f -> %s\n", members[0]->direct_cal_us,
+                        members[0]->overlap_cal_us[0], members[0]->overlap_cal_us[1], choice ? "direct" : (members[0]->overlap_choice == 1 ? "staged, overlapped" : "staged, in line"));
+        }
+        if (!direct && overlap_auto && members[0]->overlap_cal_state < 2 && batch == 16 && ran == done + batch && !need) {
             // an undisturbed batch: its wall clock (enqueue to control-block read) is this schedule's sample
             const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - batch_t0).count() / batch;
             const int which = members[0]->overlap_cal_state;   // 0: this batch ran in line, 1: overlapped
             for (int i = 0; i < G.n; ++i) { members[i]->overlap_cal_us[which] = us; members[i]->overlap_cal_state = which + 1; }
+            // Ranks that share a physical device (a one-GPU box standing in for a node) never time the two-stream schedule: a second hardware queue per
+            // process is what it costs there, whatever it hides -- eight processes with two queues each ran 20 ms per substep in that batch and 12.8 ms in every
+            // batch after it (the queue outlives its stream), against 0.69 with one queue each.  The in-line time stands for the staged exchange.
+            if (which == 0 && members[0]->direct.shared_device) {
+                std::vector<long long> a(G.n, (long long)(us * 1000.0));
+                long long amax = 0;
+                CHK(group_max(G, a.data(), &amax));
+                for (int i = 0; i < G.n; ++i) { members[i]->overlap_cal_us[0] = amax * 1e-3; members[i]->overlap_cal_us[1] = 0.0; members[i]->overlap_cal_state = 2; members[i]->overlap_choice = 0; }
+            }
             if (which == 1) {
                 std::vector<long long> a(G.n), b(G.n);
                 for (int i = 0; i < G.n; ++i) { a[i] = (long long)(members[i]->overlap_cal_us[0] * 1000.0); b[i] = (long long)(members[i]->overlap_cal_us[1] * 1000.0); }
@@ -3516,6 +3573,7 @@ static int group_substeps_impl(SparklPipeline** members, uint32_t n_members, con
                     members[i]->overlap_cal_us[0] = amax * 1e-3; members[i]->overlap_cal_us[1] = bmax * 1e-3;
                     members[i]->overlap_choice = bmax < amax ? 1 : 0;
                 }
+                if (!exchange_auto && members[0]->overlap_choice == 0) for (int i = 0; i < G.n; ++i) overlap_release(members[i]);
             }
         }
         done = ran;
@@ -3689,6 +3747,12 @@ extern "C" int sparkl_hip_debug_run_stats(SparklPipeline* p, unsigned long long*
 // (tests, bench) out[0] = 1 while the group loop of this pipeline exchanges its halo peer-direct (kernels.h, PeerBox), out[1] = substeps it has pushed so far,
 // out[2] = bit 0: a setup attempt failed and the job fell back to the RCCL / copy exchange, bit 1: the arena is fine-grained memory, bits 8..: handshakes done;
 // out[3] = members of the job
+extern "C" int sparkl_hip_debug_direct_choice(const SparklPipeline* p, int* choice, double us[3]) {
+    if (!p || !choice || !us) return -1;
+    *choice = p->direct_choice;
+    us[0] = p->direct_cal_us; us[1] = p->overlap_cal_us[0]; us[2] = p->overlap_cal_us[1];
+    return 0;
+}
 extern "C" int sparkl_hip_debug_direct(const SparklPipeline* p, unsigned long long out[4]) {
     if (!p || !out) return -1;
     out[0] = p->direct.ready ? 1 : 0; out[1] = p->direct.epoch; out[2] = (p->direct.failed ? 1 : 0) | (p->direct.arena_fine ? 2 : 0) | ((unsigned long long)p->direct.handshakes << 8);

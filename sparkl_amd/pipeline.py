@@ -118,10 +118,15 @@ class MpmPipeline:
         return sim.value, int(nsub.value)
 
     def direct_info(self):
-        """Peer-direct halo exchange of the group loop (kernels.h, PeerBox): {"ready", "epochs", "failed", "members", "arena_fine_grained", "handshakes"}."""
+        """Peer-direct halo exchange of the group loop (kernels.h, PeerBox): {"ready", "epochs", "failed", "members", "arena_fine_grained", "handshakes", "chosen", "timed_us_per_substep"}."""
         out = (C.c_ulonglong * 4)()
         self.L.sparkl_hip_debug_direct(self.h, out)
-        return {"ready": bool(out[0]), "epochs": int(out[1]), "failed": bool(out[2] & 1), "members": int(out[3]), "arena_fine_grained": bool(out[2] & 2), "handshakes": int(out[2] >> 8)}
+        choice, us = C.c_int(-1), (C.c_double * 3)()
+        self.L.sparkl_hip_debug_direct_choice(self.h, C.byref(choice), us)
+        # "chosen": what the three-way timing of the job kept (None: nothing timed -- inside one process, or forced), "timed_us_per_substep": the MAX over
+        # the ranks of one undisturbed 16-substep batch on the direct exchange, the staged exchange in line and the staged exchange overlapped
+        return {"ready": bool(out[0]), "epochs": int(out[1]), "failed": bool(out[2] & 1), "members": int(out[3]), "arena_fine_grained": bool(out[2] & 2), "handshakes": int(out[2] >> 8),
+                "chosen": {-1: None, 0: "staged", 1: "direct"}[int(choice.value)], "timed_us_per_substep": {"direct": us[0], "staged_in_line": us[1], "staged_overlapped": us[2]}}
 
     def slab_balance(self, enable=True):
         check(self.L.sparkl_hip_slab_balance(self.h, int(bool(enable))))

@@ -81,7 +81,7 @@ def main():
     from tests.parity import save_components
     save_components(os.path.join(out_dir, f"rank{rank}.npz"), got, pos=got.position["point"], vel=got.velocity["vector"], F=got.volume["deformation_gradient"],
              C=got.velocity_gradient["m"], failed=got.status["failed"], caller=id_to_caller[local_ids], rebins=pipe.group_rebins(), n0=len(gids), n1=len(got),
-             nsub=nsub, sim=sim, overlap=np.array(pipe.overlap_info()), direct=np.array([int(pipe.direct_info()["ready"]), pipe.direct_info()["epochs"]]), direct_fine=int(pipe.direct_info()["arena_fine_grained"]), direct_handshakes=pipe.direct_info()["handshakes"], cut_lo=lo, cut_hi=hi, cut_moves=moves)
+             nsub=nsub, sim=sim, overlap=np.array(pipe.overlap_info()), direct=np.array([int(pipe.direct_info()["ready"]), pipe.direct_info()["epochs"]]), direct_fine=int(pipe.direct_info()["arena_fine_grained"]), direct_handshakes=pipe.direct_info()["handshakes"], direct_chosen=str(pipe.direct_info()["chosen"]), direct_timed_us=np.array(list(pipe.direct_info()["timed_us_per_substep"].values())), cut_lo=lo, cut_hi=hi, cut_moves=moves)
     pipe.close()
 
 

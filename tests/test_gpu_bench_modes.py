@@ -66,8 +66,10 @@ def test_bench_two_ranks_default_path_is_the_library_group_loop():
     cfg = o["config"]
     assert cfg["particles_total"] == 2 * cfg["particles_per_gpu"]
     # round 6: between the two PROCESSES the halo and the re-bin flag travel peer-direct (hipIpc-mapped arenas), for the headline job and the weak one
-    assert o["direct_exchange"]["ready"] and o["direct_exchange"]["epochs"] >= 12 and o["direct_exchange"]["members"] == 2, o["direct_exchange"]
-    assert o["weak_scaling"]["direct_exchange"]["ready"], o["weak_scaling"]
+    # between ranks the exchange is timed before the warmup (bench.py runs 112 untimed substeps for it and uploads the scene again): an answer and three numbers
+    de = o["direct_exchange"]
+    assert de["members"] == 2 and de["epochs"] >= 32 and de["chosen"] in ("direct", "staged") and de["timed_us_per_substep"]["direct"] > 0.0 and de["timed_us_per_substep"]["staged_in_line"] > 0.0, de
+    assert o["weak_scaling"]["direct_exchange"]["chosen"] in ("direct", "staged"), o["weak_scaling"]
     assert o["value"] == pytest.approx(cfg["particles_total"] / (o["ms_per_step"] * 1e-3), rel=1e-6)
     assert o["roofline"]["frac"] > 0.0 and o["halo_ms_per_step"] >= 0.0
     assert o.get("comm") == "rccl" or "overlap" in o, sorted(o)

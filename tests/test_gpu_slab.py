@@ -199,7 +199,7 @@ def test_cube_through_sand_two_slabs_match_oracle(tmp_path):
 
 
 @pytest.mark.parametrize("kind,nsteps,overlap", [("spin", 40, "0"), ("cube", 100, "0"), ("spin", 40, "1"), ("cube", 100, "1"), ("cube", 100, "1+order"),
-                                                 ("spin", 40, "0+staged"), ("cube", 100, "0+staged")])
+                                                 ("spin", 40, "0+staged"), ("cube", 100, "0+staged"), ("spin", 192, "cal+timed")])
 def test_group_substeps_two_slabs_in_the_library(kind, nsteps, overlap, monkeypatch):
     """sparkl_hip_group_substeps: the whole slab loop (re-bin agreement, halo swap, migration) inside the C ABI, no Python in
     the exchange.  Two slabs share one GPU and one stream (device-copy transport of the same loop that uses RCCL between ranks);
@@ -211,6 +211,10 @@ def test_group_substeps_two_slabs_in_the_library(kind, nsteps, overlap, monkeypa
     # "0" runs the peer-direct exchange (round 6: k_halo_push stores into the neighbour's arena, the grid update agrees on the re-bin flag); "+staged"
     # (SPARKL_HIP_DIRECT=0) and the forced two-stream schedule "1" run the flag reduce / pack / copy / merge chain of the RCCL call pattern
     want_direct = overlap == "0"
+    timed = overlap.endswith("+timed")
+    if timed:   # the three-way timing the ranks of a communicator run by default, asked for inside one process (SPARKL_HIP_DIRECT=cal with SPARKL_HIP_OVERLAP=cal)
+        overlap = overlap.split("+")[0]
+        monkeypatch.setenv("SPARKL_HIP_DIRECT", "cal")
     if overlap.endswith("+staged"):
         overlap = overlap.split("+")[0]
         monkeypatch.setenv("SPARKL_HIP_DIRECT", "0")
@@ -238,7 +242,14 @@ def test_group_substeps_two_slabs_in_the_library(kind, nsteps, overlap, monkeypa
     parts = [(p.read_particles(), id_to_caller[p.read_sorted_particle_ids()]) for p in pipes]
     rebins = [p.group_rebins() for p in pipes]
     direct = [p.direct_info() for p in pipes]
-    assert all(d["ready"] == want_direct for d in direct) and all((d["epochs"] >= nsteps) == want_direct for d in direct), direct
+    if timed:
+        # one batch let pass, one timed on each of the three exchanges, the fastest kept: the same answer and the same three numbers on both members
+        assert direct[0]["chosen"] in ("direct", "staged") and direct[0]["chosen"] == direct[1]["chosen"], direct
+        assert all(v > 0.0 for v in direct[0]["timed_us_per_substep"].values()) and direct[0]["timed_us_per_substep"] == direct[1]["timed_us_per_substep"], direct
+        assert all(32 <= d["epochs"] < nsteps for d in direct) or direct[0]["chosen"] == "direct", direct   # (two direct batches at least; not all of them unless it won)
+        print("exchange timed inside one process:", direct[0]["chosen"], direct[0]["timed_us_per_substep"])
+    else:
+        assert all(d["ready"] == want_direct for d in direct) and all((d["epochs"] >= nsteps) == want_direct for d in direct), direct
     regathers = [int(p.step_stats()["c_regathers"]) for p in pipes]
     n_after = [len(p) for p in pipes]
     for p in pipes:

@@ -49,12 +49,15 @@ def _union(tmp_path, sc, world):
     return union_components(parts, caller), parts, caller
 
 
-@pytest.mark.parametrize("exchange", ["direct", "staged", "handshake-fails", "handshake-times-out"])
+@pytest.mark.parametrize("exchange", ["direct", "timed", "staged", "handshake-fails", "handshake-times-out"])
 def test_two_processes_run_the_group_loop_and_match_pipeline_and_oracle(tmp_path, exchange):
     """cube_through_sand in small, the kinematic cube crossing the cut within the 100 substeps: the union of the two PROCESSES equals the
     single pipeline (to rounding: the halo sums are formed in another order) and passes the oracle gate.
     "direct" (round 6, the default): each process maps the other's exchange arena with hipIpcOpenMemHandle; k_halo_push stores the records and
     the re-bin flag mail straight into it and the peer's grid update waits for them inside the kernel -- no per-substep collective at all.
+    "timed" (the default between ranks): nobody is told which exchange to use -- the loop lets one 16-substep batch pass, times one on the peer-direct exchange, one
+    on the staged exchange in line and one overlapped, takes the MAX over the ranks of each and keeps the fastest; both ranks must hold the same three numbers and
+    the same answer.  ("direct" forces it with SPARKL_HIP_DIRECT=1, so that every substep of that run goes through the mapped arenas.)
     "staged": the RCCL call pattern (flag all-reduce, pack, send / recv, merge) over the host transport, with the overlap calibration.
     "handshake-fails": the arenas map, but ONE rank reports that the handshake through them failed (test hook): both ranks must agree on the staged
     exchange -- the fallback a platform without working peer / IPC coherence would take -- and still produce the same result.
@@ -64,8 +67,8 @@ def test_two_processes_run_the_group_loop_and_match_pipeline_and_oracle(tmp_path
     from oracle import Oracle
     from sparkl_amd.pipeline import MpmPipeline
     from tests.parity import parity_verdict
-    world, nsteps = 2, 100
-    env = {"staged": {"SPARKL_HIP_OVERLAP": "cal"}, "direct": {"SPARKL_HIP_COMM_TIMEOUT_S": "20"}, "handshake-fails": {"SPARKL_HIP_DIRECT_TEST_FAIL": "1"},
+    world, nsteps = 2, (160 if exchange == "timed" else 100)
+    env = {"staged": {"SPARKL_HIP_OVERLAP": "cal"}, "direct": {"SPARKL_HIP_COMM_TIMEOUT_S": "20", "SPARKL_HIP_DIRECT": "1"}, "timed": {"SPARKL_HIP_COMM_TIMEOUT_S": "20"}, "handshake-fails": {"SPARKL_HIP_DIRECT_TEST_FAIL": "1"},
            "handshake-times-out": {"SPARKL_HIP_DIRECT_TEST_FAIL": "2", "SPARKL_HIP_DIRECT_HANDSHAKE_S": "0.5"}}[exchange]
     res, el = _run_ranks(tmp_path, "cube", nsteps, world, env_extra=env)
     assert all(rc == 0 for rc, _, _ in res), res
@@ -101,6 +104,14 @@ def test_two_processes_run_the_group_loop_and_match_pipeline_and_oracle(tmp_path
     if exchange == "staged":
         assert overlap[0] == overlap[1] and overlap[0][0] in (0.0, 1.0) and overlap[0][1] > 0 and overlap[0][2] > 0, overlap   # both schedules timed, MAX over the ranks agreed
         assert all(d[1] == 0 for d in direct), direct
+    elif exchange == "timed":
+        chosen = [str(q["direct_chosen"]) for q in parts]
+        timed_us = [tuple(float(x) for x in q["direct_timed_us"]) for q in parts]
+        print("exchange timed by the two ranks:", chosen, timed_us)
+        assert chosen[0] == chosen[1] and chosen[0] in ("direct", "staged"), chosen
+        # (the two ranks share the one GPU of the box: the two-stream schedule is not a candidate there -- a second hardware queue per process -- and reads 0)
+        assert timed_us[0] == timed_us[1] and timed_us[0][0] > 0.0 and timed_us[0][1] > 0.0 and timed_us[0][2] == 0.0, timed_us
+        assert all(d[1] >= 32 for d in direct) and direct[0][1] == direct[1][1], direct
     elif exchange in ("handshake-fails", "handshake-times-out"):
         assert all(d == (0, 0) for d in direct), direct        # no rank ever pushed: the agreement held on both
     else:
@@ -118,7 +129,7 @@ def test_four_processes_exchange_peer_direct_through_every_cut(tmp_path):
     from sparkl_amd.pipeline import MpmPipeline
     from tests.parity import parity_verdict
     world, nsteps = 4, 120
-    res, el = _run_ranks(tmp_path, "long", nsteps, world, env_extra={"SPARKL_HIP_COMM_TIMEOUT_S": "20"})
+    res, el = _run_ranks(tmp_path, "long", nsteps, world, env_extra={"SPARKL_HIP_COMM_TIMEOUT_S": "20", "SPARKL_HIP_DIRECT": "1"})
     assert all(rc == 0 for rc, _, _ in res), res
     sc, dt = _scene("long")
     got, parts, caller = _union(tmp_path, sc, world)
