@@ -560,7 +560,9 @@ int sparkl_hip_substep_status(SparklPipeline* p, uint32_t* steps_done, uint32_t*
  * the grid update; no collective per substep.  A setup step that fails on any rank (no peer access, hipIpc refused, the handshake through
  * the mapped arenas times out) is agreed collectively and the job runs the round-5 chain instead: MAX all-reduce of the 4-byte re-bin
  * request, halo pack, grouped ncclSend / ncclRecv of the shared planes with both neighbours, halo merge (also: SPARKL_HIP_DIRECT=0, the
- * fluid volume sweep and the eigenerosion psi sweep).  Either way the host reads the control block once per batch of 16 substeps and
+ * fluid volume sweep and the eigenerosion psi sweep).  Between the ranks of a communicator the loop times one undisturbed batch on each exchange it has
+ * (peer-direct, staged in line, staged overlapped) early in the job and keeps the fastest on every rank: the cost of a remote store is the link's
+ * (SPARKL_HIP_DIRECT=1: direct without timing).  Either way the host reads the control block once per batch of 16 substeps and
  * re-bins (with particle migration across the cuts) are collective, through RCCL.
  * Members WITHOUT a communicator must share one device and one stream and exchange by device copies: a single-GPU test mode
  * of the same loop.  Fixed-length substeps only (adaptive steps across ranks: sparkl_hip_dt_bound_export + a MIN all-reduce,
