@@ -176,13 +176,16 @@ SPK_DEV bool direct_wait_halo(const DirectWait& W, int lane) {
     }
     return true;   // the records are read with halo_load_wt: no fence
 }
-// The halo payload travels WRITE-THROUGH and is read past the caches: two 8-byte system-scope relaxed atomics per node record on either side
-// (global_store / global_load ... sc0 sc1).  No release fence in the sender (a buffer_wbl2 per workgroup) and, above all, no acquire fence in
+// The halo payload travels WRITE-THROUGH and is read past the caches: system scope on either side (global_store / global_load ... sc0 sc1; the load as
+// two 8-byte relaxed atomics, the store as below).  No release fence in the sender (a buffer_wbl2 per workgroup) and, above all, no acquire fence in
 // the receiver: a buffer_inv per wave of the grid update serialised on the L2 and cost more than the whole staged exchange had (round 6, first cut).
+// The store as ONE 16-byte instruction with the same scope bits the two 8-byte atomics compile to (global_store_dwordx2 ... sc0 sc1): half the write
+// requests on the link for the same bytes (a record is 16 B; the lanes of a cut along x hit every fourth record of a block, so nothing wider coalesces).
+// Nobody reads a record before the sender's epoch word, which is stored behind s_waitcnt vmcnt(0) of every storing wave: tearing cannot be observed.
+typedef float spk_f4v __attribute__((ext_vector_type(4)));
 SPK_DEV void halo_store_wt(float4* p, const float4& v) {
-    const global_u64p q = (global_u64p)p;
-    __hip_atomic_store(q, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x), SPK_RLX_SYS);
-    __hip_atomic_store(q + 1, ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z), SPK_RLX_SYS);
+    const spk_f4v r = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(r) : "memory");
 }
 SPK_DEV float4 halo_load_wt(const float4* p) {
     const global_u64p q = (global_u64p)p;
