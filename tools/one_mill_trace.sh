@@ -1,3 +1,6 @@
+#!/bin/bash
+# one_mill_trace.sh: rocprofv3 --kernel-trace of the two 1 M configurations (neo1m, snow1m) over 400 substeps through tools/slab_trace.py: where a substep of a
+# short-launch scene goes (kernel, grid update, gaps, re-bins and block reorders).  GPU box: gpurun -- bash tools/one_mill_trace.sh
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/r06
