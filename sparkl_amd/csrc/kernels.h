@@ -641,6 +641,42 @@ SPK_DEV int p2g_scatter(double (*tile)[ACC_N], const Scatter& sc, bool live, int
     return nheads;
 }
 
+
+// ---- reduce-scatter over a 16-lane row (round 6) -----------------------------------------------------------------------------------------
+// When all 16 lanes of a row sit in ONE cell (the fluid configurations: 64 particles per cell, two per lane) the segmented suffix sums above make
+// every lane carry every node value through four DPP steps although one lane's result is used.  Here four nodes travel together and the row SPLITS
+// the work: lanes 0-7 keep nodes {0, 1} and lanes 8-15 nodes {2, 3} while adding their partner's share (row_ror:8), then quads {0, 2} keep the
+// first and quads {1, 3} the second of their two (row_shl:4 / row_shr:4), then the four lanes of a quad add up (two quad_perm steps): quad q ends
+// with the row's total of node q.  The destination classes are written with the DPP bank mask (a bank = a quad of the row), so nothing is selected
+// or moved: 8 v_add_f32_dpp per value triple of four nodes where the suffix sums take 16, and ONE deposit (conversion to f64 + ds_add_f64) per four
+// nodes, issued by four lanes of the row at once, where they take four.  X[k * 3 + c]: value c (of three that travel together) of node k; out: X[c].
+// (operand order inside a step: the instruction that READS a register's other half comes before the one that overwrites it; a DPP read sits at least
+// two instructions behind the VALU write of its source)
+#define SPK_RS_A1(D) "v_add_f32_dpp " D ", " D ", " D " row_ror:8 row_mask:0xf bank_mask:0x3\n"
+#define SPK_RS_A2(D, S) "v_add_f32_dpp " D ", " S ", " S " row_ror:8 row_mask:0xf bank_mask:0xc\n"
+#define SPK_RS_B1(D) "v_add_f32_dpp " D ", " D ", " D " row_shl:4 row_mask:0xf bank_mask:0x5\n"
+#define SPK_RS_B2(D, S) "v_add_f32_dpp " D ", " S ", " S " row_shr:4 row_mask:0xf bank_mask:0xa\n"
+#define SPK_RS_C1(D) "v_add_f32_dpp " D ", " D ", " D " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define SPK_RS_C2(D) "v_add_f32_dpp " D ", " D ", " D " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+SPK_DEV void row_reduce_scatter4x3(float (&X)[12]) {
+    asm volatile("s_nop 1\n"
+                 SPK_RS_A1("%0") SPK_RS_A1("%1") SPK_RS_A1("%2") SPK_RS_A1("%3") SPK_RS_A1("%4") SPK_RS_A1("%5")
+                 SPK_RS_A2("%0", "%6") SPK_RS_A2("%1", "%7") SPK_RS_A2("%2", "%8") SPK_RS_A2("%3", "%9") SPK_RS_A2("%4", "%10") SPK_RS_A2("%5", "%11")
+                 SPK_RS_B1("%0") SPK_RS_B1("%1") SPK_RS_B1("%2")
+                 SPK_RS_B2("%0", "%3") SPK_RS_B2("%1", "%4") SPK_RS_B2("%2", "%5")
+                 SPK_RS_C1("%0") SPK_RS_C1("%1") SPK_RS_C1("%2")
+                 SPK_RS_C2("%0") SPK_RS_C2("%1") SPK_RS_C2("%2")
+                 : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(X[4]), "+v"(X[5])
+                 : "v"(X[6]), "v"(X[7]), "v"(X[8]), "v"(X[9]), "v"(X[10]), "v"(X[11]));
+}
+// (sx, sy, sz) of support node idx = sx + 3 sy + 9 sz, idx < 28 (per lane: the node a quad ends up with depends on the quad)
+SPK_DEV void support_node_of(int idx, int& sx, int& sy, int& sz) {
+    sz = (idx * 57) >> 9;
+    const int rem = idx - 9 * sz;
+    sy = (rem * 11) >> 5;
+    sx = rem - 3 * sy;
+}
+
 // Two particles per lane (slots 2j, 2j + 1: neighbours in the cell-sorted order, so usually the same cell).  Their node
 // values are added in the lane first, which halves the DPP reduction, the f64 conversions and the LDS atomic
 // instructions per particle.  A pair that straddles two cells -- the usual case once cells hold odd counts: the boundary of a cell falls between
@@ -662,6 +698,47 @@ SPK_DEV int p2g_scatter_pair(double (*tile)[ACC_N], const Scatter& sa, const Sca
     const bool lone_b = live_b & !same & !join;
     const bool head = (r == 0) | (key_prev != key);
     const int nheads = (int)__popcll(__ballot(live_a & head)) + (int)__popcll(__ballot(lone_b));
+    if constexpr (REDUCE_STEPS == 4 && !WITH_MASS) {
+        // every row of the wave inside one cell, both particles of every lane in it (wave-uniform): the row reduce-scatter (see row_reduce_scatter4x3)
+        if (__all(same & ((r == 0) | (key_prev == key)))) {
+            const ScatterWeights WA = scatter_weights(sa), WB = scatter_weights(sb);
+            const int quad = (lane >> 2) & 3;
+            float X[12];
+#pragma unroll
+            for (int sz = 0; sz < 3; ++sz)
+#pragma unroll
+                for (int sy = 0; sy < 3; ++sy) {
+                    const float wa_yz = WA.w[1][sy] * WA.w[2][sz], wb_yz = WB.w[1][sy] * WB.w[2][sz];
+                    float pa[3] = {sa.qv[0] + sy * sa.A.m[3] + sz * sa.A.m[6], sa.qv[1] + sy * sa.A.m[4] + sz * sa.A.m[7], sa.qv[2] + sy * sa.A.m[5] + sz * sa.A.m[8]};
+                    float pb[3] = {sb.qv[0] + sy * sb.A.m[3] + sz * sb.A.m[6], sb.qv[1] + sy * sb.A.m[4] + sz * sb.A.m[7], sb.qv[2] + sy * sb.A.m[5] + sz * sb.A.m[8]};
+#pragma unroll
+                    for (int sx = 0; sx < 3; ++sx) {
+                        if (sx > 0) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) { pa[c] += sa.A.m[c]; pb[c] += sb.A.m[c]; }
+                        }
+                        const float wa = WA.w[0][sx] * wa_yz, wb = WB.w[0][sx] * wb_yz;
+                        const int idx = sx + 3 * sy + 9 * sz, k = idx & 3;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) X[3 * k + c] = pa[c] * wa + pb[c] * wb;
+                        if (k == 3 || idx == 26) {
+                            if (idx == 26) { X[9] = 0.f; X[10] = 0.f; X[11] = 0.f; }   // (27 nodes: the last group carries three)
+                            row_reduce_scatter4x3(X);
+                            const int node = (idx & ~3) + quad;
+                            if ((lane & 3) == 0 && node < 27) {
+                                int nx, ny, nz;
+                                support_node_of(node, nx, ny, nz);
+                                const int n = acc_plane_base(sa.base, nz) + nx + TILE_W * ny;
+                                atomicAdd(&tile[1][n], (double)X[0]);
+                                atomicAdd(&tile[2][n], (double)X[1]);
+                                atomicAdd(&tile[3][n], (double)X[2]);
+                            }
+                        }
+                    }
+                }
+            return nheads;
+        }
+    }
     const bool any_lone = __any(lone_b), any_join = __any(join);
     const float gj = dpp_shr1_f(join ? 1.f : 0.f);   // 1: the previous lane's second particle joins this lane's run
     const int i1 = ((r + 1 < G) & (key_next == key)) ? 1 : 0;
@@ -2538,6 +2615,7 @@ __global__ void k_reorder_done(Ctl* ctl, int parity) {
 
 // ------------------------------------------------------------- fluid volume recompute (config 4)
 // fluids_volume.rs:9-115: mass-only P2G (here), merge (k_grid_update<true>), then this gather.
+SPK_DEV void mass_scatter(double* mtile, const float u[3], float mass, bool live, int tid);   // (below: shared with k_g2p_mass and the psi sweep)
 __global__ __launch_bounds__(BLK_THREADS) void k_p2g_mass(ParticleArrays P, GridArrays G, const Ctl* __restrict__ ctl, StepParams S) {
     if (ctl->abort_flag[S.parity]) return;
     // same scheme as the full scatter: f64 LDS tile, same-cell lanes pre-summed over 16-lane groups with DPP (64 particles
@@ -2549,7 +2627,6 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_mass(ParticleArrays P, Grid
     const int4 rng = G.pb_info[2 * pb + 1];
     const int pfirst = rng.x, pcount = rng.y;
     __syncthreads();
-    const int lane = tid & 63, r = lane & 15;
     const int niter = (pcount + BLK_THREADS - 1) / BLK_THREADS;
     for (int it = 0; it < niter; ++it) {
         const int li = it * BLK_THREADS + tid;
@@ -2558,38 +2635,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_p2g_mass(ParticleArrays P, Grid
         const float4 q0 = P.q[0][i], kk = P.k[i];
         const bool live = active && !(__float_as_uint(kk.w) & FLAG_INVALID);
         if (!__any(live)) continue;
-        // (the same weights as mass_scatter and the momentum scatter: cell_frac of the stored block-relative position)
+        // (the same weights as the momentum scatter: cell_frac of the stored block-relative position)
         const float u[3] = {q0.x, q0.y, q0.z};
-        float fx[3], wgt[3][3];
-        int lc[3];
-        cell_frac(u, fx, lc);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) eval_all(fx[a], wgt[a]);
-        const int base = live ? lc[0] + TILE_W * lc[1] + TILE_W * TILE_W * lc[2] : 0;
-        const float m = live ? kk.x : 0.f;
-        const int key = live ? base : -1;
-        const int key_prev = dpp_shr1_i(key, -2), key_next = dpp_shl_i<1>(key);
-        const bool head = (r == 0) | (key_prev != key);
-        const int i1 = ((r + 1 < 16) & (key_next == key)) ? 1 : 0;
-        const int i2 = i1 & dpp_shl_i<1>(i1) & (r + 2 < 16 ? 1 : 0);
-        const int i4 = i2 & dpp_shl_i<2>(i2) & (r + 4 < 16 ? 1 : 0);
-        const int i8 = i4 & dpp_shl_i<4>(i4) & (r + 8 < 16 ? 1 : 0);
-        const float f1 = (float)i1, f2 = (float)i2, f4 = (float)i4, f8 = (float)i8;
-#pragma unroll
-        for (int sz = 0; sz < 3; ++sz)
-#pragma unroll
-            for (int sy = 0; sy < 3; ++sy) {
-                const float wyz = wgt[1][sy] * wgt[2][sz] * m;
-                float c0 = wgt[0][0] * wyz, c1 = wgt[0][1] * wyz, c2 = wgt[0][2] * wyz;   // three interleaved DPP chains: a dependent one sits two instructions behind
-                asm volatile("s_nop 1\n" SPK_FMAC_DPP3("1", "%3") SPK_FMAC_DPP3("2", "%4") SPK_FMAC_DPP3("4", "%5") SPK_FMAC_DPP3("8", "%6")
-                             : "+v"(c0), "+v"(c1), "+v"(c2) : "v"(f1), "v"(f2), "v"(f4), "v"(f8));
-                if (live && head) {
-                    const int n = base + TILE_W * sy + TILE_W * TILE_W * sz;
-                    atomicAdd(&tile[n], (double)c0);
-                    atomicAdd(&tile[n + 1], (double)c1);
-                    atomicAdd(&tile[n + 2], (double)c2);
-                }
-            }
+        mass_scatter(tile, u, kk.x, live, tid);
     }
     __syncthreads();
     float* out = (float*)(G.tiles + (size_t)pb * TILE_N);   // mass tile: 8^3 scalars at the head of the block's slot
@@ -2663,10 +2711,37 @@ SPK_DEV void mass_scatter(double* mtile, const float fx[3], const int lc[3], flo
     const int i4 = i2 & dpp_shl_i<2>(i2) & (r + 4 < 16 ? 1 : 0);
     const int i8 = i4 & dpp_shl_i<4>(i4) & (r + 8 < 16 ? 1 : 0);
     const float f1 = (float)i1, f2 = (float)i2, f4 = (float)i4, f8 = (float)i8;
+    // every row of the wave inside one cell (wave-uniform: the fluid configurations): twelve nodes at a time through the row reduce-scatter (three groups of
+    // four travel as the three values of row_reduce_scatter4x3), the last three nodes through the suffix sums below
+    const bool rows_uniform = __all(live & ((r == 0) | (key_prev == key)));
+    if (rows_uniform) {
+        const int quad = (tid >> 2) & 3;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float X[12];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int idx = 12 * b + 4 * c + k, sx = idx % 3, sy = (idx / 3) % 3, sz = idx / 9;
+                    X[3 * k + c] = wgt[0][sx] * (wgt[1][sy] * wgt[2][sz] * m);
+                }
+            row_reduce_scatter4x3(X);
+            if ((tid & 3) == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    int nx, ny, nz;
+                    support_node_of(12 * b + 4 * c + quad, nx, ny, nz);
+                    atomicAdd(&mtile[base + nx + TILE_W * ny + TILE_W * TILE_W * nz], (double)X[c]);
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int sz = 0; sz < 3; ++sz)
 #pragma unroll
         for (int sy = 0; sy < 3; ++sy) {
+            if (rows_uniform && !(sz == 2 && sy == 2)) continue;   // (wave-uniform: nodes 0 .. 23 are done)
             const float wyz = wgt[1][sy] * wgt[2][sz] * m;
             float c0 = wgt[0][0] * wyz, c1 = wgt[0][1] * wyz, c2 = wgt[0][2] * wyz;   // three interleaved DPP chains: a dependent one sits two instructions behind
             asm volatile("s_nop 1\n" SPK_FMAC_DPP3("1", "%3") SPK_FMAC_DPP3("2", "%4") SPK_FMAC_DPP3("4", "%5") SPK_FMAC_DPP3("8", "%6")
