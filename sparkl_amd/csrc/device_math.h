@@ -762,10 +762,14 @@ SPK_DEV SymStress corotated_tau_left(const MO& mo, float hardening, const M3& E,
 template <class MO>
 SPK_DEV M3 corotated_kirchhoff_fe(const MO& mo, float hardening, const M3& E) {
     float S[6], e[3], re[3], g[3], m6[6];
-    strain_metric(E, S);
 #ifndef SPK_STRESS_RIGHT
-    if (SPK_SERIES_MAX > 0.f && __all(series2_ok(S))) return sym_to_m3(corotated_tau_left(mo, hardening, E, !__all(series_ok(S))));   // wave-uniform, and so is the tier
+    {   // the tier test on the left metric (same norm), which corotated_tau_left forms anyway
+        float Sl[6];
+        strain_metric_left(E, Sl);
+        if (SPK_SERIES_MAX > 0.f && __all(series2_ok(Sl))) return sym_to_m3(corotated_tau_left(mo, hardening, E, !__all(series_ok(Sl))));   // wave-uniform, and so is the tier
+    }
 #endif
+    strain_metric(E, S);
     if (SPK_SERIES_MAX > 0.f && __all(series2_ok(S))) {   // wave-uniform; series path: M = I - (I + S)^(-1/2)
         // = S/2 - 3/8 S^2 + 5/16 S^3 - 35/128 S^4 + 63/256 S^5 - 231/1024 S^6 + 429/2048 S^7 (next term 0.39 |S|^7 relative), evaluated like
         // hencky_series: P2 = S^2, coefficients linear in S, Horner in P2 -- four products, S, P2 and one running factor live
@@ -1095,7 +1099,7 @@ template <class MO>
 SPK_DEV bool rare_plastic_may_act(const MO& mo, const M3& E, float q) {
     if (mo.ptag != SPARKL_PLASTIC_SNOW && mo.ptag != SPARKL_PLASTIC_RANKINE) return true;
     float S6[6];
-    strain_metric(E, S6);
+    strain_metric_left(E, S6);   // (the LEFT metric F F^T - I: the same eigenvalues and Frobenius norm as F^T F - I, and the one the stress and the energy below form too)
     const float n2 = S6[0] * S6[0] + S6[1] * S6[1] + S6[2] * S6[2] + 2.f * (S6[3] * S6[3] + S6[4] * S6[4] + S6[5] * S6[5]);
     if (!(n2 == n2)) return true;
     if (mo.ptag == SPARKL_PLASTIC_SNOW) {
@@ -1167,15 +1171,18 @@ SPK_DEV float model_pos_energy(const MO& mo, float phase, float eh, const M3& F,
         if (sv_valid) { s[0] = sm1[0]; s[1] = sm1[1]; s[2] = sm1[2]; }
         else {
             float S6[6], eps[3], re[3];
-            strain_metric(E, S6);
-            if (SPK_SERIES_MAX > 0.f && __all(series2_ok(S6))) {   // wave-uniform; series path
-                float eps6[6];
-                hencky_series(S6, eps6, !__all(series_ok(S6)));
-                sym_eigvals(eps6, eps);
+            strain_metric_left(E, S6);   // (eigenvalues and norm are those of F^T F - I; formed once for the predictor of the rare models, this sum and the stress)
+            if (SPK_SERIES_MAX > 0.f && __all(series2_ok(S6))) {   // wave-uniform; small strains
+                // sigma_k - 1 from the eigenvalues of S = F^T F - I themselves:  sigma^2 - 1 = lambda  =>  sigma - 1 = lambda / (1 + sqrt(1 + lambda)), an
+                // identity without cancellation -- no logarithm series in front of the eigenvalues and no expm1 behind them (round 6: the Hencky strain is
+                // what the return map needs, not this sum; 110 - 220 instructions per particle of every corotated model without Drucker-Prager)
+                sym_eigvals(S6, eps);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) s[k] = eps[k] * fast_rcp(1.f + fast_sqrt(1.f + eps[k]));
             } else {
                 (void)log_stretch_s(S6, eps, re);
+                s[0] = expm1_small(eps[0]); s[1] = expm1_small(eps[1]); s[2] = expm1_small(eps[2]);
             }
-            s[0] = expm1_small(eps[0]); s[1] = expm1_small(eps[1]); s[2] = expm1_small(eps[2]);
         }
         float nsq = 0.f;
 #pragma unroll
