@@ -142,4 +142,17 @@ __global__ __launch_bounds__(BLK_THREADS) void k_run_stats(ParticleArrays P, Gri
     }
 }
 
+
+// sparkl_hip_debug_row_reduce: row_reduce_scatter4x3 on known inputs (tests/test_gpu_parity.py): lane l, node k, value c carry (l + 1) (k + 1) + 100 c -- exact in
+// f32 -- and every lane writes the three values it ends with: quad q of a row must hold the row's totals of node q.
+__global__ void k_test_row_reduce(float* out) {
+    const int lane = threadIdx.x & 63;
+    float X[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) X[3 * k + c] = (float)((lane + 1) * (k + 1) + 100 * c);
+    row_reduce_scatter4x3(X);
+    out[3 * threadIdx.x] = X[0]; out[3 * threadIdx.x + 1] = X[1]; out[3 * threadIdx.x + 2] = X[2];
+}
 }  // namespace spk

@@ -3731,6 +3731,18 @@ int sparkl_hip_grid_read_nodes(SparklPipeline* p, SparklGridNode* out, uint64_t 
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------- diagnostics (probes.h)
+// (tests) the row reduce-scatter of the 64-per-cell scatters on known inputs: out[192] = the three values every lane of one wave ends with (probes.h)
+extern "C" int sparkl_hip_debug_row_reduce(SparklPipeline* p, float* out192) {
+    if (!p || !out192) return -1;
+    HIPCHK(hipSetDevice(p->device));
+    DevBuf<float> d;
+    CHK(d.reserve(192));
+    hipLaunchKernelGGL(k_test_row_reduce, dim3(1), dim3(64), 0, p->stream, d.p);
+    HIPCHK(hipMemcpyAsync(out192, d.p, 192 * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    d.release();
+    return SPARKL_OK;
+}
 extern "C" int sparkl_hip_debug_run_stats(SparklPipeline* p, unsigned long long* out, uint64_t cap) {
     if (!p || !out || cap < (uint64_t)RS_HISTS * RS_BINS) return set_error(SPARKL_ERR_INVALID_ARGUMENT, "run_stats: need %d counters", RS_HISTS * RS_BINS);
     HIPCHK(hipSetDevice(p->device));

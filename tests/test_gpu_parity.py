@@ -498,6 +498,26 @@ def test_snow_view_defers_and_carries_like_the_generic_kernel(Pipeline, monkeypa
     assert np.abs(got.volume["plastic_deformation_gradient_det"].astype(np.float64) - gen.volume["plastic_deformation_gradient_det"]).max() < 2e-5
 
 
+def test_row_reduce_scatter_on_known_inputs(Pipeline):
+    """`row_reduce_scatter4x3` (kernels.h: the reduction of the 64-per-cell scatters) on exact integers: lane l, node k, value c carry (l + 1)(k + 1) + 100 c;
+    after the 24 DPP adds every lane of quad q of a 16-lane row must hold the row's totals of node q -- the DPP bank masks (which lanes a step writes) and the
+    lane pairings (row_ror:8, row_shl:4 / row_shr:4, quad_perm) checked without a physics scene around them."""
+    import ctypes as C
+    from sparkl_amd import _lib
+    sc = scenes.sand_column(4, 4, 4)
+    with Pipeline(sc.cell_width, domain_log2_bytes=sc.domain_log2_bytes) as p:
+        out = (C.c_float * 192)()
+        _lib.check(_lib.lib().sparkl_hip_debug_row_reduce(p.h, out))
+    got = np.array(out, dtype=np.float64).reshape(64, 3)
+    lanes = np.arange(64)
+    for row in range(4):
+        in_row = lanes[(lanes >> 4) == row]
+        for l in in_row:
+            q = (l >> 2) & 3
+            want = [float(((in_row + 1) * (q + 1) + 100 * c).sum()) for c in range(3)]
+            assert list(got[l]) == want, (l, q, list(got[l]), want)
+
+
 def _edge_scenes():
     def kinematic():
         # config 5 in small: a kinematic cube ploughs through the sand bed (cube_through_sand3.rs:40-81)
